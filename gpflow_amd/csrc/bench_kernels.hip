@@ -1,0 +1,38 @@
+// Micro-benchmark kernels: fp64 MFMA issue rate (the denominator of every "fraction of peak" we
+// quote is measured, not assumed) and a streaming fp64 store (HBM write ceiling for the K builder).
+#include "gpk_internal.h"
+
+namespace {
+__global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double* sink) {
+  const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+  d4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+  if (s == 12345.678) sink[0] = s;  // never true; keeps the chain live
+}
+__global__ __launch_bounds__(256) void stream_store_kernel(double* out, long n2) {
+  d2* o = reinterpret_cast<d2*>(out);
+  const d2 v = {1.0, 2.0};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) o[i] = v;
+}
+}  // namespace
+
+// flops issued = blocks * 4 waves * iters * 8 * 2048
+extern "C" int gpk_bench_mfma_f64(void* stream, int blocks, int iters, double* sink) {
+  hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gpk_bench_stream_store(void* stream, double* out, long n_doubles) {
+  hipLaunchKernelGGL(stream_store_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, out,
+                     n_doubles / 2);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,285 @@
+// fp64 MFMA GEMM for gfx950:  C = alpha * A * B^T + beta * C   (A [m,k], B [n,k], row-major).
+//
+// Every matmul-shaped piece of the dense-GP path is this one kernel:
+//   * Cholesky panel solve  X = A21 * inv(L11)^T          (in place, b_tri = 2)
+//   * Cholesky trailing / look-ahead updates  C -= P P^T   (c_lower, alpha=-1, beta=1)
+//   * triangular solves against a cached factor            (gpk_trsm)
+//   * the projection  A^T [Lq | q_mu]  with a fused row-sum-of-squares epilogue (epi = 1)
+//
+// Design (CDNA4): 256 threads = 4 waves (2x2), workgroup tile BM x BN, wave tile (BM/2) x (BN/2)
+// built from v_mfma_f64_16x16x4_f64 (A frag: row = lane&15, k = lane>>4, one f64 per lane; same for
+// the B^T frag; D: col = lane&15, row = (lane>>4) + 4*reg).  K is walked in BK=16 slabs, staged
+// global -> VGPR -> LDS with register double-buffering and one barrier per slab.  LDS rows are
+// padded to 18 doubles (144 B): the 32-lane ds_read_b64 groups then hit 64 distinct banks.
+// 2 workgroups/CU (73.7 KB LDS each) keep one wave per SIMD issuing MFMAs while the other waits.
+// Block ids are remapped so that (a) each XCD gets a contiguous range of tiles (private L2s) and
+// (b) tiles are swept in 8-wide column groups (A/B panel reuse out of the 4 MiB L2).
+#include "gpk_internal.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int LDSS = BK + 2;
+constexpr int GROUP_N = 8;
+
+template <int BM, int BN>
+struct TileCfg {
+  static constexpr int WM = BM / 2, WN = BN / 2;
+  static constexpr int TM = WM / 16, TN = WN / 16;
+  static constexpr int A_CH = BM * (BK / 2) / 256;
+  static constexpr int B_CH = BN * (BK / 2) / 256;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDSS * sizeof(double);
+};
+
+__device__ __forceinline__ d2 load2(const double* __restrict__ base, long ld, int row, int nrows,
+                                    int k, int ke, bool vec_ok) {
+  d2 v = {0.0, 0.0};
+  if (row < nrows && k < ke) {
+    const double* ptr = base + (long)row * ld + k;
+    if (vec_ok && k + 1 < ke) {
+      v = *reinterpret_cast<const d2*>(ptr);
+    } else {
+      v.x = ptr[0];
+      if (k + 1 < ke) v.y = ptr[1];
+    }
+  }
+  return v;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int gy) {
+  using Cfg = TileCfg<BM, BN>;
+  constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
+  constexpr int A_CH = Cfg::A_CH, B_CH = Cfg::B_CH;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bz = blockIdx.y;
+
+  // ---- XCD-contiguous + column-grouped tile order -------------------------------------------
+  int tile_m, tile_n;
+  {
+    const int total = gx * gy;
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, local = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int nl = xcd * q + (xcd < r ? xcd : r) + local;
+    const int gspan = GROUP_N * gy;
+    const int group = nl / gspan, within = nl - group * gspan;
+    const int first_n = group * GROUP_N;
+    const int gsz = (gx - first_n) < GROUP_N ? (gx - first_n) : GROUP_N;
+    tile_n = first_n + within % gsz;
+    tile_m = within / gsz;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (p.c_lower && n0 > m0 + BM - 1) return;
+
+  const double* __restrict__ A = p.A + (long)bz * p.strideA;
+  const double* __restrict__ B = p.B + (long)bz * p.strideB;
+
+  int kb = 0, ke = p.k;
+  if (p.b_tri && n0 + BN <= p.b_tri_rows) {
+    if (p.b_tri == 1) {
+      int f = n0 + p.b_tri_off;
+      kb = (f > 0 ? f : 0) & ~(BK - 1);
+    } else {
+      int l = n0 + BN + p.b_tri_off;
+      ke = l < p.k ? l : p.k;
+    }
+  }
+  const bool vec_ok = ((p.lda & 1) == 0) && ((p.ldb & 1) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+
+  constexpr int BUF = (BM + BN) * LDSS;  // doubles per LDS buffer: [A tile | B tile]
+
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  // per-thread staging slots: chunk c = tid + 256 q  ->  tile row c>>3, k offset (c&7)*2.
+  // Rows are clamped (then zero-selected) so the fast path is branch-free: all loads of a slab
+  // are issued back to back and drain under the MFMAs of the previous slab.
+  d2 ra[A_CH], rb[B_CH];
+  const double* pa[A_CH];
+  const double* pb[B_CH];
+  bool va[A_CH], vb[B_CH];
+#pragma unroll
+  for (int q = 0; q < A_CH; ++q) {
+    const int c = tid + 256 * q;
+    const int row = m0 + (c >> 3);
+    va[q] = row < p.m;
+    pa[q] = A + (long)(va[q] ? row : p.m - 1) * p.lda + (c & 7) * 2;
+  }
+#pragma unroll
+  for (int q = 0; q < B_CH; ++q) {
+    const int c = tid + 256 * q;
+    const int row = n0 + (c >> 3);
+    vb[q] = row < p.n;
+    pb[q] = B + (long)(vb[q] ? row : p.n - 1) * p.ldb + (c & 7) * 2;
+  }
+  const d2 zero2 = {0.0, 0.0};
+  auto gload = [&](int k0) {
+    if (vec_ok && k0 + BK <= ke) {  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < A_CH; ++q) {
+        ra[q] = *reinterpret_cast<const d2*>(pa[q] + k0);
+      }
+#pragma unroll
+      for (int q = 0; q < B_CH; ++q) {
+        rb[q] = *reinterpret_cast<const d2*>(pb[q] + k0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < A_CH; ++q) {
+        const int c = tid + 256 * q;
+        ra[q] = load2(A, p.lda, m0 + (c >> 3), p.m, k0 + (c & 7) * 2, ke, false);
+      }
+#pragma unroll
+      for (int q = 0; q < B_CH; ++q) {
+        const int c = tid + 256 * q;
+        rb[q] = load2(B, p.ldb, n0 + (c >> 3), p.n, k0 + (c & 7) * 2, ke, false);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < A_CH; ++q) {
+      const int c = tid + 256 * q;
+      *reinterpret_cast<d2*>(&smem[buf * BUF + (c >> 3) * LDSS + (c & 7) * 2]) =
+          va[q] ? ra[q] : zero2;
+    }
+#pragma unroll
+    for (int q = 0; q < B_CH; ++q) {
+      const int c = tid + 256 * q;
+      *reinterpret_cast<d2*>(&smem[buf * BUF + (BM + (c >> 3)) * LDSS + (c & 7) * 2]) =
+          vb[q] ? rb[q] : zero2;
+    }
+  };
+
+  const int nkt = ke > kb ? (ke - kb + BK - 1) / BK : 0;
+  if (nkt > 0) {
+    gload(kb);
+    lstore(0);
+    __syncthreads();
+  }
+  const int frag_r = lane & 15, frag_k = lane >> 4;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) gload(kb + (kt + 1) * BK);
+    const double* as = smem + cur * BUF + (wm * WM + frag_r) * LDSS + frag_k;
+    const double* bs = smem + cur * BUF + (BM + wn * WN + frag_r) * LDSS + frag_k;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[i * 16 * LDSS + kk * 4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[j * 16 * LDSS + kk * 4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const int row_base = m0 + wm * WM + (lane >> 4);
+  const int col_base = n0 + wn * WN + (lane & 15);
+  if (p.epi == 0) {
+    double* __restrict__ C = p.C + (long)bz * p.strideC;
+    const double alpha = p.alpha, beta = p.beta;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row_base + i * 16 + 4 * r;
+        if (row < p.m) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = col_base + j * 16;
+            if (col < p.n) {
+              double* cp = C + (long)row * p.ldc + col;
+              double v = alpha * acc[i][j][r];
+              if (beta != 0.0) v += beta * (*cp);
+              *cp = v;
+            }
+          }
+        }
+      }
+  } else {
+    double* __restrict__ C2 = p.C2 + (long)bz * p.strideC2;
+    double* __restrict__ part = p.part + (long)bz * p.stridePart;
+    const double alpha = p.alpha;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row_base + i * 16 + 4 * r;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = col_base + j * 16;
+          const double v = alpha * acc[i][j][r];
+          if (col < p.sq_cols) {
+            s += v * v;
+          } else if (row < p.m && col - p.sq_cols < p.c2_cols && col < p.n) {
+            C2[(long)row * p.ldc2 + (col - p.sq_cols)] = v;
+          }
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        if ((lane & 15) == 0 && row < p.m) part[(long)(tile_n * 2 + wn) * p.part_ld + row] = s;
+      }
+  }
+}
+
+template <int BM, int BN>
+int launch_cfg(hipStream_t s, const GemmArgs& a) {
+  using Cfg = TileCfg<BM, BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+    attr_set = true;
+  }
+  const int gx = gpk_cdiv(a.n, BN), gy = gpk_cdiv(a.m, BM);
+  if (gx <= 0 || gy <= 0) return 0;
+  dim3 grid((unsigned)(gx * gy), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN>), grid, dim3(256), Cfg::LDS_BYTES, s, a, gx, gy);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
+
+int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
+  if (a.m <= 0 || a.n <= 0) return 0;
+  if (a.epi == 1 || a.n > 64) return launch_cfg<128, 128>(s, a);
+  return launch_cfg<128, 64>(s, a);
+}
+
+extern "C" int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, const double* A,
+                           long lda, const double* B, long ldb, double beta, double* C, long ldc,
+                           int b_tri, int c_lower, int batch, long strideA, long strideB,
+                           long strideC) {
+  if (m < 0 || n < 0 || k < 0 || !A || !B || !C) return GPK_E_ARG;
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.strideA = strideA;
+  g.B = B; g.ldb = ldb; g.strideB = strideB;
+  g.C = C; g.ldc = ldc; g.strideC = strideC;
+  g.m = m; g.n = n; g.k = k; g.alpha = alpha; g.beta = beta;
+  g.c_lower = c_lower; g.b_tri = b_tri; g.b_tri_off = 0; g.b_tri_rows = n;
+  g.epi = 0; g.batch = batch > 0 ? batch : 1;
+  return gpk_launch_gemm((hipStream_t)stream, g);
+}

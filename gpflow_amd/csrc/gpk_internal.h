@@ -1,0 +1,71 @@
+// Internal declarations shared by the libgpk translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gpk.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define GPK_HIP(call)                                   \
+  do {                                                  \
+    hipError_t e__ = (call);                            \
+    if (e__ != hipSuccess) return (int)e__;             \
+  } while (0)
+#define GPK_LAUNCH_CHECK()                              \
+  do {                                                  \
+    hipError_t e__ = hipGetLastError();                 \
+    if (e__ != hipSuccess) return (int)e__;             \
+  } while (0)
+
+static inline size_t gpk_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int gpk_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- GEMM (gemm.hip):  C = alpha * A * B^T + beta * C ----------------------------------------
+struct GemmArgs {
+  const double* A; long lda; long strideA;   // [m,k]
+  const double* B; long ldb; long strideB;   // [n,k]
+  double* C; long ldc; long strideC;         // [m,n]
+  int m, n, k;
+  double alpha, beta;
+  int c_lower;      // skip tiles strictly above the diagonal (row r / col c of C: skip if c0 > r_last)
+  int b_tri;        // 0 dense, 1 B[j,kk]==0 for kk<j, 2 B[j,kk]==0 for kk>j (+ b_tri_off on kk)
+  int b_tri_off;    // the triangular structure is B[j,kk] vs kk - b_tri_off
+  int b_tri_rows;   // structure applies to rows j < b_tri_rows of B only (rows beyond are dense)
+  // epilogue 1 ("project"): columns < sq_cols are squared and row-summed into part[(tile_n*2+wn), row];
+  // columns >= sq_cols (the q_mu rows of the operand) are stored to C2[row, col - sq_cols]; C unused.
+  int epi;
+  int sq_cols;
+  double* part; long part_ld; long stridePart;   // [2*tiles_n, m]
+  double* C2; long ldc2; long strideC2; int c2_cols;
+  int batch;
+};
+int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
+int gpk_gemm_tiles_n(int n);  // number of column tiles the launcher will use for n columns
+
+// ---- leaf (leaf.hip): NB x NB Cholesky + inverse of the diagonal block --------------------------
+// A: pointer to the diagonal block (row-major, lda); nb <= NB valid rows/cols.
+int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
+                    long strideInv, int* info, int col0, int batch, int already_factored);
+
+// ---- rbf.hip ---------------------------------------------------------------------------------
+// (entry point gpk_kernel_matrix is defined there)
+
+// ---- reduce.hip: small kernels -------------------------------------------------------------------
+int gpk_launch_zero_upper(hipStream_t s, double* A, int n, long lda, int batch, long strideA);
+int gpk_launch_sum_parts(hipStream_t s, const double* part, int nt, int rows, long stridePart, int P,
+                         double* ssq);
+int gpk_launch_final(hipStream_t s, int nterms, const double* const* part, const int* count,
+                     const double* scale, double add, double* out);
+int gpk_launch_sumsq_stage1(hipStream_t s, const double* A, int rows, int cols, long lda,
+                            int upper_only, double* part, int* count);
+int gpk_launch_varexp_stage1(hipStream_t s, const double* Y, long ldy, const double* fmean, int rows,
+                             int P, const double* s0, int s0_per_latent, const double* ssq,
+                             const double* knn_host, int knn_per_latent, double noise,
+                             double mean_const, double* fvar_out, double* part, int* count);
+int gpk_launch_kl_white_stage1(hipStream_t s, const double* q_mu, const double* q_sqrt, int m, int P,
+                               int q_diag, double* part, int* count);
+int gpk_launch_transpose_shift(hipStream_t s, const double* in, int rows, int cols, long ldin,
+                               double* out, long ldout, double shift);
+#define GPK_REDUCE_MAXPART 1024

@@ -1,0 +1,346 @@
+// Host-side orchestration (no device code here): the trapezoidal blocked Cholesky, triangular solves
+// against a cached factor, the projection onto q_sqrt, and the two fused model drivers
+// (GPR.log_marginal_likelihood, one shard of SVGP.elbo).
+//
+// Trapezoidal Cholesky.  A is [(n + extra) x n]: the top square block is factored, the `extra` rows
+// below ride along through every panel solve and trailing update and come out as  B L^-T  -- the
+// tf.linalg.triangular_solve of the reference fused into the factorisation.  Two-level right-looking:
+//   outer panels of NBO = 512 columns  -> trailing update is a K = 512 MFMA GEMM (64 flop/B on C),
+//   inner blocks of NB = 128 columns   -> leaf kernel (L11 and L11^-1), in-place panel solve
+//                                          A21 <- A21 * L11^-T as a GEMM, update of the rest of the panel.
+#include "gpk_internal.h"
+
+namespace {
+constexpr int NB = GPK_NB;
+constexpr int NBO = 512;
+
+inline GemmArgs gemm_base(int m, int n, int k, double alpha, const double* A, long lda,
+                          const double* B, long ldb, double beta, double* C, long ldc, int batch,
+                          long sA, long sB, long sC) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.strideA = sA;
+  g.B = B; g.ldb = ldb; g.strideB = sB;
+  g.C = C; g.ldc = ldc; g.strideC = sC;
+  g.m = m; g.n = n; g.k = k; g.alpha = alpha; g.beta = beta;
+  g.b_tri_rows = n; g.batch = batch > 0 ? batch : 1;
+  return g;
+}
+}  // namespace
+
+extern "C" const char* gpk_version(void) { return "gpk 0.1 (gfx950, fp64 MFMA)"; }
+
+extern "C" size_t gpk_invd_elems(int n, int batch) {
+  return (size_t)(batch > 0 ? batch : 1) * gpk_cdiv(n, NB) * NB * NB;
+}
+
+extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch,
+                         long strideA, double* invd, int zero_upper, int* info) {
+  if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (batch <= 0) batch = 1;
+  if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, s));
+  if (n == 0) return 0;
+  const int R = n + extra;
+  const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
+  int rc;
+  for (int c0 = 0; c0 < n; c0 += NBO) {
+    const int c1 = (c0 + NBO < n) ? c0 + NBO : n;
+    for (int j0 = c0; j0 < c1; j0 += NB) {
+      const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
+      const int nb = j1 - j0;
+      double* diag = A + (long)j0 * lda + j0;
+      double* invb = invd + (long)(j0 / NB) * NB * NB;
+      rc = gpk_launch_leaf(s, diag, lda, strideA, nb, invb, strideInv, info, j0, batch, 0);
+      if (rc) return rc;
+      const int below = R - j1;
+      if (below > 0) {
+        double* panel = A + (long)j1 * lda + j0;
+        // in-place panel solve: X = panel * inv(L11)^T  (single column tile => each workgroup only
+        // overwrites rows it alone has read)
+        GemmArgs g = gemm_base(below, nb, nb, 1.0, panel, lda, invb, NB, 0.0, panel, lda, batch,
+                               strideA, strideInv, strideA);
+        g.b_tri = 2;
+        rc = gpk_launch_gemm(s, g);
+        if (rc) return rc;
+        const int ncols = c1 - j1;
+        if (ncols > 0) {
+          // rest of the outer panel:  A[j1:R, j1:c1] -= X * X[0:ncols]^T
+          GemmArgs u = gemm_base(below, ncols, nb, -1.0, panel, lda, panel, lda, 1.0,
+                                 A + (long)j1 * lda + j1, lda, batch, strideA, strideA, strideA);
+          u.c_lower = 1;
+          rc = gpk_launch_gemm(s, u);
+          if (rc) return rc;
+        }
+      }
+    }
+    if (c1 < n) {
+      // outer trailing update (K = c1 - c0): A[c1:R, c1:n] -= P P[0:n-c1]^T, lower tiles only
+      const double* P = A + (long)c1 * lda + c0;
+      GemmArgs u = gemm_base(R - c1, n - c1, c1 - c0, -1.0, P, lda, P, lda, 1.0,
+                             A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
+      u.c_lower = 1;
+      rc = gpk_launch_gemm(s, u);
+      if (rc) return rc;
+    }
+  }
+  if (zero_upper) return gpk_launch_zero_upper(s, A, n, lda, batch, strideA);
+  return 0;
+}
+
+extern "C" int gpk_trtri_blocks(void* stream, const double* L, int n, long ldl, int batch,
+                                long strideL, double* invd) {
+  if (!L || !invd || n < 0) return GPK_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (batch <= 0) batch = 1;
+  const int nblk = gpk_cdiv(n, NB);
+  const long strideInv = (long)nblk * NB * NB;
+  const int nfull = n / NB;
+  for (int b = 0; b < batch; ++b) {
+    double* Lb = const_cast<double*>(L) + (long)b * strideL;  // FACTORED leaf never writes A
+    double* ib = invd + (long)b * strideInv;
+    if (nfull > 0) {
+      int rc = gpk_launch_leaf(s, Lb, ldl, (long)NB * (ldl + 1), NB, ib, (long)NB * NB, nullptr, 0,
+                               nfull, 1);
+      if (rc) return rc;
+    }
+    if (nfull < nblk) {
+      const int j0 = nfull * NB;
+      int rc = gpk_launch_leaf(s, Lb + (long)j0 * (ldl + 1), ldl, 0, n - j0, ib + (long)nfull * NB * NB,
+                               0, nullptr, 0, 1, 1);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+// trans = 0:  B <- B L^-T  with (L, invd);   trans = 1:  B <- B L^-1 with (LT = L^T, invdT)
+extern "C" int gpk_trsm(void* stream, int trans, const double* L, long ldl, const double* invd,
+                        int n, double* B, int m, long ldb, int batch, long strideL, long strideB) {
+  if (!L || !invd || !B || n < 0 || m < 0) return GPK_E_ARG;
+  if (n == 0 || m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (batch <= 0) batch = 1;
+  const int nblk = gpk_cdiv(n, NB);
+  const long strideInv = (long)nblk * NB * NB;
+  int rc;
+  if (trans == 0) {
+    for (int jb = 0; jb < nblk; ++jb) {
+      const int j0 = jb * NB, j1 = (j0 + NB < n) ? j0 + NB : n, nb = j1 - j0;
+      if (j0 > 0) {
+        GemmArgs u = gemm_base(m, nb, j0, -1.0, B, ldb, L + (long)j0 * ldl, ldl, 1.0, B + j0, ldb,
+                               batch, strideB, strideL, strideB);
+        rc = gpk_launch_gemm(s, u);
+        if (rc) return rc;
+      }
+      GemmArgs g = gemm_base(m, nb, nb, 1.0, B + j0, ldb, invd + (long)jb * NB * NB, NB, 0.0, B + j0,
+                             ldb, batch, strideB, strideInv, strideB);
+      g.b_tri = 2;
+      rc = gpk_launch_gemm(s, g);
+      if (rc) return rc;
+    }
+  } else {
+    for (int jb = nblk - 1; jb >= 0; --jb) {
+      const int j0 = jb * NB, j1 = (j0 + NB < n) ? j0 + NB : n, nb = j1 - j0;
+      if (j1 < n) {
+        // B[:, j0:j1] -= B[:, j1:n] * (LT[j0:j1, j1:n])^T
+        GemmArgs u = gemm_base(m, nb, n - j1, -1.0, B + j1, ldb, L + (long)j0 * ldl + j1, ldl, 1.0,
+                               B + j0, ldb, batch, strideB, strideL, strideB);
+        rc = gpk_launch_gemm(s, u);
+        if (rc) return rc;
+      }
+      GemmArgs g = gemm_base(m, nb, nb, 1.0, B + j0, ldb, invd + (long)jb * NB * NB, NB, 0.0, B + j0,
+                             ldb, batch, strideB, strideInv, strideB);
+      g.b_tri = 1;
+      rc = gpk_launch_gemm(s, g);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+extern "C" int gpk_transpose_factor(void* stream, const double* L, long ldl, const double* invd,
+                                    int n, double* LT, long ldlt, double* invdT) {
+  if (!L || !invd || !LT || !invdT || n < 0) return GPK_E_ARG;
+  if (n == 0) return 0;
+  int rc = gpk_transpose(stream, L, n, n, ldl, LT, ldlt, 1, 1, 0, 0);
+  if (rc) return rc;
+  const int nblk = gpk_cdiv(n, NB);
+  return gpk_transpose(stream, invd, NB, NB, NB, invdT, NB, 0, nblk, (long)NB * NB, (long)NB * NB);
+}
+
+// ---- projection:  ssq[p,b] = sum_j ( sum_k At[b,k] Lq_p[k,j] )^2 ---------------------------------------
+extern "C" size_t gpk_project_workspace_bytes(int rows, int m, int P) {
+  return (size_t)P * 2 * gpk_gemm_tiles_n(m) * rows * sizeof(double);
+}
+
+extern "C" int gpk_project(void* stream, const double* At, int rows, int m, long ldat,
+                           const double* LqT, long ldl, int P, double* ssq, void* ws,
+                           size_t ws_bytes) {
+  if (!At || !LqT || !ssq || rows < 0 || m <= 0 || P <= 0) return GPK_E_ARG;
+  if (!ws || ws_bytes < gpk_project_workspace_bytes(rows, m, P)) return GPK_E_WORKSPACE;
+  if (rows == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = 2 * gpk_gemm_tiles_n(m);
+  GemmArgs g = gemm_base(rows, m, m, 1.0, At, ldat, LqT, ldl, 0.0, nullptr, 0, P, 0, (long)m * ldl, 0);
+  g.b_tri = 1;  // LqT[j,k] = Lq[k,j] vanishes for k < j
+  g.epi = 1; g.sq_cols = m; g.c2_cols = 0;
+  g.part = (double*)ws; g.part_ld = rows; g.stridePart = (long)nt * rows;
+  g.C2 = (double*)ws; g.ldc2 = 0; g.strideC2 = 0;
+  int rc = gpk_launch_gemm(s, g);
+  if (rc) return rc;
+  return gpk_launch_sum_parts(s, (const double*)ws, nt, rows, (long)nt * rows, P, ssq);
+}
+
+// ---- fused driver: GPR.log_marginal_likelihood ----------------------------------------------------------
+namespace {
+struct LmlLayout {
+  long ld; size_t off_T, off_invd, off_part, off_logdet, total;
+};
+LmlLayout lml_layout(int n, int P) {
+  LmlLayout l{};
+  l.ld = (long)gpk_align_up((size_t)n, 8);
+  size_t o = 0;
+  l.off_T = o; o += gpk_align_up((size_t)(n + P) * l.ld * sizeof(double), 256);
+  l.off_invd = o; o += gpk_align_up(gpk_invd_elems(n, 1) * sizeof(double), 256);
+  l.off_part = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
+  l.off_logdet = o; o += 256;
+  l.total = o;
+  return l;
+}
+}  // namespace
+
+extern "C" size_t gpk_gpr_lml_workspace_bytes(int n, int d, int P) {
+  (void)d;
+  return lml_layout(n, P).total;
+}
+
+extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int d, long ldx,
+                           const double* Y, int P, long ldy, const double* ls_host, int ard,
+                           double variance, double noise_variance, double mean_const, double* out,
+                           int* info, void* ws, size_t ws_bytes) {
+  if (!X || !Y || !out || !info || n <= 0 || P <= 0) return GPK_E_ARG;
+  const LmlLayout l = lml_layout(n, P);
+  if (!ws || ws_bytes < l.total) return GPK_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)ws;
+  double* T = (double*)(w + l.off_T);
+  double* invd = (double*)(w + l.off_invd);
+  double* part = (double*)(w + l.off_part);
+  double* logdet = (double*)(w + l.off_logdet);
+  int rc;
+  // K(X,X) + noise I, lower tiles only (gpr.py:100-101)
+  rc = gpk_kernel_matrix(stream, family, X, n, ldx, nullptr, 0, 0, d, ls_host, ard, variance,
+                         noise_variance, 1, T, l.ld);
+  if (rc) return rc;
+  // (Y - m)^T as P extra rows (gpr.py:103, logdensities.py:149)
+  rc = gpk_launch_transpose_shift(s, Y, n, P, ldy, T + (long)n * l.ld, l.ld, -mean_const);
+  if (rc) return rc;
+  // L = chol(K); extra rows -> alpha^T = (L^-1 (Y-m))^T  (gpr.py:102, logdensities.py:150)
+  rc = gpk_potrf(stream, T, n, P, l.ld, 1, 0, invd, 0, info);
+  if (rc) return rc;
+  // p = -0.5 sum alpha^2 - 0.5 N log 2pi - sum log diag L, summed over the P columns
+  rc = gpk_sum_log_diag(stream, T, n, l.ld, 1, 0, logdet);
+  if (rc) return rc;
+  int cnt = 0;
+  rc = gpk_launch_sumsq_stage1(s, T + (long)n * l.ld, P, n, l.ld, 0, part, &cnt);
+  if (rc) return rc;
+  const double* parts[2] = {part, logdet};
+  const int counts[2] = {cnt, 1};
+  const double scales[2] = {-0.5, -(double)P};
+  const double add = -0.5 * (double)n * (double)P * 1.8378770664093453;
+  return gpk_launch_final(s, 2, parts, counts, scales, add, out);
+}
+
+// ---- fused driver: one shard of SVGP.elbo (whitened; shared kernel over the P latents) ----------------
+namespace {
+struct ElboLayout {
+  long ld; int nt;
+  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, total;
+};
+ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
+  ElboLayout l{};
+  l.ld = (long)gpk_align_up((size_t)m, 8);
+  l.nt = 2 * gpk_gemm_tiles_n(m);
+  size_t o = 0;
+  l.off_T = o; o += gpk_align_up((size_t)(m + rows) * l.ld * sizeof(double), 256);
+  l.off_invd = o; o += gpk_align_up(gpk_invd_elems(m, 1) * sizeof(double), 256);
+  l.off_LqT = o; o += q_diag ? 0 : gpk_align_up((size_t)P * m * l.ld * sizeof(double), 256);
+  l.off_s0 = o; o += gpk_align_up((size_t)rows * sizeof(double), 256);
+  l.off_fmean = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
+  l.off_ssq = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
+  l.off_proj = o; o += q_diag ? 0 : gpk_align_up(gpk_project_workspace_bytes(rows, m, P), 256);
+  l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
+  l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
+  l.total = o;
+  return l;
+}
+}  // namespace
+
+extern "C" size_t gpk_svgp_elbo_workspace_bytes(int m, int rows, int d, int P, int q_diag) {
+  (void)d;
+  return elbo_layout(m, rows, P, q_diag).total;
+}
+
+extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long ldz,
+                                   const double* Xb, const double* Yb, int rows, long ldxb,
+                                   long ldyb, int d, int P, const double* ls_host, int ard,
+                                   double variance, double noise_variance, double jitter,
+                                   double mean_const, const double* q_mu, const double* q_sqrt,
+                                   int q_diag, int whiten, double* out, int* info, void* ws,
+                                   size_t ws_bytes) {
+  if (!Z || !Xb || !Yb || !q_mu || !q_sqrt || !out || !info || m <= 0 || rows < 0 || P <= 0 || P > 16)
+    return GPK_E_ARG;
+  if (!whiten) return GPK_E_UNSUPPORTED;  // composed from the primitives by the Python host
+  const ElboLayout l = elbo_layout(m, rows, P, q_diag);
+  if (!ws || ws_bytes < l.total) return GPK_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)ws;
+  double* T = (double*)(w + l.off_T);
+  double* invd = (double*)(w + l.off_invd);
+  double* LqT = (double*)(w + l.off_LqT);
+  double* s0 = (double*)(w + l.off_s0);
+  double* fmean = (double*)(w + l.off_fmean);
+  double* ssq = (double*)(w + l.off_ssq);
+  double* part0 = (double*)(w + l.off_part0);
+  double* part1 = (double*)(w + l.off_part1);
+  double* At = T + (long)m * l.ld;
+  int rc;
+  // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only
+  rc = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter,
+                         1, T, l.ld);
+  if (rc) return rc;
+  // Kuf^T = k(Xb, Z) as the extra rows (posteriors.py:836, covariances/kufs.py:31-34)
+  rc = gpk_kernel_matrix(stream, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0,
+                         At, l.ld);
+  if (rc) return rc;
+  // Lm = chol(Kuu);  A^T = Kfu Lm^-T   (conditionals/util.py:67,125)
+  rc = gpk_potrf(stream, T, m, rows, l.ld, 1, 0, invd, 0, info);
+  if (rc) return rc;
+  // s0 = sum_k A^2 (util.py:133), fmean = A^T q_mu (util.py:144), q_diag: ssq = sum (A q_sqrt)^2 (:149)
+  rc = gpk_row_stats(stream, At, rows, m, l.ld, q_mu, q_diag ? q_sqrt : nullptr, P, 1.0, 0.0, s0, fmean,
+                     q_diag ? ssq : nullptr);
+  if (rc) return rc;
+  if (!q_diag) {
+    // L = band_part(q_sqrt,-1,0); LTA = L^T A; ssq = sum LTA^2   (util.py:151-164)
+    rc = gpk_transpose(stream, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
+    if (rc) return rc;
+    rc = gpk_project(stream, At, rows, m, l.ld, LqT, l.ld, P, ssq, w + l.off_proj,
+                     gpk_project_workspace_bytes(rows, m, P));
+    if (rc) return rc;
+  }
+  // sum_b var_exp_b  (likelihoods/scalar_continuous.py:139-148, svgp.py:174,181)
+  int c0 = 0, c1 = 0;
+  rc = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean, rows, P, s0, 0, ssq, &variance, 0, noise_variance,
+                                mean_const, nullptr, part0, &c0);
+  if (rc) return rc;
+  const double* p0[1] = {part0};
+  const double one = 1.0;
+  rc = gpk_launch_final(s, 1, p0, &c0, &one, 0.0, out);
+  if (rc) return rc;
+  // KL[q || N(0, I)]  (kullback_leiblers.py:45-46, 98-165)
+  rc = gpk_launch_kl_white_stage1(s, q_mu, q_sqrt, m, P, q_diag, part1, &c1);
+  if (rc) return rc;
+  const double* p1[1] = {part1};
+  const double half = 0.5;
+  return gpk_launch_final(s, 1, p1, &c1, &half, -0.5 * (double)m * (double)P, out + 1);
+}

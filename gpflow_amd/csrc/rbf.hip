@@ -1,0 +1,150 @@
+// Covariance-matrix builder for stationary kernels (SquaredExponential + Matern family), gfx950.
+//
+// Replaces, in ONE pass over the output (the reference materialises >= 6 full N x N2 tensors):
+//   Stationary.scale            gpflow/kernels/stationaries.py:77-79      X / lengthscales
+//   square_distance             gpflow/utilities/ops.py:105-122           ||x||^2 + ||y||^2 - 2 x.y
+//   K_r2 / K_r                  stationaries.py:111-116, 209-210, 254-313  sigma^2 k(r)
+//   add_noise_cov / Kuu jitter  utilities/model_utils.py:33-38, covariances/kuus.py:33
+//
+// HBM-write-bound: 64 x 64 output tile per 256-thread workgroup, the two 64 x D input slabs are
+// scaled once, transposed into LDS ([D][64]: each thread then reads its 4 rows / 4 cols with
+// ds_read_b128 pairs, conflict free) together with their squared norms; each thread produces a
+// 4 x 4 patch and stores 32 contiguous bytes per row (16 threads -> 512 B contiguous per row).
+// The expansion formula and the association (-2 x.y) + (|x|^2 + |y|^2) of the reference are kept
+// so rounding has the same structure (the diagonal is exp(-0.5 * ~1e-16), not exactly sigma^2).
+#include "gpk_internal.h"
+
+namespace {
+
+struct RbfArgs {
+  const double* X1; long ldx1; int n1;
+  const double* X2; long ldx2; int n2;
+  int d;
+  double* K; long ldk;
+  double variance, diag_add;
+  int family, sym, lower_only, ard;
+  double ls[GPK_MAX_D];
+};
+
+constexpr int T = 64;
+
+__device__ __forceinline__ double kern_eval(int family, double r2, double variance) {
+  if (family == GPK_KERN_SE) return variance * exp(-0.5 * r2);
+  const double r = sqrt(fmax(r2, 1e-36));
+  if (family == GPK_KERN_MATERN12) return variance * exp(-r);
+  if (family == GPK_KERN_MATERN32) {
+    const double sqrt3 = 1.7320508075688772;
+    return variance * (1.0 + sqrt3 * r) * exp(-sqrt3 * r);
+  }
+  const double sqrt5 = 2.23606797749979;
+  return variance * (1.0 + sqrt5 * r + 5.0 / 3.0 * (r * r)) * exp(-sqrt5 * r);
+}
+
+__global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int d = p.d;
+  double* x1t = sm;                 // [d][T]
+  double* x2t = sm + (size_t)d * T; // [d][T]
+  double* nr1 = x2t + (size_t)d * T;  // [T]
+  double* nr2 = nr1 + T;              // [T]
+
+  const int r0 = blockIdx.y * T, c0 = blockIdx.x * T;
+  if (p.sym && p.lower_only && c0 > r0 + T - 1) return;
+  const int tid = threadIdx.x;
+
+  // stage + scale (true division, as the reference) -- thread t handles (row t>>2, dims (t&3)::4)
+  for (int e = tid; e < T * d; e += 256) {
+    const int row = e / d, dd = e - row * d;
+    const double l = p.ard ? p.ls[dd] : p.ls[0];
+    const int g1 = r0 + row, g2 = c0 + row;
+    x1t[dd * T + row] = (g1 < p.n1) ? p.X1[(long)g1 * p.ldx1 + dd] / l : 0.0;
+    x2t[dd * T + row] = (g2 < p.n2) ? p.X2[(long)g2 * p.ldx2 + dd] / l : 0.0;
+  }
+  __syncthreads();
+  if (tid < 2 * T) {
+    const double* src = (tid < T) ? x1t : x2t;
+    const int row = tid & (T - 1);
+    double s = 0.0;
+    for (int dd = 0; dd < d; ++dd) {
+      const double v = src[dd * T + row];
+      s += v * v;
+    }
+    ((tid < T) ? nr1 : nr2)[row] = s;
+  }
+  __syncthreads();
+
+  const int tx = tid & 15, ty = tid >> 4;
+  double dot[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dot[i][j] = 0.0;
+  for (int dd = 0; dd < d; ++dd) {
+    const d2* a2 = reinterpret_cast<const d2*>(&x1t[dd * T + ty * 4]);
+    const d2* b2 = reinterpret_cast<const d2*>(&x2t[dd * T + tx * 4]);
+    const d2 a01 = a2[0], a23 = a2[1], b01 = b2[0], b23 = b2[1];
+    const double a[4] = {a01.x, a01.y, a23.x, a23.y};
+    const double b[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dot[i][j] = fma(a[i], b[j], dot[i][j]);
+  }
+  const bool full = (r0 + T <= p.n1) && (c0 + T <= p.n2) && ((p.ldk & 1) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(p.K) & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gr = r0 + ty * 4 + i;
+    const double ni = nr1[ty * 4 + i];
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gc = c0 + tx * 4 + j;
+      const double r2 = (-2.0 * dot[i][j]) + (ni + nr2[tx * 4 + j]);
+      double k = kern_eval(p.family, r2, p.variance);
+      if (p.sym && gr == gc) k += p.diag_add;
+      v[j] = k;
+    }
+    if (full) {
+      d2* out = reinterpret_cast<d2*>(p.K + (long)gr * p.ldk + c0 + tx * 4);
+      out[0] = (d2){v[0], v[1]};
+      out[1] = (d2){v[2], v[3]};
+    } else if (gr < p.n1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gc = c0 + tx * 4 + j;
+        if (gc < p.n2) p.K[(long)gr * p.ldk + gc] = v[j];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gpk_kernel_matrix(void* stream, int family, const double* X1, int n1, long ldx1,
+                                 const double* X2, int n2, long ldx2, int d, const double* ls_host,
+                                 int ard, double variance, double diag_add, int lower_only,
+                                 double* K, long ldk) {
+  if (!X1 || !K || !ls_host || n1 < 0 || d <= 0 || d > GPK_MAX_D) return GPK_E_ARG;
+  if (family < GPK_KERN_SE || family > GPK_KERN_MATERN52) return GPK_E_UNSUPPORTED;
+  RbfArgs a{};
+  a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1;
+  a.sym = (X2 == nullptr);
+  a.X2 = a.sym ? X1 : X2; a.ldx2 = a.sym ? ldx1 : ldx2; a.n2 = a.sym ? n1 : n2;
+  a.d = d; a.K = K; a.ldk = ldk; a.variance = variance; a.diag_add = diag_add;
+  a.family = family; a.lower_only = lower_only; a.ard = ard;
+  for (int i = 0; i < (ard ? d : 1); ++i) a.ls[i] = ls_host[i];
+  if (a.n1 == 0 || a.n2 == 0) return 0;
+  const size_t lds = ((size_t)2 * d * T + 2 * T) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(((size_t)2 * GPK_MAX_D * T + 2 * T) * sizeof(double))));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)gpk_cdiv(a.n2, T), (unsigned)gpk_cdiv(a.n1, T));
+  hipLaunchKernelGGL(rbf_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}

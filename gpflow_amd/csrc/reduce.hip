@@ -1,0 +1,423 @@
+// Small HBM-bound kernels around the factorisation: transposes/packing, row statistics of A^T,
+// and the deterministic two-stage scalar reductions (ELBO data term, KL, log-dets, LML tail).
+// All reductions are order-deterministic: stage 1 writes one partial per block, stage 2 (one block)
+// sums them in a fixed order -- no floating-point atomics anywhere on this path.
+#include "gpk_internal.h"
+
+namespace {
+
+constexpr int RB = 256;       // threads per reduction block
+constexpr int MAXPART = 1024;  // max stage-1 blocks
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+// valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+  }
+  return r;
+}
+
+// ---- stage 2: out = sum_t scale[t] * sum(part[t][0..count[t])) + add ------------------------------
+struct FinalArgs {
+  const double* part[4]; int count[4]; double scale[4]; int nterms; double add; double* out;
+};
+__global__ __launch_bounds__(RB) void final_sum_kernel(FinalArgs a) {
+  __shared__ double sh[4];
+  double total = a.add;
+  for (int t = 0; t < a.nterms; ++t) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < a.count[t]; i += RB) v += a.part[t][i];
+    const double r = block_sum(v, sh);
+    total += a.scale[t] * r;
+  }
+  if (threadIdx.x == 0) *a.out = total;
+}
+
+// ---- zero the strict upper triangle -----------------------------------------------------------------
+__global__ void zero_upper_kernel(double* A, int n, long lda, long strideA) {
+  double* M = A + (long)blockIdx.z * strideA;
+  const int r = blockIdx.y;
+  for (int c = r + 1 + blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+    M[(long)r * lda + c] = 0.0;
+}
+
+// ---- transpose with optional triangular mask -------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const double* in, int rows, int cols,
+                                                        long ldin, double* out, long ldout,
+                                                        int mode, long stride_in, long stride_out) {
+  __shared__ double tile[32][33];
+  const double* I = in + (long)blockIdx.z * stride_in;
+  double* O = out + (long)blockIdx.z * stride_out;
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = by + k, c = bx + tx;
+    double v = 0.0;
+    if (r < rows && c < cols) {
+      const bool keep = (mode == 0) || (mode == 1 && c <= r) || (mode == 2 && c >= r);
+      if (keep) v = I[(long)r * ldin + c];
+    }
+    tile[k][tx] = v;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int r = bx + k, c = by + tx;  // out[r][c] = in[c][r]
+    if (r < cols && c < rows) O[(long)r * ldout + c] = tile[tx][k];
+  }
+}
+
+// out[c][r] = in[r][c] + shift  (used to lay (Y - mean)^T under the covariance matrix)
+__global__ __launch_bounds__(256) void transpose_shift_kernel(const double* in, int rows, int cols,
+                                                              long ldin, double* out, long ldout,
+                                                              double shift) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = by + k, c = bx + tx;
+    tile[k][tx] = (r < rows && c < cols) ? in[(long)r * ldin + c] + shift : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int r = bx + k, c = by + tx;
+    if (r < cols && c < rows) out[(long)r * ldout + c] = tile[tx][k];
+  }
+}
+
+// ---- row statistics of At [rows, m]:  sumsq[b], mv[b,p] = sum_k At[b,k] V[k,p],
+//      wsq[p,b] = sum_k (At[b,k] W[k,p])^2.   One wave per row, 4 rows per block. --------------------
+template <int PC>
+__global__ __launch_bounds__(256) void row_stats_kernel(const double* __restrict__ At, int rows,
+                                                        int m, long ldat,
+                                                        const double* __restrict__ V,
+                                                        const double* __restrict__ W, int P, int p0,
+                                                        double alpha, double beta,
+                                                        double* __restrict__ sumsq,
+                                                        double* __restrict__ mv,
+                                                        double* __restrict__ wsq) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const double* a = At + (long)row * ldat;
+  double s = 0.0, dv[PC], dw[PC];
+#pragma unroll
+  for (int q = 0; q < PC; ++q) { dv[q] = 0.0; dw[q] = 0.0; }
+  for (int k = lane; k < m; k += 64) {
+    const double x = a[k];
+    s = fma(x, x, s);
+#pragma unroll
+    for (int q = 0; q < PC; ++q) {
+      if (p0 + q < P) {
+        if (V) dv[q] = fma(x, V[(long)k * P + p0 + q], dv[q]);
+        if (W) { const double t = x * W[(long)k * P + p0 + q]; dw[q] = fma(t, t, dw[q]); }
+      }
+    }
+  }
+  s = wave_sum(s);
+#pragma unroll
+  for (int q = 0; q < PC; ++q) { dv[q] = wave_sum(dv[q]); dw[q] = wave_sum(dw[q]); }
+  if (lane == 0) {
+    if (sumsq && p0 == 0) sumsq[row] = (beta != 0.0 ? beta * sumsq[row] : 0.0) + alpha * s;
+#pragma unroll
+    for (int q = 0; q < PC; ++q)
+      if (p0 + q < P) {
+        if (V && mv) mv[(long)row * P + p0 + q] = dv[q];
+        if (W && wsq) wsq[(long)(p0 + q) * rows + row] = dw[q];
+      }
+  }
+}
+
+// ---- ssq[p,b] = sum_t part[p][t][b] -------------------------------------------------------------------
+__global__ void sum_parts_kernel(const double* part, int nt, int rows, long stridePart, double* ssq) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (b >= rows) return;
+  const double* q = part + (long)p * stridePart;
+  double s = 0.0;
+  for (int t = 0; t < nt; ++t) s += q[(long)t * rows + b];
+  ssq[(long)p * rows + b] = s;
+}
+
+// ---- Gaussian variational expectations, stage 1 -----------------------------------------------------
+struct VarexpArgs {
+  const double* Y; long ldy; const double* fmean; int rows, P;
+  const double* s0; int s0_per_latent; const double* ssq;
+  double knn[16]; int knn_per_latent;
+  double noise, mean_const; double* fvar_out; double* part;
+};
+__global__ __launch_bounds__(RB) void varexp_kernel(VarexpArgs a) {
+  __shared__ double sh[4];
+  const double log2pi = 1.8378770664093453;
+  const double c0 = -0.5 * log2pi - 0.5 * log(a.noise);
+  double acc = 0.0;
+  const long total = (long)a.rows * a.P;
+  for (long e = (long)blockIdx.x * RB + threadIdx.x; e < total; e += (long)gridDim.x * RB) {
+    const int b = (int)(e / a.P), p = (int)(e - (long)b * a.P);
+    double fv = a.knn[a.knn_per_latent ? p : 0];
+    if (a.s0) fv -= a.s0_per_latent ? a.s0[(long)p * a.rows + b] : a.s0[b];
+    if (a.ssq) fv += a.ssq[(long)p * a.rows + b];
+    const double mu = a.fmean[e] + a.mean_const;
+    const double dy = a.Y[(long)b * a.ldy + p] - mu;
+    if (a.fvar_out) a.fvar_out[e] = fv;
+    acc += c0 - 0.5 * (dy * dy + fv) / a.noise;
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) a.part[blockIdx.x] = r;
+}
+
+// ---- whitened KL, stage 1: sum q_mu^2 - sum log diag^2 + sum tril^2 -----------------------------------
+__global__ __launch_bounds__(RB) void kl_white_kernel(const double* q_mu, const double* q_sqrt, int m,
+                                                      int P, int q_diag, double* part) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  const long nmu = (long)m * P;
+  const long stride = (long)gridDim.x * RB, start = (long)blockIdx.x * RB + threadIdx.x;
+  for (long e = start; e < nmu; e += stride) { const double v = q_mu[e]; acc += v * v; }
+  if (q_diag) {
+    for (long e = start; e < nmu; e += stride) {
+      const double v = q_sqrt[e];
+      acc += v * v - log(v * v);
+    }
+  } else {
+    const long tot = (long)P * m * m;
+    for (long e = start; e < tot; e += stride) {
+      const long w = e % ((long)m * m);
+      const int r = (int)(w / m), c = (int)(w - (long)r * m);
+      if (c <= r) {
+        const double v = q_sqrt[e];
+        acc += v * v;
+        if (c == r) acc -= log(v * v);
+      }
+    }
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+// ---- sum log diag(L) per batch (one block per batch) ---------------------------------------------------
+__global__ __launch_bounds__(RB) void sum_log_diag_kernel(const double* L, int n, long ldl,
+                                                          long strideL, double* out) {
+  __shared__ double sh[4];
+  const double* M = L + (long)blockIdx.x * strideL;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += RB) acc += log(M[(long)i * ldl + i]);
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
+// ---- sum of squares of a matrix, stage 1 -----------------------------------------------------------------
+__global__ __launch_bounds__(RB) void sumsq_kernel(const double* A, int rows, int cols, long lda,
+                                                   int upper_only, double* part) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const double* a = A + (long)r * lda;
+    for (int c = (upper_only ? r : 0) + threadIdx.x; c < cols; c += RB) acc = fma(a[c], a[c], acc);
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+int stage2(hipStream_t s, const FinalArgs& f) {
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(RB), 0, s, f);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+int nblocks_for(long elems) {
+  long b = (elems + RB * 4 - 1) / (RB * 4);
+  if (b < 1) b = 1;
+  if (b > MAXPART) b = MAXPART;
+  return (int)b;
+}
+
+}  // namespace
+
+// ================================================================================================
+int gpk_launch_zero_upper(hipStream_t s, double* A, int n, long lda, int batch, long strideA) {
+  if (n <= 1) return 0;
+  int gx = gpk_cdiv(n, 256);
+  if (gx > 16) gx = 16;
+  dim3 grid((unsigned)gx, (unsigned)n, (unsigned)(batch > 0 ? batch : 1));
+  hipLaunchKernelGGL(zero_upper_kernel, grid, dim3(256), 0, s, A, n, lda, strideA);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t gpk_reduce_workspace_bytes(int n) {
+  (void)n;
+  return (size_t)4 * MAXPART * sizeof(double);
+}
+
+extern "C" int gpk_transpose(void* stream, const double* in, int rows, int cols, long ldin,
+                             double* out, long ldout, int mode, int batch, long stride_in,
+                             long stride_out) {
+  if (!in || !out || rows < 0 || cols < 0) return GPK_E_ARG;
+  if (rows == 0 || cols == 0) return 0;
+  dim3 grid((unsigned)gpk_cdiv(cols, 32), (unsigned)gpk_cdiv(rows, 32),
+            (unsigned)(batch > 0 ? batch : 1));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, rows, cols, ldin,
+                     out, ldout, mode, stride_in, stride_out);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+// sumsq[b] = beta*sumsq[b] + alpha*sum_k At^2 ; mv = At V ; wsq[p,b] = sum_k (At W[:,p])^2
+extern "C" int gpk_row_stats(void* stream, const double* At, int rows, int m, long ldat,
+                             const double* V, const double* W, int P, double alpha, double beta,
+                             double* sumsq, double* mv, double* wsq) {
+  if (!At || rows < 0 || m < 0) return GPK_E_ARG;
+  if (rows == 0) return 0;
+  const int np = (V || W) ? P : 0;
+  const dim3 grid((unsigned)gpk_cdiv(rows, 4));
+  int p0 = 0;
+  do {
+    hipLaunchKernelGGL((row_stats_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, At, rows, m,
+                       ldat, V, W, np, p0, alpha, beta, sumsq, mv, wsq);
+    GPK_LAUNCH_CHECK();
+    p0 += 4;
+  } while (p0 < np);
+  return 0;
+}
+
+extern "C" int gpk_row_sumsq(void* stream, const double* A, int rows, int cols, long lda,
+                             double alpha, double beta, double* out) {
+  return gpk_row_stats(stream, A, rows, cols, lda, nullptr, nullptr, 0, alpha, beta, out, nullptr,
+                       nullptr);
+}
+
+int gpk_launch_sum_parts(hipStream_t s, const double* part, int nt, int rows, long stridePart, int P,
+                         double* ssq) {
+  if (rows == 0 || P == 0) return 0;
+  dim3 grid((unsigned)gpk_cdiv(rows, 256), (unsigned)P);
+  hipLaunchKernelGGL(sum_parts_kernel, grid, dim3(256), 0, s, part, nt, rows, stridePart, ssq);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gpk_gaussian_varexp_sum(void* stream, const double* Y, long ldy, const double* fmean,
+                                       int rows, int P, const double* s0, int s0_per_latent,
+                                       const double* ssq, const double* knn_host,
+                                       int knn_per_latent, double noise_variance, double mean_const,
+                                       double* fvar_out, double* out, void* ws, size_t ws_bytes) {
+  if (!Y || !fmean || !knn_host || !out || P <= 0 || P > 16 || rows < 0) return GPK_E_ARG;
+  if (!ws || ws_bytes < gpk_reduce_workspace_bytes(rows)) return GPK_E_WORKSPACE;
+  VarexpArgs a{};
+  a.Y = Y; a.ldy = ldy; a.fmean = fmean; a.rows = rows; a.P = P;
+  a.s0 = s0; a.s0_per_latent = s0_per_latent; a.ssq = ssq;
+  for (int i = 0; i < (knn_per_latent ? P : 1); ++i) a.knn[i] = knn_host[i];
+  a.knn_per_latent = knn_per_latent; a.noise = noise_variance; a.mean_const = mean_const;
+  a.fvar_out = fvar_out; a.part = (double*)ws;
+  const int nb = nblocks_for((long)rows * P);
+  hipLaunchKernelGGL(varexp_kernel, dim3(nb), dim3(RB), 0, (hipStream_t)stream, a);
+  GPK_LAUNCH_CHECK();
+  FinalArgs f{};
+  f.nterms = 1; f.part[0] = a.part; f.count[0] = nb; f.scale[0] = 1.0; f.add = 0.0; f.out = out;
+  return stage2((hipStream_t)stream, f);
+}
+
+extern "C" int gpk_gauss_kl_white(void* stream, const double* q_mu, const double* q_sqrt, int m,
+                                  int P, int q_diag, double* out, void* ws, size_t ws_bytes) {
+  if (!q_mu || !q_sqrt || !out || m <= 0 || P <= 0) return GPK_E_ARG;
+  if (!ws || ws_bytes < gpk_reduce_workspace_bytes(m)) return GPK_E_WORKSPACE;
+  const long elems = q_diag ? (long)m * P : (long)P * m * m;
+  const int nb = nblocks_for(elems);
+  double* part = (double*)ws;
+  hipLaunchKernelGGL(kl_white_kernel, dim3(nb), dim3(RB), 0, (hipStream_t)stream, q_mu, q_sqrt, m, P,
+                     q_diag, part);
+  GPK_LAUNCH_CHECK();
+  FinalArgs f{};
+  f.nterms = 1; f.part[0] = part; f.count[0] = nb; f.scale[0] = 0.5;
+  f.add = -0.5 * (double)m * (double)P; f.out = out;
+  return stage2((hipStream_t)stream, f);
+}
+
+extern "C" int gpk_sum_log_diag(void* stream, const double* L, int n, long ldl, int batch,
+                                long strideL, double* out) {
+  if (!L || !out || n <= 0) return GPK_E_ARG;
+  hipLaunchKernelGGL(sum_log_diag_kernel, dim3((unsigned)(batch > 0 ? batch : 1)), dim3(RB), 0,
+                     (hipStream_t)stream, L, n, ldl, strideL, out);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gpk_sumsq(void* stream, const double* A, int rows, int cols, long lda, int upper_only,
+                         double* out, void* ws, size_t ws_bytes) {
+  if (!A || !out || rows < 0 || cols < 0) return GPK_E_ARG;
+  if (!ws || ws_bytes < gpk_reduce_workspace_bytes(rows)) return GPK_E_WORKSPACE;
+  int nb = rows < MAXPART ? rows : MAXPART;
+  if (nb < 1) nb = 1;
+  double* part = (double*)ws;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(RB), 0, (hipStream_t)stream, A, rows, cols, lda,
+                     upper_only, part);
+  GPK_LAUNCH_CHECK();
+  FinalArgs f{};
+  f.nterms = 1; f.part[0] = part; f.count[0] = nb; f.scale[0] = 1.0; f.add = 0.0; f.out = out;
+  return stage2((hipStream_t)stream, f);
+}
+
+// out = sum_t scale[t]*sum(part[t][0..count[t])) + add   (used by the fused drivers)
+int gpk_launch_final(hipStream_t s, int nterms, const double* const* part, const int* count,
+                     const double* scale, double add, double* out) {
+  FinalArgs f{};
+  f.nterms = nterms;
+  for (int t = 0; t < nterms; ++t) { f.part[t] = part[t]; f.count[t] = count[t]; f.scale[t] = scale[t]; }
+  f.add = add; f.out = out;
+  return stage2(s, f);
+}
+
+// stage-1 launchers reused by the fused drivers (partials land in `part`, count returned)
+int gpk_launch_sumsq_stage1(hipStream_t s, const double* A, int rows, int cols, long lda,
+                            int upper_only, double* part, int* count) {
+  int nb = rows < MAXPART ? rows : MAXPART;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(RB), 0, s, A, rows, cols, lda, upper_only, part);
+  GPK_LAUNCH_CHECK();
+  *count = nb;
+  return 0;
+}
+int gpk_launch_varexp_stage1(hipStream_t s, const double* Y, long ldy, const double* fmean, int rows,
+                             int P, const double* s0, int s0_per_latent, const double* ssq,
+                             const double* knn_host, int knn_per_latent, double noise,
+                             double mean_const, double* fvar_out, double* part, int* count) {
+  VarexpArgs a{};
+  a.Y = Y; a.ldy = ldy; a.fmean = fmean; a.rows = rows; a.P = P;
+  a.s0 = s0; a.s0_per_latent = s0_per_latent; a.ssq = ssq;
+  for (int i = 0; i < (knn_per_latent ? P : 1); ++i) a.knn[i] = knn_host[i];
+  a.knn_per_latent = knn_per_latent; a.noise = noise; a.mean_const = mean_const;
+  a.fvar_out = fvar_out; a.part = part;
+  const int nb = nblocks_for((long)rows * P);
+  hipLaunchKernelGGL(varexp_kernel, dim3(nb), dim3(RB), 0, s, a);
+  GPK_LAUNCH_CHECK();
+  *count = nb;
+  return 0;
+}
+int gpk_launch_kl_white_stage1(hipStream_t s, const double* q_mu, const double* q_sqrt, int m, int P,
+                               int q_diag, double* part, int* count) {
+  const long elems = q_diag ? (long)m * P : (long)P * m * m;
+  const int nb = nblocks_for(elems);
+  hipLaunchKernelGGL(kl_white_kernel, dim3(nb), dim3(RB), 0, s, q_mu, q_sqrt, m, P, q_diag, part);
+  GPK_LAUNCH_CHECK();
+  *count = nb;
+  return 0;
+}
+int gpk_launch_transpose_shift(hipStream_t s, const double* in, int rows, int cols, long ldin,
+                               double* out, long ldout, double shift) {
+  if (rows == 0 || cols == 0) return 0;
+  dim3 grid((unsigned)gpk_cdiv(cols, 32), (unsigned)gpk_cdiv(rows, 32), 1);
+  hipLaunchKernelGGL(transpose_shift_kernel, grid, dim3(256), 0, s, in, rows, cols, ldin, out, ldout,
+                     shift);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,404 @@
+"""Device primitives: thin, typed wrappers from torch fp64 HIP tensors to the C-ABI of libgpk.so.
+
+torch is plumbing here (device memory, the current HIP stream, dlpack-style pointers); all arithmetic
+happens in the hand-written kernels.  Every function validates device/dtype/layout and raises --
+nothing silently falls back to torch math or to the CPU.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NB = 128
+KERNEL_FAMILIES = {"SquaredExponential": 0, "Matern12": 1, "Matern32": 2, "Matern52": 3}
+MAX_D = 64
+
+
+def device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.GpkError("gpflow_amd needs a HIP device (torch.cuda.is_available() is False); "
+                            "there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device(x, dtype=torch.float64) -> torch.Tensor:
+    """NumPy / torch / scalar -> contiguous fp64 tensor on the current HIP device."""
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=device(), dtype=dtype)
+    else:
+        t = torch.as_tensor(np.asarray(x, dtype=np.float64), dtype=dtype, device=device())
+    return t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, ndim: Optional[int] = None) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.GpkError(f"{name}: tensor must live on the HIP device (got {t.device})")
+    if t.dtype != torch.float64:
+        raise _lib.GpkError(f"{name}: dtype must be float64 (got {t.dtype})")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+
+
+def _rowmajor(t: torch.Tensor, name: str) -> int:
+    """Leading dimension of a 2-D row-major view (last stride 1)."""
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected a matrix, got shape {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise _lib.GpkError(f"{name}: last dimension must be contiguous")
+    if t.shape[0] > 1:
+        return int(t.stride(0))
+    return int(max(t.shape[1], 1))
+
+
+def _ws(nbytes: int) -> torch.Tensor:
+    return torch.empty((max(int(nbytes), 8) + 7) // 8, dtype=torch.float64, device=device())
+
+
+def _ls_host(lengthscales, d: int):
+    ls = np.atleast_1d(np.asarray(lengthscales, dtype=np.float64))
+    ard = ls.size > 1
+    if ard and ls.size != d:
+        raise ValueError(f"lengthscales has {ls.size} entries, input dimension is {d}")
+    return _lib.host_doubles(ls.tolist()), int(ard)
+
+
+# ------------------------------------------------------------------------------------------------
+def kernel_matrix(X1: torch.Tensor, X2: Optional[torch.Tensor], *, variance: float, lengthscales,
+                  family: str = "SquaredExponential", diag_add: float = 0.0, lower_only: bool = False,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K(X1, X2) (or K(X1, X1) + diag_add I when X2 is None) -> [n1, n2]."""
+    lib = _lib.load()
+    _chk(X1, "X1", 2)
+    n1, d = X1.shape
+    if d < 1 or d > MAX_D:
+        raise ValueError(f"input dimension {d} outside [1, {MAX_D}]")
+    if X2 is not None:
+        _chk(X2, "X2", 2)
+        if X2.shape[1] != d:
+            raise ValueError("X1 and X2 must have the same number of columns")
+        n2 = X2.shape[0]
+    else:
+        n2 = n1
+    if out is None:
+        out = torch.empty((n1, n2), dtype=torch.float64, device=X1.device)
+        if lower_only:
+            out.zero_()
+    _chk(out, "out", 2)
+    ls, ard = _ls_host(lengthscales, d)
+    rc = lib.gpk_kernel_matrix(_stream(), KERNEL_FAMILIES[family], X1.data_ptr(), n1, _rowmajor(X1, "X1"),
+                               X2.data_ptr() if X2 is not None else None, n2,
+                               _rowmajor(X2, "X2") if X2 is not None else 0, d, ls, ard,
+                               float(variance), float(diag_add), int(lower_only), out.data_ptr(),
+                               _rowmajor(out, "out"))
+    _lib.check(rc, "gpk_kernel_matrix")
+    return out
+
+
+def invd_alloc(n: int, batch: int = 1) -> torch.Tensor:
+    lib = _lib.load()
+    return torch.empty(int(lib.gpk_invd_elems(n, batch)), dtype=torch.float64, device=device())
+
+
+def potrf_(T: torch.Tensor, n: int, *, zero_upper: bool = False,
+           invd: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """In-place trapezoidal Cholesky of T [(n+extra), n] or batched [b, (n+extra), n].
+    Returns (invd, info) -- info is a device int32 tensor (0 ok, j+1 first bad pivot)."""
+    lib = _lib.load()
+    _chk(T, "T")
+    if T.dim() == 2:
+        batch, rows, cols, stride = 1, T.shape[0], T.shape[1], 0
+        lda = _rowmajor(T, "T")
+    elif T.dim() == 3:
+        batch, rows, cols = T.shape
+        stride = int(T.stride(0))
+        lda = _rowmajor(T[0], "T")
+    else:
+        raise ValueError("T must be 2-D or 3-D")
+    if cols != n or rows < n:
+        raise ValueError(f"T has shape {tuple(T.shape)}, expected [.., n+extra, n] with n={n}")
+    if invd is None:
+        invd = invd_alloc(n, batch)
+    info = torch.zeros(batch, dtype=torch.int32, device=T.device)
+    rc = lib.gpk_potrf(_stream(), T.data_ptr(), n, rows - n, lda, batch, stride, invd.data_ptr(),
+                       int(zero_upper), info.data_ptr())
+    _lib.check(rc, "gpk_potrf")
+    return invd, info
+
+
+def check_info(info: torch.Tensor, what: str = "Cholesky") -> None:
+    """Synchronising check of the factorisation status (the reference raises InvalidArgumentError
+    'Cholesky decomposition was not successful' from tf.linalg.cholesky on CPU)."""
+    bad = info.cpu().numpy()
+    if np.any(bad != 0):
+        j = int(bad[np.nonzero(bad)[0][0]])
+        raise _lib.GpkError(f"{what} decomposition was not successful: non-positive pivot at column {j - 1}")
+
+
+def trtri_blocks(L: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(L, "L", 2)
+    n = L.shape[0]
+    invd = invd_alloc(n, 1)
+    rc = lib.gpk_trtri_blocks(_stream(), L.data_ptr(), n, _rowmajor(L, "L"), 1, 0, invd.data_ptr())
+    _lib.check(rc, "gpk_trtri_blocks")
+    return invd
+
+
+def transpose_factor(L: torch.Tensor, invd: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    lib = _lib.load()
+    _chk(L, "L", 2)
+    n = L.shape[0]
+    LT = torch.empty((n, n), dtype=torch.float64, device=L.device)
+    invdT = torch.empty_like(invd)
+    rc = lib.gpk_transpose_factor(_stream(), L.data_ptr(), _rowmajor(L, "L"), invd.data_ptr(), n,
+                                  LT.data_ptr(), n, invdT.data_ptr())
+    _lib.check(rc, "gpk_transpose_factor")
+    return LT, invdT
+
+
+def trsm_(B: torch.Tensor, L: torch.Tensor, invd: torch.Tensor, *, trans: int = 0) -> torch.Tensor:
+    """In place: trans=0  B <- B L^-T (pass L, invd);  trans=1  B <- B L^-1 (pass LT, invdT)."""
+    lib = _lib.load()
+    _chk(B, "B", 2)
+    _chk(L, "L", 2)
+    n = L.shape[0]
+    if B.shape[1] != n:
+        raise ValueError(f"B has {B.shape[1]} columns, factor is {n}x{n}")
+    rc = lib.gpk_trsm(_stream(), int(trans), L.data_ptr(), _rowmajor(L, "L"), invd.data_ptr(), n,
+                      B.data_ptr(), B.shape[0], _rowmajor(B, "B"), 1, 0, 0)
+    _lib.check(rc, "gpk_trsm")
+    return B
+
+
+def gemm_nt(A: torch.Tensor, B: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
+            C: Optional[torch.Tensor] = None, b_tri: int = 0, c_lower: bool = False) -> torch.Tensor:
+    """C = alpha A B^T + beta C.  A [m,k] or [b,m,k]; B [n,k] or [b,n,k]."""
+    lib = _lib.load()
+    _chk(A, "A")
+    _chk(B, "B")
+    batched = A.dim() == 3 or B.dim() == 3
+    A3 = A if A.dim() == 3 else A.unsqueeze(0)
+    B3 = B if B.dim() == 3 else B.unsqueeze(0)
+    batch = max(A3.shape[0], B3.shape[0])
+    m, k = A3.shape[1], A3.shape[2]
+    n = B3.shape[1]
+    if B3.shape[2] != k:
+        raise ValueError("inner dimensions differ")
+    if C is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs C")
+        C = torch.empty((batch, m, n) if batched else (m, n), dtype=torch.float64, device=A.device)
+        if c_lower:
+            C.zero_()
+    C3 = C if C.dim() == 3 else C.unsqueeze(0)
+    sA = int(A3.stride(0)) if A3.shape[0] > 1 else 0
+    sB = int(B3.stride(0)) if B3.shape[0] > 1 else 0
+    sC = int(C3.stride(0)) if C3.shape[0] > 1 else 0
+    rc = lib.gpk_gemm_nt(_stream(), m, n, k, float(alpha), A3.data_ptr(), _rowmajor(A3[0], "A"),
+                         B3.data_ptr(), _rowmajor(B3[0], "B"), float(beta), C3.data_ptr(),
+                         _rowmajor(C3[0], "C"), int(b_tri), int(c_lower), batch, sA, sB, sC)
+    _lib.check(rc, "gpk_gemm_nt")
+    return C
+
+
+def transpose(X: torch.Tensor, *, mode: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[.., j, i] = X[.., i, j]; mode 1 keeps only the lower triangle of X, 2 only the upper."""
+    lib = _lib.load()
+    _chk(X, "X")
+    X3 = X if X.dim() == 3 else X.unsqueeze(0)
+    b, r, c = X3.shape
+    if out is None:
+        out = torch.empty((b, c, r) if X.dim() == 3 else (c, r), dtype=torch.float64, device=X.device)
+    O3 = out if out.dim() == 3 else out.unsqueeze(0)
+    rc = lib.gpk_transpose(_stream(), X3.data_ptr(), r, c, _rowmajor(X3[0], "X"), O3.data_ptr(),
+                           _rowmajor(O3[0], "out"), int(mode), b,
+                           int(X3.stride(0)) if b > 1 else 0, int(O3.stride(0)) if b > 1 else 0)
+    _lib.check(rc, "gpk_transpose")
+    return out
+
+
+def row_stats(At: torch.Tensor, *, V: Optional[torch.Tensor] = None, W: Optional[torch.Tensor] = None,
+              want_sumsq: bool = True):
+    """(sumsq [rows], mv [rows,P] = At V, wsq [P,rows] = sum_k (At W)^2) -- any may be None."""
+    lib = _lib.load()
+    _chk(At, "At", 2)
+    rows, m = At.shape
+    P = 0
+    for name, t in (("V", V), ("W", W)):
+        if t is not None:
+            _chk(t, name, 2)
+            if t.shape[0] != m or not t.is_contiguous():
+                raise ValueError(f"{name} must be contiguous [m, P]")
+            P = t.shape[1]
+    sumsq = torch.empty(rows, dtype=torch.float64, device=At.device) if want_sumsq else None
+    mv = torch.empty((rows, P), dtype=torch.float64, device=At.device) if V is not None else None
+    wsq = torch.empty((P, rows), dtype=torch.float64, device=At.device) if W is not None else None
+    rc = lib.gpk_row_stats(_stream(), At.data_ptr(), rows, m, _rowmajor(At, "At"),
+                           V.data_ptr() if V is not None else None,
+                           W.data_ptr() if W is not None else None, P, 1.0, 0.0,
+                           sumsq.data_ptr() if sumsq is not None else None,
+                           mv.data_ptr() if mv is not None else None,
+                           wsq.data_ptr() if wsq is not None else None)
+    _lib.check(rc, "gpk_row_stats")
+    return sumsq, mv, wsq
+
+
+def project(At: torch.Tensor, LqT: torch.Tensor) -> torch.Tensor:
+    """ssq [P, rows] = sum_j (At Lq_p)[b, j]^2 with LqT [P, m, m] = tril(q_sqrt_p)^T."""
+    lib = _lib.load()
+    _chk(At, "At", 2)
+    _chk(LqT, "LqT", 3)
+    rows, m = At.shape
+    P = LqT.shape[0]
+    if LqT.shape[1] != m or LqT.shape[2] != m or not LqT.is_contiguous():
+        raise ValueError("LqT must be contiguous [P, m, m]")
+    ssq = torch.empty((P, rows), dtype=torch.float64, device=At.device)
+    nbytes = int(lib.gpk_project_workspace_bytes(rows, m, P))
+    ws = _ws(nbytes)
+    rc = lib.gpk_project(_stream(), At.data_ptr(), rows, m, _rowmajor(At, "At"), LqT.data_ptr(), m, P,
+                         ssq.data_ptr(), ws.data_ptr(), ws.numel() * 8)
+    _lib.check(rc, "gpk_project")
+    return ssq
+
+
+def gaussian_varexp_sum(Y: torch.Tensor, fmean: torch.Tensor, *, s0: Optional[torch.Tensor],
+                        ssq: Optional[torch.Tensor], knn: Sequence[float], noise_variance: float,
+                        mean_const: float = 0.0, s0_per_latent: bool = False, want_fvar: bool = False):
+    """Sum over rows/outputs of the Gaussian variational expectations; returns (scalar tensor, fvar|None)."""
+    lib = _lib.load()
+    _chk(Y, "Y", 2)
+    _chk(fmean, "fmean", 2)
+    rows, P = fmean.shape
+    if not fmean.is_contiguous():
+        raise ValueError("fmean must be contiguous")
+    out = torch.empty(1, dtype=torch.float64, device=Y.device)
+    fvar = torch.empty((rows, P), dtype=torch.float64, device=Y.device) if want_fvar else None
+    ws = _ws(int(lib.gpk_reduce_workspace_bytes(rows)))
+    knn = list(np.atleast_1d(np.asarray(knn, dtype=np.float64)))
+    per = int(len(knn) > 1)
+    rc = lib.gpk_gaussian_varexp_sum(_stream(), Y.data_ptr(), _rowmajor(Y, "Y"), fmean.data_ptr(), rows, P,
+                                     s0.data_ptr() if s0 is not None else None, int(s0_per_latent),
+                                     ssq.data_ptr() if ssq is not None else None,
+                                     _lib.host_doubles(knn), per, float(noise_variance), float(mean_const),
+                                     fvar.data_ptr() if fvar is not None else None, out.data_ptr(),
+                                     ws.data_ptr(), ws.numel() * 8)
+    _lib.check(rc, "gpk_gaussian_varexp_sum")
+    return out, fvar
+
+
+def gauss_kl_white(q_mu: torch.Tensor, q_sqrt: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(q_mu, "q_mu", 2)
+    _chk(q_sqrt, "q_sqrt")
+    m, P = q_mu.shape
+    q_diag = int(q_sqrt.dim() == 2)
+    if not (q_mu.is_contiguous() and q_sqrt.is_contiguous()):
+        raise ValueError("q_mu / q_sqrt must be contiguous")
+    out = torch.empty(1, dtype=torch.float64, device=q_mu.device)
+    ws = _ws(int(lib.gpk_reduce_workspace_bytes(m)))
+    rc = lib.gpk_gauss_kl_white(_stream(), q_mu.data_ptr(), q_sqrt.data_ptr(), m, P, q_diag,
+                                out.data_ptr(), ws.data_ptr(), ws.numel() * 8)
+    _lib.check(rc, "gpk_gauss_kl_white")
+    return out
+
+
+def sum_log_diag(L: torch.Tensor) -> torch.Tensor:
+    """sum_i log L[i,i] for L [n,>=n] or batched [b,n,>=n] -> [b]."""
+    lib = _lib.load()
+    _chk(L, "L")
+    L3 = L if L.dim() == 3 else L.unsqueeze(0)
+    b = L3.shape[0]
+    n = min(L3.shape[1], L3.shape[2])
+    out = torch.empty(b, dtype=torch.float64, device=L.device)
+    rc = lib.gpk_sum_log_diag(_stream(), L3.data_ptr(), n, _rowmajor(L3[0], "L"), b,
+                              int(L3.stride(0)) if b > 1 else 0, out.data_ptr())
+    _lib.check(rc, "gpk_sum_log_diag")
+    return out
+
+
+def sumsq(A: torch.Tensor, *, upper_only: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(A, "A", 2)
+    out = torch.empty(1, dtype=torch.float64, device=A.device)
+    ws = _ws(int(lib.gpk_reduce_workspace_bytes(A.shape[0])))
+    rc = lib.gpk_sumsq(_stream(), A.data_ptr(), A.shape[0], A.shape[1], _rowmajor(A, "A"), int(upper_only),
+                       out.data_ptr(), ws.data_ptr(), ws.numel() * 8)
+    _lib.check(rc, "gpk_sumsq")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ fused
+def gpr_lml(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
+            mean_const: float = 0.0, family: str = "SquaredExponential",
+            ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(LML scalar tensor, info) -- gpk_gpr_lml."""
+    lib = _lib.load()
+    _chk(X, "X", 2)
+    _chk(Y, "Y", 2)
+    n, d = X.shape
+    P = Y.shape[1]
+    if Y.shape[0] != n:
+        raise ValueError("X and Y row counts differ")
+    nbytes = int(lib.gpk_gpr_lml_workspace_bytes(n, d, P))
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = _ws(nbytes)
+    out = torch.empty(1, dtype=torch.float64, device=X.device)
+    info = torch.zeros(1, dtype=torch.int32, device=X.device)
+    ls, ard = _ls_host(lengthscales, d)
+    rc = lib.gpk_gpr_lml(_stream(), KERNEL_FAMILIES[family], X.data_ptr(), n, d, _rowmajor(X, "X"),
+                         Y.data_ptr(), P, _rowmajor(Y, "Y"), ls, ard, float(variance),
+                         float(noise_variance), float(mean_const), out.data_ptr(), info.data_ptr(),
+                         ws.data_ptr(), ws.numel() * 8)
+    _lib.check(rc, "gpk_gpr_lml")
+    return out, info
+
+
+def svgp_elbo_workspace(m: int, rows: int, d: int, P: int, q_diag: bool) -> torch.Tensor:
+    lib = _lib.load()
+    return _ws(int(lib.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, int(q_diag))))
+
+
+def svgp_elbo_shard(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor,
+                    q_sqrt: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
+                    jitter: float, mean_const: float = 0.0, family: str = "SquaredExponential",
+                    ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                    info: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Whitened shard: out[0] = sum_b var_exp_b over this shard, out[1] = KL.  Returns (out, info)."""
+    lib = _lib.load()
+    for name, t in (("Z", Z), ("Xb", Xb), ("Yb", Yb), ("q_mu", q_mu)):
+        _chk(t, name, 2)
+    _chk(q_sqrt, "q_sqrt")
+    m, d = Z.shape
+    rows = Xb.shape[0]
+    P = q_mu.shape[1]
+    q_diag = q_sqrt.dim() == 2
+    if Xb.shape[1] != d or Yb.shape[0] != rows or Yb.shape[1] != P or q_mu.shape[0] != m:
+        raise ValueError("inconsistent shapes")
+    if not (q_mu.is_contiguous() and q_sqrt.is_contiguous()):
+        raise ValueError("q_mu / q_sqrt must be contiguous")
+    nbytes = int(lib.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, int(q_diag)))
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = _ws(nbytes)
+    if out is None:
+        out = torch.empty(2, dtype=torch.float64, device=Z.device)
+    if info is None:
+        info = torch.zeros(1, dtype=torch.int32, device=Z.device)
+    ls, ard = _ls_host(lengthscales, d)
+    rc = lib.gpk_svgp_elbo_shard(_stream(), KERNEL_FAMILIES[family], Z.data_ptr(), m, _rowmajor(Z, "Z"),
+                                 Xb.data_ptr(), Yb.data_ptr(), rows, _rowmajor(Xb, "Xb"),
+                                 _rowmajor(Yb, "Yb"), d, P, ls, ard, float(variance),
+                                 float(noise_variance), float(jitter), float(mean_const),
+                                 q_mu.data_ptr(), q_sqrt.data_ptr(), int(q_diag), 1, out.data_ptr(),
+                                 info.data_ptr(), ws.data_ptr(), ws.numel() * 8)
+    _lib.check(rc, "gpk_svgp_elbo_shard")
+    return out, info

@@ -1,0 +1,178 @@
+/* gpk.h -- C-ABI of libgpk.so: the MI355X (gfx950) dense-GP hot path behind gpflow_amd.
+ *
+ * The reference (GPflow 2.9.2) has no C/FFI boundary: every FLOP of this path is a TensorFlow op
+ * called from Python.  Each entry point below replaces one TF-op call site (or a fused group of
+ * them); the reference file:line it stands in for is cited per function (paths relative to the
+ * GPflow tree).  The reference-side binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every matrix pointer is a DEVICE pointer to row-major fp64 (gpflow default_float,
+ *     config/__config__.py:99); leading dimensions are in elements;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work,
+ *     they never synchronise and never allocate: scratch comes from the caller's workspace;
+ *   - small hyper-parameter vectors (lengthscales) are HOST pointers, copied into kernel arguments;
+ *   - return value: 0 ok, <0 bad argument (GPK_E_*), >0 HIP runtime error code (hipError_t);
+ *   - numerical failure (non-positive pivot) is reported LAPACK-style through a device int
+ *     `info` (0 = ok, j+1 = first bad pivot column) that the caller reads when it next syncs
+ *     (TF raises InvalidArgumentError "Cholesky decomposition was not successful" at the same spot);
+ *   - thread-safe per stream; no global mutable state besides a one-time kernel-attribute setup.
+ */
+#ifndef GPK_H
+#define GPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPK_NB 128 /* Cholesky inner block: diag-block inverses are GPK_NB x GPK_NB */
+#define GPK_MAX_D 64 /* max input dimension of the covariance builder */
+
+#define GPK_E_ARG (-1)
+#define GPK_E_WORKSPACE (-2)
+#define GPK_E_UNSUPPORTED (-3)
+
+/* stationary kernel families (gpflow/kernels/stationaries.py) */
+#define GPK_KERN_SE 0       /* SquaredExponential.K_r2 :209-210 */
+#define GPK_KERN_MATERN12 1 /* :254-255 */
+#define GPK_KERN_MATERN32 2 /* :281-283 */
+#define GPK_KERN_MATERN52 3 /* :311-313 */
+
+const char* gpk_version(void);
+
+/* ---- covariance builder ---------------------------------------------------------------------
+ * K[i,j] = variance * k(r2(X1_i / ls, X2_j / ls)) (+ diag_add if i == j and X2 == NULL)
+ * Replaces square_distance (utilities/ops.py:105-122, the expansion formula, kept), Stationary.scale
+ * (stationaries.py:77-79), K_r2 (:209-210 ...), add_noise_cov (utilities/model_utils.py:33-38) and
+ * the jitter add of Kuu (covariances/kuus.py:33).
+ *   X1 [n1,d] ldx1; X2 [n2,d] ldx2 or NULL (symmetric: X2 = X1);  K [n1,n2] ldk
+ *   ls: HOST pointer, d entries if ard else 1;  lower_only: with X2 == NULL write only tiles that
+ *   touch the lower triangle (what the Cholesky reads). */
+int gpk_kernel_matrix(void* stream, int family, const double* X1, int n1, long ldx1,
+                      const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
+                      double variance, double diag_add, int lower_only, double* K, long ldk);
+
+/* ---- trapezoidal Cholesky ---------------------------------------------------------------------
+ * A is [(n + extra) x n] row-major.  Top n x n block (lower triangle read): K -> L in place,
+ * K = L L^T (tf.linalg.cholesky call sites: gpr.py:102, posteriors.py:422,703, conditionals/util.py:67,
+ * kullback_leiblers.py:107).  The `extra` rows below it hold right-hand sides B [extra, n] and come
+ * back as B L^-T, i.e. (L^-1 B^T)^T -- tf.linalg.triangular_solve(L, B^T, lower=True)
+ * (conditionals/util.py:125, logdensities.py:150, kullback_leiblers.py:114,152) fused into the
+ * factorisation's panel updates.  The strict upper triangle of the top block is left untouched
+ * unless zero_upper != 0.  `batch` matrices at stride strideA (SeparateIndependent: the
+ * tf.map_fn loop of conditionals/util.py:618 becomes one batched launch sequence).
+ * invd: [batch, ceil(n/NB), NB, NB] output, the inverses of L's diagonal blocks (reused by gpk_trsm);
+ * gpk_invd_elems() gives its size in doubles.  info: device int[batch] (may be NULL). */
+size_t gpk_invd_elems(int n, int batch);
+int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch, long strideA,
+              double* invd, int zero_upper, int* info);
+
+/* inverses of the diagonal NB-blocks of an existing lower factor L [n,n] (for gpk_trsm on a cached
+ * L: GPRPosterior cache (err, Lm), posteriors.py:415-432). invd [batch, ceil(n/NB), NB, NB]. */
+int gpk_trtri_blocks(void* stream, const double* L, int n, long ldl, int batch, long strideL,
+                     double* invd);
+
+/* ---- triangular solve against an existing factor (right-side, row-major form) -------------------
+ * trans = 0:  B <- B L^-T   (rows of B are right-hand sides;  = (L^-1 B^T)^T, util.py:125)
+ *             pass L (lower, ldl) and invd.
+ * trans = 1:  B <- B L^-1   (= (L^-T B^T)^T, triangular_solve(adjoint(Lm), A, lower=False) util.py:139)
+ *             pass LT = L^T (upper, row-major) as `L` and the blockwise transposed inverses invdT as
+ *             `invd`; both come from gpk_transpose_factor.
+ * B [m,n] ldb, solved in place. */
+int gpk_trsm(void* stream, int trans, const double* L, long ldl, const double* invd, int n,
+             double* B, int m, long ldb, int batch, long strideL, long strideB);
+int gpk_transpose_factor(void* stream, const double* L, long ldl, const double* invd, int n,
+                         double* LT, long ldlt, double* invdT);
+
+/* ---- GEMM  C = alpha * A * B^T + beta * C  (A [m,k], B [n,k], C [m,n]; fp64 MFMA) ----------------
+ * tf.linalg.matmul call sites (conditionals/util.py:129,144,157,162; posteriors.py:734,803-818).
+ * b_tri: 0 dense; 1 B is upper in [n,k] (B[j,kk] == 0 for kk < j, must be stored as zeros);
+ *        2 B is lower (B[j,kk] == 0 for kk > j).  c_lower: only tiles touching the lower triangle. */
+int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, const double* A, long lda,
+                const double* B, long ldb, double beta, double* C, long ldc, int b_tri,
+                int c_lower, int batch, long strideA, long strideB, long strideC);
+
+/* out[j,i] = in[i,j]; mode 0 plain, 1 keep the lower triangle of `in` only (band_part(q_sqrt,-1,0),
+ * conditionals/util.py:151, kullback_leiblers.py:120), 2 keep upper only. in [rows,cols]. */
+int gpk_transpose(void* stream, const double* in, int rows, int cols, long ldin, double* out,
+                  long ldout, int mode, int batch, long stride_in, long stride_out);
+
+/* Row statistics of At [rows, m] (= A^T of the conditional), one pass over At:
+ *   sumsq[b]  = beta*sumsq[b] + alpha * sum_k At[b,k]^2        (util.py:133 reduce_sum(square(A), -2))
+ *   mv[b,p]   = sum_k At[b,k] V[k,p]                           (util.py:144  A^T f;  V [m,P])
+ *   wsq[p,b]  = sum_k (At[b,k] W[k,p])^2                       (util.py:149,164 q_diag; W [m,P])
+ * any of sumsq / (V,mv) / (W,wsq) may be NULL. */
+int gpk_row_stats(void* stream, const double* At, int rows, int m, long ldat, const double* V,
+                  const double* W, int P, double alpha, double beta, double* sumsq, double* mv,
+                  double* wsq);
+int gpk_row_sumsq(void* stream, const double* A, int rows, int cols, long lda, double alpha,
+                  double beta, double* out);
+
+/* Projection onto the variational square roots (util.py:151-164, triangular-aware, never
+ * materialises LTA):  ssq[p,b] = sum_j ( sum_k At[b,k] Lq_p[k,j] )^2
+ * LqT [P, m, ldl] = tril(q_sqrt_p)^T, built with gpk_transpose(mode 1). */
+size_t gpk_project_workspace_bytes(int rows, int m, int P);
+int gpk_project(void* stream, const double* At, int rows, int m, long ldat, const double* LqT,
+                long ldl, int P, double* ssq, void* ws, size_t ws_bytes);
+
+/* ---- scalar tails (deterministic two-stage reductions) ---------------------------------------------
+ * Gaussian variational expectations summed over rows and outputs
+ * (likelihoods/scalar_continuous.py:139-148 then tf.reduce_sum, svgp.py:181):
+ *   fvar[b,p] = knn - s0[b | p,b] + ssq[p,b]
+ *   out[0] = sum_b sum_p -0.5 log 2pi - 0.5 log nv - 0.5 ((Y[b,p] - fmean[b,p] - mean_const)^2 + fvar) / nv
+ * s0 [rows] or [P,rows] (s0_per_latent), may be NULL; ssq [P,rows] may be NULL; fvar_out [rows,P]
+ * optional.  knn: HOST pointer, P values if knn_per_latent else 1. */
+size_t gpk_reduce_workspace_bytes(int n);
+int gpk_gaussian_varexp_sum(void* stream, const double* Y, long ldy, const double* fmean, int rows,
+                            int P, const double* s0, int s0_per_latent, const double* ssq,
+                            const double* knn_host, int knn_per_latent, double noise_variance,
+                            double mean_const, double* fvar_out, double* out, void* ws,
+                            size_t ws_bytes);
+
+/* whitened KL (kullback_leiblers.py:98-165 with K None):
+ *   out[0] = 0.5 * ( sum q_mu^2 - M*P - sum log diag(Lq)^2 + sum tril(Lq)^2 )
+ * q_sqrt [P,m,m] (q_diag = 0) or [m,P] (q_diag = 1). */
+int gpk_gauss_kl_white(void* stream, const double* q_mu, const double* q_sqrt, int m, int P,
+                       int q_diag, double* out, void* ws, size_t ws_bytes);
+
+/* out[b] = sum_i log(L_b[i,i]) (logdensities.py:154, kullback_leiblers.py:159-160) */
+int gpk_sum_log_diag(void* stream, const double* L, int n, long ldl, int batch, long strideL,
+                     double* out);
+/* out[0] = sum of squares of A [rows,cols] (upper_only: c >= r) -- mahalanobis / trace terms */
+int gpk_sumsq(void* stream, const double* A, int rows, int cols, long lda, int upper_only,
+              double* out, void* ws, size_t ws_bytes);
+
+/* ---- fused drivers -----------------------------------------------------------------------------------
+ * GPR.log_marginal_likelihood (gpr.py:91-107), stationary kernel, Gaussian noise, constant mean:
+ * builds K(X,X)+noise*I (lower) with (Y-mean)^T as extra rows into ws, factors, reduces.
+ *   out[0] = LML (summed over the P columns of Y); info: device int. */
+size_t gpk_gpr_lml_workspace_bytes(int n, int d, int P);
+int gpk_gpr_lml(void* stream, int family, const double* X, int n, int d, long ldx, const double* Y,
+                int P, long ldy, const double* ls_host, int ard, double variance,
+                double noise_variance, double mean_const, double* out, int* info, void* ws,
+                size_t ws_bytes);
+
+/* One shard of SVGP.elbo (svgp.py:166-181), whitened, one kernel shared by all P latents
+ * (IndependentPosteriorSingleOutput posteriors.py:828-841 and the SharedIndependent branch :849-861):
+ *   out[0] = sum over this shard's rows of var_exp   (all-reduced across ranks by the caller)
+ *   out[1] = KL (replicated; identical on every rank)
+ * q_diag: q_sqrt is [m,P] instead of [P,m,m].  whiten = 0 returns GPK_E_UNSUPPORTED (the host
+ * composes that case from the primitives above). */
+size_t gpk_svgp_elbo_workspace_bytes(int m, int rows, int d, int P, int q_diag);
+int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long ldz, const double* Xb,
+                        const double* Yb, int rows, long ldxb, long ldyb, int d, int P,
+                        const double* ls_host, int ard, double variance, double noise_variance,
+                        double jitter, double mean_const, const double* q_mu,
+                        const double* q_sqrt, int q_diag, int whiten, double* out, int* info,
+                        void* ws, size_t ws_bytes);
+
+/* micro-benchmarks used by bench.py / profiles (fp64 MFMA issue rate, HBM write stream) */
+int gpk_bench_mfma_f64(void* stream, int blocks, int iters, double* sink);
+int gpk_bench_stream_store(void* stream, double* out, long n_doubles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPK_H */

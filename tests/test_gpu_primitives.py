@@ -1,0 +1,227 @@
+"""GPU parity tests of the libgpk primitives (through the C-ABI) against the NumPy/SciPy oracle.
+
+Tolerances are stated per test; fp64 throughout.  Inputs are asymmetric on purpose (transpose-detecting).
+"""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as orc  # noqa: E402  (test-side checker only)
+
+
+def _t(x):
+    from gpflow_amd import ops
+    return ops.to_device(x)
+
+
+def _spd(rng, n, d=3, noise=0.1):
+    X = rng.normal(size=(n, d))
+    return X, orc.rbf_K(X, variance=1.3, lengthscales=0.9 * np.sqrt(d)) + noise * np.eye(n)
+
+
+@pytest.mark.parametrize("family", ["SquaredExponential", "Matern12", "Matern32", "Matern52"])
+@pytest.mark.parametrize("n1,n2,d,ard", [(70, 133, 3, True), (64, 64, 8, False), (1, 5, 1, False), (257, 300, 16, True)])
+def test_kernel_matrix_cross(gpu, family, n1, n2, d, ard):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(0)
+    X1, X2 = rng.normal(size=(n1, d)), rng.normal(size=(n2, d))
+    ls = (0.7 + 0.1 * np.arange(d)) if ard else 0.8
+    K = ops.kernel_matrix(_t(X1), _t(X2), variance=2.3, lengthscales=ls, family=family).cpu().numpy()
+    ref = orc.stationary_K(family, X1, X2, variance=2.3, lengthscales=ls)
+    np.testing.assert_allclose(K, ref, rtol=0, atol=2e-14)
+
+
+@pytest.mark.parametrize("n,d", [(5, 2), (64, 8), (200, 3), (513, 8)])
+def test_kernel_matrix_sym(gpu, n, d):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(n, d))
+    K = ops.kernel_matrix(_t(X), None, variance=1.7, lengthscales=1.4, diag_add=0.25).cpu().numpy()
+    ref = orc.rbf_K(X, variance=1.7, lengthscales=1.4) + 0.25 * np.eye(n)
+    np.testing.assert_allclose(K, ref, rtol=0, atol=2e-14)
+    Kl = ops.kernel_matrix(_t(X), None, variance=1.7, lengthscales=1.4, diag_add=0.25, lower_only=True).cpu().numpy()
+    np.testing.assert_allclose(np.tril(Kl), np.tril(ref), rtol=0, atol=2e-14)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (130, 70, 37), (257, 129, 128), (64, 300, 513), (5, 3, 2), (1000, 64, 64)])
+def test_gemm_nt(gpu, m, n, k):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(2)
+    A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
+    out = ops.gemm_nt(_t(A), _t(B), alpha=-0.7, beta=1.3, C=_t(C)).cpu().numpy()
+    ref = -0.7 * A @ B.T + 1.3 * C
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12 * max(1, k))
+
+
+def test_gemm_nt_identity_asymmetric(gpu):
+    """A = I against an asymmetric B catches row/col swaps of the MFMA D layout."""
+    from gpflow_amd import ops
+    n = 128
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    out = ops.gemm_nt(_t(np.eye(n)), _t(B)).cpu().numpy()
+    np.testing.assert_array_equal(out, B.T)
+
+
+def test_gemm_nt_tri_and_batch(gpu):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(3)
+    m, n, k = 300, 256, 256
+    A = rng.normal(size=(m, k))
+    Bu = np.triu(rng.normal(size=(2, n, k)))  # zero for kk < j
+    out = ops.gemm_nt(_t(A), _t(Bu), b_tri=1).cpu().numpy()
+    np.testing.assert_allclose(out, np.einsum("mk,bnk->bmn", A, Bu), rtol=0, atol=1e-11)
+    Bl = np.tril(rng.normal(size=(n, k)))
+    out = ops.gemm_nt(_t(A), _t(Bl), b_tri=2).cpu().numpy()
+    np.testing.assert_allclose(out, A @ Bl.T, rtol=0, atol=1e-11)
+    # lower-only syrk: tiles touching the lower triangle must be exact
+    S = rng.normal(size=(384, 64))
+    C0 = rng.normal(size=(384, 384))
+    out = ops.gemm_nt(_t(S), _t(S), alpha=-1.0, beta=1.0, C=_t(C0), c_lower=True).cpu().numpy()
+    ref = C0 - S @ S.T
+    np.testing.assert_allclose(np.tril(out), np.tril(ref), rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("n,extra", [(1, 0), (17, 3), (128, 0), (129, 5), (300, 40), (640, 130), (1100, 257)])
+def test_potrf_trapezoid(gpu, n, extra):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(4)
+    _, K = _spd(rng, n)
+    Bm = rng.normal(size=(extra, n))
+    T = np.vstack([K, Bm])
+    Td = _t(T)
+    invd, info = ops.potrf_(Td, n, zero_upper=True)
+    ops.check_info(info)
+    out = Td.cpu().numpy()
+    L = out[:n]
+    Lref = np.linalg.cholesky(K)
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=5e-13)
+    assert np.all(np.triu(L, 1) == 0)
+    np.testing.assert_allclose(L @ L.T, K, rtol=0, atol=5e-13)
+    if extra:
+        ref = sla.solve_triangular(Lref, Bm.T, lower=True).T
+        np.testing.assert_allclose(out[n:], ref, rtol=0, atol=1e-11)
+    # diagonal-block inverses
+    nblk = (n + 127) // 128
+    inv = invd.cpu().numpy().reshape(nblk, 128, 128)
+    for b in range(nblk):
+        j0, j1 = b * 128, min(n, b * 128 + 128)
+        D = Lref[j0:j1, j0:j1]
+        np.testing.assert_allclose(inv[b][: j1 - j0, : j1 - j0] @ D, np.eye(j1 - j0), rtol=0, atol=1e-11)
+
+
+def test_potrf_batched(gpu):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(5)
+    n, extra, b = 260, 33, 3
+    Ts, Ks, Bs = [], [], []
+    for i in range(b):
+        _, K = _spd(rng, n, noise=0.1 + 0.1 * i)
+        Bm = rng.normal(size=(extra, n))
+        Ts.append(np.vstack([K, Bm])); Ks.append(K); Bs.append(Bm)
+    Td = _t(np.stack(Ts))
+    invd, info = ops.potrf_(Td, n)
+    ops.check_info(info)
+    out = Td.cpu().numpy()
+    for i in range(b):
+        Lref = np.linalg.cholesky(Ks[i])
+        np.testing.assert_allclose(np.tril(out[i, :n]), Lref, rtol=0, atol=5e-13)
+        np.testing.assert_allclose(out[i, n:], sla.solve_triangular(Lref, Bs[i].T, lower=True).T, rtol=0, atol=1e-11)
+
+
+def test_potrf_not_pd_reports_info(gpu):
+    from gpflow_amd import ops, _lib
+    K = np.eye(200)
+    K[150, 150] = -1.0
+    Td = _t(K)
+    _, info = ops.potrf_(Td, 200)
+    assert int(info.cpu()[0]) == 151
+    with pytest.raises(_lib.GpkError):
+        ops.check_info(info)
+
+
+@pytest.mark.parametrize("n,m", [(100, 7), (256, 300), (700, 129)])
+def test_trsm_both(gpu, n, m):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(6)
+    _, K = _spd(rng, n)
+    L = np.linalg.cholesky(K)
+    Bm = rng.normal(size=(m, n))
+    Ld = _t(L)
+    invd = ops.trtri_blocks(Ld)
+    X0 = ops.trsm_(_t(Bm), Ld, invd, trans=0).cpu().numpy()
+    np.testing.assert_allclose(X0, sla.solve_triangular(L, Bm.T, lower=True).T, rtol=0, atol=1e-11)
+    LT, invdT = ops.transpose_factor(Ld, invd)
+    np.testing.assert_array_equal(LT.cpu().numpy(), L.T)
+    X1 = ops.trsm_(_t(Bm), LT, invdT, trans=1).cpu().numpy()
+    np.testing.assert_allclose(X1, sla.solve_triangular(L.T, Bm.T, lower=False).T, rtol=0, atol=1e-10)
+
+
+def test_row_stats_project_reductions(gpu):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(7)
+    rows, m, P = 333, 200, 3
+    At = rng.normal(size=(rows, m))
+    V, W = rng.normal(size=(m, P)), rng.uniform(0.5, 1.5, size=(m, P))
+    s, mv, wsq = ops.row_stats(_t(At), V=_t(V), W=_t(W))
+    np.testing.assert_allclose(s.cpu().numpy(), (At ** 2).sum(1), rtol=1e-13)
+    np.testing.assert_allclose(mv.cpu().numpy(), At @ V, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(wsq.cpu().numpy(), np.einsum("bk,kp->pb", At ** 2, W ** 2), rtol=1e-13)
+    q_sqrt = rng.normal(size=(P, m, m))  # upper part must be ignored (band_part)
+    LqT = ops.transpose(_t(q_sqrt), mode=1)
+    np.testing.assert_array_equal(LqT.cpu().numpy(), np.transpose(np.tril(q_sqrt), (0, 2, 1)))
+    ssq = ops.project(_t(At), LqT).cpu().numpy()
+    ref = np.stack([((At @ np.tril(q_sqrt[p])) ** 2).sum(1) for p in range(P)])
+    np.testing.assert_allclose(ssq, ref, rtol=1e-12)
+    # scalar tails
+    Y = rng.normal(size=(rows, P)); fmean = rng.normal(size=(rows, P))
+    s0 = rng.uniform(0, 0.5, size=rows)
+    out, fvar = ops.gaussian_varexp_sum(_t(Y), _t(fmean), s0=_t(s0), ssq=_t(ref), knn=[1.3], noise_variance=0.2,
+                                        mean_const=0.1, want_fvar=True)
+    fv = 1.3 - s0[:, None] + ref.T
+    np.testing.assert_allclose(fvar.cpu().numpy(), fv, rtol=1e-13)
+    refsum = orc.gaussian_variational_expectations(fmean + 0.1, fv, Y, 0.2).sum()
+    np.testing.assert_allclose(out.cpu().numpy()[0], refsum, rtol=1e-13)
+    q_mu = rng.normal(size=(m, P))
+    kl = ops.gauss_kl_white(_t(q_mu), _t(q_sqrt)).cpu().numpy()[0]
+    np.testing.assert_allclose(kl, orc.gauss_kl(q_mu, q_sqrt), rtol=1e-13)
+    kld = ops.gauss_kl_white(_t(q_mu), _t(W)).cpu().numpy()[0]
+    np.testing.assert_allclose(kld, orc.gauss_kl(q_mu, W), rtol=1e-13)
+    L = np.tril(rng.uniform(0.5, 2.0, size=(m, m)))
+    np.testing.assert_allclose(ops.sum_log_diag(_t(L)).cpu().numpy()[0], np.log(np.diag(L)).sum(), rtol=1e-13)
+    np.testing.assert_allclose(ops.sumsq(_t(At)).cpu().numpy()[0], (At ** 2).sum(), rtol=1e-13)
+
+
+@pytest.mark.parametrize("n,d,P", [(50, 1, 1), (512, 2, 1), (700, 8, 3)])
+def test_fused_gpr_lml(gpu, n, d, P):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(8)
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(n, P))
+    kw = dict(variance=1.2, lengthscales=0.8 + 0.1 * np.arange(d) if d > 1 else 0.9, noise_variance=0.1)
+    out, info = ops.gpr_lml(_t(X), _t(Y), mean_const=0.05, **kw)
+    ops.check_info(info)
+    ref = orc.gpr_log_marginal_likelihood(X, Y, mean=0.05, **kw)
+    np.testing.assert_allclose(out.cpu().numpy()[0], ref, rtol=1e-10)
+
+
+@pytest.mark.parametrize("m,rows,d,P,q_diag", [(20, 50, 1, 2, False), (200, 300, 8, 1, False), (300, 1000, 8, 4, False), (130, 257, 3, 2, True)])
+def test_fused_svgp_elbo_shard(gpu, m, rows, d, P, q_diag):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(rows, d))
+    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(rows, P))
+    Z = X[:m] + 0.01 * rng.normal(size=(m, d)) if m <= rows else rng.normal(size=(m, d))
+    q_mu = 0.1 * rng.normal(size=(m, P))
+    if q_diag:
+        q_sqrt = rng.uniform(0.3, 0.8, size=(m, P))
+    else:
+        q_sqrt = np.stack([np.tril(0.05 * rng.normal(size=(m, m))) + 0.5 * np.eye(m) for _ in range(P)])
+    kw = dict(variance=1.1, lengthscales=np.sqrt(d) * (0.8 + 0.05 * np.arange(d)) if d > 1 else 0.7, noise_variance=0.1)
+    out, info = ops.svgp_elbo_shard(_t(Z), _t(X), _t(Y), _t(q_mu), _t(q_sqrt), jitter=1e-6, **kw)
+    ops.check_info(info)
+    s_ref, kl_ref = orc.svgp_elbo_terms(X, Y, Z, q_mu, q_sqrt, whiten=True, **kw)
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o[0], s_ref, rtol=1e-9)
+    np.testing.assert_allclose(o[1], kl_ref, rtol=1e-12)
