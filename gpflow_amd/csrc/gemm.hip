@@ -22,9 +22,9 @@ constexpr int BK = 16;
 constexpr int LDSS = BK + 2;
 constexpr int GROUP_N = 8;
 
-template <int BM, int BN>
+template <int BM, int BN, int WGM, int WGN>
 struct TileCfg {
-  static constexpr int WM = BM / 2, WN = BN / 2;
+  static constexpr int WM = BM / WGM, WN = BN / WGN;
   static constexpr int TM = WM / 16, TN = WN / 16;
   static constexpr int A_CH = BM * (BK / 2) / 256;
   static constexpr int B_CH = BN * (BK / 2) / 256;
@@ -46,31 +46,62 @@ __device__ __forceinline__ d2 load2(const double* __restrict__ base, long ld, in
   return v;
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int gy) {
-  using Cfg = TileCfg<BM, BN>;
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int gy, int total, int compact) {
+  using Cfg = TileCfg<BM, BN, WGM, WGN>;
   constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
   constexpr int A_CH = Cfg::A_CH, B_CH = Cfg::B_CH;
   extern __shared__ __attribute__((aligned(16))) double smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int bz = blockIdx.y;
 
   // ---- XCD-contiguous + column-grouped tile order -------------------------------------------
+  // Tiles are numbered group-of-8-columns major, row-major inside a group; each XCD takes a
+  // contiguous 1/8 of that sequence.  With c_lower (and square tiles) only the tiles on or below
+  // the diagonal are numbered, so every XCD gets the same amount of work.
   int tile_m, tile_n;
   {
-    const int total = gx * gy;
     const int lin = blockIdx.x;
     const int xcd = lin & 7, local = lin >> 3;
     const int q = total >> 3, r = total & 7;
-    const int nl = xcd * q + (xcd < r ? xcd : r) + local;
-    const int gspan = GROUP_N * gy;
-    const int group = nl / gspan, within = nl - group * gspan;
-    const int first_n = group * GROUP_N;
-    const int gsz = (gx - first_n) < GROUP_N ? (gx - first_n) : GROUP_N;
-    tile_n = first_n + within % gsz;
-    tile_m = within / gsz;
+    int nl = xcd * q + (xcd < r ? xcd : r) + local;
+    // triangular-K work (b_tri = 1, many column tiles) is heaviest in the first column groups:
+    // keep plain round-robin there so all XCDs walk the groups together, heaviest first
+    if (p.b_tri == 1 && gx > GROUP_N) nl = lin;
+    if (compact) {
+      int g = 0;
+      for (;; ++g) {
+        const int first = g * GROUP_N;
+        const int gsz = (gx - first) < GROUP_N ? (gx - first) : GROUP_N;
+        const int avail = gy - first;
+        const int tr = avail < gsz ? avail : gsz;
+        const int cnt = tr * (tr + 1) / 2 + (avail > gsz ? (avail - gsz) * gsz : 0);
+        if (nl < cnt) {
+          int ro = 0, co = nl;
+          const int tri = gsz * (gsz + 1) / 2;
+          if (nl < tri) {
+            while (co > ro) { co -= ro + 1; ++ro; }
+          } else {
+            const int w = nl - tri;
+            ro = gsz + w / gsz;
+            co = w - (w / gsz) * gsz;
+          }
+          tile_m = first + ro;
+          tile_n = first + co;
+          break;
+        }
+        nl -= cnt;
+      }
+    } else {
+      const int gspan = GROUP_N * gy;
+      const int group = nl / gspan, within = nl - group * gspan;
+      const int first_n = group * GROUP_N;
+      const int gsz = (gx - first_n) < GROUP_N ? (gx - first_n) : GROUP_N;
+      tile_n = first_n + within % gsz;
+      tile_m = within / gsz;
+    }
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (p.c_lower && n0 > m0 + BM - 1) return;
@@ -242,19 +273,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(hipStream_t s, const GemmArgs& a) {
-  using Cfg = TileCfg<BM, BN>;
+  using Cfg = TileCfg<BM, BN, WGM, WGN>;
   static bool attr_set = false;
   if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN>),
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, WGM, WGN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
     attr_set = true;
   }
   const int gx = gpk_cdiv(a.n, BN), gy = gpk_cdiv(a.m, BM);
   if (gx <= 0 || gy <= 0) return 0;
-  dim3 grid((unsigned)(gx * gy), (unsigned)(a.batch > 0 ? a.batch : 1), 1);
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN>), grid, dim3(256), Cfg::LDS_BYTES, s, a, gx, gy);
+  int total = gx * gy, compact = 0;
+  if (a.c_lower && BM == BN && a.epi == 0) {
+    compact = 1;
+    total = 0;
+    for (int first = 0; first < gx; first += GROUP_N) {
+      const int gsz = (gx - first) < GROUP_N ? (gx - first) : GROUP_N;
+      const int avail = gy - first;
+      if (avail <= 0) break;
+      const int tr = avail < gsz ? avail : gsz;
+      total += tr * (tr + 1) / 2 + (avail > gsz ? (avail - gsz) * gsz : 0);
+    }
+    if (total <= 0) return 0;
+  }
+  dim3 grid((unsigned)total, (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN>), grid, dim3(256), Cfg::LDS_BYTES, s, a, gx, gy, total,
+                     compact);
   GPK_LAUNCH_CHECK();
   return 0;
 }
@@ -265,8 +310,12 @@ int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
 
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
   if (a.m <= 0 || a.n <= 0) return 0;
-  if (a.epi == 1 || a.n > 64) return launch_cfg<128, 128>(s, a);
-  return launch_cfg<128, 64>(s, a);
+  if (a.epi == 1) return launch_cfg<128, 128, 2, 2>(s, a);
+  if (a.n <= 64) return launch_cfg<128, 64, 2, 2>(s, a);
+  // narrow / small problems: 64-row tiles double the number of workgroups (256 CUs to fill)
+  const long tiles128 = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
+  if (tiles128 < 192 && a.m > 64) return launch_cfg<64, 128, 1, 4>(s, a);
+  return launch_cfg<128, 128, 2, 2>(s, a);
 }
 
 extern "C" int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, const double* A,

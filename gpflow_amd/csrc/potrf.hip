@@ -9,6 +9,7 @@
 //   inner blocks of NB = 128 columns   -> leaf kernel (L11 and L11^-1), in-place panel solve
 //                                          A21 <- A21 * L11^-T as a GEMM, update of the rest of the panel.
 #include "gpk_internal.h"
+#include <stdlib.h>
 
 namespace {
 constexpr int NB = GPK_NB;
@@ -33,57 +34,167 @@ extern "C" size_t gpk_invd_elems(int n, int batch) {
   return (size_t)(batch > 0 ? batch : 1) * gpk_cdiv(n, NB) * NB * NB;
 }
 
-extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch,
-                         long strideA, double* invd, int zero_upper, int* info) {
-  if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  if (batch <= 0) batch = 1;
-  if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, s));
-  if (n == 0) return 0;
-  const int R = n + extra;
-  const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
+// ---- auxiliary "panel" stream + event pool (one per device, created lazily) ---------------------
+// The caller's stream S carries the bulk MFMA work (outer trailing updates, extra-row solves);
+// the high-priority panel stream P carries the latency-bound critical path (leaf, panel solve,
+// inner updates) of the NEXT outer panel, so the two overlap (look-ahead).  Fork/join is done with
+// events only, so the whole sequence is also hipGraph-capturable.  Not re-entrant across host
+// threads for one device (one event pool).
+namespace {
+struct Aux {
+  hipStream_t P = nullptr;
+  hipEvent_t* ev = nullptr;
+  int nev = 0;
+};
+Aux g_aux[16];
+
+int aux_get(int need, Aux** out) {
+  int dev = 0;
+  GPK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return GPK_E_UNSUPPORTED;
+  Aux& a = g_aux[dev];
+  if (!a.P) {
+    int lo = 0, hi = 0;
+    GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    GPK_HIP(hipStreamCreateWithPriority(&a.P, hipStreamNonBlocking, hi));
+  }
+  if (a.nev < need) {
+    hipEvent_t* n = (hipEvent_t*)realloc(a.ev, sizeof(hipEvent_t) * need);
+    if (!n) return GPK_E_ARG;
+    a.ev = n;
+    for (int i = a.nev; i < need; ++i) GPK_HIP(hipEventCreateWithFlags(&a.ev[i], hipEventDisableTiming));
+    a.nev = need;
+  }
+  *out = &a;
+  return 0;
+}
+
+// factor the outer panel [c0,c1) of the square part (rows up to `rows`) on stream s
+int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, int batch, long strideA,
+                 double* invd, long strideInv, int* info) {
   int rc;
-  for (int c0 = 0; c0 < n; c0 += NBO) {
-    const int c1 = (c0 + NBO < n) ? c0 + NBO : n;
-    for (int j0 = c0; j0 < c1; j0 += NB) {
-      const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
-      const int nb = j1 - j0;
-      double* diag = A + (long)j0 * lda + j0;
-      double* invb = invd + (long)(j0 / NB) * NB * NB;
-      rc = gpk_launch_leaf(s, diag, lda, strideA, nb, invb, strideInv, info, j0, batch, 0);
-      if (rc) return rc;
-      const int below = R - j1;
-      if (below > 0) {
-        double* panel = A + (long)j1 * lda + j0;
-        // in-place panel solve: X = panel * inv(L11)^T  (single column tile => each workgroup only
-        // overwrites rows it alone has read)
-        GemmArgs g = gemm_base(below, nb, nb, 1.0, panel, lda, invb, NB, 0.0, panel, lda, batch,
-                               strideA, strideInv, strideA);
-        g.b_tri = 2;
-        rc = gpk_launch_gemm(s, g);
-        if (rc) return rc;
-        const int ncols = c1 - j1;
-        if (ncols > 0) {
-          // rest of the outer panel:  A[j1:R, j1:c1] -= X * X[0:ncols]^T
-          GemmArgs u = gemm_base(below, ncols, nb, -1.0, panel, lda, panel, lda, 1.0,
-                                 A + (long)j1 * lda + j1, lda, batch, strideA, strideA, strideA);
-          u.c_lower = 1;
-          rc = gpk_launch_gemm(s, u);
-          if (rc) return rc;
-        }
-      }
-    }
-    if (c1 < n) {
-      // outer trailing update (K = c1 - c0): A[c1:R, c1:n] -= P P[0:n-c1]^T, lower tiles only
-      const double* P = A + (long)c1 * lda + c0;
-      GemmArgs u = gemm_base(R - c1, n - c1, c1 - c0, -1.0, P, lda, P, lda, 1.0,
-                             A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
+  for (int j0 = c0; j0 < c1; j0 += NB) {
+    const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
+    const int nb = j1 - j0;
+    double* invb = invd + (long)(j0 / NB) * NB * NB;
+    rc = gpk_launch_leaf(s, A + (long)j0 * lda + j0, lda, strideA, nb, invb, strideInv, info, j0, batch, 0);
+    if (rc) return rc;
+    const int below = rows - j1;
+    if (below <= 0) continue;
+    double* panel = A + (long)j1 * lda + j0;
+    // in-place panel solve X = panel * inv(L11)^T: one column tile, so each workgroup only
+    // overwrites rows that it alone has read
+    GemmArgs g = gemm_base(below, nb, nb, 1.0, panel, lda, invb, NB, 0.0, panel, lda, batch, strideA,
+                           strideInv, strideA);
+    g.b_tri = 2;
+    rc = gpk_launch_gemm(s, g);
+    if (rc) return rc;
+    const int ncols = c1 - j1;
+    if (ncols > 0) {
+      GemmArgs u = gemm_base(below, ncols, nb, -1.0, panel, lda, panel, lda, 1.0,
+                             A + (long)j1 * lda + j1, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
       rc = gpk_launch_gemm(s, u);
       if (rc) return rc;
     }
   }
-  if (zero_upper) return gpk_launch_zero_upper(s, A, n, lda, batch, strideA);
+  return 0;
+}
+
+// extra rows E = A[n:n+extra, :], columns of panel [c0,c1): left-looking solve against the
+// finished factor:  E[:,c0:c1] <- (E[:,c0:c1] - E[:,0:c0] L[c0:c1,0:c0]^T) L[c0:c1,c0:c1]^-T
+int extra_panel(hipStream_t s, double* A, int n, int extra, int c0, int c1, long lda, int batch,
+                long strideA, const double* invd, long strideInv) {
+  double* E = A + (long)n * lda;
+  int rc;
+  if (c0 > 0) {
+    GemmArgs u = gemm_base(extra, c1 - c0, c0, -1.0, E, lda, A + (long)c0 * lda, lda, 1.0, E + c0, lda,
+                           batch, strideA, strideA, strideA);
+    rc = gpk_launch_gemm(s, u);
+    if (rc) return rc;
+  }
+  for (int j0 = c0; j0 < c1; j0 += NB) {
+    const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
+    const int nb = j1 - j0;
+    if (j0 > c0) {
+      GemmArgs u = gemm_base(extra, nb, j0 - c0, -1.0, E + c0, lda, A + (long)j0 * lda + c0, lda, 1.0,
+                             E + j0, lda, batch, strideA, strideA, strideA);
+      rc = gpk_launch_gemm(s, u);
+      if (rc) return rc;
+    }
+    GemmArgs g = gemm_base(extra, nb, nb, 1.0, E + j0, lda, invd + (long)(j0 / NB) * NB * NB, NB, 0.0,
+                           E + j0, lda, batch, strideA, strideInv, strideA);
+    g.b_tri = 2;
+    rc = gpk_launch_gemm(s, g);
+    if (rc) return rc;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch,
+                         long strideA, double* invd, int zero_upper, int* info) {
+  if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
+  hipStream_t S = (hipStream_t)stream;
+  if (batch <= 0) batch = 1;
+  if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, S));
+  if (n == 0) return 0;
+  const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
+  const int nbo = (n >= 4096) ? NBO : 256;  // outer panel width
+  const int npanels = gpk_cdiv(n, nbo);
+  int rc;
+  if (n <= NB) {  // one leaf; nothing to overlap
+    rc = factor_panel(S, A, n, 0, n, lda, batch, strideA, invd, strideInv, info);
+    if (rc) return rc;
+    if (extra > 0) {
+      rc = extra_panel(S, A, n, extra, 0, n, lda, batch, strideA, invd, strideInv);
+      if (rc) return rc;
+    }
+    return zero_upper ? gpk_launch_zero_upper(S, A, n, lda, batch, strideA) : 0;
+  }
+  Aux* aux = nullptr;
+  rc = aux_get(2 * npanels + 2, &aux);
+  if (rc) return rc;
+  hipStream_t P = aux->P;
+  hipEvent_t* evF = aux->ev;            // [npanels]   panel p factored (recorded on P)
+  hipEvent_t* evT = aux->ev + npanels;  // [npanels+1] strip for panel p up to date (recorded on S)
+  GPK_HIP(hipEventRecord(evT[0], S));   // fork: P starts after everything already queued on S
+  for (int p = 0; p < npanels; ++p) {
+    const int c0 = p * nbo;
+    const int c1 = (c0 + nbo < n) ? c0 + nbo : n;
+    const int c2 = (c1 + nbo < n) ? c1 + nbo : n;
+    // ---- P: critical path of panel p (square rows only) ---------------------------------------
+    GPK_HIP(hipStreamWaitEvent(P, evT[p], 0));
+    rc = factor_panel(P, A, n, c0, c1, lda, batch, strideA, invd, strideInv, info);
+    if (rc) return rc;
+    GPK_HIP(hipEventRecord(evF[p], P));
+    // ---- S: bulk work that depends on panel p -----------------------------------------------------
+    GPK_HIP(hipStreamWaitEvent(S, evF[p], 0));
+    const double* Pn = A + (long)c1 * lda + c0;  // panel rows c1.. (solved), K = c1 - c0
+    if (c1 < n) {
+      // strip first: columns of the NEXT panel, so P can go on while S does the rest
+      GemmArgs u = gemm_base(n - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0,
+                             A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
+      u.c_lower = 1;
+      rc = gpk_launch_gemm(S, u);
+      if (rc) return rc;
+      GPK_HIP(hipEventRecord(evT[p + 1], S));
+    }
+    if (extra > 0) {
+      rc = extra_panel(S, A, n, extra, c0, c1, lda, batch, strideA, invd, strideInv);
+      if (rc) return rc;
+    }
+    if (c2 < n) {
+      // rest of the outer trailing update: A[c2:n, c2:n] -= P[c2:] P[c2:]^T, lower tiles only
+      const double* P2 = A + (long)c2 * lda + c0;
+      GemmArgs u = gemm_base(n - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
+                             A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
+      u.c_lower = 1;
+      rc = gpk_launch_gemm(S, u);
+      if (rc) return rc;
+    }
+  }
+  if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, batch, strideA);
   return 0;
 }
 
