@@ -37,6 +37,7 @@ _SIGS = {
                               c_long]),
     "gpk_row_stats": (c_int, [c_void_p, _dp, c_int, c_int, c_long, _dp, _dp, c_int, c_double, c_double,
                               _dp, _dp, _dp]),
+    "gpk_row_dot": (c_int, [c_void_p, _dp, c_long, _dp, c_long, c_int, c_int, c_double, c_double, _dp]),
     "gpk_row_sumsq": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_double, c_double, _dp]),
     "gpk_project_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gpk_project": (c_int, [c_void_p, _dp, c_int, c_int, c_long, _dp, c_long, c_int, _dp, _dp, c_size_t]),

@@ -139,6 +139,22 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const double* __restrict
   }
 }
 
+// ---- out[i] = beta*out[i] + alpha * sum_j A[i,j] B[i,j]  (one wave per row) --------------------------
+__global__ __launch_bounds__(256) void row_dot_kernel(const double* __restrict__ A, long lda,
+                                                      const double* __restrict__ B, long ldb, int rows,
+                                                      int cols, double alpha, double beta,
+                                                      double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const double* a = A + (long)row * lda;
+  const double* b = B + (long)row * ldb;
+  double s = 0.0;
+  for (int k = lane; k < cols; k += 64) s = fma(a[k], b[k], s);
+  s = wave_sum(s);
+  if (lane == 0) out[row] = (beta != 0.0 ? beta * out[row] : 0.0) + alpha * s;
+}
+
 // ---- ssq[p,b] = sum_t part[p][t][b] -------------------------------------------------------------------
 __global__ void sum_parts_kernel(const double* part, int nt, int rows, long stridePart, double* ssq) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
@@ -288,6 +304,16 @@ extern "C" int gpk_row_stats(void* stream, const double* At, int rows, int m, lo
     GPK_LAUNCH_CHECK();
     p0 += 4;
   } while (p0 < np);
+  return 0;
+}
+
+extern "C" int gpk_row_dot(void* stream, const double* A, long lda, const double* B, long ldb,
+                           int rows, int cols, double alpha, double beta, double* out) {
+  if (!A || !B || !out || rows < 0 || cols < 0) return GPK_E_ARG;
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)gpk_cdiv(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, A, lda, B, ldb, rows, cols, alpha, beta, out);
+  GPK_LAUNCH_CHECK();
   return 0;
 }
 

@@ -1,0 +1,70 @@
+"""GPR (gpflow/models/gpr.py:36-196)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import ops, posteriors
+from ..kernels import Kernel
+from ..kernels.stationaries import Stationary
+from ..likelihoods import Gaussian
+from ..logdensities import multivariate_normal
+from ..mean_functions import MeanFunction
+from .model import GPModel
+from .training_mixins import InternalDataTrainingLossMixin
+
+
+class GPR(GPModel, InternalDataTrainingLossMixin):
+    def __init__(self, data, kernel: Kernel, mean_function: Optional[MeanFunction] = None,
+                 noise_variance=None, likelihood: Optional[Gaussian] = None):
+        assert (noise_variance is None) or (likelihood is None), \
+            "Cannot set both `noise_variance` and `likelihood`."
+        if likelihood is None:
+            if noise_variance is None:
+                noise_variance = 1.0
+            likelihood = Gaussian(noise_variance)
+        X, Y = data
+        self.data = (ops.to_device(X), ops.to_device(Y))  # data_input_to_tensor, models/util.py:91-107
+        if self.data[0].dim() != 2 or self.data[1].dim() != 2 or self.data[0].shape[0] != self.data[1].shape[0]:
+            raise ValueError("data must be (X [N,D], Y [N,P])")
+        super().__init__(kernel, likelihood, mean_function, num_latent_gps=self.data[1].shape[-1])
+        self._ws = None
+
+    def maximum_log_likelihood_objective(self):
+        return self.log_marginal_likelihood()
+
+    def log_marginal_likelihood(self) -> torch.Tensor:
+        """gpr.py:91-107.  With a stationary kernel and a constant mean the whole chain
+        K -> +noise -> cholesky -> triangular_solve -> reductions is ONE C-ABI call (gpk_gpr_lml);
+        otherwise it is composed from the same primitives."""
+        X, Y = self.data
+        c = self.mean_function.constant_value()
+        if isinstance(self.kernel, Stationary) and c is not None:
+            Xs, _ = self.kernel.slice(X, None)
+            family, var, ls = self.kernel.hyper()
+            out, info = ops.gpr_lml(Xs, Y, variance=var, lengthscales=ls,
+                                    noise_variance=self.likelihood.noise_variance(), mean_const=c,
+                                    family=family, ws=self._ws)
+            ops.check_info(info)
+            return out[0]
+        K = self.kernel(X)
+        n = K.shape[0]
+        idx = torch.arange(n, device=K.device)
+        K[idx, idx] += self.likelihood.noise_variance()  # add_noise_cov, model_utils.py:33-38
+        _, info = ops.potrf_(K, n, zero_upper=True)
+        ops.check_info(info)
+        m = self.mean_function(X)
+        return multivariate_normal(Y, m, K).sum()
+
+    def posterior(self, precompute_cache=posteriors.PrecomputeCacheType.TENSOR) -> posteriors.GPRPosterior:
+        """gpr.py:146-175"""
+        return posteriors.GPRPosterior(kernel=self.kernel, data=self.data, likelihood=self.likelihood,
+                                       mean_function=self.mean_function,
+                                       precompute_cache=posteriors._validate_precompute_cache_type(precompute_cache)
+                                       if precompute_cache is not None else None)
+
+    def predict_f(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        """gpr.py:178-190: fused (no-cache) prediction."""
+        return self.posterior(posteriors.PrecomputeCacheType.NOCACHE).fused_predict_f(
+            Xnew, full_cov=full_cov, full_output_cov=full_output_cov)

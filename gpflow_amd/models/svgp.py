@@ -1,0 +1,124 @@
+"""SVGP (gpflow/models/svgp.py:37-261)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import config, kullback_leiblers, ops, posteriors
+from ..base import Parameter, positive, triangular
+from ..conditionals import conditional
+from ..inducing_variables import (InducingPoints, SharedIndependentInducingVariables,
+                                  inducingpoint_wrapper)
+from ..kernels import Kernel, SharedIndependent
+from ..kernels.stationaries import Stationary
+from ..likelihoods import Gaussian, Likelihood
+from ..mean_functions import MeanFunction
+from .model import GPModel
+from .training_mixins import ExternalDataTrainingLossMixin
+
+
+class SVGP(GPModel, ExternalDataTrainingLossMixin):
+    def __init__(self, kernel: Kernel, likelihood: Likelihood, inducing_variable, *,
+                 mean_function: Optional[MeanFunction] = None, num_latent_gps: int = 1,
+                 q_diag: bool = False, q_mu=None, q_sqrt=None, whiten: bool = True, num_data=None):
+        super().__init__(kernel, likelihood, mean_function, num_latent_gps)
+        self.num_data = num_data
+        self.whiten = whiten
+        self.inducing_variable = inducingpoint_wrapper(inducing_variable)
+        num_inducing = self.inducing_variable.num_inducing
+        self._init_variational_parameters(num_inducing, q_mu, q_sqrt, q_diag)
+        self._ws = None
+
+    def _init_variational_parameters(self, num_inducing, q_mu, q_sqrt, q_diag) -> None:
+        """svgp.py:90-148"""
+        q_mu = np.zeros((num_inducing, self.num_latent_gps)) if q_mu is None else q_mu
+        self.q_mu = Parameter(q_mu)  # [M, P]
+        if q_sqrt is None:
+            if q_diag:
+                self.q_sqrt = Parameter(np.ones((num_inducing, self.num_latent_gps)), transform=positive())
+            else:
+                eye = np.array([np.eye(num_inducing) for _ in range(self.num_latent_gps)])
+                self.q_sqrt = Parameter(eye, transform=triangular())  # [P, M, M]
+        else:
+            q_sqrt = np.asarray(q_sqrt, dtype=np.float64)
+            if q_diag:
+                assert q_sqrt.ndim == 2
+                self.num_latent_gps = q_sqrt.shape[1]
+                self.q_sqrt = Parameter(q_sqrt, transform=positive())  # [M, L|P]
+            else:
+                assert q_sqrt.ndim == 3
+                self.num_latent_gps = q_sqrt.shape[0]
+                self.q_sqrt = Parameter(q_sqrt, transform=triangular())  # [L|P, M, M]
+
+    def prior_kl(self) -> torch.Tensor:
+        """svgp.py:153-156"""
+        return kullback_leiblers.prior_kl(self.inducing_variable, self.kernel, self.q_mu.device_value(),
+                                          self.q_sqrt.device_value(), whiten=self.whiten)
+
+    def maximum_log_likelihood_objective(self, data):
+        return self.elbo(data)
+
+    # ---- fused device path ---------------------------------------------------------------------
+    def _fused_config(self):
+        """(stationary kernel, Z tensor, mean constant) when the whole ELBO shard is one C-ABI call:
+        whitened, Gaussian likelihood, constant mean, and one stationary kernel shared by all latents
+        (plain kernel + InducingPoints, or SharedIndependent + SharedIndependentInducingVariables)."""
+        if not self.whiten or not isinstance(self.likelihood, Gaussian):
+            return None
+        c = self.mean_function.constant_value()
+        if c is None:
+            return None
+        k, iv = self.kernel, self.inducing_variable
+        if isinstance(k, SharedIndependent) and isinstance(iv, SharedIndependentInducingVariables):
+            k, iv = k.kernel, iv.inducing_variable
+        if not (isinstance(k, Stationary) and isinstance(iv, InducingPoints)):
+            return None
+        return k, iv.Z.device_value(), c
+
+    def elbo_terms(self, data):
+        """(sum_b var_exp_b over the given rows, KL) as a 2-element device tensor -- the two pieces
+        svgp.py:172-174 combines; the first is what gets all-reduced when the minibatch is sharded."""
+        X, Y = ops.to_device(data[0]), ops.to_device(data[1])
+        fused = self._fused_config()
+        if fused is not None:
+            k, Z, c = fused
+            Xs, Zs = k.slice(X, Z)
+            family, var, ls = k.hyper()
+            m, rows, d, P = Zs.shape[0], Xs.shape[0], Zs.shape[1], self.q_mu.shape[1]
+            q_sqrt = self.q_sqrt.device_value()
+            key = (m, rows, d, P, q_sqrt.dim() == 2)
+            if self._ws is None or self._ws[0] != key:
+                self._ws = (key, ops.svgp_elbo_workspace(m, rows, d, P, q_sqrt.dim() == 2))
+            out, info = ops.svgp_elbo_shard(Zs, Xs, Y, self.q_mu.device_value(), q_sqrt, variance=var,
+                                            lengthscales=ls, noise_variance=self.likelihood.noise_variance(),
+                                            jitter=config.default_jitter(), mean_const=c, family=family,
+                                            ws=self._ws[1])
+            ops.check_info(info)
+            return out
+        kl = self.prior_kl()
+        f_mean, f_var = self.predict_f(X, full_cov=False, full_output_cov=False)
+        var_exp = self.likelihood.variational_expectations(X, f_mean, f_var, Y)
+        return torch.stack([var_exp.sum(), kl])
+
+    def elbo(self, data) -> torch.Tensor:
+        """svgp.py:166-181"""
+        X = data[0]
+        terms = self.elbo_terms(data)
+        if self.num_data is not None:
+            scale = float(self.num_data) / float(X.shape[0])
+        else:
+            scale = 1.0
+        return terms[0] * scale - terms[1]
+
+    def posterior(self, precompute_cache=posteriors.PrecomputeCacheType.TENSOR):
+        """svgp.py:210-240"""
+        return posteriors.create_posterior(self.kernel, self.inducing_variable, self.q_mu, self.q_sqrt,
+                                           whiten=self.whiten, mean_function=self.mean_function,
+                                           precompute_cache=precompute_cache)
+
+    def predict_f(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        """svgp.py:243-255"""
+        return self.posterior(posteriors.PrecomputeCacheType.NOCACHE).fused_predict_f(
+            Xnew, full_cov=full_cov, full_output_cov=full_output_cov)

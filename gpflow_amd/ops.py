@@ -253,6 +253,20 @@ def row_stats(At: torch.Tensor, *, V: Optional[torch.Tensor] = None, W: Optional
     return sumsq, mv, wsq
 
 
+def row_dot(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """out[i] = sum_j A[i,j] B[i,j]"""
+    lib = _lib.load()
+    _chk(A, "A", 2)
+    _chk(B, "B", 2)
+    if A.shape != B.shape:
+        raise ValueError("shape mismatch")
+    out = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
+    rc = lib.gpk_row_dot(_stream(), A.data_ptr(), _rowmajor(A, "A"), B.data_ptr(), _rowmajor(B, "B"),
+                         A.shape[0], A.shape[1], 1.0, 0.0, out.data_ptr())
+    _lib.check(rc, "gpk_row_dot")
+    return out
+
+
 def project(At: torch.Tensor, LqT: torch.Tensor) -> torch.Tensor:
     """ssq [P, rows] = sum_j (At Lq_p)[b, j]^2 with LqT [P, m, m] = tril(q_sqrt_p)^T."""
     lib = _lib.load()

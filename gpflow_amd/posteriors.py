@@ -1,0 +1,376 @@
+"""Posterior objects (gpflow/posteriors.py:97-114, 193-443, 640-887, 1039-1108): fused (no cache)
+and cached prediction for GPR and for the independent single-/multi-output SVGP posteriors."""
+from __future__ import annotations
+
+import enum
+from abc import ABC, abstractmethod
+from typing import Optional, Tuple, Type, Union
+
+import torch
+
+from . import config, covariances, ops
+from .base import Module
+from .conditionals import (Factor, base_conditional, conditional_tail, expand_independent_outputs,
+                           factor_with_rows, separate_independent_conditional_implementation)
+from .inducing_variables import (InducingPoints, InducingVariables,
+                                 SeparateIndependentInducingVariables,
+                                 SharedIndependentInducingVariables)
+from .kernels import Kernel, MultioutputKernel, SeparateIndependent, SharedIndependent
+
+
+class PrecomputeCacheType(enum.Enum):
+    """posteriors.py:97-114"""
+    TENSOR = "tensor"
+    VARIABLE = "variable"
+    NOCACHE = "nocache"
+
+
+def _validate_precompute_cache_type(value) -> PrecomputeCacheType:
+    """posteriors.py:146-160"""
+    if value is None:
+        return PrecomputeCacheType.NOCACHE
+    elif isinstance(value, PrecomputeCacheType):
+        return value
+    elif isinstance(value, str):
+        return PrecomputeCacheType(value.lower())
+    else:
+        raise ValueError(
+            f"{value} is not a valid PrecomputeCacheType."
+            " Valid options: 'tensor', 'variable', 'nocache' (or None).")
+
+
+def assert_params_false(called_method, **kwargs: bool) -> None:
+    """gpflow/utilities/model_utils.py:10-25"""
+    true_kwargs = {k for k, v in kwargs.items() if v}
+    if true_kwargs:
+        raise NotImplementedError(
+            f"{called_method.__name__} does not currently support: {' and '.join(sorted(true_kwargs))}")
+
+
+def _flatten_rows(Xnew: torch.Tensor):
+    """[..., T, D] -> ([prod*T, D], leading shape) (posteriors handle leading batch dims by
+    broadcasting, conditionals/util.py:108-124; here they become rows)."""
+    lead = tuple(Xnew.shape[:-1])
+    return Xnew.reshape(-1, Xnew.shape[-1]).contiguous(), lead
+
+
+class AbstractPosterior(Module, ABC):
+    """posteriors.py:193-358"""
+
+    def __init__(self, kernel, X_data, cache=None, mean_function=None) -> None:
+        self.kernel = kernel
+        self.X_data = X_data
+        self.cache = cache
+        self.mean_function = mean_function
+        self._precompute_cache: Optional[PrecomputeCacheType] = None
+
+    def _add_mean_function(self, Xnew, mean):
+        if self.mean_function is None:
+            return mean
+        return mean + self.mean_function(Xnew)
+
+    @abstractmethod
+    def _precompute(self) -> Tuple[torch.Tensor, ...]:
+        ...
+
+    def fused_predict_f(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        """Predictive mean and (co)variance at Xnew including the mean function; no cache."""
+        Xnew = ops.to_device(Xnew)
+        mean, cov = self._conditional_fused(Xnew, full_cov=full_cov, full_output_cov=full_output_cov)
+        return self._add_mean_function(Xnew, mean), cov
+
+    @abstractmethod
+    def _conditional_fused(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        ...
+
+    def predict_f(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        """Uses the precomputed cache (posteriors.py:285-299)."""
+        if self.cache is None:
+            raise ValueError(
+                "Cache has not been precomputed yet. Call update_cache first or use fused_predict_f")
+        Xnew = ops.to_device(Xnew)
+        mean, cov = self._conditional_with_precompute(self.cache, Xnew, full_cov=full_cov,
+                                                      full_output_cov=full_output_cov)
+        return self._add_mean_function(Xnew, mean), cov
+
+    @abstractmethod
+    def _conditional_with_precompute(self, cache, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        ...
+
+    def update_cache(self, precompute_cache: Optional[PrecomputeCacheType] = None) -> None:
+        """posteriors.py:322-358 (TENSOR and VARIABLE both hold device tensors here)."""
+        if precompute_cache is None:
+            if self._precompute_cache is None:
+                raise ValueError(
+                    "You must pass precompute_cache explicitly (the cache had not been updated before).")
+            precompute_cache = self._precompute_cache
+        else:
+            self._precompute_cache = precompute_cache
+        if precompute_cache is PrecomputeCacheType.NOCACHE:
+            self.cache = None
+        elif precompute_cache is PrecomputeCacheType.TENSOR:
+            self.cache = tuple(self._precompute())
+        elif precompute_cache is PrecomputeCacheType.VARIABLE:
+            new = tuple(self._precompute())
+            if self.cache is not None and len(self.cache) == len(new) and all(
+                    c.shape == n.shape for c, n in zip(self.cache, new)):
+                for c, n in zip(self.cache, new):
+                    c.copy_(n)  # re-use the existing buffers (tf.Variable.assign in the reference)
+            else:
+                self.cache = new
+
+
+class GPRPosterior(AbstractPosterior):
+    """posteriors.py:361-443"""
+
+    def __init__(self, kernel, data, likelihood, mean_function, *, precompute_cache) -> None:
+        X, Y = data
+        super().__init__(kernel, ops.to_device(X), mean_function=mean_function)
+        self.Y_data = ops.to_device(Y)
+        self.likelihood = likelihood
+        self._factor: Optional[Factor] = None
+        if precompute_cache is not None:
+            self.update_cache(precompute_cache)
+
+    def _err(self):
+        return self.Y_data - self.mean_function(self.X_data)
+
+    def _precompute(self):
+        """cache = (err, Lm) (posteriors.py:415-432); the block inverses stay alongside Lm."""
+        X = self.kernel.slice(self.X_data, None)[0]
+        n = X.shape[0]
+        Lm = torch.empty((n, n), dtype=torch.float64, device=X.device)
+        self.kernel.K_into(X, None, Lm, diag_add=self.likelihood.noise_variance(), lower_only=True)
+        invd, info = ops.potrf_(Lm, n, zero_upper=True)
+        ops.check_info(info)
+        self._factor = Factor(Lm, invd)
+        return self._err(), Lm
+
+    def _conditional_with_precompute(self, cache, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        """posteriors.py:384-409"""
+        assert_params_false(self._conditional_with_precompute, full_output_cov=full_output_cov)
+        err, Lm = cache
+        fac = self._factor if (self._factor is not None and self._factor.L is Lm) else Factor(
+            Lm, ops.trtri_blocks(Lm))
+        Xf, lead = _flatten_rows(Xnew)
+        if full_cov and len(lead) > 1:
+            raise NotImplementedError("full_cov with leading batch dimensions")
+        Xs, Xd = self.kernel.slice(Xf, self.X_data)
+        At = self.kernel.K_into(Xs, Xd, None)  # Kmn^T [T, N]
+        ops.trsm_(At, fac.L, fac.invd, trans=0)
+        Knn = self.kernel(Xf, full_cov=full_cov)
+        fmean, fvar = conditional_tail(At, fac, Knn, err, full_cov=full_cov, q_sqrt=None, white=False)
+        if len(lead) > 1:
+            fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
+        return fmean, fvar
+
+    def _conditional_fused(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        """posteriors.py:435-443: Cholesky redone on every call, as in the reference -- here fused
+        with the solve of Kmn (extra rows of one trapezoidal factorisation)."""
+        assert_params_false(self._conditional_fused, full_output_cov=full_output_cov)
+        Xf, lead = _flatten_rows(Xnew)
+        if full_cov and len(lead) > 1:
+            raise NotImplementedError("full_cov with leading batch dimensions")
+        Xs, Xd = self.kernel.slice(Xf, self.X_data)
+        n, t = Xd.shape[0], Xs.shape[0]
+        T = torch.empty((n + t, n), dtype=torch.float64, device=Xd.device)
+        self.kernel.K_into(Xd, None, T[:n], diag_add=self.likelihood.noise_variance(), lower_only=True)
+        self.kernel.K_into(Xs, Xd, T[n:])
+        invd, info = ops.potrf_(T, n, zero_upper=True)
+        ops.check_info(info)
+        fac = Factor(T[:n], invd)
+        Knn = self.kernel(Xf, full_cov=full_cov)
+        fmean, fvar = conditional_tail(T[n:], fac, Knn, self._err(), full_cov=full_cov, q_sqrt=None,
+                                       white=False)
+        if len(lead) > 1:
+            fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
+        return fmean, fvar
+
+
+class BasePosterior(AbstractPosterior):
+    """posteriors.py:640-746"""
+
+    def __init__(self, kernel, inducing_variable, q_mu, q_sqrt, whiten: bool = True, mean_function=None,
+                 *, precompute_cache):
+        super().__init__(kernel, inducing_variable, mean_function=mean_function)
+        self.whiten = whiten
+        self._set_qdist(q_mu, q_sqrt)
+        if precompute_cache is not None:
+            self.update_cache(precompute_cache)
+
+    @staticmethod
+    def _dev(v):
+        from .base import Parameter
+        if v is None:
+            return None
+        if isinstance(v, Parameter):
+            return v.device_value()
+        return ops.to_device(v)
+
+    def _set_qdist(self, q_mu, q_sqrt) -> None:
+        self._q_mu_src, self._q_sqrt_src = q_mu, q_sqrt
+
+    @property
+    def q_mu(self) -> torch.Tensor:
+        return self._dev(self._q_mu_src)
+
+    @property
+    def q_sqrt(self) -> Optional[torch.Tensor]:
+        return self._dev(self._q_sqrt_src)
+
+    def _precompute(self):
+        """alpha [M,L], Qinv [L,M,M] (posteriors.py:694-746) for [M,M] Kuu (single kernel)."""
+        Kuu = covariances.Kuu(self.X_data, self.kernel, jitter=config.default_jitter())
+        if Kuu.dim() != 2:
+            raise NotImplementedError("cached posterior for separate kernels: use fused_predict_f")
+        q_mu, q_sqrt = self.q_mu, self.q_sqrt
+        M, Lnum = q_mu.shape
+        fac, _ = factor_with_rows(Kuu, None)
+        LT, invdT = fac.transposed()
+        alphaT = ops.transpose(q_mu)  # [L, M] rows
+        if not self.whiten:
+            ops.trsm_(alphaT, fac.L, fac.invd, trans=0)  # L^-1 q_mu
+        ops.trsm_(alphaT, LT, invdT, trans=1)  # L^-T (.)
+        alpha = ops.transpose(alphaT)  # [M, L]
+        I = torch.eye(M, dtype=torch.float64, device=q_mu.device)
+        if q_sqrt is None:
+            Bs = I[None]
+        else:
+            qs = torch.diag_embed(q_sqrt.t().contiguous()) if q_sqrt.dim() == 2 else ops.transpose(
+                ops.transpose(q_sqrt, mode=1))  # tril(q_sqrt)
+            covs = []
+            for l in range(qs.shape[0]):
+                G = qs[l].contiguous()
+                if not self.whiten:
+                    Gt = ops.transpose(G)  # rows = q_sqrt^T
+                    ops.trsm_(Gt, fac.L, fac.invd, trans=0)  # (L^-1 q_sqrt)^T
+                    G = ops.transpose(Gt)
+                covs.append(ops.gemm_nt(G, G))  # (L^-1) S (L^-T)  or  S
+            Bs = I[None] - torch.stack(covs)
+        Qinv = []
+        for b in Bs:
+            Y = b.contiguous().clone()
+            ops.trsm_(Y, LT, invdT, trans=1)  # B L^-1
+            Yt = ops.transpose(Y)
+            ops.trsm_(Yt, LT, invdT, trans=1)  # (L^-T B L^-1)^T, symmetric
+            Qinv.append(Yt)
+        Qinv = torch.stack(Qinv)
+        if Qinv.shape[0] != Lnum:
+            Qinv = Qinv.expand(Lnum, M, M).contiguous()
+        return alpha, Qinv
+
+
+class IndependentPosterior(BasePosterior):
+    """posteriors.py:749-822"""
+
+    def _post_process_mean_and_cov(self, mean, cov, full_cov: bool, full_output_cov: bool):
+        return mean, expand_independent_outputs(cov, full_cov, full_output_cov)
+
+    def _get_Kff(self, Xnew, full_cov: bool):
+        if isinstance(self.kernel, SeparateIndependent):
+            return torch.stack([k(Xnew, full_cov=full_cov) for k in self.kernel.kernels], dim=0)
+        elif isinstance(self.kernel, MultioutputKernel):
+            return self.kernel.kernel(Xnew, full_cov=full_cov)
+        return self.kernel(Xnew, full_cov=full_cov)
+
+    def _conditional_with_precompute(self, cache, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        """posteriors.py:794-822 in the row-major form: mean = Kfu alpha, cov = Kff - rowdot(Kfu Qinv, Kfu)."""
+        alpha, Qinv = cache
+        Xf, lead = _flatten_rows(Xnew)
+        if full_cov and len(lead) > 1:
+            raise NotImplementedError("full_cov with leading batch dimensions")
+        Kfu = covariances.Kfu(self.X_data, self.kernel, Xf)
+        if Kfu.dim() != 2:
+            raise NotImplementedError("cached posterior for separate kernels: use fused_predict_f")
+        Kff = self._get_Kff(Xf, full_cov)
+        _, mean, _ = ops.row_stats(Kfu, V=alpha.contiguous(), want_sumsq=False)
+        Lnum = Qinv.shape[0]
+        covs = []
+        for l in range(Lnum):
+            W = ops.gemm_nt(Kfu, Qinv[l])  # Kfu Qinv (Qinv symmetric)
+            if full_cov:
+                covs.append(Kff - ops.gemm_nt(W, Kfu))
+            else:
+                covs.append(Kff - ops.row_dot(W, Kfu))
+        cov = torch.stack(covs, dim=0) if full_cov else torch.stack(covs, dim=-1)
+        if len(lead) > 1:
+            mean, cov = mean.reshape(*lead, -1), cov.reshape(*lead, -1)
+        return self._post_process_mean_and_cov(mean, cov, full_cov, full_output_cov)
+
+    # shared machinery of the fused paths ---------------------------------------------------------
+    def _fused_single_kernel(self, kernel: Kernel, Z: torch.Tensor, Xnew, full_cov: bool):
+        """Kuu (+jitter), Kuf and base_conditional for ONE kernel shared by all latents
+        (posteriors.py:828-841 / 849-861), as one trapezoidal factorisation built in place."""
+        Xf, lead = _flatten_rows(Xnew)
+        if full_cov and len(lead) > 1:
+            raise NotImplementedError("full_cov with leading batch dimensions")
+        Xs, Zs = kernel.slice(Xf, Z)
+        M, N = Zs.shape[0], Xs.shape[0]
+        T = torch.empty((M + N, M), dtype=torch.float64, device=Zs.device)
+        kernel.K_into(Zs, None, T[:M], diag_add=config.default_jitter(), lower_only=True)
+        kernel.K_into(Xs, Zs, T[M:])
+        invd, info = ops.potrf_(T, M, zero_upper=True)
+        ops.check_info(info)
+        Knn = kernel(Xf, full_cov=full_cov)
+        fmean, fvar = conditional_tail(T[M:], Factor(T[:M], invd), Knn, self.q_mu, full_cov=full_cov,
+                                       q_sqrt=self.q_sqrt, white=self.whiten)
+        if len(lead) > 1:
+            fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
+        return fmean, fvar
+
+
+class IndependentPosteriorSingleOutput(IndependentPosterior):
+    """posteriors.py:825-841"""
+
+    def _conditional_fused(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        fmean, fvar = self._fused_single_kernel(self.kernel, self.X_data.Z.device_value(), Xnew, full_cov)
+        return self._post_process_mean_and_cov(fmean, fvar, full_cov, full_output_cov)
+
+
+class IndependentPosteriorMultiOutput(IndependentPosterior):
+    """posteriors.py:844-887"""
+
+    def _conditional_fused(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
+        if isinstance(self.X_data, SharedIndependentInducingVariables) and isinstance(self.kernel, SharedIndependent):
+            fmean, fvar = self._fused_single_kernel(self.kernel.kernel,
+                                                    self.X_data.inducing_variable.Z.device_value(), Xnew,
+                                                    full_cov)
+        else:
+            Xf, lead = _flatten_rows(Xnew)
+            if len(lead) > 1:
+                raise NotImplementedError("leading batch dimensions with separate kernels")
+            Kmms = covariances.Kuu(self.X_data, self.kernel, jitter=config.default_jitter())  # [P,M,M]
+            Kmns = covariances.Kuf(self.X_data, self.kernel, Xf)  # [P,M,N]
+            if isinstance(self.kernel, SeparateIndependent):
+                kernel_list = self.kernel.kernels
+            else:
+                kernel_list = [self.kernel.kernel] * len(self.X_data.inducing_variable_list)
+            Knns = torch.stack([k.K(Xf) if full_cov else k.K_diag(Xf) for k in kernel_list], dim=0)
+            fmean, fvar = separate_independent_conditional_implementation(
+                Kmns, Kmms, Knns, self.q_mu, q_sqrt=self.q_sqrt, full_cov=full_cov, white=self.whiten)
+        return self._post_process_mean_and_cov(fmean, fvar, full_cov, full_output_cov)
+
+
+def get_posterior_class(kernel, inducing_variable) -> Type[BasePosterior]:
+    """posteriors.py:1039-1086 (rows on the path; everything else is out of scope)."""
+    if isinstance(kernel, (SharedIndependent, SeparateIndependent)):
+        if isinstance(inducing_variable, (SeparateIndependentInducingVariables,
+                                          SharedIndependentInducingVariables)):
+            return IndependentPosteriorMultiOutput
+        raise NotImplementedError(
+            "multi-output kernels with plain InducingPoints (FullyCorrelatedPosterior) are out of scope")
+    if isinstance(kernel, MultioutputKernel):
+        raise NotImplementedError(f"posterior for {type(kernel).__name__} is out of scope")
+    if isinstance(kernel, Kernel) and isinstance(inducing_variable, InducingVariables):
+        return IndependentPosteriorSingleOutput
+    raise NotImplementedError(
+        f"no posterior registered for ({type(kernel).__name__}, {type(inducing_variable).__name__})")
+
+
+def create_posterior(kernel, inducing_variable, q_mu, q_sqrt, whiten, mean_function=None,
+                     precompute_cache: Union[PrecomputeCacheType, str, None] = PrecomputeCacheType.TENSOR):
+    """posteriors.py:1089-1108"""
+    posterior_class = get_posterior_class(kernel, inducing_variable)
+    precompute_cache = _validate_precompute_cache_type(precompute_cache)
+    return posterior_class(kernel, inducing_variable, q_mu, q_sqrt, whiten, mean_function,
+                           precompute_cache=precompute_cache)

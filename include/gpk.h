@@ -109,6 +109,10 @@ int gpk_row_stats(void* stream, const double* At, int rows, int m, long ldat, co
                   double* wsq);
 int gpk_row_sumsq(void* stream, const double* A, int rows, int cols, long lda, double alpha,
                   double beta, double* out);
+/* out[i] = beta*out[i] + alpha * sum_j A[i,j] B[i,j]   (tf.reduce_sum(Kuf * matmul(Qinv, Kuf), -2),
+ * posteriors.py:818, in the row-major transposed form) */
+int gpk_row_dot(void* stream, const double* A, long lda, const double* B, long ldb, int rows,
+                int cols, double alpha, double beta, double* out);
 
 /* Projection onto the variational square roots (util.py:151-164, triangular-aware, never
  * materialises LTA):  ssq[p,b] = sum_j ( sum_k At[b,k] Lq_p[k,j] )^2

@@ -1,0 +1,330 @@
+"""GPU parity of the GPflow-surface layer (models / posteriors / conditionals / KL) against the oracle,
+plus the reference's own relational tests re-stated on this implementation.  Calls go
+Python host -> ctypes -> libgpk.so; fp64; tolerances per test."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as orc  # noqa: E402  (checker only)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def gp(gpu):
+    import gpflow_amd
+    return gpflow_amd
+
+
+# ---------------------------------------------------------------------------------------- GPR
+def _gpr_fixture():
+    """tests/gpflow/models/test_gpr.py:21-30 style data (RandomState(0), N=10, D=1)."""
+    rng = np.random.RandomState(0)
+    X = rng.randn(10, 1)
+    Y = np.sin(X) + 0.1 * rng.randn(10, 1)
+    return X, Y
+
+
+@pytest.mark.parametrize("N,D,P,ard", [(10, 1, 1, False), (512, 2, 1, False), (300, 5, 3, True)])
+def test_gpr_lml_and_predict(gp, N, D, P, ard):
+    rng = np.random.default_rng(1)
+    if N == 10:
+        X, Y = _gpr_fixture()
+    else:
+        X = rng.normal(size=(N, D))
+        Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P))
+    ls = (0.7 + 0.2 * np.arange(D)) if ard else 2.0
+    kern = gp.kernels.SquaredExponential(variance=1.3, lengthscales=ls)
+    m = gp.models.GPR((X, Y), kern, noise_variance=0.1)
+    kw = dict(variance=1.3, lengthscales=ls, noise_variance=0.1)
+    ref = orc.gpr_log_marginal_likelihood(X, Y, **kw)
+    np.testing.assert_allclose(float(m.log_marginal_likelihood()), ref, rtol=1e-10)
+    np.testing.assert_allclose(float(m.training_loss()), -ref, rtol=1e-10)
+    Xnew = rng.normal(size=(37, D))
+    mu, var = m.predict_f(Xnew)
+    mu_r, var_r = orc.gpr_predict_f(X, Y, Xnew, **kw)
+    np.testing.assert_allclose(_np(mu), mu_r, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(_np(var), var_r, rtol=0, atol=1e-9)
+    mu_c, var_c = m.predict_f(Xnew, full_cov=True)
+    mu_rc, var_rc = orc.gpr_predict_f(X, Y, Xnew, full_cov=True, **kw)
+    np.testing.assert_allclose(_np(var_c), var_rc, rtol=0, atol=1e-9)
+    # diag(full_cov) == var (tests/gpflow/models/test_model_predict.py:105-152)
+    np.testing.assert_allclose(np.stack([np.diag(c) for c in _np(var_c)], -1), _np(var), atol=1e-9)
+    # cached posterior == fused (tests/gpflow/models/test_gpr_posterior.py:42-73)
+    post = m.posterior()
+    mu2, var2 = post.predict_f(Xnew)
+    np.testing.assert_allclose(_np(mu2), _np(mu), atol=1e-9)
+    np.testing.assert_allclose(_np(var2), _np(var), atol=1e-9)
+    # predict_y = predict_f + sigma^2
+    my, vy = m.predict_y(Xnew)
+    np.testing.assert_allclose(_np(vy), _np(var) + 0.1, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        m.predict_f(Xnew, full_output_cov=True)
+    with pytest.raises(NotImplementedError):
+        m.predict_y(Xnew, full_cov=True)
+
+
+def test_gpr_batched_xnew_and_mean_function(gp):
+    rng = np.random.default_rng(2)
+    X = rng.normal(size=(40, 3)); Y = rng.normal(size=(40, 2))
+    m = gp.models.GPR((X, Y), gp.kernels.Matern52(lengthscales=1.1), mean_function=gp.mean_functions.Constant(0.3),
+                      noise_variance=0.2)
+    ref = orc.gpr_log_marginal_likelihood(X, Y, variance=1.0, lengthscales=1.1, noise_variance=0.2, mean=0.3,
+                                          kernel="Matern52")
+    np.testing.assert_allclose(float(m.log_marginal_likelihood()), ref, rtol=1e-10)
+    Xnew = rng.normal(size=(3, 5, 3))  # leading batch dims (tests/gpflow/models/test_gpr_posterior.py:36-39)
+    mu, var = m.predict_f(Xnew)
+    assert mu.shape == (3, 5, 2) and var.shape == (3, 5, 2)
+    mu_r, var_r = orc.gpr_predict_f(X, Y, Xnew.reshape(-1, 3), variance=1.0, lengthscales=1.1,
+                                    noise_variance=0.2, mean=0.3, kernel="Matern52")
+    np.testing.assert_allclose(_np(mu).reshape(-1, 2), mu_r, atol=1e-9)
+    np.testing.assert_allclose(_np(var).reshape(-1, 2), var_r, atol=1e-9)
+
+
+def test_gpr_not_pd_raises(gp):
+    from gpflow_amd._lib import GpkError
+    X = np.zeros((20, 1)); Y = np.zeros((20, 1))
+    lik = gp.likelihoods.Gaussian(variance=2e-6)
+    m = gp.models.GPR((X, Y), gp.kernels.RBF(), likelihood=lik)
+    # K = ones + 2e-6 I is numerically singular in fp64 -> must raise or give a finite value; a silent NaN is a bug
+    try:
+        v = float(m.log_marginal_likelihood())
+        assert np.isfinite(v)
+    except GpkError:
+        pass
+
+
+# ---------------------------------------------------------------------------------------- SVGP
+def _svgp_data(rng, N, D, P, M):
+    X = rng.normal(size=(N, D))
+    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P))
+    Z = X[:M] + 0.01 * rng.normal(size=(M, D))
+    q_mu = 0.3 * rng.normal(size=(M, P))
+    q_sqrt = np.stack([np.tril(0.1 * rng.normal(size=(M, M))) + 0.5 * np.eye(M) for _ in range(P)])
+    return X, Y, Z, q_mu, q_sqrt
+
+
+@pytest.mark.parametrize("whiten", [True, False])
+@pytest.mark.parametrize("q_diag", [False, True])
+@pytest.mark.parametrize("N,D,P,M", [(20, 1, 2, 3), (300, 4, 1, 150), (257, 3, 3, 130)])
+def test_svgp_elbo_predict(gp, whiten, q_diag, N, D, P, M):
+    rng = np.random.default_rng(3)
+    X, Y, Z, q_mu, q_sqrt = _svgp_data(rng, N, D, P, M)
+    if q_diag:
+        q_sqrt = np.abs(q_sqrt[:, np.arange(M), np.arange(M)]).T + 0.1  # [M,P]
+    ls = 0.9 * np.sqrt(D)
+    kern = gp.kernels.RBF(variance=1.2, lengthscales=ls)
+    m = gp.models.SVGP(kern, gp.likelihoods.Gaussian(0.1), Z, num_latent_gps=P, q_mu=q_mu, q_sqrt=q_sqrt,
+                       q_diag=q_diag, whiten=whiten, num_data=5 * N)
+    kw = dict(variance=1.2, lengthscales=ls)
+    ref = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt, noise_variance=0.1, whiten=whiten, num_data=5 * N, **kw)
+    np.testing.assert_allclose(float(m.elbo((X, Y))), ref, rtol=1e-9)
+    np.testing.assert_allclose(float(m.prior_kl()), orc.prior_kl(Z, q_mu, q_sqrt, whiten=whiten, **kw), rtol=1e-9)
+    Xnew = rng.normal(size=(29, D))
+    mu, var = m.predict_f(Xnew)
+    mu_r, var_r = orc.svgp_predict_f(Xnew, Z, q_mu, q_sqrt, whiten=whiten, **kw)
+    # Z sits on top of data rows: kappa(Kuu + 1e-6 I) ~ 1e6..1e7, and the unwhitened path applies
+    # Kuu^-1 twice, so two correct fp64 implementations differ by ~kappa*eps*|value| there.
+    tol = dict(atol=2e-9) if whiten else dict(rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(_np(mu), mu_r, **tol)
+    np.testing.assert_allclose(_np(var), var_r, **tol)
+    muc, varc = m.predict_f(Xnew, full_cov=True)
+    mu_rc, var_rc = orc.svgp_predict_f(Xnew, Z, q_mu, q_sqrt, whiten=whiten, full_cov=True, **kw)
+    np.testing.assert_allclose(_np(varc), var_rc, **tol)
+    # cached posterior vs fused (tests/gpflow/models/test_svgp_posterior.py:62-90)
+    post = m.posterior()
+    mu2, var2 = post.predict_f(Xnew)
+    np.testing.assert_allclose(_np(mu2), _np(mu), atol=1e-7)
+    np.testing.assert_allclose(_np(var2), _np(var), atol=1e-7)
+    a_r, Q_r = orc.svgp_precompute(Z, q_mu, q_sqrt, whiten=whiten, **kw)
+    np.testing.assert_allclose(_np(post.cache[0]), a_r, rtol=1e-6, atol=1e-8)
+    # conditional() is the same code path as fused_predict_f: bit-equal (tests/gpflow/posteriors/test_posteriors.py:179-180)
+    cm, cv = gp.conditionals.conditional(Xnew, m.inducing_variable, m.kernel, m.q_mu.device_value(),
+                                         q_sqrt=m.q_sqrt.device_value(), white=whiten)
+    fm, fv = m.posterior(gp.posteriors.PrecomputeCacheType.NOCACHE).fused_predict_f(Xnew)
+    np.testing.assert_array_equal(_np(cm), _np(fm))
+    np.testing.assert_array_equal(_np(cv), _np(fv))
+
+
+def test_svgp_qdiag_equals_diag_embedded_and_upper_ignored(gp):
+    """tests/gpflow/models/test_svgp.py:60-129 and test_kullback_leiblers.py:247-279."""
+    rng = np.random.default_rng(4)
+    X, Y, Z, q_mu, _ = _svgp_data(rng, 50, 2, 2, 7)
+    qd = rng.uniform(0.3, 0.9, size=(7, 2))
+    full = np.stack([np.diag(qd[:, p]) for p in range(2)])
+    noisy = full + np.triu(rng.normal(size=full.shape), 1)  # junk above the diagonal must be ignored
+    for whiten in (True, False):
+        vals = []
+        for qs, diag in ((qd, True), (full, False), (noisy, False)):
+            m = gp.models.SVGP(gp.kernels.RBF(lengthscales=1.3), gp.likelihoods.Gaussian(0.2), Z, q_mu=q_mu,
+                               q_sqrt=qs, q_diag=diag, whiten=whiten, num_latent_gps=2)
+            vals.append(float(m.elbo((X, Y))))
+        np.testing.assert_allclose(vals[0], vals[1], rtol=1e-10)
+        np.testing.assert_allclose(vals[1], vals[2], rtol=1e-10)
+    # the conditional / KL themselves must ignore the upper triangle of a raw tensor
+    from gpflow_amd import ops
+    iv = gp.inducing_variables.InducingPoints(Z)
+    k = gp.kernels.RBF(lengthscales=1.3)
+    a = gp.conditionals.conditional(X, iv, k, ops.to_device(q_mu), q_sqrt=ops.to_device(full), white=True)
+    b = gp.conditionals.conditional(X, iv, k, ops.to_device(q_mu), q_sqrt=ops.to_device(noisy), white=True)
+    np.testing.assert_allclose(_np(a[1]), _np(b[1]), atol=1e-12)
+    for K in (None, orc.Kuu(Z, variance=1.0, lengthscales=1.3, jitter=1e-6)):
+        np.testing.assert_allclose(float(gp.kullback_leiblers.gauss_kl(q_mu, full, K)),
+                                   float(gp.kullback_leiblers.gauss_kl(q_mu, noisy, K)), rtol=1e-12)
+
+
+def test_gauss_kl_variants(gp):
+    """tests/gpflow/test_kullback_leiblers.py:121-229 relations + oracle values."""
+    rng = np.random.RandomState(0)
+    M, L = 5, 4
+    q_mu = rng.randn(M, L)
+    q_sqrt = np.array([np.tril(rng.randn(M, M)) for _ in range(L)])
+    q_diag = rng.rand(M, L) + 0.2
+    A = rng.randn(M, M); K = A @ A.T + 1e-2 * np.eye(M)
+    Kb = np.stack([K + i * np.eye(M) for i in range(L)])
+    kl = gp.kullback_leiblers.gauss_kl
+    for qs in (q_sqrt, q_diag):
+        np.testing.assert_allclose(float(kl(q_mu, qs)), orc.gauss_kl(q_mu, qs), rtol=1e-12)
+        np.testing.assert_allclose(float(kl(q_mu, qs, K)), orc.gauss_kl(q_mu, qs, K), rtol=1e-10)
+        np.testing.assert_allclose(float(kl(q_mu, qs, Kb)), orc.gauss_kl(q_mu, qs, Kb), rtol=1e-10)
+        np.testing.assert_allclose(float(kl(q_mu, qs, K_cholesky=np.linalg.cholesky(K))),
+                                   float(kl(q_mu, qs, K)), rtol=1e-10)
+        np.testing.assert_allclose(float(kl(q_mu, qs, np.eye(M))), float(kl(q_mu, qs)), rtol=1e-10)
+    with pytest.raises(ValueError):
+        kl(q_mu, q_sqrt, K, K_cholesky=K)
+    # sum over columns == batch (test_kullback_leiblers.py:181-190)
+    tot = sum(float(kl(q_mu[:, i:i + 1], q_sqrt[i:i + 1], K)) for i in range(L))
+    np.testing.assert_allclose(tot, float(kl(q_mu, q_sqrt, K)), rtol=1e-10)
+
+
+def test_base_conditional_vs_explicit_inverse(gp):
+    """tests/gpflow/conditionals/test_conditionals.py:166-214 (Dy=5, N=4, M=3, Dx=2, Matern52(0.5))."""
+    rng = np.random.RandomState(0)
+    Dy, N, M, Dx = 5, 4, 3, 2
+    X, Z = rng.randn(N, Dx), rng.randn(M, Dx)
+    q_mu = rng.randn(M, Dy)
+    q_sqrt = np.tril(rng.randn(Dy, M, M))
+    k = gp.kernels.Matern52(lengthscales=0.5)
+    Kmm = orc.stationary_K("Matern52", Z, variance=1.0, lengthscales=0.5) + 1e-6 * np.eye(M)
+    Kmn = orc.stationary_K("Matern52", Z, X, variance=1.0, lengthscales=0.5)
+    Knn = orc.stationary_K("Matern52", X, variance=1.0, lengthscales=0.5)
+    Kinv = np.linalg.inv(Kmm)
+    S = np.einsum("rij,rkj->rik", q_sqrt, q_sqrt)
+    mean_ref = np.einsum("mn,mk,kr->nr", Kmn, Kinv, q_mu)
+    cov_ref = Knn[None] + np.einsum("mn,mk,rkl,lj,jp->rnp", Kmn, Kinv, S - Kmm[None], Kinv, Kmn)
+    iv = gp.inducing_variables.InducingPoints(Z)
+    mean, cov = gp.conditionals.conditional(X, iv, k, q_mu, q_sqrt=q_sqrt, white=False, full_cov=True)
+    np.testing.assert_allclose(_np(mean), mean_ref, atol=1e-7)
+    np.testing.assert_allclose(_np(cov), cov_ref, atol=1e-7)
+    mean2, var2 = gp.conditionals.conditional(X, iv, k, q_mu, q_sqrt=q_sqrt, white=False, full_cov=False)
+    np.testing.assert_allclose(_np(var2), np.stack([np.diag(c) for c in cov_ref], -1), atol=1e-7)
+    # base_conditional with materialised matrices, [M, batch..., N] Kmn
+    from gpflow_amd import ops
+    fm, fv = gp.conditionals.base_conditional(Kmn, Kmm, np.diag(Knn), q_mu, q_sqrt=q_sqrt, white=False)
+    np.testing.assert_allclose(_np(fm), mean_ref, atol=1e-7)
+    Lm = np.linalg.cholesky(Kmm)
+    fm2, fv2 = gp.conditionals.base_conditional_with_lm(Kmn, Lm, np.diag(Knn), q_mu, q_sqrt=q_sqrt, white=False)
+    np.testing.assert_allclose(_np(fv2), _np(fv), atol=1e-9)
+
+
+def test_whitened_equals_unwhitened_after_transform(gp):
+    """tests/gpflow/conditionals/test_conditionals.py:100-129: V = L^-1 mu, same predictions."""
+    rng = np.random.default_rng(5)
+    X, Y, Z, q_mu, q_sqrt = _svgp_data(rng, 60, 2, 2, 9)
+    Kuu = orc.Kuu(Z, variance=1.0, lengthscales=1.0, jitter=1e-6)
+    L = np.linalg.cholesky(Kuu)
+    V = np.linalg.solve(L, q_mu)
+    V_sqrt = np.stack([np.linalg.solve(L, q) for q in q_sqrt])
+    iv = gp.inducing_variables.InducingPoints(Z)
+    k = gp.kernels.RBF()
+    a = gp.conditionals.conditional(X, iv, k, q_mu, q_sqrt=q_sqrt, white=False)
+    b = gp.conditionals.conditional(X, iv, k, V, q_sqrt=V_sqrt, white=True)
+    np.testing.assert_allclose(_np(a[0]), _np(b[0]), atol=1e-8)
+    np.testing.assert_allclose(_np(a[1]), _np(b[1]), atol=1e-8)
+
+
+def test_gpr_equals_svgp_at_optimum(gp):
+    """tests/integration/test_method_equivalence.py:181-223 in closed form: with Z = X and the optimal
+    Gaussian q(u), the SVGP bound equals the GPR log marginal likelihood."""
+    rng = np.random.RandomState(0)
+    N = 20
+    X = rng.rand(N, 1) * 2; Y = np.sin(3 * X) + 0.3 * rng.randn(N, 1)
+    var, ls, nv = 1.3, 0.6, 0.09
+    K = orc.rbf_K(X, variance=var, lengthscales=ls) + 1e-6 * np.eye(N)
+    Sigma = np.linalg.inv(np.linalg.inv(K) + np.eye(N) / nv)
+    mu = Sigma @ (Y / nv)
+    q_sqrt = np.linalg.cholesky(Sigma)[None]
+    m = gp.models.SVGP(gp.kernels.RBF(variance=var, lengthscales=ls), gp.likelihoods.Gaussian(nv), X.copy(),
+                       q_mu=mu, q_sqrt=q_sqrt, whiten=False)
+    g = gp.models.GPR((X, Y), gp.kernels.RBF(variance=var, lengthscales=ls), noise_variance=nv)
+    np.testing.assert_allclose(float(m.elbo((X, Y))), float(g.log_marginal_likelihood()), rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------- multi-output
+def test_shared_independent_mok(gp):
+    """tests/gpflow/conditionals/test_multioutput.py:534-627 relation: SharedIndependent + shared IV ==
+    plain kernel + InducingPoints (same q), and both equal the oracle."""
+    rng = np.random.default_rng(6)
+    X, Y, Z, q_mu, q_sqrt = _svgp_data(rng, 120, 3, 4, 40)
+    ls = 1.5
+    m1 = gp.models.SVGP(gp.kernels.RBF(lengthscales=ls), gp.likelihoods.Gaussian(0.1), Z, q_mu=q_mu, q_sqrt=q_sqrt,
+                        num_latent_gps=4)
+    k2 = gp.kernels.SharedIndependent(gp.kernels.RBF(lengthscales=ls), output_dim=4)
+    iv2 = gp.inducing_variables.SharedIndependentInducingVariables(gp.inducing_variables.InducingPoints(Z))
+    m2 = gp.models.SVGP(k2, gp.likelihoods.Gaussian(0.1), iv2, q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=4)
+    ref = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt, variance=1.0, lengthscales=ls, noise_variance=0.1)
+    np.testing.assert_allclose(float(m1.elbo((X, Y))), ref, rtol=1e-9)
+    np.testing.assert_allclose(float(m2.elbo((X, Y))), ref, rtol=1e-9)
+    a, b = m1.predict_f(X[:10]), m2.predict_f(X[:10])
+    np.testing.assert_allclose(_np(a[0]), _np(b[0]), atol=1e-12)
+    np.testing.assert_allclose(_np(a[1]), _np(b[1]), atol=1e-12)
+    # full_output_cov shapes (posteriors.py:760-763)
+    mu, cov = m2.predict_f(X[:10], full_output_cov=True)
+    assert cov.shape == (10, 4, 4)
+    mu, cov = m2.predict_f(X[:6], full_cov=True, full_output_cov=True)
+    assert cov.shape == (6, 4, 6, 4)
+
+
+@pytest.mark.parametrize("whiten", [True, False])
+def test_separate_independent_mok(gp, whiten):
+    """SeparateIndependent kernels: batched [L,M,M] Cholesky + batched solves vs the oracle's map_fn loop."""
+    rng = np.random.default_rng(7)
+    X, Y, Z, q_mu, q_sqrt = _svgp_data(rng, 150, 2, 3, 140)
+    variances, lss = [1.0, 0.7, 1.4], [0.9, 1.3, 1.7]
+    kern = gp.kernels.SeparateIndependent([gp.kernels.RBF(variance=v, lengthscales=l) for v, l in zip(variances, lss)])
+    iv = gp.inducing_variables.SharedIndependentInducingVariables(gp.inducing_variables.InducingPoints(Z))
+    m = gp.models.SVGP(kern, gp.likelihoods.Gaussian(0.1), iv, q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=3,
+                       whiten=whiten, num_data=1000)
+    ref = orc.svgp_elbo_separate(X, Y, [Z] * 3, q_mu, q_sqrt, variances=variances, lengthscales_list=lss,
+                                 noise_variance=0.1, whiten=whiten, num_data=1000)
+    np.testing.assert_allclose(float(m.elbo((X, Y))), ref, rtol=1e-9)
+    iv2 = gp.inducing_variables.SeparateIndependentInducingVariables(
+        [gp.inducing_variables.InducingPoints(Z + 0.01 * i) for i in range(3)])
+    m2 = gp.models.SVGP(kern, gp.likelihoods.Gaussian(0.1), iv2, q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=3,
+                        whiten=whiten)
+    ref2 = orc.svgp_elbo_separate(X, Y, [Z + 0.01 * i for i in range(3)], q_mu, q_sqrt, variances=variances,
+                                  lengthscales_list=lss, noise_variance=0.1, whiten=whiten)
+    np.testing.assert_allclose(float(m2.elbo((X, Y))), ref2, rtol=1e-9)
+
+
+def test_golden_vectors(gp):
+    """The committed golden fixtures (tests/golden/*.npz, generated from the oracle on the reference's
+    own test fixtures) reproduce on the device."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hotpath_golden.npz"))
+    m = gp.models.GPR((g["gpr_X"], g["gpr_Y"]), gp.kernels.RBF(variance=float(g["gpr_var"]), lengthscales=float(g["gpr_ls"])),
+                      noise_variance=float(g["gpr_noise"]))
+    np.testing.assert_allclose(float(m.log_marginal_likelihood()), float(g["gpr_lml"]), rtol=1e-10)
+    mu, var = m.predict_f(g["gpr_Xnew"])
+    np.testing.assert_allclose(_np(mu), g["gpr_mu"], atol=1e-9)
+    np.testing.assert_allclose(_np(var), g["gpr_var_pred"], atol=1e-9)
+    for whiten in (0, 1):
+        s = gp.models.SVGP(gp.kernels.RBF(variance=float(g["svgp_var"]), lengthscales=float(g["svgp_ls"])),
+                           gp.likelihoods.Gaussian(float(g["svgp_noise"])), g["svgp_Z"], q_mu=g["svgp_q_mu"],
+                           q_sqrt=g["svgp_q_sqrt"], whiten=bool(whiten), num_latent_gps=2)
+        np.testing.assert_allclose(float(s.elbo((g["svgp_X"], g["svgp_Y"]))), float(g[f"svgp_elbo_w{whiten}"]), rtol=1e-9)
+    m1 = gp.models.GPR((g["c1_X"], g["c1_Y"]), gp.kernels.RBF(), noise_variance=0.1)
+    np.testing.assert_allclose(float(m1.log_marginal_likelihood()), float(g["c1_lml"]), rtol=1e-10)

@@ -1,0 +1,169 @@
+"""CPU: host-side logic of the GPflow surface (parameters, transforms, config, argument checking, error
+behaviour) and the C-ABI library itself (loads, exports every symbol include/gpk.h declares).  No
+compute calls: there is no GPU here and gpflow_amd has no CPU path."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    from gpflow_amd import _lib
+    if not os.path.exists(_lib.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "gpk.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gpk_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    from gpflow_amd import _lib
+    for name in declared:
+        assert hasattr(built_lib, name), f"libgpk.so lacks {name} declared in include/gpk.h"
+    # and the ctypes table binds exactly the declared interface
+    assert set(_lib.EXPORTED_SYMBOLS) == declared
+    assert built_lib.gpk_version().decode().startswith("gpk")
+    assert built_lib.gpk_invd_elems(300, 2) == 2 * 3 * 128 * 128
+    assert built_lib.gpk_svgp_elbo_workspace_bytes(2048, 8192, 8, 1, 0) > (2048 + 8192) * 2048 * 8
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    from gpflow_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_no_gpu_means_error_not_fallback(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import gpflow_amd as gpflow
+    from gpflow_amd._lib import GpkError
+    m_kernel = gpflow.kernels.RBF()
+    with pytest.raises(GpkError, match="no CPU path"):
+        m_kernel(np.zeros((3, 1)))
+    from gpflow_amd import ops
+    with pytest.raises(GpkError):
+        ops.kernel_matrix(torch.zeros(3, 1, dtype=torch.float64), None, variance=1.0, lengthscales=1.0)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under gpflow_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gpflow_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "gp_oracle" not in src, f
+
+
+def test_parameter_transforms():
+    from gpflow_amd.base import Parameter, positive, triangular
+    from oracle import gp_oracle as orc
+    p = Parameter(2.5, transform=positive())
+    np.testing.assert_allclose(p.numpy(), 2.5)
+    np.testing.assert_allclose(p.unconstrained_variable, orc.softplus_inverse(2.5))
+    p.assign(0.3)
+    np.testing.assert_allclose(p.numpy(), 0.3, rtol=1e-15)
+    q = Parameter(1.0, transform=positive(lower=1e-6))
+    np.testing.assert_allclose(q.unconstrained_variable, orc.positive_inverse(1.0, 1e-6))
+    # tests/gpflow/test_base.py:30-37: a value at/below the lower bound is rejected
+    with pytest.raises(ValueError, match="incompatible with this parameter's transform"):
+        Parameter(0.0, transform=positive(lower=1e-6))
+    with pytest.raises(ValueError):
+        q.assign(-1.0)
+    L = np.tril(np.arange(1.0, 10.0).reshape(3, 3))[None]
+    t = Parameter(L + np.triu(np.ones((1, 3, 3)), 1), transform=triangular())  # upper part dropped
+    np.testing.assert_array_equal(t.numpy(), L)
+    np.testing.assert_array_equal(t.unconstrained_variable, orc.fill_triangular_inverse(L))
+    e = Parameter(2.0, transform=positive(base="exp"))
+    np.testing.assert_allclose(e.unconstrained_variable, np.log(2.0))
+    pp = Parameter(p)
+    assert pp.transform is p.transform and pp.trainable
+
+
+def test_config():
+    from gpflow_amd import config
+    assert config.default_float() is np.float64
+    assert config.default_jitter() == 1e-6
+    assert config.default_likelihood_positive_minimum() == 1e-6
+    assert config.default_positive_bijector() == "softplus"
+    with config.as_context():
+        config.set_default_jitter(1e-3)
+        assert config.default_jitter() == 1e-3
+    assert config.default_jitter() == 1e-6
+    with pytest.raises(TypeError):
+        config.set_default_float(np.float32)
+    with pytest.raises(ValueError):
+        config.set_default_positive_bijector("nope")
+    with pytest.raises(ValueError):
+        config.set_default_jitter(-1.0)
+
+
+def test_model_construction_and_module_traversal():
+    import gpflow_amd as gpflow
+    k = gpflow.kernels.SquaredExponential(variance=2.0, lengthscales=[1.0, 3.0])
+    assert k.ard and gpflow.kernels.RBF is gpflow.kernels.SquaredExponential
+    with pytest.raises(TypeError, match="Unknown keyword argument"):
+        gpflow.kernels.SquaredExponential(foo=1)
+    with pytest.raises(ValueError, match="does not match size of ard parameter"):
+        gpflow.kernels.RBF(lengthscales=[1.0, 2.0], active_dims=[0, 1, 2])
+    lik = gpflow.likelihoods.Gaussian(0.5)
+    assert lik.noise_variance() == pytest.approx(0.5)
+    assert gpflow.likelihoods.Gaussian(scale=2.0).noise_variance() == pytest.approx(4.0)
+    with pytest.raises(AssertionError):
+        gpflow.likelihoods.Gaussian(1.0, scale=1.0)
+    with pytest.raises(ValueError):
+        gpflow.likelihoods.Gaussian(1e-7)  # below the 1e-6 lower bound
+    Z = np.random.default_rng(0).normal(size=(4, 2))
+    m = gpflow.models.SVGP(k, lik, Z, num_latent_gps=3)
+    assert m.q_mu.shape == (4, 3) and m.q_sqrt.shape == (3, 4, 4)
+    np.testing.assert_array_equal(m.q_sqrt.numpy()[1], np.eye(4))
+    md = gpflow.models.SVGP(k, lik, Z, num_latent_gps=2, q_diag=True)
+    assert md.q_sqrt.shape == (4, 2)
+    m2 = gpflow.models.SVGP(k, lik, gpflow.inducing_variables.InducingPoints(Z), q_mu=np.zeros((4, 5)),
+                            q_sqrt=np.stack([np.eye(4)] * 5))
+    assert m2.num_latent_gps == 5
+    names = set(gpflow.utilities.parameter_dict(m).keys())
+    assert {".kernel.variance", ".kernel.lengthscales", ".likelihood.variance", ".inducing_variable.Z", ".q_mu",
+            ".q_sqrt"} <= names
+    assert len(m.trainable_parameters) == 6
+    gpflow.set_trainable(m.kernel, False)
+    assert len(m.trainable_parameters) == 4
+    vals = gpflow.utilities.read_values(m)
+    gpflow.utilities.multiple_assign(m, {".kernel.variance": 3.0})
+    assert float(m.kernel.variance.numpy()) == pytest.approx(3.0) and vals[".kernel.variance"] == pytest.approx(2.0)
+    cls = gpflow.posteriors.get_posterior_class
+    iv = gpflow.inducing_variables.InducingPoints(Z)
+    assert cls(k, iv) is gpflow.posteriors.IndependentPosteriorSingleOutput
+    shared = gpflow.kernels.SharedIndependent(k, 3)
+    siv = gpflow.inducing_variables.SharedIndependentInducingVariables(iv)
+    assert cls(shared, siv) is gpflow.posteriors.IndependentPosteriorMultiOutput
+    with pytest.raises(NotImplementedError):
+        cls(shared, iv)
+    assert gpflow.posteriors._validate_precompute_cache_type("Tensor") is gpflow.posteriors.PrecomputeCacheType.TENSOR
+    assert gpflow.posteriors._validate_precompute_cache_type(None) is gpflow.posteriors.PrecomputeCacheType.NOCACHE
+    with pytest.raises(ValueError):
+        gpflow.posteriors._validate_precompute_cache_type(3)
+
+
+def test_shard_bounds():
+    from gpflow_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 8192, 8193):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
