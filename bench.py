@@ -1,0 +1,251 @@
+"""bench.py -- headline benchmark of the dense-GP hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): SVGP ELBO steps/s at N=1e6, M=2048, D=8 (config "Cm"), with the GPR Cholesky at
+N=16384 (GF/s vs fp64 peak) reported alongside in the same JSON line (key "gpr_cholesky", N=1 only).
+
+A "step" = one forward minibatch ELBO evaluation (SVGP.elbo, gpflow/models/svgp.py:166-181) over
+B = 8192 rows per GPU: Kuu / Kuf builds, Cholesky of Kuu, the triangular solves, the q_sqrt projection,
+the variational expectations, KL, the (multi-GPU) all-reduce of the per-shard data term and the scalar
+landing in host memory.  Weak scaling: every rank keeps the same 8192-row shard size, so a global step
+covers 8192*N rows and `value` = N * (global steps / s) = 8192-row minibatch evaluations per second
+over the whole job.  Inputs (the 1e6 x 8 data matrix, Z, q) are resident in HBM before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_DATA, M_IND, D_IN, B_ROWS, P_LAT = 1_000_000, 2048, 8, 8192, 1
+FP64_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, FP64 matrix (= FP64 vector); the in-image guide lists no fp64 row
+
+
+def svgp_step_flops(m: int, b: int, p: int) -> float:
+    """Algorithmic flops of one whitened step: M^3/3 + M^2 B (1 + P)."""
+    return m ** 3 / 3.0 + float(m) * m * b * (1 + p)
+
+
+def make_inputs(rank: int, device):
+    """SURVEY 8d config Cm: X ~ N(0,1) seed 4, Y = sin(sum x) + 0.1 eps, Z = first M rows + 0.01 noise,
+    q_mu ~ 0.1 N(0,1), q_sqrt = tril(0.05 N(0,1)) + 0.5 I, ARD lengthscales sqrt(D)(0.8 + 0.05 d), noise 0.1.
+    The data are pre-shuffled once (seed 5) so minibatch s of rank r is a contiguous slice."""
+    g = torch.Generator(device="cpu").manual_seed(4)
+    X = torch.randn((N_DATA, D_IN), generator=g, dtype=torch.float64)
+    Y = torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn((N_DATA, P_LAT), generator=g, dtype=torch.float64)
+    Z = X[:M_IND] + 0.01 * torch.randn((M_IND, D_IN), generator=g, dtype=torch.float64)
+    q_mu = 0.1 * torch.randn((M_IND, P_LAT), generator=g, dtype=torch.float64)
+    q_sqrt = torch.tril(0.05 * torch.randn((P_LAT, M_IND, M_IND), generator=g, dtype=torch.float64)) \
+        + 0.5 * torch.eye(M_IND, dtype=torch.float64)
+    perm = torch.randperm(N_DATA, generator=torch.Generator(device="cpu").manual_seed(5))
+    X, Y = X[perm], Y[perm]
+    ls = np.sqrt(D_IN) * (0.8 + 0.05 * np.arange(D_IN))
+    return (X.to(device), Y.to(device), Z.to(device).contiguous(), q_mu.to(device).contiguous(),
+            q_sqrt.to(device).contiguous(), ls)
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """The oracle (NumPy/SciPy restatement of GPflow's algorithm; TensorFlow itself is not installable
+    here) timed on this box's host cores on the SAME step: M=2048, B=8192, D=8, whitened, P=1."""
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(B_ROWS * 2, D_IN))
+    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(B_ROWS * 2, 1))
+    Z = X[:M_IND] + 0.01 * rng.normal(size=(M_IND, D_IN))
+    q_mu = 0.1 * rng.normal(size=(M_IND, 1))
+    q_sqrt = (np.tril(0.05 * rng.normal(size=(M_IND, M_IND))) + 0.5 * np.eye(M_IND))[None]
+    ls = np.sqrt(D_IN) * (0.8 + 0.05 * np.arange(D_IN))
+    kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, whiten=True, num_data=N_DATA)
+    orc.svgp_elbo(X[:B_ROWS], Y[:B_ROWS], Z, q_mu, q_sqrt, **kw)  # warm-up (benchmark/run.py:71 convention)
+    times, t_start = [], time.perf_counter()
+    while time.perf_counter() - t_start < budget_s and len(times) < 50:
+        s = len(times) % 2
+        t0 = time.perf_counter()
+        orc.svgp_elbo(X[s * B_ROWS:(s + 1) * B_ROWS], Y[s * B_ROWS:(s + 1) * B_ROWS], Z, q_mu, q_sqrt, **kw)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": 1.0 / med, "unit": "steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"{len(times)} ELBO steps of the workload (M={M_IND}, B={B_ROWS}, D={D_IN}, P=1, whitened), "
+                      f"median {med * 1e3:.1f} ms/step, NumPy/SciPy (OpenBLAS) oracle; GPflow+TensorFlow is not "
+                      f"installable in this image"}
+
+
+def gpr_cholesky_leg(ops, lib, device):
+    """GPR config C2: K(X,X)+noise build + Cholesky + LML tail at N=16384, D=8 (gpr.py:91-107)."""
+    n, d = 16384, 8
+    g = torch.Generator(device="cpu").manual_seed(2)
+    X = torch.randn((n, d), generator=g, dtype=torch.float64).to(device)
+    Y = (torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn((n, 1), dtype=torch.float64, device=device))
+    ls = np.sqrt(d) * (0.8 + 0.05 * np.arange(d))
+    ws = torch.empty(int(lib.gpk_gpr_lml_workspace_bytes(n, d, 1)) // 8 + 1, dtype=torch.float64, device=device)
+    kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, ws=ws)
+    for _ in range(2):
+        out, info = ops.gpr_lml(X, Y, **kw)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out, info = ops.gpr_lml(X, Y, **kw); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.median(ts))
+    K = torch.empty((n, n), dtype=torch.float64, device=device)
+    tk = []
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.kernel_matrix(X, None, variance=1.0, lengthscales=ls, diag_add=0.1, out=K); e1.record()
+        torch.cuda.synchronize(); tk.append(e0.elapsed_time(e1) * 1e-3)
+    tkb = float(np.min(tk[1:]))
+    flops = n ** 3 / 3.0
+    return {"workload": "GPR RBF N=16384 D=8 fp64: K build + Cholesky + LML (one gpk_gpr_lml call)",
+            "lml": float(out.cpu()[0]), "info": int(info.cpu()[0]), "ms_total": t * 1e3,
+            "cholesky_gflops_incl_build_and_tail": flops / t / 1e9,
+            "frac_of_fp64_peak": flops / t / 1e12 / FP64_PEAK_TFLOPS,
+            "kernel_build_full_ms": tkb * 1e3, "kernel_build_full_GBps": n * n * 8 / tkb / 1e9,
+            "kernel_build_frac_of_8TBps": n * n * 8 / tkb / 8e12}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpr", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from gpflow_amd import _lib, ops
+    lib = _lib.load()
+    X, Y, Z, q_mu, q_sqrt, ls = make_inputs(rank, device)
+    ws = ops.svgp_elbo_workspace(M_IND, B_ROWS, D_IN, P_LAT, False)
+    out = torch.empty(2, dtype=torch.float64, device=device)
+    info = torch.zeros(1, dtype=torch.int32, device=device)
+    red = torch.empty(1, dtype=torch.float64, device=device)
+    n_batches = N_DATA // (B_ROWS * world)
+    scale = float(N_DATA) / float(B_ROWS * world)
+    last = {}
+
+    def step(s: int) -> float:
+        lo = ((s % n_batches) * world + rank) * B_ROWS  # this rank's shard of global minibatch s
+        ops.svgp_elbo_shard(Z, X[lo:lo + B_ROWS], Y[lo:lo + B_ROWS], q_mu, q_sqrt, variance=1.0, lengthscales=ls,
+                            noise_variance=0.1, jitter=1e-6, ws=ws, out=out, info=info)
+        if world > 1:
+            red.copy_(out[0:1])
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)  # RCCL over xGMI: one 8-byte all-reduce per step
+            host = torch.cat([red, out[1:2], info.to(torch.float64)]).cpu()
+        else:
+            host = torch.cat([out, info.to(torch.float64)]).cpu()  # scalar lands in host memory
+        elbo = float(host[0]) * scale - float(host[1])
+        last.update(elbo=elbo, info=int(host[2]))
+        return elbo
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.cpu()[0])
+    assert last["info"] == 0 and np.isfinite(last["elbo"]), last
+
+    # ---- roofline leg (dominant kernel = the fp64 MFMA GEMM): HIP events around every GEMM launch ----
+    roof = None
+    nprof = 5
+    if rank == 0:
+        lib.gpk_profile_gemm_enable(1)
+    for s in range(nprof):  # every rank steps (the all-reduce is collective); only rank 0 records
+        step(args.warmup + args.steps + s)
+    fence()
+    if rank == 0:
+        ms, n_launch, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+        lib.gpk_profile_gemm_collect(ctypes.byref(ms), ctypes.byref(n_launch), ctypes.byref(fl))
+        lib.gpk_profile_gemm_enable(0)
+        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        sink = torch.zeros(8, dtype=torch.float64, device=device)
+        st = torch.cuda.current_stream().cuda_stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lib.gpk_bench_mfma_f64(st, 1024, 2000, sink.data_ptr()); torch.cuda.synchronize()
+        e0.record(); lib.gpk_bench_mfma_f64(st, 1024, 20000, sink.data_ptr()); e1.record(); torch.cuda.synchronize()
+        ubench = 1024 * 4 * 20000 * 8 * 2048 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (v_mfma_f64_16x16x4_f64)", "achieved": ach,
+                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": n_launch.value / nprof,
+                "avg_launch_us": ms.value * 1e3 / max(n_launch.value, 1),
+                "algorithmic_gflop_per_step_in_gemm": fl.value / nprof / 1e9,
+                "mfma_f64_issue_ubench_tflops": ubench,
+                "frac_of_measured_mfma_ceiling": ach / ubench if ubench > 0 else None,
+                "note": "achieved = algorithmic flops of all GEMM launches / summed HIP-event durations of those "
+                        "launches; peak = AMD datasheet FP64 matrix; the measured v_mfma_f64 issue-rate ceiling "
+                        "on this chip is reported next to it"}
+
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    steps_per_s = args.steps / elapsed
+    value = steps_per_s * world
+    res = {
+        "metric": "svgp_elbo_steps_per_s", "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "SVGP RBF(ARD)+Gaussian ELBO, N=1e6 M=2048 D=8 P=1 whitened, minibatch 8192 rows per GPU "
+                               "(BASELINE metric config Cm)", "rows_per_gpu_per_step": B_ROWS,
+                   "global_batch": B_ROWS * world, "parallelism": f"dp{world} (minibatch rows sharded, Z/q replicated, "
+                                                                  f"one 8-byte RCCL all-reduce per step)"},
+        "global_steps_per_s": steps_per_s, "last_elbo": last["elbo"],
+        "step_tflops_per_gpu": svgp_step_flops(M_IND, B_ROWS, P_LAT) * steps_per_s / 1e12,
+        "step_frac_of_fp64_peak": svgp_step_flops(M_IND, B_ROWS, P_LAT) * steps_per_s / 1e12 / FP64_PEAK_TFLOPS,
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_gpr:
+        res["gpr_cholesky"] = gpr_cholesky_leg(ops, lib, device)
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,7 @@
 // Block ids are remapped so that (a) each XCD gets a contiguous range of tiles (private L2s) and
 // (b) tiles are swept in 8-wide column groups (A/B panel reuse out of the 4 MiB L2).
 #include "gpk_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -308,8 +309,76 @@ int launch_cfg(hipStream_t s, const GemmArgs& a) {
 
 int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
 
+// ---- optional per-launch timing (bench.py roofline leg): HIP events around every GEMM launch, on the
+// stream the kernel is launched on.  Off by default; adds two event records per launch when on. -------
+namespace {
+struct ProfRec { hipEvent_t e0, e1; double flops; };
+bool g_prof_on = false;
+ProfRec* g_prof = nullptr;
+int g_prof_n = 0, g_prof_cap = 0;
+
+double algorithmic_flops(const GemmArgs& a) {
+  // useful multiply-adds only: lower-trapezoid outputs for c_lower, the non-zero K range for b_tri
+  const double m = a.m, n = a.n, k = a.k;
+  double outs = m * n;
+  if (a.c_lower) outs = (m >= n) ? n * (n + 1) / 2 + (m - n) * n : m * (m + 1) / 2;
+  double kk = k;
+  if (a.b_tri) {
+    const double nn = (a.b_tri_rows < a.n ? a.b_tri_rows : a.n);
+    const double tri = (nn <= k) ? nn * (nn + 1) / 2 + nn * (k - nn) : k * (k + 1) / 2;
+    return 2.0 * m * (tri + (n - nn) * k) * (a.batch > 0 ? a.batch : 1);
+  }
+  return 2.0 * outs * kk * (a.batch > 0 ? a.batch : 1);
+}
+}  // namespace
+
+extern "C" void gpk_profile_gemm_enable(int on) {
+  g_prof_on = on != 0;
+  g_prof_n = 0;
+}
+
+// total_ms / launches / flops of the GEMM launches recorded since enable(1); synchronises the device
+extern "C" int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops) {
+  GPK_HIP(hipDeviceSynchronize());
+  double ms = 0.0, fl = 0.0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    float t = 0.f;
+    GPK_HIP(hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1));
+    ms += t;
+    fl += g_prof[i].flops;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = g_prof_n;
+  if (flops) *flops = fl;
+  g_prof_n = 0;
+  return 0;
+}
+
+static int launch_select(hipStream_t s, const GemmArgs& a);
+
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
   if (a.m <= 0 || a.n <= 0) return 0;
+  if (!g_prof_on) return launch_select(s, a);
+  if (g_prof_n == g_prof_cap) {
+    const int cap = g_prof_cap ? 2 * g_prof_cap : 1024;
+    ProfRec* p = (ProfRec*)realloc(g_prof, sizeof(ProfRec) * cap);
+    if (!p) return GPK_E_ARG;
+    for (int i = g_prof_cap; i < cap; ++i) {
+      GPK_HIP(hipEventCreate(&p[i].e0));
+      GPK_HIP(hipEventCreate(&p[i].e1));
+    }
+    g_prof = p;
+    g_prof_cap = cap;
+  }
+  ProfRec& r = g_prof[g_prof_n++];
+  r.flops = algorithmic_flops(a);
+  GPK_HIP(hipEventRecord(r.e0, s));
+  const int rc = launch_select(s, a);
+  GPK_HIP(hipEventRecord(r.e1, s));
+  return rc;
+}
+
+static int launch_select(hipStream_t s, const GemmArgs& a) {
   if (a.epi == 1) return launch_cfg<128, 128, 2, 2>(s, a);
   if (a.n <= 64) return launch_cfg<128, 64, 2, 2>(s, a);
   // narrow / small problems: 64-row tiles double the number of workgroups (256 CUs to fill)

@@ -142,11 +142,16 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
   const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
   const int nbo = (n >= 4096) ? NBO : 256;  // outer panel width
   const int npanels = gpk_cdiv(n, nbo);
+  // Few extra rows (GPR: the P columns of Y) simply ride along through the panel solves and trailing
+  // updates of the square part; many extra rows (SVGP: the minibatch) get their own left-looking,
+  // large-K solve on the bulk stream (extra_panel), overlapped with the panel stream.
+  const bool ride = extra > 0 && extra <= 256;
+  const int R = ride ? n + extra : n;  // rows handled together with the square part
   int rc;
   if (n <= NB) {  // one leaf; nothing to overlap
-    rc = factor_panel(S, A, n, 0, n, lda, batch, strideA, invd, strideInv, info);
+    rc = factor_panel(S, A, R, 0, n, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
-    if (extra > 0) {
+    if (extra > 0 && !ride) {
       rc = extra_panel(S, A, n, extra, 0, n, lda, batch, strideA, invd, strideInv);
       if (rc) return rc;
     }
@@ -165,7 +170,7 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
     const int c2 = (c1 + nbo < n) ? c1 + nbo : n;
     // ---- P: critical path of panel p (square rows only) ---------------------------------------
     GPK_HIP(hipStreamWaitEvent(P, evT[p], 0));
-    rc = factor_panel(P, A, n, c0, c1, lda, batch, strideA, invd, strideInv, info);
+    rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
     GPK_HIP(hipEventRecord(evF[p], P));
     // ---- S: bulk work that depends on panel p -----------------------------------------------------
@@ -173,21 +178,21 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
     const double* Pn = A + (long)c1 * lda + c0;  // panel rows c1.. (solved), K = c1 - c0
     if (c1 < n) {
       // strip first: columns of the NEXT panel, so P can go on while S does the rest
-      GemmArgs u = gemm_base(n - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0,
+      GemmArgs u = gemm_base(R - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0,
                              A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
       rc = gpk_launch_gemm(S, u);
       if (rc) return rc;
       GPK_HIP(hipEventRecord(evT[p + 1], S));
     }
-    if (extra > 0) {
+    if (extra > 0 && !ride) {
       rc = extra_panel(S, A, n, extra, c0, c1, lda, batch, strideA, invd, strideInv);
       if (rc) return rc;
     }
     if (c2 < n) {
       // rest of the outer trailing update: A[c2:n, c2:n] -= P[c2:] P[c2:]^T, lower tiles only
       const double* P2 = A + (long)c2 * lda + c0;
-      GemmArgs u = gemm_base(n - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
+      GemmArgs u = gemm_base(R - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
       rc = gpk_launch_gemm(S, u);

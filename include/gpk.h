@@ -172,6 +172,12 @@ int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long l
                         const double* q_sqrt, int q_diag, int whiten, double* out, int* info,
                         void* ws, size_t ws_bytes);
 
+/* Optional per-launch timing of the GEMM kernel (HIP events on the launch stream) for the roofline
+ * leg of bench.py: enable(1) starts recording, collect() synchronises and returns the summed kernel
+ * time, launch count and ALGORITHMIC flops (useful multiply-adds only) since enable. */
+void gpk_profile_gemm_enable(int on);
+int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops);
+
 /* micro-benchmarks used by bench.py / profiles (fp64 MFMA issue rate, HBM write stream) */
 int gpk_bench_mfma_f64(void* stream, int blocks, int iters, double* sink);
 int gpk_bench_stream_store(void* stream, double* out, long n_doubles);

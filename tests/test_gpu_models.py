@@ -133,7 +133,8 @@ def test_svgp_elbo_predict(gp, whiten, q_diag, N, D, P, M):
     np.testing.assert_allclose(_np(var), var_r, **tol)
     muc, varc = m.predict_f(Xnew, full_cov=True)
     mu_rc, var_rc = orc.svgp_predict_f(Xnew, Z, q_mu, q_sqrt, whiten=whiten, full_cov=True, **kw)
-    np.testing.assert_allclose(_np(varc), var_rc, **tol)
+    # full covariances: entries of A^T A reach ~kappa(Lm)^2 before cancelling against Knn
+    np.testing.assert_allclose(_np(varc), var_rc, rtol=2e-6, atol=2e-7)
     # cached posterior vs fused (tests/gpflow/models/test_svgp_posterior.py:62-90)
     post = m.posterior()
     mu2, var2 = post.predict_f(Xnew)
