@@ -16,6 +16,7 @@
 // (b) tiles are swept in 8-wide column groups (A/B panel reuse out of the 4 MiB L2).
 #include "gpk_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -31,6 +32,54 @@ struct TileCfg {
   static constexpr int B_CH = BN * (BK / 2) / 256;
   static constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDSS * sizeof(double);
 };
+
+// ---- XCD-contiguous + column-grouped tile order -------------------------------------------------
+// Tiles are numbered group-of-8-columns major, row-major inside a group; each XCD takes a
+// contiguous 1/8 of that sequence.  With c_lower (and square tiles) only the tiles on or below
+// the diagonal are numbered, so every XCD gets the same amount of work.
+__device__ __forceinline__ void tile_order(int b_tri, int gx, int gy, int total, int compact, int& tile_m,
+                                           int& tile_n) {
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, local = lin >> 3;
+  const int q = total >> 3, r = total & 7;
+  int nl = xcd * q + (xcd < r ? xcd : r) + local;
+  // triangular-K work (b_tri = 1, many column tiles) is heaviest in the first column groups:
+  // keep plain round-robin there so all XCDs walk the groups together, heaviest first
+  if (b_tri == 1 && gx > GROUP_N) nl = lin;
+  tile_m = 0; tile_n = 0;
+  if (compact) {
+    int g = 0;
+    for (;; ++g) {
+      const int first = g * GROUP_N;
+      const int gsz = (gx - first) < GROUP_N ? (gx - first) : GROUP_N;
+      const int avail = gy - first;
+      const int tr = avail < gsz ? avail : gsz;
+      const int cnt = tr * (tr + 1) / 2 + (avail > gsz ? (avail - gsz) * gsz : 0);
+      if (nl < cnt) {
+        int ro = 0, co = nl;
+        const int tri = gsz * (gsz + 1) / 2;
+        if (nl < tri) {
+          while (co > ro) { co -= ro + 1; ++ro; }
+        } else {
+          const int w = nl - tri;
+          ro = gsz + w / gsz;
+          co = w - (w / gsz) * gsz;
+        }
+        tile_m = first + ro;
+        tile_n = first + co;
+        break;
+      }
+      nl -= cnt;
+    }
+  } else {
+    const int gspan = GROUP_N * gy;
+    const int group = nl / gspan, within = nl - group * gspan;
+    const int first_n = group * GROUP_N;
+    const int gsz = (gx - first_n) < GROUP_N ? (gx - first_n) : GROUP_N;
+    tile_n = first_n + within % gsz;
+    tile_m = within / gsz;
+  }
+}
 
 __device__ __forceinline__ d2 load2(const double* __restrict__ base, long ld, int row, int nrows,
                                     int k, int ke, bool vec_ok) {
@@ -58,52 +107,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
   const int wm = wave / WGN, wn = wave % WGN;
   const int bz = blockIdx.y;
 
-  // ---- XCD-contiguous + column-grouped tile order -------------------------------------------
-  // Tiles are numbered group-of-8-columns major, row-major inside a group; each XCD takes a
-  // contiguous 1/8 of that sequence.  With c_lower (and square tiles) only the tiles on or below
-  // the diagonal are numbered, so every XCD gets the same amount of work.
   int tile_m, tile_n;
-  {
-    const int lin = blockIdx.x;
-    const int xcd = lin & 7, local = lin >> 3;
-    const int q = total >> 3, r = total & 7;
-    int nl = xcd * q + (xcd < r ? xcd : r) + local;
-    // triangular-K work (b_tri = 1, many column tiles) is heaviest in the first column groups:
-    // keep plain round-robin there so all XCDs walk the groups together, heaviest first
-    if (p.b_tri == 1 && gx > GROUP_N) nl = lin;
-    if (compact) {
-      int g = 0;
-      for (;; ++g) {
-        const int first = g * GROUP_N;
-        const int gsz = (gx - first) < GROUP_N ? (gx - first) : GROUP_N;
-        const int avail = gy - first;
-        const int tr = avail < gsz ? avail : gsz;
-        const int cnt = tr * (tr + 1) / 2 + (avail > gsz ? (avail - gsz) * gsz : 0);
-        if (nl < cnt) {
-          int ro = 0, co = nl;
-          const int tri = gsz * (gsz + 1) / 2;
-          if (nl < tri) {
-            while (co > ro) { co -= ro + 1; ++ro; }
-          } else {
-            const int w = nl - tri;
-            ro = gsz + w / gsz;
-            co = w - (w / gsz) * gsz;
-          }
-          tile_m = first + ro;
-          tile_n = first + co;
-          break;
-        }
-        nl -= cnt;
-      }
-    } else {
-      const int gspan = GROUP_N * gy;
-      const int group = nl / gspan, within = nl - group * gspan;
-      const int first_n = group * GROUP_N;
-      const int gsz = (gx - first_n) < GROUP_N ? (gx - first_n) : GROUP_N;
-      tile_n = first_n + within % gsz;
-      tile_m = within / gsz;
-    }
-  }
+  tile_order(p.b_tri, gx, gy, total, compact, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (p.c_lower && n0 > m0 + BM - 1) return;
 
@@ -274,6 +279,269 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
   }
 }
 
+
+// =====================================================================================================
+// Fast path: 128 x 128 x 16 tiles, every K range a multiple of 16, 16-byte aligned rows.
+//
+// v_mfma_f64_16x16x4_f64 occupies a SIMD's matrix pipe for 64 cycles (measured: 77.4 TFLOP/s chip-wide
+// from ONE wave per SIMD, tools/ubench_f64.hip), so a wave has ~16 issue slots per MFMA for everything
+// else and the only way to lose throughput is to let the pipe run dry.  The loop is therefore a
+// software pipeline in which no MFMA ever waits for data requested in the same phase:
+//   * global -> VGPR loads of slab s+1 are issued at the top of slab s (a full slab = 4096 cycles early),
+//   * MFMA fragments are double-buffered in registers: the 8 ds_read_b64 of step kk+1 are issued before
+//     the 16 MFMAs of step kk,
+//   * the VGPR -> LDS stores of slab s+1 are interleaved one-per-MFMA into step kk=2, the workgroup
+//     barrier sits between steps 2 and 3, and step 3 (whose fragments were fetched before the barrier)
+//     covers the LDS latency of the first fragments of slab s+1.
+// With beta != 0 the accumulators start as (beta/alpha) C, loaded in the prologue next to the first
+// slab, so the epilogue is store-only.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int gy, int total, int compact) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int BUF = (BM + BN) * LDSS;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bz = blockIdx.y;
+  int tile_m, tile_n;
+  tile_order(p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (p.c_lower && n0 > m0 + BM - 1) return;
+
+  const double* __restrict__ A = p.A + (long)bz * p.strideA;
+  const double* __restrict__ B = p.B + (long)bz * p.strideB;
+  int kb = 0, ke = p.k;
+  if (p.b_tri && n0 + BN <= p.b_tri_rows) {
+    if (p.b_tri == 1) {
+      const int f = n0 + p.b_tri_off;
+      kb = (f > 0 ? f : 0) & ~(BK - 1);
+    } else {
+      const int l = n0 + BN + p.b_tri_off;
+      ke = l < p.k ? l : p.k;
+    }
+  }
+  const int nk = ke > kb ? (ke - kb) / BK : 0;
+
+  // ---- staging: thread t moves 16 B of row (t>>3) + 32 q, k offset 2 (t&7), for A and for B -----
+  // addresses = wave-uniform 64-bit base (advanced per slab) + per-thread 32-bit byte offset
+  const int srow = tid >> 3, scol = (tid & 7) * 2;
+  const int mrows = p.m - m0, nrows = p.n - n0;  // rows of this tile that exist (clamp the rest)
+  const char* abase = reinterpret_cast<const char*>(A + (long)m0 * p.lda + kb);
+  const char* bbase = reinterpret_cast<const char*>(B + (long)n0 * p.ldb + kb);
+  unsigned oa[4], ob[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int ra = srow + 32 * q, rb = srow + 32 * q;
+    ra = ra < mrows ? ra : mrows - 1;  // clamped rows only feed outputs that are never stored
+    rb = rb < nrows ? rb : nrows - 1;
+    oa[q] = (unsigned)(((long)ra * p.lda + scol) * 8);
+    ob[q] = (unsigned)(((long)rb * p.ldb + scol) * 8);
+  }
+  const int woff = srow * LDSS + scol;
+  d2 st[8];
+  auto gload = [&](int s) {
+    const char* ab = abase + (long)s * (BK * 8);
+    const char* bb = bbase + (long)s * (BK * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st[q] = *reinterpret_cast<const d2*>(ab + oa[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st[4 + q] = *reinterpret_cast<const d2*>(bb + ob[q]);
+  };
+  auto lstore1 = [&](int buf, int q) {
+    const int row = (q < 4) ? 32 * q : BM + 32 * (q - 4);
+    *reinterpret_cast<d2*>(&smem[buf * BUF + row * LDSS + woff]) = st[q];
+  };
+
+  d4 acc[4][4];
+  const int row_base = m0 + wm * 64 + (lane >> 4);
+  const int col_base = n0 + wn * 64 + (lane & 15);
+  const bool load_c = (EPI == 0) && (p.beta != 0.0);
+  if (nk > 0) gload(0);
+  if (load_c) {
+    const double* __restrict__ C = p.C + (long)bz * p.strideC;
+    const double sc = p.beta / p.alpha;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row_base + i * 16 + 4 * r;
+        row = row < p.m ? row : p.m - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int col = col_base + j * 16;
+          col = col < p.n ? col : p.n - 1;
+          acc[i][j][r] = sc * C[(long)row * p.ldc + col];
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+
+  const double* as = smem + (wm * 64 + (lane & 15)) * LDSS + (lane >> 4);
+  const double* bs = smem + (BM + wn * 64 + (lane & 15)) * LDSS + (lane >> 4);
+  double fa[2][4], fb[2][4];
+  auto fload = [&](int buf, int kk, int f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[f][i] = as[buf * BUF + i * 16 * LDSS + kk * 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[f][j] = bs[buf * BUF + j * 16 * LDSS + kk * 4];
+  };
+#define GPK_MFMA_ROW(f, i)                                                                         \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] =                                       \
+      __builtin_amdgcn_mfma_f64_16x16x4f64(fa[f][i], fb[f][j], acc[i][j], 0, 0, 0)
+
+  if (nk > 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lstore1(0, q);
+    __syncthreads();
+    fload(0, 0, 0);
+  }
+  // one K slab; MORE = another slab follows (its loads / LDS stores / first fragments ride along)
+  auto slab = [&](int s, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const int cur = s & 1;
+    // ---- kk = 0 ------------------------------------------------------------------------------
+    if constexpr (MORE) gload(s + 1);
+    fload(cur, 1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { GPK_MFMA_ROW(0, i); }
+    if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);  // 8 global loads
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                      // 8 fragment reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                     // 16 MFMA
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- kk = 1 ------------------------------------------------------------------------------
+    fload(cur, 2, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { GPK_MFMA_ROW(1, i); }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- kk = 2: also park slab s+1 in the other LDS buffer, one store per MFMA -------------------
+    fload(cur, 3, 1);
+    if constexpr (MORE) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lstore1(cur ^ 1, q);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { GPK_MFMA_ROW(0, i); }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    if constexpr (MORE) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 DS write
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MORE) __syncthreads();
+    // ---- kk = 3 (fragments fetched before the barrier) hides the first reads of slab s+1 -------------
+    if constexpr (MORE) fload(cur ^ 1, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { GPK_MFMA_ROW(1, i); }
+    if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int s = 0; s + 1 < nk; ++s) slab(s, std::true_type{});
+  if (nk > 0) slab(nk - 1, std::false_type{});
+#undef GPK_MFMA_ROW
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  if constexpr (EPI == 0) {
+    double* __restrict__ C = p.C + (long)bz * p.strideC;
+    const double alpha = p.alpha;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row_base + i * 16 + 4 * r;
+        if (row < p.m) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int col = col_base + j * 16;
+            if (col < p.n) C[(long)row * p.ldc + col] = alpha * acc[i][j][r];
+          }
+        }
+      }
+  } else {
+    double* __restrict__ C2 = p.C2 + (long)bz * p.strideC2;
+    double* __restrict__ part = p.part + (long)bz * p.stridePart;
+    const double alpha = p.alpha;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row_base + i * 16 + 4 * r;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = col_base + j * 16;
+          const double v = alpha * acc[i][j][r];
+          if (col < p.sq_cols) {
+            s += v * v;
+          } else if (row < p.m && col - p.sq_cols < p.c2_cols && col < p.n) {
+            C2[(long)row * p.ldc2 + (col - p.sq_cols)] = v;
+          }
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        if ((lane & 15) == 0 && row < p.m) part[(long)(tile_n * 2 + wn) * p.part_ld + row] = s;
+      }
+  }
+}
+
+template <int EPI>
+int launch_fast(hipStream_t s, const GemmArgs& a) {
+  constexpr size_t LDS_BYTES = 2 * (size_t)256 * LDSS * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    attr_set = true;
+  }
+  const int gx = gpk_cdiv(a.n, 128), gy = gpk_cdiv(a.m, 128);
+  if (gx <= 0 || gy <= 0) return 0;
+  int total = gx * gy, compact = 0;
+  if (a.c_lower && EPI == 0) {
+    compact = 1;
+    total = 0;
+    for (int first = 0; first < gx; first += GROUP_N) {
+      const int gsz = (gx - first) < GROUP_N ? (gx - first) : GROUP_N;
+      const int avail = gy - first;
+      if (avail <= 0) break;
+      const int tr = avail < gsz ? avail : gsz;
+      total += tr * (tr + 1) / 2 + (avail > gsz ? (avail - gsz) * gsz : 0);
+    }
+    if (total <= 0) return 0;
+  }
+  dim3 grid((unsigned)total, (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  hipLaunchKernelGGL((gemm_nt_fast<EPI>), grid, dim3(256), LDS_BYTES, s, a, gx, gy, total, compact);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+// 16-byte aligned rows and K ranges that are multiples of 16 everywhere (per-tile b_tri ranges too)
+bool fast_ok(const GemmArgs& a) {
+  static const bool disabled = getenv("GPK_GEMM_NO_FAST") != nullptr;
+  if (disabled) return false;
+  if (a.k <= 0 || (a.k & 15) || (a.b_tri && (a.b_tri_off & 15))) return false;
+  if ((a.lda & 1) || (a.ldb & 1) || (a.strideA & 1) || (a.strideB & 1)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
+  if (a.epi == 0 && a.beta != 0.0 && a.alpha == 0.0) return false;
+  if (a.lda > (1L << 21) || a.ldb > (1L << 21)) return false;  // 32-bit byte offsets inside a tile
+  return true;
+}
+
 template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(hipStream_t s, const GemmArgs& a) {
   using Cfg = TileCfg<BM, BN, WGM, WGN>;
@@ -379,6 +647,10 @@ int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
 }
 
 static int launch_select(hipStream_t s, const GemmArgs& a) {
+  const long tiles = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
+  if (fast_ok(a) && (a.epi == 1 || (a.n > 64 && (tiles >= 192 || a.m <= 64)))) {
+    return a.epi == 1 ? launch_fast<1>(s, a) : launch_fast<0>(s, a);
+  }
   if (a.epi == 1) return launch_cfg<128, 128, 2, 2>(s, a);
   if (a.n <= 64) return launch_cfg<128, 64, 2, 2>(s, a);
   // narrow / small problems: 64-row tiles double the number of workgroups (256 CUs to fill)

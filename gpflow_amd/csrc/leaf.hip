@@ -1,26 +1,38 @@
-// Diagonal-block kernel of the blocked Cholesky (NB = 128): one workgroup (4 waves) factors
-// A = L L^T and, in the same sweep, forms X = L^-1, which turns the panel solve into a plain MFMA
-// GEMM  A21 * X^T.  Replaces the innermost part of tf.linalg.cholesky (gpr.py:102,
-// conditionals/util.py:67, kullback_leiblers.py:107, posteriors.py:422,703).
+// Diagonal-block kernel of the blocked Cholesky (NB = 128): one workgroup (8 waves) factors
+// A = L L^T and forms X = L^-1, which turns every panel solve into a plain MFMA GEMM  A21 * X^T.
+// Replaces the innermost part of tf.linalg.cholesky (gpr.py:102, conditionals/util.py:67,
+// kullback_leiblers.py:107, posteriors.py:422,703).  This kernel IS the critical path of the
+// factorisation (serial in the 128 pivots), so it is organised around latency, not throughput.
 //
-// The whole block lives in LDS (128 x 130 doubles = 130 KB): L in the lower triangle, the running
-// inverse stored TRANSPOSED in the strict upper triangle (exactly the [n][k] layout the NT MFMA
-// fragments want) and its diagonal in a side array.  Right-looking over 16-column sub-blocks k:
-//   A. wave 0: 16x16 Cholesky + inverse of the diagonal sub-block in registers (lane = row,
-//      cross-lane traffic by v_readlane; rsqrt = v_rsq_f64 + 2 Newton steps) -- the serial chain;
-//   B. all waves (v_mfma_f64_16x16x4): X_kj = X_kk W_kj (j<k) and L_ik = A_ik X_kk^T (i>k);
-//   C. all waves: for i>k:  A_ij -= L_ik L_jk^T (k<j<=i),  W_ik = -L_ik X_kk,  W_ij -= L_ik X_kj (j<k)
-// i.e. the row operations of [L | I] -> [I | L^-1] ride along with the trailing update.
+// The block lives in LDS (128 x 130 doubles): L in the lower triangle, the off-diagonal 16x16 tiles of
+// X stored TRANSPOSED in the strict upper triangle, the eight diagonal 16x16 tiles of X dense in a side
+// buffer.  Right-looking over 16-column sub-blocks k:
+//   diag  wave 0 factors the 16x16 diagonal tile and inverts it ENTIRELY IN REGISTERS with
+//         v_mfma_f64_16x16x4_f64: a symmetric tile held in the MFMA C/D layout (lane (c,g), reg e <->
+//         S[g+4e][c] = S[c][g+4e]) is, register e = p, already the A- and the B-operand of the 4-column
+//         panel p, so a panel step is: gather the 4x4 pivot block (v_readlane), factor/invert it with
+//         scalar-valued VALU math (the 4 rsqrt chains are the inherent serial part), then four MFMAs
+//         (scale the panel, new rows of X, rank-4 update of S, row operations on X) with no data movement.
+//   B     all waves:  L_ik = A_ik X_kk^T  (i > k), one 16x16x16 tile product each.
+//   C     waves 1..7: A_ij -= L_ik L_jk^T (k < j <= i); wave 0 takes tile (k+1,k+1) first and goes
+//         straight on to the next diagonal tile, so the pivot chain overlaps the trailing update.
+// Afterwards the off-diagonal part of X is assembled by recursive doubling
+//   X21 = -X22 (L21 X11)  at block sizes 16, 32, 64  (log-depth, all tiles of a level in parallel).
 // FACTORED = true skips the Cholesky arithmetic and only inverts an existing factor's diagonal block.
 #include "gpk_internal.h"
 
 namespace {
 
 constexpr int NB = GPK_NB;
-constexpr int LD = NB + 2;
-constexpr int SB = 16;        // sub-block
-constexpr int NT = 512;       // threads per workgroup (8 waves: 2 per SIMD hide LDS/MFMA latency)
-constexpr size_t LEAF_LDS = ((size_t)NB * LD + NB + 2) * sizeof(double);
+constexpr int LD = NB + 2;     // 130: A-layout fragment reads hit 64 distinct banks
+constexpr int SB = 16;         // sub-block
+constexpr int NSB = NB / SB;   // 8
+constexpr int XLD = SB + 1;    // row stride of the dense diagonal tiles of X
+constexpr int NT = 512;        // 8 waves
+constexpr int NW = NT / 64;
+constexpr int XD_OFF = NB * LD;                  // doubles: [NSB][SB][XLD]
+constexpr int LDS_DOUBLES = XD_OFF + NSB * SB * XLD;
+constexpr size_t LEAF_LDS = (size_t)LDS_DOUBLES * sizeof(double);
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
   union { double d; int i[2]; } u;
@@ -40,294 +52,367 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
   return y;
 }
 
-
-// broadcast lane J (of each row of 16 lanes) to the whole row: DPP row_share, no SGPR round trip
-template <int J, bool NOP>
-__device__ __forceinline__ double row_share_d(double v) {
-  // one 64-bit DPP move (gfx90a+ "DP ALU DPP", row_newbcast only).  NOP: cover the
-  // VALU-write -> DPP-read hazard on the first move of a batch (hipcc does not pad inline asm).
-  double out;
-  if constexpr (NOP)
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-                 : "=v"(out) : "v"(v), "n"(J));
-  else
-    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-                 : "=v"(out) : "v"(v), "n"(J));
-  return out;
-}
-
-// batch the broadcasts, then the FMAs: a dependent DPP->FMA pair would stall the in-order wave
-template <int C, int J>
-struct LBcast {  // lj[j] = l of lane j, j = J..15
-  static __device__ __forceinline__ void run(double (&lj)[16], double l) {
-    if constexpr (J < 16) {
-      lj[J] = row_share_d<J, (J == C + 1)>(l);
-      LBcast<C, J + 1>::run(lj, l);
-    }
-  }
-};
-template <int C, int J>
-struct XBcast {  // xc[j] = x[j] of lane C, j = J..C-1
-  static __device__ __forceinline__ void run(double (&xc)[16], const double (&x)[16]) {
-    if constexpr (J < C) {
-      xc[J] = row_share_d<C, (J == 0)>(x[J]);
-      XBcast<C, J + 1>::run(xc, x);
-    }
-  }
-};
-
-// one column step of the 16x16 diagonal sub-block (all lanes; lane&15 = row, rows mirrored x4)
-template <bool FACTORED, int C>
-struct DiagStep {
-  static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16], double& myrinv, int row,
-                                             int& bad_col, int kb) {
-    if constexpr (C < 16) {
-      const double p = row_share_d<C, true>(a[C]);
-      double xc[16];
-      XBcast<C, 0>::run(xc, x);  // independent of the rsqrt chain: issue first
-      double rinv, l;
-      if constexpr (FACTORED) {
-        rinv = 1.0 / p;
-        l = a[C];
-      } else {
-        if (!(p > 0.0) && bad_col < 0) bad_col = kb + C;
-        rinv = rsqrt_nr(p);
-        l = a[C] * rinv;
-        a[C] = l;
-      }
-      myrinv = (row == C) ? rinv : myrinv;
-      const double le = (row > C) ? l : 0.0;
-      if constexpr (!FACTORED) {
-        double lj[16];
-        LBcast<C, C + 1>::run(lj, l);
-#pragma unroll
-        for (int j = C + 1; j < 16; ++j) a[j] = fma(-le, lj[j], a[j]);
-      }
-      const double ler = le * rinv;
-#pragma unroll
-      for (int j = 0; j < C; ++j) x[j] = fma(-ler, xc[j], x[j]);
-      x[C] = -ler;
-      DiagStep<FACTORED, C + 1>::run(a, x, myrinv, row, bad_col, kb);
-    }
-  }
-};
-
 __device__ __forceinline__ d4 mfma4(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// ---- 16x16x16 block-product tasks on the LDS-resident matrix ------------------------------------------
-// acc[e] (m = g + 4e, n = r)  =  (init ? S[c[e]] : 0)  +  sum_q (neg ? -1 : 1) * S[a[kk]] * S[b[kk]]
-// All operands are plain LDS offsets (the triangular X_kk accessor resolves to an offset too, with a
-// dedicated zero slot), so tasks are uniform and software-pipelined: the operands of task t+1 are in
-// flight while the 4 MFMAs of task t issue.
-constexpr int ZERO_SLOT = NB * LD + NB;  // S[ZERO_SLOT] == 0.0
-
-struct Task {
-  int a[4], b[4], c[4];
-  bool neg, init;
-};
-
-// offset of X_kk[row][col] (lower; stored transposed in the strict upper part + diagonal in xd)
-__device__ __forceinline__ int xkk_off(int k, int row, int col) {
-  const int b = k * SB;
-  if (col < row) return (b + col) * LD + b + row;
-  if (col == row) return NB * LD + b + row;
-  return ZERO_SLOT;
-}
-
-struct TaskRegs {
-  double a[4], b[4], c[4];
-};
-
-__device__ __forceinline__ void task_load(const double* S, const Task& T, TaskRegs& R) {
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    R.a[kk] = S[T.a[kk]];
-    R.b[kk] = S[T.b[kk]];
-    R.c[kk] = T.init ? S[T.c[kk]] : 0.0;
-  }
-}
-
-__device__ __forceinline__ void task_exec(double* S, const Task& T, const TaskRegs& R) {
-  d4 acc = {R.c[0], R.c[1], R.c[2], R.c[3]};
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) acc = mfma4(T.neg ? -R.a[kk] : R.a[kk], R.b[kk], acc);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) S[T.c[e]] = acc[e];
-}
-
-template <class F>
-__device__ __forceinline__ void run_tasks(double* S, int wave, int ntask, F make) {
-  constexpr int NWV = NT / 64;
-  Task T0, T1;
-  TaskRegs R0, R1;
-  int t = wave;
-  if (t >= ntask) return;
-  make(t, T0);
-  task_load(S, T0, R0);
-  for (;;) {
-    const int t1 = t + NWV;
-    const bool has1 = t1 < ntask;
-    if (has1) { make(t1, T1); task_load(S, T1, R1); }
-    task_exec(S, T0, R0);
-    if (!has1) break;
-    const int t2 = t1 + NWV;
-    const bool has2 = t2 < ntask;
-    if (has2) { make(t2, T0); task_load(S, T0, R0); }
-    task_exec(S, T1, R1);
-    if (!has2) break;
-    t = t2;
+// ---- 16x16 diagonal tile: Cholesky + inverse in the registers of one wave ---------------------------------
+// c = lane & 15, g = lane >> 4.  On entry (FACTORED = false) d[e] = S[g+4e][c] of the symmetric tile; on
+// entry (FACTORED = true) d[e] = L[c][4e+g] (zero above the diagonal).  On exit d[e] = L[c][4e+g] and
+// x[e] = X[4e+g][c]  (X = L^-1, exact zeros above the diagonal).
+template <bool FACTORED, int P>
+__device__ __forceinline__ void diag_panel(d4& d, d4& x, int c, int g, int lane, int& bad_col, int col0) {
+  if constexpr (P < 4) {
+    // 4x4 pivot block  s[a][b] = S[4P+a][4P+b]  (a >= b), wave-uniform
+    auto pick = [&](int a, int b) -> double {
+      // !FACTORED: d[P] of lane (c = 4P+b, g = a);  FACTORED: d[P] of lane (c = 4P+a, g = b)
+      return FACTORED ? readlane_d(d[P], 4 * P + a + 16 * b) : readlane_d(d[P], 4 * P + b + 16 * a);
+    };
+    const double s00 = pick(0, 0), s10 = pick(1, 0), s20 = pick(2, 0), s30 = pick(3, 0);
+    const double s11 = pick(1, 1), s21 = pick(2, 1), s31 = pick(3, 1);
+    const double s22 = pick(2, 2), s32 = pick(3, 2), s33 = pick(3, 3);
+    double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3;
+    if constexpr (FACTORED) {
+      l10 = s10; l20 = s20; l30 = s30; l21 = s21; l31 = s31; l32 = s32;
+      r0 = 1.0 / s00; r1 = 1.0 / s11; r2 = 1.0 / s22; r3 = 1.0 / s33;
+    } else {
+      r0 = rsqrt_nr(s00);
+      l10 = s10 * r0; l20 = s20 * r0; l30 = s30 * r0;
+      const double p1 = fma(-l10, l10, s11);
+      r1 = rsqrt_nr(p1);
+      l21 = fma(-l20, l10, s21) * r1;
+      l31 = fma(-l30, l10, s31) * r1;
+      const double p2 = fma(-l21, l21, fma(-l20, l20, s22));
+      r2 = rsqrt_nr(p2);
+      l32 = fma(-l31, l21, fma(-l30, l20, s32)) * r2;
+      const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
+      r3 = rsqrt_nr(p3);
+      if (bad_col < 0) {
+        if (!(s00 > 0.0)) bad_col = col0 + 4 * P;
+        else if (!(p1 > 0.0)) bad_col = col0 + 4 * P + 1;
+        else if (!(p2 > 0.0)) bad_col = col0 + 4 * P + 2;
+        else if (!(p3 > 0.0)) bad_col = col0 + 4 * P + 3;
+      }
+    }
+    // Y = inv(L4), lower triangular
+    const double y10 = -r1 * (l10 * r0);
+    const double y21 = -r2 * (l21 * r1);
+    const double y32 = -r3 * (l32 * r2);
+    const double y20 = -r2 * fma(l21, y10, l20 * r0);
+    const double y31 = -r3 * fma(l32, y21, l31 * r1);
+    const double y30 = -r3 * fma(l32, y20, fma(l31, y10, l30 * r0));
+    // A-operand  Yop[m][k] = Y[m][k] (m < 4), lane (m = c, k = g)
+    double yop = 0.0;
+    if (c == 0) yop = (g == 0) ? r0 : 0.0;
+    if (c == 1) yop = (g == 0) ? y10 : ((g == 1) ? r1 : 0.0);
+    if (c == 2) yop = (g == 0) ? y20 : ((g == 1) ? y21 : ((g == 2) ? r2 : 0.0));
+    if (c == 3) yop = (g == 0) ? y30 : ((g == 1) ? y31 : ((g == 2) ? y32 : r3));
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    // panel of L:  D[m][n] = sum_k Y[m][k] S[n][4P+k]  ->  reg 0 of lane (n, g) = L[n][4P+g]
+    double lp;
+    if constexpr (FACTORED) {
+      lp = d[P];
+    } else {
+      const d4 t = mfma4(yop, d[P], zero);
+      lp = (c >= 4 * P + g) ? t[0] : 0.0;  // rows above the panel and the upper part of the 4x4 block
+    }
+    if constexpr (!FACTORED && P < 3) d = mfma4(-lp, lp, d);  // S -= Lp Lp^T  (critical: next pivots)
+    // new rows of X:  Xp[m][n] = sum_k Y[m][k] Xtmp[4P+k][n]  ->  reg 0 of lane (n, g) = X[4P+g][n]
+    const d4 u = mfma4(yop, x[P], zero);
+    const double xp = u[0];
+    if constexpr (P < 3) x = mfma4(-lp, xp, x);  // Xtmp[m][:] -= L[m][4P+k] X[4P+k][:]
+    d[P] = lp;
+    x[P] = xp;
+    diag_panel<FACTORED, P + 1>(d, x, c, g, lane, bad_col, col0);
   }
 }
 
 template <bool FACTORED>
-__global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, long lda,
-                                                   long strideA, int nb,
+__device__ __forceinline__ void diag16(double* __restrict__ S, int k, int lane, int& bad_col, int col0) {
+  const int c = lane & 15, g = lane >> 4;
+  const int kb = k * SB;
+  d4 d, x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = g + 4 * e;  // the other index
+    if constexpr (FACTORED) {
+      d[e] = (c >= j) ? S[(kb + c) * LD + kb + j] : 0.0;           // L[c][4e+g]
+    } else {
+      d[e] = (j >= c) ? S[(kb + j) * LD + kb + c] : S[(kb + c) * LD + kb + j];  // S[g+4e][c], symmetric
+    }
+    x[e] = (j == c) ? 1.0 : 0.0;
+  }
+  diag_panel<FACTORED, 0>(d, x, c, g, lane, bad_col, col0 + kb);
+  double* __restrict__ Xd = S + XD_OFF + k * (SB * XLD);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * e + g;
+    if (!FACTORED && c >= j) S[(kb + c) * LD + kb + j] = d[e];  // L[c][j]
+    Xd[j * XLD + c] = x[e];                                     // X[j][c]
+  }
+}
+
+// ---- 16x16 tile products on LDS-resident operands --------------------------------------------------------
+// A tile reference: element (r, q) lives at S[base + r * rs + q * cs].
+struct TRef { int base, rs, cs; };
+__device__ __forceinline__ TRef tile_L(int i, int j) { return {i * SB * LD + j * SB, LD, 1}; }       // L_ij[r][q]
+__device__ __forceinline__ TRef tile_X(int i, int j) { return {j * SB * LD + i * SB, 1, LD}; }       // X_ij (i>j), stored transposed
+__device__ __forceinline__ TRef tile_Xd(int k) { return {XD_OFF + k * SB * XLD, XLD, 1}; }          // X_kk dense
+__device__ __forceinline__ TRef tr(TRef t) { return {t.base, t.cs, t.rs}; }                          // transposed view
+
+struct Frag { double a[4], b[4]; };
+// operands of  D[m][n] += sum_q A[m][q] * B[n][q]   (NT form; pass tr(B) for a plain product)
+__device__ __forceinline__ void frag_load(const double* __restrict__ S, TRef A, TRef B, int lane, Frag& f) {
+  const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    f.a[kk] = S[A.base + r * A.rs + (4 * kk + kq) * A.cs];
+    f.b[kk] = S[B.base + r * B.rs + (4 * kk + kq) * B.cs];
+  }
+}
+template <bool NEG>
+__device__ __forceinline__ d4 frag_mma(const Frag& f, d4 acc) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) acc = mfma4(NEG ? -f.a[kk] : f.a[kk], f.b[kk], acc);
+  return acc;
+}
+__device__ __forceinline__ d4 tile_load(const double* __restrict__ S, TRef C, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  d4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = S[C.base + (g + 4 * e) * C.rs + c * C.cs];
+  return v;
+}
+__device__ __forceinline__ void tile_store(double* __restrict__ S, TRef C, int lane, d4 v) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) S[C.base + (g + 4 * e) * C.rs + c * C.cs] = v[e];
+}
+// second factor already in registers in D layout (T[q][n]: lane (n, g) reg kk = T[4kk+g][n]):
+//   D[m][n] += sum_q A[m][q] * T[q][n]
+template <bool NEG>
+__device__ __forceinline__ d4 reg_mma(const double* __restrict__ S, TRef A, d4 t, int lane, d4 acc) {
+  const int r = lane & 15, kq = lane >> 4;
+  double a[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) a[kk] = S[A.base + r * A.rs + (4 * kk + kq) * A.cs];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) acc = mfma4(NEG ? -a[kk] : a[kk], t[kk], acc);
+  return acc;
+}
+
+// linear index u over the lower-triangular tile list  (i, j), j0 <= j <= i, row-major from i = j0
+__device__ __forceinline__ void tri_decode(int u, int j0, int& i, int& j) {
+  int row = 0;
+  while (u > row) { u -= row + 1; ++row; }
+  i = j0 + row;
+  j = j0 + u;
+}
+
+template <bool FACTORED>
+__global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, long lda, long strideA, int nb,
                                                    double* __restrict__ invbase, long strideInv,
                                                    int* __restrict__ info, int col0,
                                                    long long* __restrict__ dbg) {
-  extern __shared__ __attribute__((aligned(16))) double S[];  // [NB][LD] then xd[NB]
-  double* xd = S + NB * LD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
+  extern __shared__ __attribute__((aligned(16))) double S[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* __restrict__ A = Abase + (long)blockIdx.x * strideA;
   double* __restrict__ inv = invbase + (long)blockIdx.x * strideInv;
   const int nsb = (nb + SB - 1) / SB;
-  const int npad = nsb * SB;
+  const long long t_begin = dbg ? wall_clock64() : 0;
 
-  const long long t_load0 = dbg ? wall_clock64() : 0;
-  // ---- load: lower triangle of A (identity beyond nb), zero strict upper -----------------------
+  // ---- load: lower triangle of A (identity beyond nb), zero strict upper; all loads issued up front ----
   {
-    // thread t owns column pair (2*(t&63), +1) of rows (t>>6) + NW*it: 64 lanes read one 1 KiB row
+    // thread t owns the column pair (2 (t & 63), +1) of rows (t >> 6) + 8 it
     const int jp = 2 * (tid & 63), r0 = tid >> 6;
     const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-    constexpr int NW = NT / 64, NIT = NB / NW;
-#pragma unroll 8
+    constexpr int NIT = NB / NW;
+    d2 v[NIT];
+#pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = r0 + NW * it;
-      d2 v = {0.0, 0.0};
+      v[it] = (d2){0.0, 0.0};
       if (i < nb && jp <= i) {
         const double* src = A + (long)i * lda + jp;
-        if (vec && jp + 1 < nb) v = *reinterpret_cast<const d2*>(src);
-        else { v.x = src[0]; if (jp + 1 < nb) v.y = src[1]; }
+        if (vec && jp + 1 < nb) v[it] = *reinterpret_cast<const d2*>(src);
+        else { v[it].x = src[0]; if (jp + 1 < nb) v[it].y = src[1]; }
       }
-      if (jp > i) v.x = 0.0; else if (i >= nb) v.x = (jp == i) ? 1.0 : 0.0;
-      if (jp + 1 > i) v.y = 0.0; else if (i >= nb) v.y = (jp + 1 == i) ? 1.0 : 0.0;
-      *reinterpret_cast<d2*>(&S[i * LD + jp]) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = r0 + NW * it;
+      d2 w = v[it];
+      if (jp > i) w.x = 0.0; else if (i >= nb) w.x = (jp == i) ? 1.0 : 0.0;
+      if (jp + 1 > i) w.y = 0.0; else if (i >= nb) w.y = (jp + 1 == i) ? 1.0 : 0.0;
+      *reinterpret_cast<d2*>(&S[i * LD + jp]) = w;
+    }
+    // diagonal tiles of X beyond the factored range are the identity
+    for (int e = tid; e < NSB * SB * XLD; e += NT) {
+      const int r = (e / XLD) % SB, q = e % XLD;
+      S[XD_OFF + e] = (r == q) ? 1.0 : 0.0;
     }
   }
-  if (tid == 0) { S[NB * LD + NB] = 0.0; S[NB * LD + NB + 1] = 0.0; }
   __syncthreads();
-  long long tA = 0, tB = 0, tC = 0, t_prev = wall_clock64();
-  const long long t_start = t_prev;
-  const long long c_start = clock64();
-  if (dbg && tid == 0) dbg[0] = t_prev - t_load0;
+  const long long t_loaded = dbg ? wall_clock64() : 0;
 
   int bad_col = -1;
-
-  for (int k = 0; k < nsb; ++k) {
-    const int kb = k * SB;
-    // ================= A: diagonal sub-block, wave 0 ================================================
-    if (wave == 0) {
-      double a[SB], x[SB];
-      const int row = lane & 15;  // lanes 16..63 mirror lanes 0..15 (each DPP row is a full copy)
-#pragma unroll
-      for (int j = 0; j < SB; ++j) {
-        a[j] = (j <= row) ? S[(kb + row) * LD + kb + j] : 0.0;
-        x[j] = 0.0;
+  if constexpr (FACTORED) {
+    if (wave < nsb) diag16<true>(S, wave, lane, bad_col, 0);
+    __syncthreads();
+  } else {
+    if (wave == 0) diag16<false>(S, 0, lane, bad_col, 0);
+    __syncthreads();
+    for (int k = 0; k < nsb - 1; ++k) {
+      // ---- B:  L_ik = A_ik X_kk^T,  i = k+1 .. nsb-1 ---------------------------------------------
+      for (int i = k + 1 + wave; i < nsb; i += NW) {
+        Frag f;
+        frag_load(S, tile_L(i, k), tile_Xd(k), lane, f);
+        const d4 r = frag_mma<false>(f, (d4){0.0, 0.0, 0.0, 0.0});
+        tile_store(S, tile_L(i, k), lane, r);
       }
-      double myrinv = 0.0;
-      DiagStep<FACTORED, 0>::run(a, x, myrinv, row, bad_col, kb);
-      if (lane < SB) {
-#pragma unroll
-        for (int j = 0; j < SB; ++j) {
-          if (!FACTORED && j <= row) S[(kb + row) * LD + kb + j] = a[j];
-          if (j < row) S[(kb + j) * LD + kb + row] = x[j] * myrinv;  // X[row][j], transposed
+      __syncthreads();
+      // ---- C:  A_ij -= L_ik L_jk^T ; wave 0: tile (k+1,k+1) then the next diagonal tile ------------
+      if (wave == 0) {
+        Frag f;
+        frag_load(S, tile_L(k + 1, k), tile_L(k + 1, k), lane, f);
+        d4 acc = tile_load(S, tile_L(k + 1, k + 1), lane);
+        acc = frag_mma<true>(f, acc);
+        tile_store(S, tile_L(k + 1, k + 1), lane, acc);
+        // the tile was written and is re-read by this wave only (LDS ops of one wave stay ordered)
+        diag16<false>(S, k + 1, lane, bad_col, 0);
+      } else {
+        const int rem = nsb - 1 - k;                 // rows k+1 .. nsb-1
+        const int ntile = rem * (rem + 1) / 2;       // u = 0 is tile (k+1,k+1): wave 0's
+        int u = wave;                                // waves 1..7 -> u = 1.., stride 7
+        Frag f0, f1;
+        d4 c0, c1;
+        int i0 = 0, j0 = 0, i1 = 0, j1 = 0;
+        if (u < ntile) {
+          tri_decode(u, k + 1, i0, j0);
+          frag_load(S, tile_L(i0, k), tile_L(j0, k), lane, f0);
+          c0 = tile_load(S, tile_L(i0, j0), lane);
         }
-        xd[kb + row] = myrinv;
+        while (u < ntile) {
+          const int u1 = u + (NW - 1);
+          if (u1 < ntile) {
+            tri_decode(u1, k + 1, i1, j1);
+            frag_load(S, tile_L(i1, k), tile_L(j1, k), lane, f1);
+            c1 = tile_load(S, tile_L(i1, j1), lane);
+          }
+          c0 = frag_mma<true>(f0, c0);
+          tile_store(S, tile_L(i0, j0), lane, c0);
+          if (u1 >= ntile) break;
+          const int u2 = u1 + (NW - 1);
+          if (u2 < ntile) {
+            tri_decode(u2, k + 1, i0, j0);
+            frag_load(S, tile_L(i0, k), tile_L(j0, k), lane, f0);
+            c0 = tile_load(S, tile_L(i0, j0), lane);
+          }
+          c1 = frag_mma<true>(f1, c1);
+          tile_store(S, tile_L(i1, j1), lane, c1);
+          u = u2;
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
-    if (dbg) { const long long t = wall_clock64(); tA += t - t_prev; t_prev = t; }
-    // ================= B: X_kj = X_kk W_kj (j<k);  L_ik = A_ik X_kk^T (i>k) ===========================
-    {
-      const int ntask = FACTORED ? k : (nsb - 1);  // j in [0,k) then i in (k, nsb)
-      run_tasks(S, wave, ntask, [&](int t, Task& T) {
-        T.neg = false; T.init = false;
-        if (t < k) {
-          const int jb = t * SB;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int q = 4 * kk + g;
-            T.a[kk] = xkk_off(k, r, q);
-            T.b[kk] = (jb + r) * LD + kb + q;
-            T.c[kk] = (jb + r) * LD + kb + g + 4 * kk;  // X_kj[m][n] -> S[jb + n][kb + m]
-          }
-        } else {
-          const int ib = (t + 1) * SB;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int q = 4 * kk + g;
-            T.a[kk] = (ib + r) * LD + kb + q;
-            T.b[kk] = xkk_off(k, r, q);
-            T.c[kk] = (ib + g + 4 * kk) * LD + kb + r;
-          }
-        }
-      });
-    }
-    __syncthreads();
-    if (dbg) { const long long t = wall_clock64(); tB += t - t_prev; t_prev = t; }
-    // ================= C: trailing update + inverse row operations =======================================
-    {
-      // tasks: rows i in (k, nsb), cols j in [0, i] (FACTORED: j in [0, k])
-      //   j<k: W_ij -= L_ik X_kj    j==k: W_ik = -L_ik X_kk    j>k: A_ij -= L_ik L_jk^T
-      const int rows_below = nsb - 1 - k;
-      int ntask;
-      if (FACTORED) ntask = rows_below * (k + 1);
-      else ntask = (nsb * (nsb + 1)) / 2 - ((k + 1) * (k + 2)) / 2;
-      run_tasks(S, wave, ntask, [&](int t, Task& T) {
-        int i, j;
-        if (FACTORED) {
-          i = k + 1 + t / (k + 1);
-          j = t - (i - k - 1) * (k + 1);
-        } else {
-          i = k + 1;
-          int rem = t;
-          while (rem > i) { rem -= i + 1; ++i; }
-          j = rem;
-        }
-        const int ib = i * SB, jb = j * SB;
-        T.neg = true;
-        T.init = (j != k);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int q = 4 * kk + g;
-          T.a[kk] = (ib + r) * LD + kb + q;
-          if (j == k) {
-            T.b[kk] = xkk_off(k, q, r);                  // Bop[n][q] = X_kk[q][n]
-            T.c[kk] = (kb + r) * LD + ib + g + 4 * kk;   // W_ik^T
-          } else if (j < k) {
-            T.b[kk] = (jb + r) * LD + kb + q;            // X_kj^T
-            T.c[kk] = (jb + r) * LD + ib + g + 4 * kk;   // W_ij^T
-          } else {
-            T.b[kk] = (jb + r) * LD + kb + q;            // L_jk
-            T.c[kk] = (ib + g + 4 * kk) * LD + jb + r;   // A_ij
-          }
-        }
-      });
-    }
-    __syncthreads();
-    if (dbg) { const long long t = wall_clock64(); tC += t - t_prev; t_prev = t; }
   }
-  if (dbg && tid == 0) { dbg[1] = tA; dbg[2] = tB; dbg[3] = tC; dbg[4] = t_prev - t_start; }
+  const long long t_factored = dbg ? wall_clock64() : 0;
+
+  // ---- off-diagonal tiles of X by recursive doubling:  X21 = -X22 (L21 X11) ----------------------------------
+  // level 1 (16-blocks): node p -> tile (2p+1, 2p); one wave per node, T stays in registers
+  if (wave < 4) {
+    const int p = wave;
+    Frag f;
+    frag_load(S, tile_L(2 * p + 1, 2 * p), tr(tile_Xd(2 * p)), lane, f);            // T = L21 X11
+    const d4 t = frag_mma<false>(f, (d4){0.0, 0.0, 0.0, 0.0});
+    const d4 r = reg_mma<true>(S, tile_Xd(2 * p + 1), t, lane, (d4){0.0, 0.0, 0.0, 0.0});  // -X22 T
+    tile_store(S, tile_X(2 * p + 1, 2 * p), lane, r);
+  }
+  __syncthreads();
+  // level 2 (32-blocks): node q in {0,1}, rows 4q+2.. , cols 4q..; wave (q, b, a) -> tile X21(a, b)
+  {
+    const int q = wave >> 2, b = (wave >> 1) & 1, a = wave & 1;
+    const int r0 = 4 * q + 2, c0 = 4 * q;  // tile coordinates of the node's L21 / X21 block
+    // T(t, b) = sum_{s >= b} L21(t, s) X11(s, b),  t = 0..a   (X11(s,b): s == b diagonal tile, s > b off-diagonal)
+    d4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+    for (int s = b; s < 2; ++s) {
+      const TRef xs = (s == b) ? tile_Xd(c0 + b) : tile_X(c0 + s, c0 + b);
+      Frag f;
+      frag_load(S, tile_L(r0, c0 + s), tr(xs), lane, f);
+      t0 = frag_mma<false>(f, t0);
+      if (a == 1) {
+        frag_load(S, tile_L(r0 + 1, c0 + s), tr(xs), lane, f);
+        t1 = frag_mma<false>(f, t1);
+      }
+    }
+    // X21(a, b) = -sum_{t <= a} X22(a, t) T(t, b)
+    d4 r = {0.0, 0.0, 0.0, 0.0};
+    if (a == 0) {
+      r = reg_mma<true>(S, tile_Xd(r0), t0, lane, r);
+    } else {
+      r = reg_mma<true>(S, tile_X(r0 + 1, r0), t0, lane, r);
+      r = reg_mma<true>(S, tile_Xd(r0 + 1), t1, lane, r);
+    }
+    tile_store(S, tile_X(r0 + a, c0 + b), lane, r);
+  }
+  __syncthreads();
+  // level 3 (64-blocks): T = L21 X11 parked (transposed, like X) in the still-unused X21 region, then
+  // X21 = -X22 T.  16 tiles per phase, two per wave, pairing heavy with light rows.
+  {
+    // phase 1: T(t, b) = sum_{s=b}^{3} L(4+t, s) X(s, b)
+    d4 tt[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = wave >> 1, t = 2 * (wave & 1) + h;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int s = b; s < 4; ++s) {
+        const TRef xs = (s == b) ? tile_Xd(b) : tile_X(s, b);
+        Frag f;
+        frag_load(S, tile_L(4 + t, s), tr(xs), lane, f);
+        acc = frag_mma<false>(f, acc);
+      }
+      tt[h] = acc;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = wave >> 1, t = 2 * (wave & 1) + h;
+      tile_store(S, tile_X(4 + t, b), lane, tt[h]);
+    }
+    __syncthreads();
+    // phase 2: X21(a, b) = -sum_{t=0}^{a} X22(a, t) T(t, b);  wave -> b = wave>>1, a in {w&1 ? (1,2) : (0,3)}
+    d4 rr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = wave >> 1;
+      const int a = (wave & 1) ? (1 + h) : (3 * h);
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int t = 0; t <= a; ++t) {
+        const TRef xa = (t == a) ? tile_Xd(4 + a) : tile_X(4 + a, 4 + t);
+        Frag f;
+        frag_load(S, xa, tr(tile_X(4 + t, b)), lane, f);
+        acc = frag_mma<true>(f, acc);
+      }
+      rr[h] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = wave >> 1;
+      const int a = (wave & 1) ? (1 + h) : (3 * h);
+      tile_store(S, tile_X(4 + a, b), lane, rr[h]);
+    }
+  }
+  __syncthreads();
+  const long long t_inverted = dbg ? wall_clock64() : 0;
 
   // ---- write L (lower triangle, valid part) and the inverse block ------------------------------------
   {
     const int jp = 2 * (tid & 63), r0 = tid >> 6;
     const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-    constexpr int NW = NT / 64, NIT = NB / NW;
-#pragma unroll 8
+    constexpr int NIT = NB / NW;
+    const double* __restrict__ Xd = S + XD_OFF;
+#pragma unroll 4
     for (int it = 0; it < NIT; ++it) {
       const int i = r0 + NW * it;
       if (!FACTORED && i < nb && jp <= i) {
@@ -336,21 +421,22 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
         if (vec && jp + 1 <= i) *reinterpret_cast<d2*>(dst) = lv;
         else { dst[0] = lv.x; if (jp + 1 <= i) dst[1] = lv.y; }
       }
-      d2 xv;
       auto xval = [&](int j) -> double {
-        if (i < npad) {
-          if (j < i) return S[j * LD + i];
-          if (j == i) return xd[i];
-          return 0.0;
-        }
-        return (j == i) ? 1.0 : 0.0;
+        if (j > i) return 0.0;
+        if ((j >> 4) == (i >> 4)) return Xd[(i >> 4) * (SB * XLD) + (i & 15) * XLD + (j & 15)];
+        return S[j * LD + i];
       };
+      d2 xv;
       xv.x = xval(jp);
       xv.y = xval(jp + 1);
       *reinterpret_cast<d2*>(&inv[i * NB + jp]) = xv;
     }
   }
-  if (dbg && tid == 0) { dbg[5] = wall_clock64() - t_start; dbg[6] = clock64() - c_start; }
+  if (dbg && tid == 0) {
+    const long long t_end = wall_clock64();
+    dbg[0] = t_loaded - t_begin; dbg[1] = t_factored - t_loaded; dbg[2] = t_inverted - t_factored;
+    dbg[3] = t_end - t_inverted; dbg[4] = t_end - t_begin;
+  }
   if (!FACTORED && info) {
     // bad_col is wave-0 state; lane 0 of wave 0 reports (first failing pivot of the matrix wins)
     if (tid == 0 && bad_col >= 0 && info[blockIdx.x] == 0) info[blockIdx.x] = col0 + bad_col + 1;
