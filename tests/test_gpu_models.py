@@ -138,10 +138,15 @@ def test_svgp_elbo_predict(gp, whiten, q_diag, N, D, P, M):
     # cached posterior vs fused (tests/gpflow/models/test_svgp_posterior.py:62-90)
     post = m.posterior()
     mu2, var2 = post.predict_f(Xnew)
-    np.testing.assert_allclose(_np(mu2), _np(mu), atol=1e-7)
-    np.testing.assert_allclose(_np(var2), _np(var), atol=1e-7)
+    # The cache holds Kuu^-1-like quantities, the fused path solves against Lm: two routes whose fp64
+    # results differ by ~kappa(Kuu) * eps * |value| (the NumPy oracle shows the same gap between ITS fused and
+    # cached routes: 2.8e-4 / 2.0e-3 on the unwhitened cases here, kappa = 5e7 / 7e7).
+    kappa = np.linalg.cond(orc.Kuu(Z, jitter=1e-6, **kw))
+    ctol = 200 * kappa * np.finfo(np.float64).eps
+    np.testing.assert_allclose(_np(mu2), _np(mu), rtol=ctol, atol=ctol * np.abs(_np(mu)).max())
+    np.testing.assert_allclose(_np(var2), _np(var), rtol=ctol, atol=ctol * np.abs(_np(var)).max())
     a_r, Q_r = orc.svgp_precompute(Z, q_mu, q_sqrt, whiten=whiten, **kw)
-    np.testing.assert_allclose(_np(post.cache[0]), a_r, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(_np(post.cache[0]), a_r, rtol=max(1e-9, ctol), atol=max(1e-9, ctol) * np.abs(a_r).max())
     # conditional() is the same code path as fused_predict_f: bit-equal (tests/gpflow/posteriors/test_posteriors.py:179-180)
     cm, cv = gp.conditionals.conditional(Xnew, m.inducing_variable, m.kernel, m.q_mu.device_value(),
                                          q_sqrt=m.q_sqrt.device_value(), white=whiten)
