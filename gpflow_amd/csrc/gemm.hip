@@ -296,16 +296,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
 // With beta != 0 the accumulators start as (beta/alpha) C, loaded in the prologue next to the first
 // slab, so the epilogue is store-only.
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int gy, int total, int compact) {
+__device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int tile_n, double* smem) {
   constexpr int BM = 128, BN = 128;
   constexpr int BUF = (BM + BN) * LDSS;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int bz = blockIdx.y;
-  int tile_m, tile_n;
-  tile_order(p.b_tri, gx, gy, total, compact, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (p.c_lower && n0 > m0 + BM - 1) return;
 
@@ -500,13 +496,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
   }
 }
 
+// pair = 0: one tile per workgroup, XCD-contiguous / column-grouped order.
+// pair = 1 (triangular-K operand, b_tri = 1): the K range of column tile j shrinks with j, so a workgroup
+// takes column tiles j and gx-1-j back to back -- every workgroup then carries the same number of K slabs
+// and the launch finishes together instead of waiting for the full-K tiles.
+template <int EPI, bool PAIR>
+__global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int gy, int total, int compact) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if constexpr (!PAIR) {
+    int tile_m, tile_n;
+    tile_order(p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+    fast_tile<EPI>(p, tile_m, tile_n, smem);
+  } else {
+    const int tile_m = blockIdx.x % gy, j = blockIdx.x / gy;
+    fast_tile<EPI>(p, tile_m, j, smem);
+    if (gx - 1 - j != j) {
+      __syncthreads();  // both LDS buffers are about to be refilled
+      fast_tile<EPI>(p, tile_m, gx - 1 - j, smem);
+    }
+  }
+}
+
 template <int EPI>
 int launch_fast(hipStream_t s, const GemmArgs& a) {
   constexpr size_t LDS_BYTES = 2 * (size_t)256 * LDSS * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI>),
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    if constexpr (EPI == 1)
+      GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr_set = true;
   }
   const int gx = gpk_cdiv(a.n, 128), gy = gpk_cdiv(a.m, 128);
@@ -524,8 +544,18 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     }
     if (total <= 0) return 0;
   }
-  dim3 grid((unsigned)total, (unsigned)(a.batch > 0 ? a.batch : 1), 1);
-  hipLaunchKernelGGL((gemm_nt_fast<EPI>), grid, dim3(256), LDS_BYTES, s, a, gx, gy, total, compact);
+  const unsigned nb = (unsigned)(a.batch > 0 ? a.batch : 1);
+  if constexpr (EPI == 1) {
+    if (a.b_tri == 1 && gx >= 4 && a.b_tri_rows >= a.n) {
+      total = ((gx + 1) / 2) * gy;
+      hipLaunchKernelGGL((gemm_nt_fast<EPI, true>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy,
+                         total, compact);
+      GPK_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy, total,
+                     compact);
   GPK_LAUNCH_CHECK();
   return 0;
 }
@@ -540,6 +570,121 @@ bool fast_ok(const GemmArgs& a) {
   if (a.epi == 0 && a.beta != 0.0 && a.alpha == 0.0) return false;
   if (a.lda > (1L << 21) || a.ldb > (1L << 21)) return false;  // 32-bit byte offsets inside a tile
   return true;
+}
+
+
+// =====================================================================================================
+// Latency path for the short GEMMs on the critical path of the factorisation (panel solve  A21 inv(L11)^T,
+// inner updates: K <= 128, a few thousand rows).  There the K loop of the tiled kernels is pure latency
+// (every 16-wide slab waits a full global-load round trip), so this kernel stages EVERYTHING at once:
+// one workgroup = 16 rows x 128 columns, its A rows and the whole B tile go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: one 1 KiB row per wave instruction, no VGPR staging, padded row stride),
+// one barrier, then each of the 8 waves runs its 16x16 output tile over the full K with two
+// independent accumulators.  One column tile covers n <= 128, so the in-place solve (C aliases A)
+// only overwrites rows the workgroup alone has read.
+constexpr int SM_BM = 16, SM_BN = 128, SM_THREADS = 512;
+
+__global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bz = blockIdx.z;
+  const int m0 = blockIdx.y * SM_BM, n0 = blockIdx.x * SM_BN;
+  if (p.c_lower && n0 > m0 + SM_BM - 1) return;
+  const double* __restrict__ A = p.A + (long)bz * p.strideA;
+  const double* __restrict__ B = p.B + (long)bz * p.strideB;
+  int kb = 0, ke = p.k;
+  if (p.b_tri && n0 + SM_BN <= p.b_tri_rows) {
+    if (p.b_tri == 1) {
+      const int f = n0 + p.b_tri_off;
+      kb = (f > 0 ? f : 0) & ~(BK - 1);
+    } else {
+      const int l = n0 + SM_BN + p.b_tri_off;
+      ke = l < p.k ? l : p.k;
+    }
+  }
+  const int kc = ke > kb ? ke - kb : 0;  // multiple of 16
+  double* As = smem;                  // [16][ldk]
+  double* Bs = smem + SM_BM * ldk;    // [128][ldk]
+  // ---- stage: row q of the 144 (16 A rows, 128 B rows), one LDS-DMA instruction each ----------------
+  if (2 * lane < kc) {
+    for (int q = wave; q < SM_BM + SM_BN; q += SM_THREADS / 64) {
+      const double* src;
+      if (q < SM_BM) {
+        int r = m0 + q;
+        r = r < p.m ? r : p.m - 1;
+        src = A + (long)r * p.lda + kb;
+      } else {
+        int r = n0 + q - SM_BM;
+        r = r < p.n ? r : p.n - 1;
+        src = B + (long)r * p.ldb + kb;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * lane),
+                                       (__attribute__((address_space(3))) void*)(smem + q * ldk), 16, 0, 0);
+    }
+  }
+  // ---- this wave's 16x16 output tile: columns n0 + 16 wave .. ------------------------------------------
+  const int r = lane & 15, g = lane >> 4;
+  const int col = n0 + wave * 16 + r;
+  d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  if (p.beta != 0.0) {
+    const double* __restrict__ C = p.C + (long)bz * p.strideC;
+    const double sc = p.beta / p.alpha;
+    const int cc = col < p.n ? col : p.n - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int row = m0 + g + 4 * e;
+      row = row < p.m ? row : p.m - 1;
+      acc0[e] = sc * C[(long)row * p.ldc + cc];
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the LDS-DMA rows of this wave have landed
+  __syncthreads();
+  const double* ap = As + r * ldk + g;
+  const double* bp = Bs + (wave * 16 + r) * ldk + g;
+  const int nkk = kc >> 2;
+#pragma unroll 4
+  for (int kk = 0; kk < nkk; kk += 2) {
+    const double a0 = ap[kk * 4], b0 = bp[kk * 4];
+    const double a1 = ap[kk * 4 + 4], b1 = bp[kk * 4 + 4];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+  }
+  double* __restrict__ C = p.C + (long)bz * p.strideC;
+  if (col < p.n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = m0 + g + 4 * e;
+      if (row < p.m) C[(long)row * p.ldc + col] = p.alpha * (acc0[e] + acc1[e]);
+    }
+  }
+}
+
+int launch_small(hipStream_t s, const GemmArgs& a) {
+  const int ldk = a.k + 2;
+  const size_t lds = (size_t)(SM_BM + SM_BN) * ldk * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((SM_BM + SM_BN) * 130 * sizeof(double))));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)gpk_cdiv(a.n, SM_BN), (unsigned)gpk_cdiv(a.m, SM_BM), (unsigned)(a.batch > 0 ? a.batch : 1));
+  hipLaunchKernelGGL(gemm_nt_small, grid, dim3(SM_THREADS), lds, s, a, ldk);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+// small-K latency path: K <= 128 in whole 16-slabs, 16-byte aligned rows, modest row count
+bool small_ok(const GemmArgs& a) {
+  static const bool disabled = getenv("GPK_GEMM_NO_SMALL") != nullptr;
+  if (disabled || a.epi != 0) return false;
+  if (a.k <= 0 || a.k > 128 || (a.k & 15) || (a.b_tri && (a.b_tri_off & 15))) return false;
+  if ((a.lda & 1) || (a.ldb & 1) || (a.strideA & 1) || (a.strideB & 1)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
+  if (a.beta != 0.0 && a.alpha == 0.0) return false;
+  return (long)gpk_cdiv(a.m, SM_BM) * gpk_cdiv(a.n, SM_BN) * (a.batch > 0 ? a.batch : 1) <= 512 && a.batch < 65536;
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -648,7 +793,8 @@ int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
 
 static int launch_select(hipStream_t s, const GemmArgs& a) {
   const long tiles = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
-  if (fast_ok(a) && (a.epi == 1 || (a.n > 64 && (tiles >= 192 || a.m <= 64)))) {
+  if (small_ok(a)) return launch_small(s, a);  // K <= 128, <= 512 workgroups: the latency path
+  if (fast_ok(a) && (a.epi == 1 || (a.n > 64 && (tiles >= 24 || a.m <= 64)))) {
     return a.epi == 1 ? launch_fast<1>(s, a) : launch_fast<0>(s, a);
   }
   if (a.epi == 1) return launch_cfg<128, 128, 2, 2>(s, a);

@@ -34,19 +34,37 @@ extern "C" size_t gpk_invd_elems(int n, int batch) {
   return (size_t)(batch > 0 ? batch : 1) * gpk_cdiv(n, NB) * NB * NB;
 }
 
-// ---- auxiliary "panel" stream + event pool (one per device, created lazily) ---------------------
-// The caller's stream S carries the bulk MFMA work (outer trailing updates, extra-row solves);
-// the high-priority panel stream P carries the latency-bound critical path (leaf, panel solve,
-// inner updates) of the NEXT outer panel, so the two overlap (look-ahead).  Fork/join is done with
-// events only, so the whole sequence is also hipGraph-capturable.  Not re-entrant across host
-// threads for one device (one event pool).
+// ---- auxiliary streams + event pool (one set per device, created lazily) --------------------------
+// The factorisation runs on two streams of its own, forked from / joined to the caller's stream with
+// events only (so the whole sequence stays hipGraph-capturable):
+//   P  "panel" stream, high priority, all CUs: the latency-bound critical path (leaf, panel solve, inner
+//      updates) of the NEXT outer panel (look-ahead);
+//   B  "bulk" stream: the big MFMA GEMMs of the outer trailing updates.  For n >= 4096 it is CU-masked;
+//   X  "extra rows" stream: the right-looking solve of the extra rows (SVGP minibatch), which nothing on
+//      the critical path waits for; confined to the upper 5/8 of the CUs so that the latency chain of
+//      an SVGP-sized factorisation (P and B) always finds free CUs.
+//      B's mask leaves GPK_RESERVED_CUS compute units (default 16 = 2 per XCD; mask bit i is CU
+//      i/8 of XCD i%8 on MI355X, tools/cumask_test.hip) to the panel stream: without that the one-workgroup
+//      leaf kernel, which needs a whole CU's LDS, queues behind thousands of resident GEMM workgroups
+//      (a 2 ms stall per panel at N = 16384 in the rocprof trace) and the look-ahead never overlaps.
+// Not re-entrant across host threads for one device (one event pool).
 namespace {
 struct Aux {
-  hipStream_t P = nullptr;
+  hipStream_t P = nullptr;   // panel stream, high priority, all CUs
+  hipStream_t B = nullptr;   // bulk stream for large n: every CU except the reserved ones
+  hipStream_t Bs = nullptr;  // bulk stream for small n: all CUs (its GEMMs are on the critical path there)
+  hipStream_t X = nullptr;   // extra rows: the upper GPK_EXTRA_CUS_FROM.. CUs only
   hipEvent_t* ev = nullptr;
   int nev = 0;
 };
 Aux g_aux[16];
+
+int masked_stream(hipStream_t* out, int ncu, int first, int last) {  // CUs [first, last)
+  if (first <= 0 && last >= ncu) return (int)hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  uint32_t mask[32] = {0};
+  for (int i = first; i < last; ++i) mask[i >> 5] |= 1u << (i & 31);
+  return (int)hipExtStreamCreateWithCUMask(out, (uint32_t)((ncu + 31) / 32), mask);
+}
 
 int aux_get(int need, Aux** out) {
   int dev = 0;
@@ -57,6 +75,19 @@ int aux_get(int need, Aux** out) {
     int lo = 0, hi = 0;
     GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     GPK_HIP(hipStreamCreateWithPriority(&a.P, hipStreamNonBlocking, hi));
+    hipDeviceProp_t prop;
+    GPK_HIP(hipGetDeviceProperties(&prop, dev));
+    const int ncu = prop.multiProcessorCount;
+    int reserved = 16, xfrom = ncu * 3 / 8;
+    if (const char* e = getenv("GPK_RESERVED_CUS")) reserved = atoi(e);
+    if (const char* e = getenv("GPK_EXTRA_CUS_FROM")) xfrom = atoi(e);
+    if (ncu > 1024 || reserved < 0 || reserved >= ncu) reserved = 0;
+    if (ncu > 1024 || xfrom < 0 || xfrom >= ncu) xfrom = 0;
+    int rc = masked_stream(&a.B, ncu, reserved, ncu);
+    if (rc) return rc;
+    rc = masked_stream(&a.X, ncu, xfrom, ncu);
+    if (rc) return rc;
+    GPK_HIP(hipStreamCreateWithFlags(&a.Bs, hipStreamNonBlocking));
   }
   if (a.nev < need) {
     hipEvent_t* n = (hipEvent_t*)realloc(a.ev, sizeof(hipEvent_t) * need);
@@ -101,18 +132,13 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
   return 0;
 }
 
-// extra rows E = A[n:n+extra, :], columns of panel [c0,c1): left-looking solve against the
-// finished factor:  E[:,c0:c1] <- (E[:,c0:c1] - E[:,0:c0] L[c0:c1,0:c0]^T) L[c0:c1,c0:c1]^-T
+// extra rows E = A[n:n+extra, :] against the finished outer panel [c0,c1), right-looking:
+//   E[:,c0:c1] <- E[:,c0:c1] L[c0:c1,c0:c1]^-T            (NB-blocked, diagonal-block inverses)
+//   E[:,c1:n]  -= E[:,c0:c1] L[c1:n,c0:c1]^T               (one large GEMM, K = c1 - c0)
 int extra_panel(hipStream_t s, double* A, int n, int extra, int c0, int c1, long lda, int batch,
                 long strideA, const double* invd, long strideInv) {
   double* E = A + (long)n * lda;
   int rc;
-  if (c0 > 0) {
-    GemmArgs u = gemm_base(extra, c1 - c0, c0, -1.0, E, lda, A + (long)c0 * lda, lda, 1.0, E + c0, lda,
-                           batch, strideA, strideA, strideA);
-    rc = gpk_launch_gemm(s, u);
-    if (rc) return rc;
-  }
   for (int j0 = c0; j0 < c1; j0 += NB) {
     const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
     const int nb = j1 - j0;
@@ -128,6 +154,12 @@ int extra_panel(hipStream_t s, double* A, int n, int extra, int c0, int c1, long
     rc = gpk_launch_gemm(s, g);
     if (rc) return rc;
   }
+  if (c1 < n) {
+    GemmArgs u = gemm_base(extra, n - c1, c1 - c0, -1.0, E + c0, lda, A + (long)c1 * lda + c0, lda, 1.0,
+                           E + c1, lda, batch, strideA, strideA, strideA);
+    rc = gpk_launch_gemm(s, u);
+    if (rc) return rc;
+  }
   return 0;
 }
 }  // namespace
@@ -140,11 +172,13 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
   if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, S));
   if (n == 0) return 0;
   const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
-  const int nbo = (n >= 4096) ? NBO : 256;  // outer panel width
+  // outer panel width: 512 for the large GPR factorisations (K = 512 trailing GEMMs), one leaf block for
+  // the SVGP-sized ones, where the whole factorisation is a latency chain of leaf -> solve -> strip
+  const int nbo = (n >= 4096) ? NBO : NB;
   const int npanels = gpk_cdiv(n, nbo);
   // Few extra rows (GPR: the P columns of Y) simply ride along through the panel solves and trailing
-  // updates of the square part; many extra rows (SVGP: the minibatch) get their own left-looking,
-  // large-K solve on the bulk stream (extra_panel), overlapped with the panel stream.
+  // updates of the square part; many extra rows (SVGP: the minibatch) are solved right-looking on their
+  // own stream (extra_panel), overlapped with the factorisation.
   const bool ride = extra > 0 && extra <= 256;
   const int R = ride ? n + extra : n;  // rows handled together with the square part
   int rc;
@@ -158,46 +192,64 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
     return zero_upper ? gpk_launch_zero_upper(S, A, n, lda, batch, strideA) : 0;
   }
   Aux* aux = nullptr;
-  rc = aux_get(2 * npanels + 2, &aux);
+  rc = aux_get(2 * npanels + 6, &aux);
   if (rc) return rc;
-  hipStream_t P = aux->P;
-  hipEvent_t* evF = aux->ev;            // [npanels]   panel p factored (recorded on P)
-  hipEvent_t* evT = aux->ev + npanels;  // [npanels+1] strip for panel p up to date (recorded on S)
-  GPK_HIP(hipEventRecord(evT[0], S));   // fork: P starts after everything already queued on S
+  hipStream_t P = aux->P, B = (n >= 4096) ? aux->B : aux->Bs, X = aux->X;
+  hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
+  hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
+  hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1],
+             evJoinB = aux->ev[2 * npanels + 2], evJoinX = aux->ev[2 * npanels + 3];
+  const bool useX = extra > 0 && !ride;
+  GPK_HIP(hipEventRecord(evFork, S));  // fork: everything already queued on S comes first
+  GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
+  GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
+  if (useX) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
   for (int p = 0; p < npanels; ++p) {
     const int c0 = p * nbo;
     const int c1 = (c0 + nbo < n) ? c0 + nbo : n;
     const int c2 = (c1 + nbo < n) ? c1 + nbo : n;
-    // ---- P: critical path of panel p (square rows only) ---------------------------------------
-    GPK_HIP(hipStreamWaitEvent(P, evT[p], 0));
+    // ---- P: the critical path.  Panel p, then the strip = columns of panel p+1 (look-ahead) -----------
     rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
     GPK_HIP(hipEventRecord(evF[p], P));
-    // ---- S: bulk work that depends on panel p -----------------------------------------------------
-    GPK_HIP(hipStreamWaitEvent(S, evF[p], 0));
     const double* Pn = A + (long)c1 * lda + c0;  // panel rows c1.. (solved), K = c1 - c0
     if (c1 < n) {
-      // strip first: columns of the NEXT panel, so P can go on while S does the rest
+      // columns c1:c2 also receive the rest-update of panel p-1 (on B): order the two
+      if (p > 0) GPK_HIP(hipStreamWaitEvent(P, evR[p - 1], 0));
       GemmArgs u = gemm_base(R - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0,
                              A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
-      rc = gpk_launch_gemm(S, u);
-      if (rc) return rc;
-      GPK_HIP(hipEventRecord(evT[p + 1], S));
-    }
-    if (extra > 0 && !ride) {
-      rc = extra_panel(S, A, n, extra, c0, c1, lda, batch, strideA, invd, strideInv);
+      rc = gpk_launch_gemm(P, u);
       if (rc) return rc;
     }
+    // ---- B: rest of the outer trailing update  A[c2:, c2:] -= P[c2:] P[c2:]^T, lower tiles only --------
     if (c2 < n) {
-      // rest of the outer trailing update: A[c2:n, c2:n] -= P[c2:] P[c2:]^T, lower tiles only
+      GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));
       const double* P2 = A + (long)c2 * lda + c0;
       GemmArgs u = gemm_base(R - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
-      rc = gpk_launch_gemm(S, u);
+      rc = gpk_launch_gemm(B, u);
+      if (rc) return rc;
+      GPK_HIP(hipEventRecord(evR[p], B));
+    }
+    // ---- X: the extra rows against panel p -----------------------------------------------------------
+    // (in groups of up to 512 columns, so that its big right-looking update is a K = 512 GEMM)
+    if (useX && (c1 == n || (c1 % NBO) == 0)) {
+      const int g0 = ((c1 - 1) / NBO) * NBO;
+      GPK_HIP(hipStreamWaitEvent(X, evF[p], 0));
+      rc = extra_panel(X, A, n, extra, g0, c1, lda, batch, strideA, invd, strideInv);
       if (rc) return rc;
     }
+  }
+  // join: P has waited for every rest-update it depends on; B's last event covers the rest
+  GPK_HIP(hipEventRecord(evJoinP, P));
+  GPK_HIP(hipEventRecord(evJoinB, B));
+  GPK_HIP(hipStreamWaitEvent(S, evJoinP, 0));
+  GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
+  if (useX) {
+    GPK_HIP(hipEventRecord(evJoinX, X));
+    GPK_HIP(hipStreamWaitEvent(S, evJoinX, 0));
   }
   if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, batch, strideA);
   return 0;
