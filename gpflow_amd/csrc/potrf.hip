@@ -40,9 +40,10 @@ extern "C" size_t gpk_invd_elems(int n, int batch) {
 //   P  "panel" stream, high priority, all CUs: the latency-bound critical path (leaf, panel solve, inner
 //      updates) of the NEXT outer panel (look-ahead);
 //   B  "bulk" stream: the big MFMA GEMMs of the outer trailing updates.  For n >= 4096 it is CU-masked;
-//   X  "extra rows" stream: the right-looking solve of the extra rows (SVGP minibatch), which nothing on
-//      the critical path waits for; confined to the upper 5/8 of the CUs so that the latency chain of
-//      an SVGP-sized factorisation (P and B) always finds free CUs.
+//   X  four "extra rows" streams: the right-looking solve of the extra rows (SVGP minibatch), one row
+//      quarter per stream (the in-group steps are short dependent GEMMs: four of them in flight fill the
+//      machine), which nothing on the critical path waits for; confined to the upper 5/8 of the CUs so
+//      that the latency chain of an SVGP-sized factorisation (P and B) always finds free CUs.
 //      B's mask leaves GPK_RESERVED_CUS compute units (default 16 = 2 per XCD; mask bit i is CU
 //      i/8 of XCD i%8 on MI355X, tools/cumask_test.hip) to the panel stream: without that the one-workgroup
 //      leaf kernel, which needs a whole CU's LDS, queues behind thousands of resident GEMM workgroups
@@ -53,7 +54,8 @@ struct Aux {
   hipStream_t P = nullptr;   // panel stream, high priority, all CUs
   hipStream_t B = nullptr;   // bulk stream for large n: every CU except the reserved ones
   hipStream_t Bs = nullptr;  // bulk stream for small n: all CUs (its GEMMs are on the critical path there)
-  hipStream_t X = nullptr;   // extra rows: the upper GPK_EXTRA_CUS_FROM.. CUs only
+  hipStream_t X[4] = {nullptr, nullptr, nullptr, nullptr};  // extra rows: in-group steps (short dependent GEMMs), unmasked
+  hipStream_t Xb = nullptr;  // extra rows: the big right-looking updates, CU-masked (leaves GPK_EXTRA_RESERVED_CUS free)
   hipEvent_t* ev = nullptr;
   int nev = 0;
 };
@@ -78,22 +80,35 @@ int aux_get(int need, Aux** out) {
     hipDeviceProp_t prop;
     GPK_HIP(hipGetDeviceProperties(&prop, dev));
     const int ncu = prop.multiProcessorCount;
-    int reserved = 16, xfrom = ncu * 3 / 8;
+    int reserved = 16, xfrom = 0;  // X unmasked by default: CU-masked queues dispatched the short extra-row GEMMs slower (A/B: 385 vs 305 steps/s)
     if (const char* e = getenv("GPK_RESERVED_CUS")) reserved = atoi(e);
     if (const char* e = getenv("GPK_EXTRA_CUS_FROM")) xfrom = atoi(e);
     if (ncu > 1024 || reserved < 0 || reserved >= ncu) reserved = 0;
     if (ncu > 1024 || xfrom < 0 || xfrom >= ncu) xfrom = 0;
     int rc = masked_stream(&a.B, ncu, reserved, ncu);
     if (rc) return rc;
-    rc = masked_stream(&a.X, ncu, xfrom, ncu);
-    if (rc) return rc;
+    for (int i = 0; i < 4; ++i) {
+      rc = masked_stream(&a.X[i], ncu, xfrom, ncu);
+      if (rc) return rc;
+    }
+    // optional: a CU-masked stream for the one big GEMM per group (A/B on MI355X: the two event hops per group
+    // cost more than the leaf stalls they avoid -- 363 vs 385 steps/s -- so it is off unless requested)
+    if (const char* e = getenv("GPK_EXTRA_RESERVED_CUS")) {
+      int xres = atoi(e);
+      if (ncu > 1024 || xres < 0 || xres >= ncu) xres = 0;
+      rc = masked_stream(&a.Xb, ncu, xres, ncu);
+      if (rc) return rc;
+    }
     GPK_HIP(hipStreamCreateWithFlags(&a.Bs, hipStreamNonBlocking));
   }
   if (a.nev < need) {
     hipEvent_t* n = (hipEvent_t*)realloc(a.ev, sizeof(hipEvent_t) * need);
     if (!n) return GPK_E_ARG;
     a.ev = n;
-    for (int i = a.nev; i < need; ++i) GPK_HIP(hipEventCreateWithFlags(&a.ev[i], hipEventDisableTiming));
+    // (hipEventDisableSystemFence measured SLOWER here: 283 vs 308 steps/s on the SVGP step)
+    static const unsigned ev_flags =
+        getenv("GPK_EVENT_NO_SYSTEM_FENCE") ? (hipEventDisableTiming | hipEventDisableSystemFence) : hipEventDisableTiming;
+    for (int i = a.nev; i < need; ++i) GPK_HIP(hipEventCreateWithFlags(&a.ev[i], ev_flags));
     a.nev = need;
   }
   *out = &a;
@@ -135,9 +150,9 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
 // extra rows E = A[n:n+extra, :] against the finished outer panel [c0,c1), right-looking:
 //   E[:,c0:c1] <- E[:,c0:c1] L[c0:c1,c0:c1]^-T            (NB-blocked, diagonal-block inverses)
 //   E[:,c1:n]  -= E[:,c0:c1] L[c1:n,c0:c1]^T               (one large GEMM, K = c1 - c0)
-int extra_panel(hipStream_t s, double* A, int n, int extra, int c0, int c1, long lda, int batch,
-                long strideA, const double* invd, long strideInv) {
-  double* E = A + (long)n * lda;
+int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev_big, double* A, int n, int row0,
+                int extra, int c0, int c1, long lda, int batch, long strideA, const double* invd, long strideInv) {
+  double* E = A + (long)(n + row0) * lda;  // rows [row0, row0 + extra) of the extra block
   int rc;
   for (int j0 = c0; j0 < c1; j0 += NB) {
     const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
@@ -155,10 +170,20 @@ int extra_panel(hipStream_t s, double* A, int n, int extra, int c0, int c1, long
     if (rc) return rc;
   }
   if (c1 < n) {
+    // the one large GEMM of the group goes to the CU-masked stream `sbig` (it would otherwise fill every CU
+    // with long-running workgroups and starve the one-workgroup leaf kernel of the panel stream)
+    if (sbig != s) {
+      GPK_HIP(hipEventRecord(ev_in, s));
+      GPK_HIP(hipStreamWaitEvent(sbig, ev_in, 0));
+    }
     GemmArgs u = gemm_base(extra, n - c1, c1 - c0, -1.0, E + c0, lda, A + (long)c1 * lda + c0, lda, 1.0,
                            E + c1, lda, batch, strideA, strideA, strideA);
-    rc = gpk_launch_gemm(s, u);
+    rc = gpk_launch_gemm(sbig, u);
     if (rc) return rc;
+    if (sbig != s) {
+      GPK_HIP(hipEventRecord(ev_big, sbig));
+      GPK_HIP(hipStreamWaitEvent(s, ev_big, 0));
+    }
   }
   return 0;
 }
@@ -186,24 +211,31 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
     rc = factor_panel(S, A, R, 0, n, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
     if (extra > 0 && !ride) {
-      rc = extra_panel(S, A, n, extra, 0, n, lda, batch, strideA, invd, strideInv);
+      rc = extra_panel(S, S, nullptr, nullptr, A, n, 0, extra, 0, n, lda, batch, strideA, invd, strideInv);
       if (rc) return rc;
     }
     return zero_upper ? gpk_launch_zero_upper(S, A, n, lda, batch, strideA) : 0;
   }
   Aux* aux = nullptr;
-  rc = aux_get(2 * npanels + 6, &aux);
+  rc = aux_get(2 * npanels + 12, &aux);
   if (rc) return rc;
-  hipStream_t P = aux->P, B = (n >= 4096) ? aux->B : aux->Bs, X = aux->X;
+  hipStream_t P = aux->P, B = (n >= 4096) ? aux->B : aux->Bs;
+  // extra rows in up to 4 chunks of whole 128-row tiles, one stream each
+  int nx = 0, xrow[5] = {0, 0, 0, 0, 0};
+  if (extra > 0 && !ride) {
+    nx = 1;  // more streams than hardware queues serialise against each other (measured: 4 were slower than 1)
+    const int per = gpk_cdiv(gpk_cdiv(extra, nx), NB) * NB;
+    for (int i = 0; i <= nx; ++i) xrow[i] = (i * per < extra) ? i * per : extra;
+  }
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
   hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
   hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1],
-             evJoinB = aux->ev[2 * npanels + 2], evJoinX = aux->ev[2 * npanels + 3];
+             evJoinB = aux->ev[2 * npanels + 2];
   const bool useX = extra > 0 && !ride;
   GPK_HIP(hipEventRecord(evFork, S));  // fork: everything already queued on S comes first
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
   GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
-  if (useX) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
+  for (int i = 0; i < nx; ++i) GPK_HIP(hipStreamWaitEvent(aux->X[i], evFork, 0));
   for (int p = 0; p < npanels; ++p) {
     const int c0 = p * nbo;
     const int c1 = (c0 + nbo < n) ? c0 + nbo : n;
@@ -237,9 +269,13 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
     // (in groups of up to 512 columns, so that its big right-looking update is a K = 512 GEMM)
     if (useX && (c1 == n || (c1 % NBO) == 0)) {
       const int g0 = ((c1 - 1) / NBO) * NBO;
-      GPK_HIP(hipStreamWaitEvent(X, evF[p], 0));
-      rc = extra_panel(X, A, n, extra, g0, c1, lda, batch, strideA, invd, strideInv);
-      if (rc) return rc;
+      for (int i = 0; i < nx; ++i) {
+        if (xrow[i + 1] <= xrow[i]) continue;
+        GPK_HIP(hipStreamWaitEvent(aux->X[i], evF[p], 0));
+        rc = extra_panel(aux->X[i], aux->Xb ? aux->Xb : aux->X[i], aux->ev[2 * npanels + 7], aux->ev[2 * npanels + 8], A, n, xrow[i],
+                         xrow[i + 1] - xrow[i], g0, c1, lda, batch, strideA, invd, strideInv);
+        if (rc) return rc;
+      }
     }
   }
   // join: P has waited for every rest-update it depends on; B's last event covers the rest
@@ -247,9 +283,10 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
   GPK_HIP(hipEventRecord(evJoinB, B));
   GPK_HIP(hipStreamWaitEvent(S, evJoinP, 0));
   GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
-  if (useX) {
-    GPK_HIP(hipEventRecord(evJoinX, X));
-    GPK_HIP(hipStreamWaitEvent(S, evJoinX, 0));
+  for (int i = 0; i < nx; ++i) {
+    hipEvent_t ej = aux->ev[2 * npanels + 3 + i];
+    GPK_HIP(hipEventRecord(ej, aux->X[i]));
+    GPK_HIP(hipStreamWaitEvent(S, ej, 0));
   }
   if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, batch, strideA);
   return 0;
