@@ -87,7 +87,7 @@ def cpu_baseline(budget_s: float = 12.0):
                       f"installable in this image"}
 
 
-def gpr_cholesky_leg(ops, lib, device):
+def gpr_cholesky_leg(ops, lib, device):  # noqa: C901
     """GPR config C2: K(X,X)+noise build + Cholesky + LML tail at N=16384, D=8 (gpr.py:91-107)."""
     n, d = 16384, 8
     g = torch.Generator(device="cpu").manual_seed(2)
@@ -113,7 +113,10 @@ def gpr_cholesky_leg(ops, lib, device):
         torch.cuda.synchronize(); tk.append(e0.elapsed_time(e1) * 1e-3)
     tkb = float(np.min(tk[1:]))
     flops = n ** 3 / 3.0
+    kb_alg = n * n * 8 + n * d * 8  # algorithmic bytes: the full N x N fp64 write + the N x D read
     return {"workload": "GPR RBF N=16384 D=8 fp64: K build + Cholesky + LML (one gpk_gpr_lml call)",
+            "kernel_build_roofline": {"bound": "hbm", "kernel": "rbf_kernel (full N x N)", "achieved": kb_alg / tkb / 1e9,
+                                      "peak": 8000.0, "unit": "GB/s", "frac": kb_alg / tkb / 8e12, "traffic": None},
             "lml": float(out.cpu()[0]), "info": int(info.cpu()[0]), "ms_total": t * 1e3,
             "cholesky_gflops_incl_build_and_tail": flops / t / 1e9,
             "frac_of_fp64_peak": flops / t / 1e12 / FP64_PEAK_TFLOPS,
@@ -195,26 +198,49 @@ def main():
         step(args.warmup + args.steps + s)
     fence()
     if rank == 0:
-        ms, n_launch, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
-        lib.gpk_profile_gemm_collect(ctypes.byref(ms), ctypes.byref(n_launch), ctypes.byref(fl))
+        def collect(min_flops, keep):
+            ms, n_launch, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+            lib.gpk_profile_gemm_collect_min(ctypes.c_double(min_flops), int(keep), ctypes.byref(ms),
+                                             ctypes.byref(n_launch), ctypes.byref(fl))
+            return ms.value, n_launch.value, fl.value
+        # dominant kernel of a step = the q_sqrt projection launch of gemm_nt_fast (EPI=1, paired triangular-K
+        # tiles): the only launch with >= 3e10 algorithmic flop, one per step, fixed shape -> its HIP-event
+        # duration is directly comparable with rocprofv3's average for `gemm_nt_fast<1, true>` (profiles/).
+        ms_dom, n_dom, fl_dom = collect(3e10, True)
+        ms_big, n_big, fl_big = collect(1e9, True)
+        ms_all, n_all, fl_all = collect(0.0, False)
         lib.gpk_profile_gemm_enable(0)
-        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        ach = fl_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         sink = torch.zeros(8, dtype=torch.float64, device=device)
         st = torch.cuda.current_stream().cuda_stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        lib.gpk_bench_mfma_f64(st, 1024, 2000, sink.data_ptr()); torch.cuda.synchronize()
-        e0.record(); lib.gpk_bench_mfma_f64(st, 1024, 20000, sink.data_ptr()); e1.record(); torch.cuda.synchronize()
-        ubench = 1024 * 4 * 20000 * 8 * 2048 / (e0.elapsed_time(e1) * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (v_mfma_f64_16x16x4_f64)", "achieved": ach,
-                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
-                "launches_per_step": n_launch.value / nprof,
-                "avg_launch_us": ms.value * 1e3 / max(n_launch.value, 1),
-                "algorithmic_gflop_per_step_in_gemm": fl.value / nprof / 1e9,
+        lib.gpk_bench_mfma_f64(st, 512, 2000, sink.data_ptr()); torch.cuda.synchronize()
+        e0.record(); lib.gpk_bench_mfma_f64(st, 512, 20000, sink.data_ptr()); e1.record(); torch.cuda.synchronize()
+        ubench = 512 * 8 * 20000 * 8 * 2048 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        traffic = None
+        try:  # HBM bytes per launch of this kernel from the committed PMC passes (tools/profile_round.sh)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = float(json.load(f)["gemm_nt_fast<1,true>"]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
+        roof = {"bound": "mfma", "kernel": "gemm_nt_fast<1,true>: q_sqrt projection, v_mfma_f64_16x16x4_f64, 128x128x16 tiles",
+                "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                "traffic": traffic, "launches_per_step": n_dom / nprof, "avg_launch_us": ms_dom * 1e3 / max(n_dom, 1),
+                "algorithmic_gflop_per_launch": fl_dom / max(n_dom, 1) / 1e9,
+                "big_gemm_launches": {"launches_per_step": n_big / nprof, "avg_launch_us": ms_big * 1e3 / max(n_big, 1),
+                                      "algorithmic_gflop_per_step": fl_big / nprof / 1e9,
+                                      "tflops_over_summed_durations": fl_big / (ms_big * 1e-3) / 1e12 if ms_big > 0 else 0.0},
+                "all_gemm_launches": {"launches_per_step": n_all / nprof, "avg_launch_us": ms_all * 1e3 / max(n_all, 1),
+                                      "algorithmic_gflop_per_step": fl_all / nprof / 1e9,
+                                      "tflops_over_summed_durations": fl_all / (ms_all * 1e-3) / 1e12 if ms_all > 0 else 0.0},
                 "mfma_f64_issue_ubench_tflops": ubench,
                 "frac_of_measured_mfma_ceiling": ach / ubench if ubench > 0 else None,
-                "note": "achieved = algorithmic flops of all GEMM launches / summed HIP-event durations of those "
-                        "launches; peak = AMD datasheet FP64 matrix; the measured v_mfma_f64 issue-rate ceiling "
-                        "on this chip is reported next to it"}
+                "note": "achieved = algorithmic flops of the launch (2 * B * sum over column tiles of the non-zero K range: "
+                        "M^2 B with the triangle of q_sqrt counted once) / its HIP-event duration, events recorded on the "
+                        "launch stream; peak = AMD datasheet FP64 matrix (the in-image guide lists no fp64 peak; the "
+                        "v_mfma_f64_16x16x4 issue rate measured on this chip is next to it); traffic = FETCH_SIZE x2 "
+                        "(gfx950 correction for 16-B coalesced loads) + WRITE_SIZE of the same kernel from the PMC passes "
+                        "in profiles/ (MALL hits included, so an upper bound on HBM bytes)"}
 
     if world > 1:
         dist.barrier()

@@ -3,7 +3,10 @@
 #include "gpk_internal.h"
 
 namespace {
-__global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double* sink) {
+// 512-thread blocks: with <= 256 registers per lane hipcc keeps the accumulators in VGPRs; under
+// __launch_bounds__(256) it parks them in AGPRs and copies all 64 of them through v_accvgpr_read/write on
+// every iteration, which measures the copy loop (48 TFLOP/s) instead of the matrix pipe (77.4 TFLOP/s).
+__global__ __launch_bounds__(512) void mfma_f64_rate_kernel(int iters, double* sink) {
   const long long t0 = clock64();
   const long long w0 = wall_clock64();
   const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
@@ -33,9 +36,9 @@ __global__ __launch_bounds__(256) void stream_store_kernel(double* out, long n2)
 }
 }  // namespace
 
-// flops issued = blocks * 4 waves * iters * 8 * 2048
+// flops issued = blocks * 8 waves * iters * 8 * 2048
 extern "C" int gpk_bench_mfma_f64(void* stream, int blocks, int iters, double* sink) {
-  hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, iters, sink);
   GPK_LAUNCH_CHECK();
   return 0;
 }

@@ -750,21 +750,29 @@ extern "C" void gpk_profile_gemm_enable(int on) {
   g_prof_n = 0;
 }
 
-// total_ms / launches / flops of the GEMM launches recorded since enable(1); synchronises the device
-extern "C" int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops) {
+// total_ms / launches / flops of the GEMM launches recorded since enable(1) whose ALGORITHMIC flop count is at
+// least min_flops (0 = all); synchronises the device.  keep != 0 leaves the records in place for another query.
+extern "C" int gpk_profile_gemm_collect_min(double min_flops, int keep, double* total_ms, long* launches,
+                                            double* flops) {
   GPK_HIP(hipDeviceSynchronize());
   double ms = 0.0, fl = 0.0;
+  long cnt = 0;
   for (int i = 0; i < g_prof_n; ++i) {
+    if (g_prof[i].flops < min_flops) continue;
     float t = 0.f;
     GPK_HIP(hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1));
     ms += t;
     fl += g_prof[i].flops;
+    ++cnt;
   }
   if (total_ms) *total_ms = ms;
-  if (launches) *launches = g_prof_n;
+  if (launches) *launches = cnt;
   if (flops) *flops = fl;
-  g_prof_n = 0;
+  if (!keep) g_prof_n = 0;
   return 0;
+}
+extern "C" int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops) {
+  return gpk_profile_gemm_collect_min(0.0, 0, total_ms, launches, flops);
 }
 
 static int launch_select(hipStream_t s, const GemmArgs& a);

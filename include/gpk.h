@@ -177,6 +177,8 @@ int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long l
  * time, launch count and ALGORITHMIC flops (useful multiply-adds only) since enable. */
 void gpk_profile_gemm_enable(int on);
 int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops);
+/* same, restricted to launches with at least min_flops algorithmic flops; keep != 0 keeps the records */
+int gpk_profile_gemm_collect_min(double min_flops, int keep, double* total_ms, long* launches, double* flops);
 
 /* micro-benchmarks used by bench.py / profiles (fp64 MFMA issue rate, HBM write stream) */
 int gpk_bench_mfma_f64(void* stream, int blocks, int iters, double* sink);
