@@ -54,6 +54,7 @@ struct Aux {
   hipStream_t P = nullptr;   // panel stream, high priority, all CUs
   hipStream_t B = nullptr;   // bulk stream for large n: every CU except the reserved ones
   hipStream_t Bs = nullptr;  // bulk stream for small n: all CUs (its GEMMs are on the critical path there)
+  hipStream_t Bl = nullptr;  // bulk stream for the chain-bound tail of a large factorisation: leaves half the CUs to P
   hipStream_t X[4] = {nullptr, nullptr, nullptr, nullptr};  // extra rows: in-group steps (short dependent GEMMs), unmasked
   hipStream_t Xb = nullptr;  // extra rows: the big right-looking updates, CU-masked (leaves GPK_EXTRA_RESERVED_CUS free)
   hipEvent_t* ev = nullptr;
@@ -100,6 +101,11 @@ int aux_get(int need, Aux** out) {
       if (rc) return rc;
     }
     GPK_HIP(hipStreamCreateWithFlags(&a.Bs, hipStreamNonBlocking));
+    int late_res = ncu / 2;
+    if (const char* e = getenv("GPK_LATE_RESERVED_CUS")) late_res = atoi(e);
+    if (ncu > 1024 || late_res < 0 || late_res >= ncu) late_res = 0;
+    rc = masked_stream(&a.Bl, ncu, late_res, ncu);
+    if (rc) return rc;
   }
   if (a.nev < need) {
     hipEvent_t* n = (hipEvent_t*)realloc(a.ev, sizeof(hipEvent_t) * need);
@@ -236,6 +242,7 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
   GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
   for (int i = 0; i < nx; ++i) GPK_HIP(hipStreamWaitEvent(aux->X[i], evFork, 0));
+  hipStream_t last_bulk = B;
   for (int p = 0; p < npanels; ++p) {
     const int c0 = p * nbo;
     const int c1 = (c0 + nbo < n) ? c0 + nbo : n;
@@ -255,15 +262,28 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
       if (rc) return rc;
     }
     // ---- B: rest of the outer trailing update  A[c2:, c2:] -= P[c2:] P[c2:]^T, lower tiles only --------
+    // While the trailing matrix is large the factorisation is bound by these GEMMs and they start as soon as
+    // panel p is solved.  Near the end it is bound by the latency chain of P instead: there the strip goes
+    // first (alone on the chip) and the rest-update overlaps the NEXT panel's chain rather than the strip.
+    const bool strip_first = (n >= 4096) && (n - c1 <= 6144) && (c1 < n);
     if (c2 < n) {
-      GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));
+      hipStream_t Bp = B;
+      if (strip_first) {
+        Bp = aux->Bl;  // (in-order with the earlier rest-updates through evR below)
+        GPK_HIP(hipEventRecord(aux->ev[2 * npanels + 9], P));
+        GPK_HIP(hipStreamWaitEvent(Bp, aux->ev[2 * npanels + 9], 0));
+        if (p > 0) GPK_HIP(hipStreamWaitEvent(Bp, evR[p - 1], 0));
+      } else {
+        GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));
+      }
       const double* P2 = A + (long)c2 * lda + c0;
       GemmArgs u = gemm_base(R - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
-      rc = gpk_launch_gemm(B, u);
+      rc = gpk_launch_gemm(Bp, u);
       if (rc) return rc;
-      GPK_HIP(hipEventRecord(evR[p], B));
+      GPK_HIP(hipEventRecord(evR[p], Bp));
+      last_bulk = Bp;
     }
     // ---- X: the extra rows against panel p -----------------------------------------------------------
     // (in groups of up to 512 columns, so that its big right-looking update is a K = 512 GEMM)
@@ -280,7 +300,7 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
   }
   // join: P has waited for every rest-update it depends on; B's last event covers the rest
   GPK_HIP(hipEventRecord(evJoinP, P));
-  GPK_HIP(hipEventRecord(evJoinB, B));
+  GPK_HIP(hipEventRecord(evJoinB, last_bulk));  // rest-updates are chained through evR, the last one covers all
   GPK_HIP(hipStreamWaitEvent(S, evJoinP, 0));
   GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
   for (int i = 0; i < nx; ++i) {
