@@ -243,6 +243,11 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
   GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
   for (int i = 0; i < nx; ++i) GPK_HIP(hipStreamWaitEvent(aux->X[i], evFork, 0));
   hipStream_t last_bulk = B;
+  // Deferred rest-updates: while the trailing matrix is large, the far trailing update is applied once per TWO
+  // outer panels, as a K = 1024 GEMM (65 vs 59 TFLOP/s for K = 512 on this chip); the strip of the look-ahead
+  // carries whatever panels are still pending for the next panel's columns.  r0 = first pending column.
+  int r0 = 0, last_rest = -1;  // last_rest: panel index whose evR marks the most recent rest-update
+  static const int defer_rows = getenv("GPK_DEFER_ROWS") ? atoi(getenv("GPK_DEFER_ROWS")) : (1 << 30);  // off by default: A/B 33.7 vs 32.7 ms at N = 16384 (the K = 1024 strips starve on the panel stream)
   for (int p = 0; p < npanels; ++p) {
     const int c0 = p * nbo;
     const int c1 = (c0 + nbo < n) ? c0 + nbo : n;
@@ -251,11 +256,12 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
     rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
     GPK_HIP(hipEventRecord(evF[p], P));
-    const double* Pn = A + (long)c1 * lda + c0;  // panel rows c1.. (solved), K = c1 - c0
+    const int kpend = c1 - r0;                   // pending columns r0:c1 (one or two panels)
+    const double* Pn = A + (long)c1 * lda + r0;  // rows c1.. of the pending panels (solved)
     if (c1 < n) {
-      // columns c1:c2 also receive the rest-update of panel p-1 (on B): order the two
-      if (p > 0) GPK_HIP(hipStreamWaitEvent(P, evR[p - 1], 0));
-      GemmArgs u = gemm_base(R - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0,
+      // columns c1:c2 also received the most recent rest-update (on a bulk stream): order the two
+      if (last_rest >= 0) GPK_HIP(hipStreamWaitEvent(P, evR[last_rest], 0));
+      GemmArgs u = gemm_base(R - c1, c2 - c1, kpend, -1.0, Pn, lda, Pn, lda, 1.0,
                              A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
       rc = gpk_launch_gemm(P, u);
@@ -266,24 +272,29 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
     // panel p is solved.  Near the end it is bound by the latency chain of P instead: there the strip goes
     // first (alone on the chip) and the rest-update overlaps the NEXT panel's chain rather than the strip.
     const bool strip_first = (n >= 4096) && (n - c1 <= 6144) && (c1 < n);
-    if (c2 < n) {
+    const bool defer = (nbo == NBO) && (kpend < 2 * NBO) && (n - c2 >= defer_rows) && (c2 + nbo < n);
+    if (c2 < n && !defer) {
       hipStream_t Bp = B;
       if (strip_first) {
         Bp = aux->Bl;  // (in-order with the earlier rest-updates through evR below)
         GPK_HIP(hipEventRecord(aux->ev[2 * npanels + 9], P));
         GPK_HIP(hipStreamWaitEvent(Bp, aux->ev[2 * npanels + 9], 0));
-        if (p > 0) GPK_HIP(hipStreamWaitEvent(Bp, evR[p - 1], 0));
+        if (last_rest >= 0) GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
       } else {
         GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));
       }
-      const double* P2 = A + (long)c2 * lda + c0;
-      GemmArgs u = gemm_base(R - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
+      const double* P2 = A + (long)c2 * lda + r0;
+      GemmArgs u = gemm_base(R - c2, n - c2, kpend, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
       rc = gpk_launch_gemm(Bp, u);
       if (rc) return rc;
       GPK_HIP(hipEventRecord(evR[p], Bp));
       last_bulk = Bp;
+      last_rest = p;
+      r0 = c1;
+    } else if (!defer) {
+      r0 = c1;
     }
     // ---- X: the extra rows against panel p -----------------------------------------------------------
     // (in groups of up to 512 columns, so that its big right-looking update is a K = 512 GEMM)
