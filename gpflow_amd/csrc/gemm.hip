@@ -37,9 +37,8 @@ struct TileCfg {
 // Tiles are numbered group-of-8-columns major, row-major inside a group; each XCD takes a
 // contiguous 1/8 of that sequence.  With c_lower (and square tiles) only the tiles on or below
 // the diagonal are numbered, so every XCD gets the same amount of work.
-__device__ __forceinline__ void tile_order(int b_tri, int gx, int gy, int total, int compact, int& tile_m,
+__device__ __forceinline__ void tile_order(int lin, int b_tri, int gx, int gy, int total, int compact, int& tile_m,
                                            int& tile_n) {
-  const int lin = blockIdx.x;
   const int xcd = lin & 7, local = lin >> 3;
   const int q = total >> 3, r = total & 7;
   int nl = xcd * q + (xcd < r ? xcd : r) + local;
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
   const int bz = blockIdx.y;
 
   int tile_m, tile_n;
-  tile_order(p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+  tile_order(blockIdx.x, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (p.c_lower && n0 > m0 + BM - 1) return;
 
@@ -504,9 +503,14 @@ template <int EPI, bool PAIR>
 __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int gy, int total, int compact) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if constexpr (!PAIR) {
-    int tile_m, tile_n;
-    tile_order(p.b_tri, gx, gy, total, compact, tile_m, tile_n);
-    fast_tile<EPI>(p, tile_m, tile_n, smem);
+    // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x (used to cap
+    // the number of CUs a bulk GEMM may occupy while a latency-critical stream needs free ones)
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+      int tile_m, tile_n;
+      tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+      fast_tile<EPI>(p, tile_m, tile_n, smem);
+      if (t + (int)gridDim.x < total) __syncthreads();  // both LDS buffers are about to be refilled
+    }
   } else {
     const int tile_m = blockIdx.x % gy, j = blockIdx.x / gy;
     fast_tile<EPI>(p, tile_m, j, smem);
@@ -554,7 +558,9 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
       return 0;
     }
   }
-  hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy, total,
+  unsigned nwg = (unsigned)total;
+  if (a.max_wgs > 0 && (unsigned)a.max_wgs < nwg) nwg = (unsigned)a.max_wgs;
+  hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy, total,
                      compact);
   GPK_LAUNCH_CHECK();
   return 0;

@@ -40,6 +40,7 @@ struct GemmArgs {
   double* part; long part_ld; long stridePart;   // [2*tiles_n, m]
   double* C2; long ldc2; long strideC2; int c2_cols;
   int batch;
+  int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
 int gpk_gemm_tiles_n(int n);  // number of column tiles the launcher will use for n columns

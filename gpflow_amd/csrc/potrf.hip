@@ -184,6 +184,10 @@ int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev
     }
     GemmArgs u = gemm_base(extra, n - c1, c1 - c0, -1.0, E + c0, lda, A + (long)c1 * lda + c0, lda, 1.0,
                            E + c1, lda, batch, strideA, strideA, strideA);
+    // persistent workgroups, fewer than CUs: the hardware spreads them one per CU, so some CUs stay empty for
+    // the panel stream's one-workgroup leaf kernel (which needs a whole CU's LDS) -- see DESIGN.md
+    static const int xwgs = getenv("GPK_EXTRA_MAX_WGS") ? atoi(getenv("GPK_EXTRA_MAX_WGS")) : 224;
+    u.max_wgs = xwgs;
     rc = gpk_launch_gemm(sbig, u);
     if (rc) return rc;
     if (sbig != s) {

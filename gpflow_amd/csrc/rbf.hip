@@ -28,7 +28,8 @@ struct RbfArgs {
 
 constexpr int T = 64;
 
-__device__ __forceinline__ double kern_eval(int family, double r2, double variance) {
+template <int family>
+__device__ __forceinline__ double kern_eval(double r2, double variance) {
   if (family == GPK_KERN_SE) return variance * exp(-0.5 * r2);
   const double r = sqrt(fmax(r2, 1e-36));
   if (family == GPK_KERN_MATERN12) return variance * exp(-r);
@@ -40,6 +41,10 @@ __device__ __forceinline__ double kern_eval(int family, double r2, double varian
   return variance * (1.0 + sqrt5 * r + 5.0 / 3.0 * (r * r)) * exp(-sqrt5 * r);
 }
 
+// MIRROR (symmetric full build): only tiles on or below the diagonal are computed; each is also written
+// transposed to its mirror position (K(X,X) from the expansion formula is bitwise symmetric: products and the
+// two-term sums commute), which halves the fp64 exp/FMA work of what is otherwise a store-bound kernel.
+template <int FAMILY>
 __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int d = p.d;
@@ -49,7 +54,8 @@ __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
   double* nr2 = nr1 + T;              // [T]
 
   const int r0 = blockIdx.y * T, c0 = blockIdx.x * T;
-  if (p.sym && p.lower_only && c0 > r0 + T - 1) return;
+  const bool mirror = p.sym && !p.lower_only;
+  if (p.sym && c0 > r0 + T - 1) return;  // strictly upper tile: skipped (lower_only) or written by its mirror
   const int tid = threadIdx.x;
 
   // stage + scale (true division, as the reference) -- thread t handles (row t>>2, dims (t&3)::4)
@@ -92,28 +98,49 @@ __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
   }
   const bool full = (r0 + T <= p.n1) && (c0 + T <= p.n2) && ((p.ldk & 1) == 0) &&
                     ((reinterpret_cast<uintptr_t>(p.K) & 15) == 0);
+  double v[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int gr = r0 + ty * 4 + i;
     const double ni = nr1[ty * 4 + i];
-    double v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int gc = c0 + tx * 4 + j;
       const double r2 = (-2.0 * dot[i][j]) + (ni + nr2[tx * 4 + j]);
-      double k = kern_eval(p.family, r2, p.variance);
+      double k = kern_eval<FAMILY>(r2, p.variance);
       if (p.sym && gr == gc) k += p.diag_add;
-      v[j] = k;
+      v[i][j] = k;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gr = r0 + ty * 4 + i;
     if (full) {
       d2* out = reinterpret_cast<d2*>(p.K + (long)gr * p.ldk + c0 + tx * 4);
-      out[0] = (d2){v[0], v[1]};
-      out[1] = (d2){v[2], v[3]};
+      out[0] = (d2){v[i][0], v[i][1]};
+      out[1] = (d2){v[i][2], v[i][3]};
     } else if (gr < p.n1) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int gc = c0 + tx * 4 + j;
-        if (gc < p.n2) p.K[(long)gr * p.ldk + gc] = v[j];
+        if (gc < p.n2) p.K[(long)gr * p.ldk + gc] = v[i][j];
+      }
+    }
+  }
+  if (mirror && r0 != c0) {  // transposed copy: rows c0 + tx*4 + j, columns r0 + ty*4 + i
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gr = c0 + tx * 4 + j;
+      if (full) {
+        d2* out = reinterpret_cast<d2*>(p.K + (long)gr * p.ldk + r0 + ty * 4);
+        out[0] = (d2){v[0][j], v[1][j]};
+        out[1] = (d2){v[2][j], v[3][j]};
+      } else if (gr < p.n1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int gc = r0 + ty * 4 + i;
+          if (gc < p.n2) p.K[(long)gr * p.ldk + gc] = v[i][j];
+        }
       }
     }
   }
@@ -137,14 +164,26 @@ extern "C" int gpk_kernel_matrix(void* stream, int family, const double* X1, int
   if (a.n1 == 0 || a.n2 == 0) return 0;
   const size_t lds = ((size_t)2 * d * T + 2 * T) * sizeof(double);
   static bool attr_set = false;
+  const int max_lds = (int)(((size_t)2 * GPK_MAX_D * T + 2 * T) * sizeof(double));
   if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(((size_t)2 * GPK_MAX_D * T + 2 * T) * sizeof(double))));
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_SE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN12>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN52>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     attr_set = true;
   }
   dim3 grid((unsigned)gpk_cdiv(a.n2, T), (unsigned)gpk_cdiv(a.n1, T));
-  hipLaunchKernelGGL(rbf_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  switch (family) {
+    case GPK_KERN_SE: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_SE>, grid, dim3(256), lds, st, a); break;
+    case GPK_KERN_MATERN12: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_MATERN12>, grid, dim3(256), lds, st, a); break;
+    case GPK_KERN_MATERN32: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_MATERN32>, grid, dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_MATERN52>, grid, dim3(256), lds, st, a); break;
+  }
   GPK_LAUNCH_CHECK();
   return 0;
 }
