@@ -42,14 +42,16 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return u.d;
 }
 
+// 1/sqrt(p): v_rsq_f64 (2^-23 relative) + ONE third-order step  y (1 + e/2 + 3e^2/8),  e = 1 - p y^2
+// (error 5/16 e^3 ~ 2^-70).  Five dependent fp64 ops instead of the seven of two Newton steps: the
+// dependent-issue latency of fp64 VALU ops (~38 cycles) times the 128 pivots IS the leaf's critical path.
 __device__ __forceinline__ double rsqrt_nr(double p) {
-  double y = __builtin_amdgcn_rsq(p);
-  const double h = 0.5 * p;
-  double e = fma(-h * y, y, 0.5);
-  y = fma(y, e, y);
-  e = fma(-h * y, y, 0.5);
-  y = fma(y, e, y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(p);
+  const double t = p * y;
+  const double e = fma(-t, y, 1.0);
+  const double q = fma(0.375, e, 0.5);
+  const double s = y * e;
+  return fma(s, q, y);
 }
 
 __device__ __forceinline__ d4 mfma4(double a, double b, d4 c) {
@@ -87,12 +89,13 @@ __device__ __forceinline__ void diag_panel(d4& d, d4& x, int c, int g, int lane,
       l32 = fma(-l31, l21, fma(-l30, l20, s32)) * r2;
       const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
       r3 = rsqrt_nr(p3);
-      if (bad_col < 0) {
-        if (!(s00 > 0.0)) bad_col = col0 + 4 * P;
-        else if (!(p1 > 0.0)) bad_col = col0 + 4 * P + 1;
-        else if (!(p2 > 0.0)) bad_col = col0 + 4 * P + 2;
-        else if (!(p3 > 0.0)) bad_col = col0 + 4 * P + 3;
-      }
+      // first non-positive pivot of this panel, branch-free (all values are wave-uniform)
+      int idx = -1;
+      idx = !(p3 > 0.0) ? 3 : idx;
+      idx = !(p2 > 0.0) ? 2 : idx;
+      idx = !(p1 > 0.0) ? 1 : idx;
+      idx = !(s00 > 0.0) ? 0 : idx;
+      bad_col = (bad_col < 0 && idx >= 0) ? col0 + 4 * P + idx : bad_col;
     }
     // Y = inv(L4), lower triangular
     const double y10 = -r1 * (l10 * r0);
@@ -101,12 +104,20 @@ __device__ __forceinline__ void diag_panel(d4& d, d4& x, int c, int g, int lane,
     const double y20 = -r2 * fma(l21, y10, l20 * r0);
     const double y31 = -r3 * fma(l32, y21, l31 * r1);
     const double y30 = -r3 * fma(l32, y20, fma(l31, y10, l30 * r0));
-    // A-operand  Yop[m][k] = Y[m][k] (m < 4), lane (m = c, k = g)
+    // A-operand  Yop[m][k] = Y[m][k] (m < 4), lane (m = c, k = g): flat select chain on a per-lane slot index
+    // (no divergent control flow: every Y value is wave-uniform and already computed)
+    const int slot = (c < 4 && g <= c) ? c * 4 + g : -1;
     double yop = 0.0;
-    if (c == 0) yop = (g == 0) ? r0 : 0.0;
-    if (c == 1) yop = (g == 0) ? y10 : ((g == 1) ? r1 : 0.0);
-    if (c == 2) yop = (g == 0) ? y20 : ((g == 1) ? y21 : ((g == 2) ? r2 : 0.0));
-    if (c == 3) yop = (g == 0) ? y30 : ((g == 1) ? y31 : ((g == 2) ? y32 : r3));
+    yop = (slot == 0) ? r0 : yop;
+    yop = (slot == 4) ? y10 : yop;
+    yop = (slot == 5) ? r1 : yop;
+    yop = (slot == 8) ? y20 : yop;
+    yop = (slot == 9) ? y21 : yop;
+    yop = (slot == 10) ? r2 : yop;
+    yop = (slot == 12) ? y30 : yop;
+    yop = (slot == 13) ? y31 : yop;
+    yop = (slot == 14) ? y32 : yop;
+    yop = (slot == 15) ? r3 : yop;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     // panel of L:  D[m][n] = sum_k Y[m][k] S[n][4P+k]  ->  reg 0 of lane (n, g) = L[n][4P+g]
     double lp;
@@ -209,6 +220,63 @@ __device__ __forceinline__ void tri_decode(int u, int j0, int& i, int& j) {
   j = j0 + u;
 }
 
+// ---- pieces of the recursive-doubling assembly of X = L^-1 (X21 = -X22 (L21 X11) at block sizes 16, 32, 64) ------
+// level 1, node p: tile (2p+1, 2p); one wave, the intermediate T stays in registers
+__device__ __forceinline__ void inv_level1(double* __restrict__ S, int p, int lane) {
+  Frag f;
+  frag_load(S, tile_L(2 * p + 1, 2 * p), tr(tile_Xd(2 * p)), lane, f);            // T = L21 X11
+  const d4 t = frag_mma<false>(f, (d4){0.0, 0.0, 0.0, 0.0});
+  const d4 r = reg_mma<true>(S, tile_Xd(2 * p + 1), t, lane, (d4){0.0, 0.0, 0.0, 0.0});  // -X22 T
+  tile_store(S, tile_X(2 * p + 1, 2 * p), lane, r);
+}
+// level 2, node q (blocks 4q..4q+3): tile X21(a, b), one wave per (b, a)
+__device__ __forceinline__ void inv_level2(double* __restrict__ S, int q, int b, int a, int lane) {
+  const int r0 = 4 * q + 2, c0 = 4 * q;  // tile coordinates of the node's L21 / X21 block
+  // T(t, b) = sum_{s >= b} L21(t, s) X11(s, b),  t = 0..a   (X11(s,b): s == b diagonal tile, s > b off-diagonal)
+  d4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+  for (int s2 = b; s2 < 2; ++s2) {
+    const TRef xs = (s2 == b) ? tile_Xd(c0 + b) : tile_X(c0 + s2, c0 + b);
+    Frag f;
+    frag_load(S, tile_L(r0, c0 + s2), tr(xs), lane, f);
+    t0 = frag_mma<false>(f, t0);
+    if (a == 1) {
+      frag_load(S, tile_L(r0 + 1, c0 + s2), tr(xs), lane, f);
+      t1 = frag_mma<false>(f, t1);
+    }
+  }
+  // X21(a, b) = -sum_{t <= a} X22(a, t) T(t, b)
+  d4 r = {0.0, 0.0, 0.0, 0.0};
+  if (a == 0) {
+    r = reg_mma<true>(S, tile_Xd(r0), t0, lane, r);
+  } else {
+    r = reg_mma<true>(S, tile_X(r0 + 1, r0), t0, lane, r);
+    r = reg_mma<true>(S, tile_Xd(r0 + 1), t1, lane, r);
+  }
+  tile_store(S, tile_X(r0 + a, c0 + b), lane, r);
+}
+// level 3, phase 1: T(t, b) = sum_{s=b}^{3} L(4+t, s) X(s, b), parked (transposed, like X) in the X21 region
+__device__ __forceinline__ void inv_level3_T(double* __restrict__ S, int t, int b, int lane) {
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int s2 = b; s2 < 4; ++s2) {
+    const TRef xs = (s2 == b) ? tile_Xd(b) : tile_X(s2, b);
+    Frag f;
+    frag_load(S, tile_L(4 + t, s2), tr(xs), lane, f);
+    acc = frag_mma<false>(f, acc);
+  }
+  tile_store(S, tile_X(4 + t, b), lane, acc);
+}
+// level 3, phase 2: X21(a, b) = -sum_{t=0}^{a} X22(a, t) T(t, b)   (result returned, stored after a barrier)
+__device__ __forceinline__ d4 inv_level3_X(const double* __restrict__ S, int a, int b, int lane) {
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t <= a; ++t) {
+    const TRef xa = (t == a) ? tile_Xd(4 + a) : tile_X(4 + a, 4 + t);
+    Frag f;
+    frag_load(S, xa, tr(tile_X(4 + t, b)), lane, f);
+    acc = frag_mma<true>(f, acc);
+  }
+  return acc;
+}
+
 template <bool FACTORED>
 __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, long lda, long strideA, int nb,
                                                    double* __restrict__ invbase, long strideInv,
@@ -257,6 +325,7 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
   const long long t_loaded = dbg ? wall_clock64() : 0;
 
   int bad_col = -1;
+  const bool overlap_inv = !FACTORED && nsb == NSB;
   if constexpr (FACTORED) {
     if (wave < nsb) diag16<true>(S, wave, lane, bad_col, 0);
     __syncthreads();
@@ -313,6 +382,15 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
           tile_store(S, tile_L(i1, j1), lane, c1);
           u = u2;
         }
+        // idle time of waves 1..7 while wave 0 runs the pivot chain: the parts of X = L^-1 whose inputs are
+        // already final (full 128 leaf only; inputs were completed before the barrier that opened this phase)
+        if (overlap_inv) {
+          if ((k & 1) && wave == 1) inv_level1(S, (k - 1) >> 1, lane);             // k = 1, 3, 5: nodes 0, 1, 2
+          if (k == 4 && wave <= 4) inv_level2(S, 0, (wave - 1) >> 1, (wave - 1) & 1, lane);
+          if (k == 5 && wave >= 2) {                                               // 16 T tiles on waves 2..7
+            for (int id = wave - 2; id < 16; id += NW - 2) inv_level3_T(S, id & 3, id >> 2, lane);
+          }
+        }
       }
       __syncthreads();
     }
@@ -320,80 +398,30 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
   const long long t_factored = dbg ? wall_clock64() : 0;
 
   // ---- off-diagonal tiles of X by recursive doubling:  X21 = -X22 (L21 X11) ----------------------------------
-  // level 1 (16-blocks): node p -> tile (2p+1, 2p); one wave per node, T stays in registers
-  if (wave < 4) {
-    const int p = wave;
-    Frag f;
-    frag_load(S, tile_L(2 * p + 1, 2 * p), tr(tile_Xd(2 * p)), lane, f);            // T = L21 X11
-    const d4 t = frag_mma<false>(f, (d4){0.0, 0.0, 0.0, 0.0});
-    const d4 r = reg_mma<true>(S, tile_Xd(2 * p + 1), t, lane, (d4){0.0, 0.0, 0.0, 0.0});  // -X22 T
-    tile_store(S, tile_X(2 * p + 1, 2 * p), lane, r);
-  }
-  __syncthreads();
-  // level 2 (32-blocks): node q in {0,1}, rows 4q+2.. , cols 4q..; wave (q, b, a) -> tile X21(a, b)
-  {
-    const int q = wave >> 2, b = (wave >> 1) & 1, a = wave & 1;
-    const int r0 = 4 * q + 2, c0 = 4 * q;  // tile coordinates of the node's L21 / X21 block
-    // T(t, b) = sum_{s >= b} L21(t, s) X11(s, b),  t = 0..a   (X11(s,b): s == b diagonal tile, s > b off-diagonal)
-    d4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
-    for (int s = b; s < 2; ++s) {
-      const TRef xs = (s == b) ? tile_Xd(c0 + b) : tile_X(c0 + s, c0 + b);
-      Frag f;
-      frag_load(S, tile_L(r0, c0 + s), tr(xs), lane, f);
-      t0 = frag_mma<false>(f, t0);
-      if (a == 1) {
-        frag_load(S, tile_L(r0 + 1, c0 + s), tr(xs), lane, f);
-        t1 = frag_mma<false>(f, t1);
-      }
-    }
-    // X21(a, b) = -sum_{t <= a} X22(a, t) T(t, b)
-    d4 r = {0.0, 0.0, 0.0, 0.0};
-    if (a == 0) {
-      r = reg_mma<true>(S, tile_Xd(r0), t0, lane, r);
-    } else {
-      r = reg_mma<true>(S, tile_X(r0 + 1, r0), t0, lane, r);
-      r = reg_mma<true>(S, tile_Xd(r0 + 1), t1, lane, r);
-    }
-    tile_store(S, tile_X(r0 + a, c0 + b), lane, r);
-  }
-  __syncthreads();
-  // level 3 (64-blocks): T = L21 X11 parked (transposed, like X) in the still-unused X21 region, then
-  // X21 = -X22 T.  16 tiles per phase, two per wave, pairing heavy with light rows.
-  {
-    // phase 1: T(t, b) = sum_{s=b}^{3} L(4+t, s) X(s, b)
-    d4 tt[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int b = wave >> 1, t = 2 * (wave & 1) + h;
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
-      for (int s = b; s < 4; ++s) {
-        const TRef xs = (s == b) ? tile_Xd(b) : tile_X(s, b);
-        Frag f;
-        frag_load(S, tile_L(4 + t, s), tr(xs), lane, f);
-        acc = frag_mma<false>(f, acc);
-      }
-      tt[h] = acc;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int b = wave >> 1, t = 2 * (wave & 1) + h;
-      tile_store(S, tile_X(4 + t, b), lane, tt[h]);
-    }
+  if (overlap_inv) {
+    // levels 1 (nodes 0..2), 2 (node 0) and the T phase of level 3 were done in the shadow of the pivot chain
+    if (wave == 0) inv_level1(S, 3, lane);
     __syncthreads();
-    // phase 2: X21(a, b) = -sum_{t=0}^{a} X22(a, t) T(t, b);  wave -> b = wave>>1, a in {w&1 ? (1,2) : (0,3)}
+    if (wave < 4) inv_level2(S, 1, wave >> 1, wave & 1, lane);
+    __syncthreads();
+  } else {
+    if (wave < 4) inv_level1(S, wave, lane);
+    __syncthreads();
+    inv_level2(S, wave >> 2, (wave >> 1) & 1, wave & 1, lane);
+    __syncthreads();
+    // level 3 phase 1: 16 T tiles, two per wave
+#pragma unroll
+    for (int h = 0; h < 2; ++h) inv_level3_T(S, 2 * (wave & 1) + h, wave >> 1, lane);
+    __syncthreads();
+  }
+  {
+    // level 3 phase 2: 16 tiles, two per wave, pairing heavy with light rows: wave -> b = wave>>1, a in (1,2) or (0,3)
     d4 rr[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int b = wave >> 1;
       const int a = (wave & 1) ? (1 + h) : (3 * h);
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
-      for (int t = 0; t <= a; ++t) {
-        const TRef xa = (t == a) ? tile_Xd(4 + a) : tile_X(4 + a, 4 + t);
-        Frag f;
-        frag_load(S, xa, tr(tile_X(4 + t, b)), lane, f);
-        acc = frag_mma<true>(f, acc);
-      }
-      rr[h] = acc;
+      rr[h] = inv_level3_X(S, a, b, lane);
     }
     __syncthreads();
 #pragma unroll
