@@ -50,11 +50,16 @@ int gpk_gemm_tiles_n(int n);  // number of column tiles the launcher will use fo
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
                     long strideInv, int* info, int col0, int batch, int already_factored);
 
+// ---- trsm.hip: Eout[:, 0:128 nb] = Ein[:, 0:128 nb] L_gg^-T in one launch (16 rows per workgroup) ----------
+int gpk_launch_trsm_group(hipStream_t s, const double* Ein, long ldein, double* Eout, long ldeout, int rows,
+                          const double* Lgg, long lda, const double* invg, int nb);
+
 // ---- rbf.hip ---------------------------------------------------------------------------------
 // (entry point gpk_kernel_matrix is defined there)
 
 // ---- reduce.hip: small kernels -------------------------------------------------------------------
 int gpk_launch_zero_upper(hipStream_t s, double* A, int n, long lda, int batch, long strideA);
+int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda);
 int gpk_launch_sum_parts(hipStream_t s, const double* part, int nt, int rows, long stridePart, int P,
                          double* ssq);
 int gpk_launch_final(hipStream_t s, int nterms, const double* const* part, const int* count,

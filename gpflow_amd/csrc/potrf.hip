@@ -157,36 +157,53 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
 //   E[:,c0:c1] <- E[:,c0:c1] L[c0:c1,c0:c1]^-T            (NB-blocked, diagonal-block inverses)
 //   E[:,c1:n]  -= E[:,c0:c1] L[c1:n,c0:c1]^T               (one large GEMM, K = c1 - c0)
 int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev_big, double* A, int n, int row0,
-                int extra, int c0, int c1, long lda, int batch, long strideA, const double* invd, long strideInv) {
+                int extra, int c0, int c1, long lda, int batch, long strideA, const double* invd, long strideInv,
+                double* Eout, long ldeout) {
   double* E = A + (long)(n + row0) * lda;  // rows [row0, row0 + extra) of the extra block
+  // solved panel: in place, or (gpk_potrf_ex) in the separate output matrix
+  double* So = Eout ? Eout + (long)row0 * ldeout : E;
+  const long ldso = Eout ? ldeout : lda;
   int rc;
-  for (int j0 = c0; j0 < c1; j0 += NB) {
-    const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
-    const int nb = j1 - j0;
-    if (j0 > c0) {
-      GemmArgs u = gemm_base(extra, nb, j0 - c0, -1.0, E + c0, lda, A + (long)j0 * lda + c0, lda, 1.0,
-                             E + j0, lda, batch, strideA, strideA, strideA);
-      rc = gpk_launch_gemm(s, u);
+  // Fused one-launch group solve (trsm.hip): correct, but measured SLOWER than the seven short GEMMs on the SVGP
+  // step (354 vs 382 steps/s): 512 workgroups re-read the same 128 KB operand blocks from L2 and occupy every
+  // CU while the leaf kernel waits.  Opt-in until it stages its B operands through LDS.
+  static const bool use_group = getenv("GPK_TRSM_GROUP") != nullptr;
+  if (use_group && batch == 1 && (c1 - c0) % NB == 0 && (c1 - c0) <= 4 * NB) {
+    // the whole group in one launch (trsm.hip): rows are independent, 16 per workgroup
+    rc = gpk_launch_trsm_group(s, E + c0, lda, So + c0, ldso, extra, A + (long)c0 * lda + c0, lda,
+                               invd + (long)(c0 / NB) * NB * NB, (c1 - c0) / NB);
+    if (rc) return rc;
+  } else {
+    for (int j0 = c0; j0 < c1; j0 += NB) {
+      const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
+      const int nb = j1 - j0;
+      if (j0 > c0) {
+        GemmArgs u = gemm_base(extra, nb, j0 - c0, -1.0, E + c0, lda, A + (long)j0 * lda + c0, lda, 1.0,
+                               E + j0, lda, batch, strideA, strideA, strideA);
+        rc = gpk_launch_gemm(s, u);
+        if (rc) return rc;
+      }
+      GemmArgs g = gemm_base(extra, nb, nb, 1.0, E + j0, lda, invd + (long)(j0 / NB) * NB * NB, NB, 0.0,
+                             E + j0, lda, batch, strideA, strideInv, strideA);
+      g.b_tri = 2;
+      rc = gpk_launch_gemm(s, g);
       if (rc) return rc;
     }
-    GemmArgs g = gemm_base(extra, nb, nb, 1.0, E + j0, lda, invd + (long)(j0 / NB) * NB * NB, NB, 0.0,
-                           E + j0, lda, batch, strideA, strideInv, strideA);
-    g.b_tri = 2;
-    rc = gpk_launch_gemm(s, g);
-    if (rc) return rc;
+    if (Eout) {  // (only reached with batch == 1 and a ragged last group)
+      GPK_HIP(hipMemcpy2DAsync(So + c0, ldso * sizeof(double), E + c0, lda * sizeof(double),
+                               (size_t)(c1 - c0) * sizeof(double), (size_t)extra, hipMemcpyDeviceToDevice, s));
+    }
   }
   if (c1 < n) {
-    // the one large GEMM of the group goes to the CU-masked stream `sbig` (it would otherwise fill every CU
-    // with long-running workgroups and starve the one-workgroup leaf kernel of the panel stream)
+    // the one large GEMM of the group: E[:, c1:n] -= S[:, c0:c1] L[c1:n, c0:c1]^T
     if (sbig != s) {
       GPK_HIP(hipEventRecord(ev_in, s));
       GPK_HIP(hipStreamWaitEvent(sbig, ev_in, 0));
     }
-    GemmArgs u = gemm_base(extra, n - c1, c1 - c0, -1.0, E + c0, lda, A + (long)c1 * lda + c0, lda, 1.0,
-                           E + c1, lda, batch, strideA, strideA, strideA);
-    // persistent workgroups, fewer than CUs: the hardware spreads them one per CU, so some CUs stay empty for
-    // the panel stream's one-workgroup leaf kernel (which needs a whole CU's LDS) -- see DESIGN.md
-    static const int xwgs = getenv("GPK_EXTRA_MAX_WGS") ? atoi(getenv("GPK_EXTRA_MAX_WGS")) : 224;
+    GemmArgs u = gemm_base(extra, n - c1, c1 - c0, -1.0, So + c0, ldso, A + (long)c1 * lda + c0, lda, 1.0,
+                           E + c1, lda, batch, Eout ? 0 : strideA, strideA, strideA);
+    // optional cap on (persistent) workgroups so that some CUs stay free for the panel stream's leaf kernel
+    static const int xwgs = getenv("GPK_EXTRA_MAX_WGS") ? atoi(getenv("GPK_EXTRA_MAX_WGS")) : 0;
     u.max_wgs = xwgs;
     rc = gpk_launch_gemm(sbig, u);
     if (rc) return rc;
@@ -199,10 +216,38 @@ int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev
 }
 }  // namespace
 
+namespace {
+
+int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
+               int* info, double* Eout, long ldeout, double* ws);
+}  // namespace
+
 extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch,
                          long strideA, double* invd, int zero_upper, int* info) {
+  return potrf_core((hipStream_t)stream, A, n, extra, lda, batch, strideA, invd, zero_upper, info, nullptr, 0, nullptr);
+}
+
+extern "C" size_t gpk_potrf_ex_workspace_bytes(void) { return 0; }
+
+// Same factorisation, but the solved extra rows  B L^-T  are written to Eout [extra, n] (leading dimension
+// ldeout) instead of in place (the extra rows of A are consumed as scratch).  batch must be 1.
+extern "C" int gpk_potrf_ex(void* stream, double* A, int n, int extra, long lda, int batch, long strideA, double* invd,
+                            int zero_upper, int* info, double* Eout, long ldeout, void* ws, size_t ws_bytes) {
+  (void)ws; (void)ws_bytes;
+  if (!Eout || ldeout < n || batch > 1) return GPK_E_ARG;
+  if (extra > 256 && n > NB)  // the only shape in which the extra rows are solved apart from the square part
+    return potrf_core((hipStream_t)stream, A, n, extra, lda, 1, strideA, invd, zero_upper, info, Eout, ldeout, nullptr);
+  int rc = potrf_core((hipStream_t)stream, A, n, extra, lda, 1, strideA, invd, zero_upper, info, nullptr, 0, nullptr);
+  if (rc || extra == 0) return rc;
+  GPK_HIP(hipMemcpy2DAsync(Eout, ldeout * sizeof(double), A + (long)n * lda, lda * sizeof(double),
+                           (size_t)n * sizeof(double), (size_t)extra, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+namespace {
+int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
+               int* info, double* Eout, long ldeout, double* ws) {
   if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
-  hipStream_t S = (hipStream_t)stream;
   if (batch <= 0) batch = 1;
   if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, S));
   if (n == 0) return 0;
@@ -221,13 +266,13 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
     rc = factor_panel(S, A, R, 0, n, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
     if (extra > 0 && !ride) {
-      rc = extra_panel(S, S, nullptr, nullptr, A, n, 0, extra, 0, n, lda, batch, strideA, invd, strideInv);
+      rc = extra_panel(S, S, nullptr, nullptr, A, n, 0, extra, 0, n, lda, batch, strideA, invd, strideInv, Eout, ldeout);
       if (rc) return rc;
     }
     return zero_upper ? gpk_launch_zero_upper(S, A, n, lda, batch, strideA) : 0;
   }
   Aux* aux = nullptr;
-  rc = aux_get(2 * npanels + 12, &aux);
+  rc = aux_get(2 * npanels + 16, &aux);
   if (rc) return rc;
   hipStream_t P = aux->P, B = (n >= 4096) ? aux->B : aux->Bs;
   // extra rows in up to 4 chunks of whole 128-row tiles, one stream each
@@ -308,7 +353,7 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
         if (xrow[i + 1] <= xrow[i]) continue;
         GPK_HIP(hipStreamWaitEvent(aux->X[i], evF[p], 0));
         rc = extra_panel(aux->X[i], aux->Xb ? aux->Xb : aux->X[i], aux->ev[2 * npanels + 7], aux->ev[2 * npanels + 8], A, n, xrow[i],
-                         xrow[i + 1] - xrow[i], g0, c1, lda, batch, strideA, invd, strideInv);
+                         xrow[i + 1] - xrow[i], g0, c1, lda, batch, strideA, invd, strideInv, Eout, ldeout);
         if (rc) return rc;
       }
     }
@@ -326,6 +371,7 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
   if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, batch, strideA);
   return 0;
 }
+}  // namespace
 
 extern "C" int gpk_trtri_blocks(void* stream, const double* L, int n, long ldl, int batch,
                                 long strideL, double* invd) {
@@ -495,7 +541,7 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
 namespace {
 struct ElboLayout {
   long ld; int nt;
-  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, total;
+  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_At, off_pex, total;
 };
 ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   ElboLayout l{};
@@ -511,6 +557,8 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   l.off_proj = o; o += q_diag ? 0 : gpk_align_up(gpk_project_workspace_bytes(rows, m, P), 256);
   l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
+  l.off_At = o; o += gpk_align_up((size_t)rows * l.ld * sizeof(double), 256);   // A^T = Kfu Lm^-T (gpk_potrf_ex output)
+  l.off_pex = o; o += gpk_align_up(gpk_potrf_ex_workspace_bytes(), 256);
   l.total = o;
   return l;
 }
@@ -543,7 +591,8 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   double* ssq = (double*)(w + l.off_ssq);
   double* part0 = (double*)(w + l.off_part0);
   double* part1 = (double*)(w + l.off_part1);
-  double* At = T + (long)m * l.ld;
+  double* Kfu = T + (long)m * l.ld;        // extra rows of the trapezoid: Kfu, consumed by the factorisation
+  double* At = (double*)(w + l.off_At);   // A^T = Kfu Lm^-T
   int rc;
   // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only
   rc = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter,
@@ -551,10 +600,16 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   if (rc) return rc;
   // Kuf^T = k(Xb, Z) as the extra rows (posteriors.py:836, covariances/kufs.py:31-34)
   rc = gpk_kernel_matrix(stream, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0,
-                         At, l.ld);
+                         Kfu, l.ld);
   if (rc) return rc;
   // Lm = chol(Kuu);  A^T = Kfu Lm^-T   (conditionals/util.py:67,125)
-  rc = gpk_potrf(stream, T, m, rows, l.ld, 1, 0, invd, 0, info);
+  static const bool out_of_place = getenv("GPK_TRSM_GROUP") != nullptr;
+  if (out_of_place) {
+    rc = gpk_potrf_ex(stream, T, m, rows, l.ld, 1, 0, invd, 0, info, At, l.ld, nullptr, 0);
+  } else {
+    At = Kfu;  // in place: the extra rows of the trapezoid come back as A^T
+    rc = gpk_potrf(stream, T, m, rows, l.ld, 1, 0, invd, 0, info);
+  }
   if (rc) return rc;
   // s0 = sum_k A^2 (util.py:133), fmean = A^T q_mu (util.py:144), q_diag: ssq = sum (A q_sqrt)^2 (:149)
   rc = gpk_row_stats(stream, At, rows, m, l.ld, q_mu, q_diag ? q_sqrt : nullptr, P, 1.0, 0.0, s0, fmean,

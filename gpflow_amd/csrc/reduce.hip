@@ -261,6 +261,20 @@ int nblocks_for(long elems) {
 }  // namespace
 
 // ================================================================================================
+namespace {
+__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int n, long lda) {
+  const int row = blockIdx.y;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) A[(long)row * lda + c] = (c == row) ? 1.0 : 0.0;
+}
+}  // namespace
+int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda) {
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)gpk_cdiv(n, 256), (unsigned)n, 1);
+  hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, A, n, lda);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
 int gpk_launch_zero_upper(hipStream_t s, double* A, int n, long lda, int batch, long strideA) {
   if (n <= 1) return 0;
   int gx = gpk_cdiv(n, 256);

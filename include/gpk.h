@@ -69,6 +69,14 @@ size_t gpk_invd_elems(int n, int batch);
 int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch, long strideA,
               double* invd, int zero_upper, int* info);
 
+/* gpk_potrf with the solved extra rows  B L^-T  written to Eout [extra, n] (ldeout) instead of in place (the
+ * extra rows of A are consumed).  With ws_bytes >= gpk_potrf_ex_workspace_bytes(), n a multiple of 512 below
+ * 4096, batch 1 and more than 256 extra rows (the SVGP minibatch), each 512-column group of the extra rows is
+ * solved with one GEMM against the explicit inverse of the group's diagonal block. */
+size_t gpk_potrf_ex_workspace_bytes(void);
+int gpk_potrf_ex(void* stream, double* A, int n, int extra, long lda, int batch, long strideA, double* invd,
+                 int zero_upper, int* info, double* Eout, long ldeout, void* ws, size_t ws_bytes);
+
 /* inverses of the diagonal NB-blocks of an existing lower factor L [n,n] (for gpk_trsm on a cached
  * L: GPRPosterior cache (err, Lm), posteriors.py:415-432). invd [batch, ceil(n/NB), NB, NB]. */
 int gpk_trtri_blocks(void* stream, const double* L, int n, long ldl, int batch, long strideL,

@@ -225,3 +225,26 @@ def test_fused_svgp_elbo_shard(gpu, m, rows, d, P, q_diag):
     o = out.cpu().numpy()
     np.testing.assert_allclose(o[0], s_ref, rtol=1e-9)
     np.testing.assert_allclose(o[1], kl_ref, rtol=1e-12)
+
+
+def test_potrf_ex_out_of_place(gpu):
+    """gpk_potrf_ex: same factor, solved extra rows written to a separate matrix (batch 1)."""
+    import ctypes
+    import torch
+    from gpflow_amd import _lib, ops
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    n, extra = 640, 300
+    _, K = _spd(rng, n)
+    Bm = rng.normal(size=(extra, n))
+    Td = _t(np.vstack([K, Bm]))
+    Eout = torch.zeros((extra, n), dtype=torch.float64, device=Td.device)
+    invd = ops.invd_alloc(n)
+    info = torch.zeros(1, dtype=torch.int32, device=Td.device)
+    rc = lib.gpk_potrf_ex(torch.cuda.current_stream().cuda_stream, Td.data_ptr(), n, extra, n, 1, 0, invd.data_ptr(), 1,
+                          info.data_ptr(), Eout.data_ptr(), n, None, 0)
+    assert rc == 0 and int(info[0]) == 0
+    Lref = np.linalg.cholesky(K)
+    np.testing.assert_allclose(Td[:n].cpu().numpy(), Lref, rtol=0, atol=5e-13)
+    ref = sla.solve_triangular(Lref, Bm.T, lower=True).T
+    np.testing.assert_allclose(Eout.cpu().numpy(), ref, rtol=0, atol=1e-11)
