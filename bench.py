@@ -22,6 +22,11 @@ import os
 import sys
 import time
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The factorisation runs a latency-critical
+# panel stream next to bulk streams; with 2 hardware queues the SVGP step measured 415 steps/s vs 380 with 4 and
+# 350 with 8 (A/B on one MI355X, tools/ab.sh).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import numpy as np
 import torch
 

@@ -275,10 +275,18 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   rc = aux_get(2 * npanels + 16, &aux);
   if (rc) return rc;
   hipStream_t P = aux->P, B = (n >= 4096) ? aux->B : aux->Bs;
+  // GPK_MERGE_BULK: the extra-row work shares the bulk stream (rest-updates and extra-row GEMMs then execute in
+  // issue order instead of competing for CUs)
+  static const bool merge_bulk = getenv("GPK_MERGE_BULK") != nullptr;
+  hipStream_t Xq[4] = {aux->X[0], aux->X[1], aux->X[2], aux->X[3]};
+  if (merge_bulk) Xq[0] = B;
   // extra rows in up to 4 chunks of whole 128-row tiles, one stream each
   int nx = 0, xrow[5] = {0, 0, 0, 0, 0};
   if (extra > 0 && !ride) {
-    nx = 1;  // more streams than hardware queues serialise against each other (measured: 4 were slower than 1)
+    // more streams than hardware queues serialise against each other (measured: 4 were slower than 1)
+    static const int nx_env = getenv("GPK_EXTRA_STREAMS") ? atoi(getenv("GPK_EXTRA_STREAMS")) : 1;
+    nx = nx_env < 1 ? 1 : (nx_env > 4 ? 4 : nx_env);
+    while (nx > 1 && extra < nx * 512) --nx;
     const int per = gpk_cdiv(gpk_cdiv(extra, nx), NB) * NB;
     for (int i = 0; i <= nx; ++i) xrow[i] = (i * per < extra) ? i * per : extra;
   }
@@ -290,7 +298,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   GPK_HIP(hipEventRecord(evFork, S));  // fork: everything already queued on S comes first
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
   GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
-  for (int i = 0; i < nx; ++i) GPK_HIP(hipStreamWaitEvent(aux->X[i], evFork, 0));
+  for (int i = 0; i < nx; ++i) GPK_HIP(hipStreamWaitEvent(Xq[i], evFork, 0));
   hipStream_t last_bulk = B;
   // Deferred rest-updates: while the trailing matrix is large, the far trailing update is applied once per TWO
   // outer panels, as a K = 1024 GEMM (65 vs 59 TFLOP/s for K = 512 on this chip); the strip of the look-ahead
@@ -351,8 +359,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       const int g0 = ((c1 - 1) / NBO) * NBO;
       for (int i = 0; i < nx; ++i) {
         if (xrow[i + 1] <= xrow[i]) continue;
-        GPK_HIP(hipStreamWaitEvent(aux->X[i], evF[p], 0));
-        rc = extra_panel(aux->X[i], aux->Xb ? aux->Xb : aux->X[i], aux->ev[2 * npanels + 7], aux->ev[2 * npanels + 8], A, n, xrow[i],
+        GPK_HIP(hipStreamWaitEvent(Xq[i], evF[p], 0));
+        rc = extra_panel(Xq[i], aux->Xb ? aux->Xb : Xq[i], aux->ev[2 * npanels + 7], aux->ev[2 * npanels + 8], A, n, xrow[i],
                          xrow[i + 1] - xrow[i], g0, c1, lda, batch, strideA, invd, strideInv, Eout, ldeout);
         if (rc) return rc;
       }
@@ -365,7 +373,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
   for (int i = 0; i < nx; ++i) {
     hipEvent_t ej = aux->ev[2 * npanels + 3 + i];
-    GPK_HIP(hipEventRecord(ej, aux->X[i]));
+    GPK_HIP(hipEventRecord(ej, Xq[i]));
     GPK_HIP(hipStreamWaitEvent(S, ej, 0));
   }
   if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, batch, strideA);
