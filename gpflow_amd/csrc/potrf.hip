@@ -304,6 +304,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // outer panels, as a K = 1024 GEMM (65 vs 59 TFLOP/s for K = 512 on this chip); the strip of the look-ahead
   // carries whatever panels are still pending for the next panel's columns.  r0 = first pending column.
   int r0 = 0, last_rest = -1;  // last_rest: panel index whose evR marks the most recent rest-update
+  int xg0 = 0;                 // first column of the current extra-row group
   static const int defer_rows = getenv("GPK_DEFER_ROWS") ? atoi(getenv("GPK_DEFER_ROWS")) : (1 << 30);  // off by default: A/B 33.7 vs 32.7 ms at N = 16384 (the K = 1024 strips starve on the panel stream)
   for (int p = 0; p < npanels; ++p) {
     const int c0 = p * nbo;
@@ -355,8 +356,13 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     }
     // ---- X: the extra rows against panel p -----------------------------------------------------------
     // (in groups of up to 512 columns, so that its big right-looking update is a K = 512 GEMM)
-    if (useX && (c1 == n || (c1 % NBO) == 0)) {
-      const int g0 = ((c1 - 1) / NBO) * NBO;
+    // Groups shrink towards the end (.., n-256, n-128, n): whatever is left of the extra-row solve when the LAST leaf
+    // finishes is exposed latency, and with one-block groups that is a single short launch instead of seven.
+    const bool tail_group = (nbo == NB) && (n >= 8 * NB) && (c1 == n - 2 * NB || c1 == n - NB);
+    const bool full_group = (c1 % NBO) == 0 && !((nbo == NB) && (n >= 8 * NB) && c1 > n - 2 * NB && c1 < n);
+    if (useX && (c1 == n || full_group || tail_group)) {
+      const int g0 = xg0;
+      xg0 = c1;
       for (int i = 0; i < nx; ++i) {
         if (xrow[i + 1] <= xrow[i]) continue;
         GPK_HIP(hipStreamWaitEvent(Xq[i], evF[p], 0));
@@ -602,13 +608,25 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   double* Kfu = T + (long)m * l.ld;        // extra rows of the trapezoid: Kfu, consumed by the factorisation
   double* At = (double*)(w + l.off_At);   // A^T = Kfu Lm^-T
   int rc;
+  // Kuf^T = k(Xb, Z) as the extra rows (posteriors.py:836, covariances/kufs.py:31-34).  Only the extra-row
+  // stream of the factorisation consumes it, so it is built THERE (ordered after everything already queued on
+  // the caller's stream) and the panel chain starts right after the much smaller Kuu build.
+  static const bool plain_streams = !getenv("GPK_EXTRA_STREAMS") && !getenv("GPK_MERGE_BULK");
+  hipStream_t kfu_stream = s;
+  if (plain_streams && m > GPK_NB && rows > 256) {
+    Aux* aux = nullptr;
+    rc = aux_get(8, &aux);
+    if (rc) return rc;
+    GPK_HIP(hipEventRecord(aux->ev[0], s));  // (event slot 0 is re-recorded by gpk_potrf only after this wait was queued)
+    GPK_HIP(hipStreamWaitEvent(aux->X[0], aux->ev[0], 0));
+    kfu_stream = aux->X[0];
+  }
+  rc = gpk_kernel_matrix((void*)kfu_stream, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0,
+                         Kfu, l.ld);
+  if (rc) return rc;
   // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only
   rc = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter,
                          1, T, l.ld);
-  if (rc) return rc;
-  // Kuf^T = k(Xb, Z) as the extra rows (posteriors.py:836, covariances/kufs.py:31-34)
-  rc = gpk_kernel_matrix(stream, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0,
-                         Kfu, l.ld);
   if (rc) return rc;
   // Lm = chol(Kuu);  A^T = Kfu Lm^-T   (conditionals/util.py:67,125)
   static const bool out_of_place = getenv("GPK_TRSM_GROUP") != nullptr;
