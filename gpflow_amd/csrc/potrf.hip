@@ -174,20 +174,23 @@ int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev
                                invd + (long)(c0 / NB) * NB * NB, (c1 - c0) / NB);
     if (rc) return rc;
   } else {
+    // right-looking inside the group too: after block j is solved, ALL remaining columns of the group are updated
+    // by one K = 128 GEMM (192 / 128 / 64 tiles) -- the left-looking form (K = 128, 256, 384 on 64 tiles each) was
+    // latency-bound at 44 / 58 / 74 us per launch
     for (int j0 = c0; j0 < c1; j0 += NB) {
       const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
       const int nb = j1 - j0;
-      if (j0 > c0) {
-        GemmArgs u = gemm_base(extra, nb, j0 - c0, -1.0, E + c0, lda, A + (long)j0 * lda + c0, lda, 1.0,
-                               E + j0, lda, batch, strideA, strideA, strideA);
-        rc = gpk_launch_gemm(s, u);
-        if (rc) return rc;
-      }
       GemmArgs g = gemm_base(extra, nb, nb, 1.0, E + j0, lda, invd + (long)(j0 / NB) * NB * NB, NB, 0.0,
                              E + j0, lda, batch, strideA, strideInv, strideA);
       g.b_tri = 2;
       rc = gpk_launch_gemm(s, g);
       if (rc) return rc;
+      if (j1 < c1) {
+        GemmArgs u = gemm_base(extra, c1 - j1, nb, -1.0, E + j0, lda, A + (long)j1 * lda + j0, lda, 1.0,
+                               E + j1, lda, batch, strideA, strideA, strideA);
+        rc = gpk_launch_gemm(s, u);
+        if (rc) return rc;
+      }
     }
     if (Eout) {  // (only reached with batch == 1 and a ragged last group)
       GPK_HIP(hipMemcpy2DAsync(So + c0, ldso * sizeof(double), E + c0, lda * sizeof(double),
@@ -203,7 +206,8 @@ int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev
     GemmArgs u = gemm_base(extra, n - c1, c1 - c0, -1.0, So + c0, ldso, A + (long)c1 * lda + c0, lda, 1.0,
                            E + c1, lda, batch, Eout ? 0 : strideA, strideA, strideA);
     // optional cap on (persistent) workgroups so that some CUs stay free for the panel stream's leaf kernel
-    static const int xwgs = getenv("GPK_EXTRA_MAX_WGS") ? atoi(getenv("GPK_EXTRA_MAX_WGS")) : 0;
+    // (A/B on the SVGP step: cap 320 -> 448 steps/s, no cap 435, cap 224 -> 431)
+    static const int xwgs = getenv("GPK_EXTRA_MAX_WGS") ? atoi(getenv("GPK_EXTRA_MAX_WGS")) : 320;
     u.max_wgs = xwgs;
     rc = gpk_launch_gemm(sbig, u);
     if (rc) return rc;
