@@ -333,7 +333,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // While the trailing matrix is large the factorisation is bound by these GEMMs and they start as soon as
     // panel p is solved.  Near the end it is bound by the latency chain of P instead: there the strip goes
     // first (alone on the chip) and the rest-update overlaps the NEXT panel's chain rather than the strip.
-    const bool strip_first = (n >= 4096) && (n - c1 <= 6144) && (c1 < n);
+    static const int late_rows = getenv("GPK_LATE_ROWS") ? atoi(getenv("GPK_LATE_ROWS")) : 3072;  // A/B at N = 16384: 3072 -> 32.9 ms, 6144 -> 33.8, off -> 33.1
+    const bool strip_first = (n >= 4096) && (n - c1 <= late_rows) && (c1 < n);
     const bool defer = (nbo == NBO) && (kpend < 2 * NBO) && (n - c2 >= defer_rows) && (c2 + nbo < n);
     if (c2 < n && !defer) {
       hipStream_t Bp = B;
