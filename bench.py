@@ -156,23 +156,25 @@ def main():
     ws = ops.svgp_elbo_workspace(M_IND, B_ROWS, D_IN, P_LAT, False)
     out = torch.empty(2, dtype=torch.float64, device=device)
     info = torch.zeros(1, dtype=torch.int32, device=device)
-    red = torch.empty(1, dtype=torch.float64, device=device)
     n_batches = N_DATA // (B_ROWS * world)
     scale = float(N_DATA) / float(B_ROWS * world)
     last = {}
+
+    # the step's scalars land in pinned host memory by two async copies + one stream synchronise
+    h_out = torch.empty(2, dtype=torch.float64).pin_memory()
+    h_info = torch.empty(1, dtype=torch.int32).pin_memory()
 
     def step(s: int) -> float:
         lo = ((s % n_batches) * world + rank) * B_ROWS  # this rank's shard of global minibatch s
         ops.svgp_elbo_shard(Z, X[lo:lo + B_ROWS], Y[lo:lo + B_ROWS], q_mu, q_sqrt, variance=1.0, lengthscales=ls,
                             noise_variance=0.1, jitter=1e-6, ws=ws, out=out, info=info)
         if world > 1:
-            red.copy_(out[0:1])
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)  # RCCL over xGMI: one 8-byte all-reduce per step
-            host = torch.cat([red, out[1:2], info.to(torch.float64)]).cpu()
-        else:
-            host = torch.cat([out, info.to(torch.float64)]).cpu()  # scalar lands in host memory
-        elbo = float(host[0]) * scale - float(host[1])
-        last.update(elbo=elbo, info=int(host[2]))
+            dist.all_reduce(out[0:1], op=dist.ReduceOp.SUM)  # RCCL over xGMI: one 8-byte all-reduce per step
+        h_out.copy_(out, non_blocking=True)
+        h_info.copy_(info, non_blocking=True)
+        torch.cuda.current_stream().synchronize()  # scalar is in host memory
+        elbo = float(h_out[0]) * scale - float(h_out[1])
+        last.update(elbo=elbo, info=int(h_info[0]))
         return elbo
 
     def fence():
