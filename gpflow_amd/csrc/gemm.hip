@@ -751,6 +751,8 @@ double algorithmic_flops(const GemmArgs& a) {
 }
 }  // namespace
 
+int gpk_profile_gemm_is_on() { return g_prof_on ? 1 : 0; }
+
 extern "C" void gpk_profile_gemm_enable(int on) {
   g_prof_on = on != 0;
   g_prof_n = 0;

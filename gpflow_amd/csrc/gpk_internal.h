@@ -8,15 +8,23 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-#define GPK_HIP(call)                                   \
-  do {                                                  \
-    hipError_t e__ = (call);                            \
-    if (e__ != hipSuccess) return (int)e__;             \
+#include <stdio.h>
+#include <stdlib.h>
+#define GPK_HIP(call)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e__ = (call);                                                                            \
+    if (e__ != hipSuccess) {                                                                            \
+      if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] %s:%d: %s -> %d\n", __FILE__, __LINE__, #call, (int)e__); \
+      return (int)e__;                                                                                  \
+    }                                                                                                   \
   } while (0)
-#define GPK_LAUNCH_CHECK()                              \
-  do {                                                  \
-    hipError_t e__ = hipGetLastError();                 \
-    if (e__ != hipSuccess) return (int)e__;             \
+#define GPK_LAUNCH_CHECK()                                                                              \
+  do {                                                                                                  \
+    hipError_t e__ = hipGetLastError();                                                                 \
+    if (e__ != hipSuccess) {                                                                            \
+      if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] %s:%d: kernel launch -> %d\n", __FILE__, __LINE__, (int)e__); \
+      return (int)e__;                                                                                  \
+    }                                                                                                   \
   } while (0)
 
 static inline size_t gpk_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -43,7 +51,8 @@ struct GemmArgs {
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
-int gpk_gemm_tiles_n(int n);  // number of column tiles the launcher will use for n columns
+int gpk_gemm_tiles_n(int n);
+int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg): graph capture is bypassed  // number of column tiles the launcher will use for n columns
 
 // ---- leaf (leaf.hip): NB x NB Cholesky + inverse of the diagonal block --------------------------
 // A: pointer to the diagonal block (row-major, lda); nb <= NB valid rows/cols.

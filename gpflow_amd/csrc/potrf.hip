@@ -226,9 +226,92 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
                int* info, double* Eout, long ldeout, double* ws);
 }  // namespace
 
+// ---- hipGraph replay of an SVGP-sized factorisation ------------------------------------------------------------
+// The chain  leaf -> solve -> strip  of a 2048-column factorisation is ~50 launches and ~60 event operations on
+// three streams, and at 7-40 us per kernel the HOST issue rate, not the GPU, paced it (removing the device-side
+// event waits changed nothing: A/B).  The enqueue sequence depends only on the arguments, so the second call with the
+// same arguments captures it (stream capture follows the event fork/join onto the internal streams) and later
+// calls replay the instantiated graph: one hipGraphLaunch per factorisation.
+namespace {
+struct GraphKey {
+  void* stream; double* A; int n, extra; long lda; int batch; long strideA; double* invd; int zero_upper; int* info;
+  double* Eout; long ldeout;
+  bool operator==(const GraphKey& o) const {
+    return stream == o.stream && A == o.A && n == o.n && extra == o.extra && lda == o.lda && batch == o.batch &&
+           strideA == o.strideA && invd == o.invd && zero_upper == o.zero_upper && info == o.info && Eout == o.Eout &&
+           ldeout == o.ldeout;
+  }
+};
+struct GraphEntry { GraphKey key; int seen; hipGraphExec_t exec; };
+GraphEntry g_graphs[8];
+int g_ngraphs = 0, g_graph_next = 0;
+
+int potrf_maybe_graph(const GraphKey& k) {
+  // Opt-in (GPK_GRAPH=1).  Measured on MI355X / ROCm 7.2: replay is SLOWER than eager issue (339 vs 370 steps/s on a
+  // created stream; eager on the default stream reaches 435-450), and the HIP 7.0 runtime bundled with PyTorch
+  // overflows its stack in hipStreamEndCapture on this cross-linked stream topology (infinite recursion).
+  static const bool enabled = getenv("GPK_GRAPH") != nullptr;
+  hipStream_t S = (hipStream_t)k.stream;
+  // (the legacy default stream cannot be captured: callers on stream 0 get the eager path)
+  const bool eligible = enabled && S != nullptr && k.batch <= 1 && k.n > NB && k.n < 4096 && k.extra > 256 &&
+                        !gpk_profile_gemm_is_on();
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (eligible && hipStreamIsCapturing(S, &cs) != hipSuccess) cs = hipStreamCaptureStatusActive;
+  if (!eligible || cs != hipStreamCaptureStatusNone)
+    return potrf_core(S, k.A, k.n, k.extra, k.lda, k.batch, k.strideA, k.invd, k.zero_upper, k.info, k.Eout, k.ldeout, nullptr);
+  GraphEntry* e = nullptr;
+  for (int i = 0; i < g_ngraphs; ++i)
+    if (g_graphs[i].key == k) { e = &g_graphs[i]; break; }
+  if (e && e->exec) {
+    const hipError_t le = hipGraphLaunch(e->exec, S);
+    if (le != hipSuccess && getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] hipGraphLaunch (replay) -> %d\n", (int)le);
+    return (int)le;
+  }
+  if (!e) {  // first sighting: run eagerly (also performs the one-time kernel attribute / stream / event setup)
+    if (g_ngraphs < 8) e = &g_graphs[g_ngraphs++];
+    else {
+      e = &g_graphs[g_graph_next];
+      g_graph_next = (g_graph_next + 1) % 8;
+      if (e->exec) (void)hipGraphExecDestroy(e->exec);
+    }
+    e->key = k; e->seen = 1; e->exec = nullptr;
+    return potrf_core(S, k.A, k.n, k.extra, k.lda, k.batch, k.strideA, k.invd, k.zero_upper, k.info, k.Eout, k.ldeout, nullptr);
+  }
+  // second sighting: capture, instantiate, launch
+  hipGraph_t graph = nullptr;
+  if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] begin capture on %p\n", (void*)S);
+  if (hipStreamBeginCapture(S, hipStreamCaptureModeRelaxed) != hipSuccess)
+    return potrf_core(S, k.A, k.n, k.extra, k.lda, k.batch, k.strideA, k.invd, k.zero_upper, k.info, k.Eout, k.ldeout, nullptr);
+  const int rc = potrf_core(S, k.A, k.n, k.extra, k.lda, k.batch, k.strideA, k.invd, k.zero_upper, k.info, k.Eout, k.ldeout, nullptr);
+  const hipError_t ce = hipStreamEndCapture(S, &graph);
+  if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] capture: enqueue rc %d, end-capture %d, graph %p\n", rc, (int)ce, (void*)graph);
+  if (rc != 0 || ce != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    e->seen = -1000000;  // never try again for this key
+    if (rc != 0) return rc;
+    return potrf_core(S, k.A, k.n, k.extra, k.lda, k.batch, k.strideA, k.invd, k.zero_upper, k.info, k.Eout, k.ldeout, nullptr);
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] instantiate -> %d\n", (int)ie);
+  if (ie != hipSuccess || !exec) {
+    (void)hipGetLastError();
+    return potrf_core(S, k.A, k.n, k.extra, k.lda, k.batch, k.strideA, k.invd, k.zero_upper, k.info, k.Eout, k.ldeout, nullptr);
+  }
+  e->exec = exec;
+  const hipError_t le = hipGraphLaunch(exec, S);
+  if (le != hipSuccess && getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] hipGraphLaunch (first) -> %d\n", (int)le);
+  return (int)le;
+}
+}  // namespace
+
 extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch,
                          long strideA, double* invd, int zero_upper, int* info) {
-  return potrf_core((hipStream_t)stream, A, n, extra, lda, batch, strideA, invd, zero_upper, info, nullptr, 0, nullptr);
+  if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
+  GraphKey k{stream, A, n, extra, lda, batch, strideA, invd, zero_upper, info, nullptr, 0};
+  return potrf_maybe_graph(k);
 }
 
 extern "C" size_t gpk_potrf_ex_workspace_bytes(void) { return 0; }
@@ -299,6 +382,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1],
              evJoinB = aux->ev[2 * npanels + 2];
   const bool useX = extra > 0 && !ride;
+  if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] potrf_core: fork\n");
   GPK_HIP(hipEventRecord(evFork, S));  // fork: everything already queued on S comes first
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
   GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
@@ -317,18 +401,21 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // ---- P: the critical path.  Panel p, then the strip = columns of panel p+1 (look-ahead) -----------
     rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
-    GPK_HIP(hipEventRecord(evF[p], P));
+    static const bool dbg_late_record = getenv("GPK_DBG_LATE_RECORD") != nullptr;   // timing experiments only
+    static const bool dbg_no_wait = getenv("GPK_DBG_NO_WAIT") != nullptr;           // (races: wrong results)
+    if (!dbg_late_record) GPK_HIP(hipEventRecord(evF[p], P));
     const int kpend = c1 - r0;                   // pending columns r0:c1 (one or two panels)
     const double* Pn = A + (long)c1 * lda + r0;  // rows c1.. of the pending panels (solved)
     if (c1 < n) {
       // columns c1:c2 also received the most recent rest-update (on a bulk stream): order the two
-      if (last_rest >= 0) GPK_HIP(hipStreamWaitEvent(P, evR[last_rest], 0));
+      if (last_rest >= 0 && !dbg_no_wait) GPK_HIP(hipStreamWaitEvent(P, evR[last_rest], 0));
       GemmArgs u = gemm_base(R - c1, c2 - c1, kpend, -1.0, Pn, lda, Pn, lda, 1.0,
                              A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
       rc = gpk_launch_gemm(P, u);
       if (rc) return rc;
     }
+    if (dbg_late_record) GPK_HIP(hipEventRecord(evF[p], P));
     // ---- B: rest of the outer trailing update  A[c2:, c2:] -= P[c2:] P[c2:]^T, lower tiles only --------
     // While the trailing matrix is large the factorisation is bound by these GEMMs and they start as soon as
     // panel p is solved.  Near the end it is bound by the latency chain of P instead: there the strip goes
@@ -377,6 +464,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       }
     }
   }
+  if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] potrf_core: join\n");
   // join: P has waited for every rest-update it depends on; B's last event covers the rest
   GPK_HIP(hipEventRecord(evJoinP, P));
   GPK_HIP(hipEventRecord(evJoinB, last_bulk));  // rest-updates are chained through evR, the last one covers all
@@ -618,7 +706,10 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   // the caller's stream) and the panel chain starts right after the much smaller Kuu build.
   static const bool plain_streams = !getenv("GPK_EXTRA_STREAMS") && !getenv("GPK_MERGE_BULK");
   hipStream_t kfu_stream = s;
-  if (plain_streams && m > GPK_NB && rows > 256) {
+  // (with hipGraph replay of the factorisation the graph is launched on the caller's stream and cannot depend on
+  // eager work of an internal stream: the build then stays on the caller's stream)
+  static const bool graphs = getenv("GPK_GRAPH") != nullptr;
+  if (plain_streams && !graphs && m > GPK_NB && rows > 256) {
     Aux* aux = nullptr;
     rc = aux_get(8, &aux);
     if (rc) return rc;
