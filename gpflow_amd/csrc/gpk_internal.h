@@ -59,6 +59,11 @@ int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
                     long strideInv, int* info, int col0, int batch, int already_factored);
 
+// persistent chain kernel (leaf.hip): whole latency chain of an n <= 2048 factorisation in one launch
+size_t gpk_chain_flag_bytes();
+int gpk_chain_flag_index(int which);  // 0: PP (panels published), 1: RB (rest-updates done), 2: ERR
+int gpk_launch_chain(hipStream_t s, double* A, long lda, int n, double* invd, int* info, int* flags);
+
 // ---- trsm.hip: Eout[:, 0:128 nb] = Ein[:, 0:128 nb] L_gg^-T in one launch (16 rows per workgroup) ----------
 int gpk_launch_trsm_group(hipStream_t s, const double* Ein, long ldein, double* Eout, long ldeout, int rows,
                           const double* Lgg, long lda, const double* invg, int nb);

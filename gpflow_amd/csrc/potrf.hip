@@ -59,6 +59,7 @@ struct Aux {
   hipStream_t Xb = nullptr;  // extra rows: the big right-looking updates, CU-masked (leaves GPK_EXTRA_RESERVED_CUS free)
   hipEvent_t* ev = nullptr;
   int nev = 0;
+  int* chain_flags = nullptr;  // device ints of the persistent chain kernel (leaf.hip)
 };
 Aux g_aux[16];
 
@@ -101,6 +102,7 @@ int aux_get(int need, Aux** out) {
       if (rc) return rc;
     }
     GPK_HIP(hipStreamCreateWithFlags(&a.Bs, hipStreamNonBlocking));
+    GPK_HIP(hipMalloc((void**)&a.chain_flags, gpk_chain_flag_bytes()));  // one-time, 768 bytes of sync words
     int late_res = ncu / 2;
     if (const char* e = getenv("GPK_LATE_RESERVED_CUS")) late_res = atoi(e);
     if (ncu > 1024 || late_res < 0 || late_res >= ncu) late_res = 0;
@@ -387,6 +389,57 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
   GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
   for (int i = 0; i < nx; ++i) GPK_HIP(hipStreamWaitEvent(Xq[i], evFork, 0));
+  // ---- SVGP-sized factorisations: the whole latency chain is ONE persistent kernel (leaf.hip) -----------------------
+  static const bool no_chain = getenv("GPK_NO_CHAIN") != nullptr;
+  if (!no_chain && batch == 1 && n % NB == 0 && n >= 2 * NB && n <= 2048 && !ride && aux->chain_flags) {
+    const int np = n / NB;
+    int* flags = aux->chain_flags;
+    int* fPP = flags + gpk_chain_flag_index(0);
+    int* fRB = flags + gpk_chain_flag_index(1);
+    hipEvent_t evZ = aux->ev[2 * npanels + 9];
+    GPK_HIP(hipMemsetAsync(flags, 0, gpk_chain_flag_bytes(), P));
+    GPK_HIP(hipEventRecord(evZ, P));
+    rc = gpk_launch_chain(P, A, lda, n, invd, info, flags);
+    if (rc) return rc;
+    GPK_HIP(hipStreamWaitEvent(B, evZ, 0));
+    hipStream_t Xs = Xq[0];
+    if (useX) GPK_HIP(hipStreamWaitEvent(Xs, evZ, 0));
+    int g0 = 0;
+    // (stream value-waits are issued in the order the chain will satisfy them: the host call can block until an
+    //  earlier wait of the same hardware queue has been consumed)
+    for (int p = 0; p < np; ++p) {
+      const int c0 = p * NB, c1 = c0 + NB, c2 = c0 + 2 * NB;
+      if (c2 < n) {  // rest-update of panel p: columns from panel p + 2 on, K = 128
+        GPK_HIP(hipStreamWaitValue32(B, fPP, (uint32_t)(p + 1), hipStreamWaitValueGte, 0xffffffffu));
+        const double* P2 = A + (long)c2 * lda + c0;
+        GemmArgs u = gemm_base(n - c2, n - c2, NB, -1.0, P2, lda, P2, lda, 1.0, A + (long)c2 * lda + c2, lda, 1, 0, 0, 0);
+        u.c_lower = 1;
+        rc = gpk_launch_gemm(B, u);
+        if (rc) return rc;
+        GPK_HIP(hipStreamWriteValue32(B, fRB, (uint32_t)(p + 1), 0));
+      }
+      if (useX) {
+        const bool tail_group = (n >= 8 * NB) && (c1 == n - 2 * NB || c1 == n - NB);
+        const bool full_group = (c1 % NBO) == 0 && !((n >= 8 * NB) && c1 > n - 2 * NB && c1 < n);
+        if (c1 == n || full_group || tail_group) {
+          GPK_HIP(hipStreamWaitValue32(Xs, fPP, (uint32_t)(c1 / NB), hipStreamWaitValueGte, 0xffffffffu));
+          rc = extra_panel(Xs, Xs, nullptr, nullptr, A, n, 0, extra, g0, c1, lda, 1, strideA, invd, strideInv, Eout, ldeout);
+          if (rc) return rc;
+          g0 = c1;
+        }
+      }
+    }
+    if (useX) {
+      GPK_HIP(hipEventRecord(aux->ev[2 * npanels + 3], Xs));
+      GPK_HIP(hipStreamWaitEvent(S, aux->ev[2 * npanels + 3], 0));
+    }
+    GPK_HIP(hipEventRecord(evJoinP, P));
+    GPK_HIP(hipEventRecord(evJoinB, B));
+    GPK_HIP(hipStreamWaitEvent(S, evJoinP, 0));
+    GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
+    if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, 1, strideA);
+    return 0;
+  }
   hipStream_t last_bulk = B;
   // Deferred rest-updates: while the trailing matrix is large, the far trailing update is applied once per TWO
   // outer panels, as a K = 1024 GEMM (65 vs 59 TFLOP/s for K = 512 on this chip); the strip of the look-ahead
