@@ -62,7 +62,8 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
 // persistent chain kernel (leaf.hip): whole latency chain of an n <= 2048 factorisation in one launch
 size_t gpk_chain_flag_bytes();
 int gpk_chain_flag_index(int which);  // 0: PP (panels published), 1: RB (rest-updates done), 2: ERR
-int gpk_launch_chain(hipStream_t s, double* A, long lda, int n, double* invd, int* info, int* flags);
+int gpk_launch_chain(hipStream_t s_leaf, hipStream_t s_workers, double* A, long lda, int n, double* invd, int* info,
+                     int* flags);
 
 // ---- trsm.hip: Eout[:, 0:128 nb] = Ein[:, 0:128 nb] L_gg^-T in one launch (16 rows per workgroup) ----------
 int gpk_launch_trsm_group(hipStream_t s, const double* Ein, long ldein, double* Eout, long ldeout, int rows,

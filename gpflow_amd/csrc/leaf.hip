@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
 // resident grid cannot deadlock; the grid (<= 121 workgroups) fits the chip beside the bulk GEMMs.
 enum { CF_F = 0, CF_ERR = 1, CF_RB = 32, CF_PP = 64, CF_PS = 96, CF_XT = 128, CF_DG = 160, CF_COUNT = 192 };
 constexpr int LDW = NB + 2;
-constexpr long CHAIN_SPIN_LIMIT = 40L * 1000 * 1000;  // ~ seconds; a healthy wait is microseconds
+constexpr long CHAIN_SPIN_LIMIT = 1500L * 1000;  // ~1-2 s; a healthy wait is microseconds
 
 __device__ __forceinline__ bool chain_wait_ge(int* __restrict__ flags, int idx, int v, bool system_scope) {
   __shared__ int st;
@@ -551,68 +551,104 @@ __device__ __forceinline__ void chain_stage_rows(double* __restrict__ dst, const
   }
 }
 
-// this wave's 16 x 16 tile of  Arows[16 x 128] * Brows[n = 16 wave + r][128]^T  (both in LDS, row stride LDW)
+// B operands are staged in K chunks of 32 so that a row-block owner needs only 82 KB of LDS and shares its CU with
+// one workgroup of the bulk GEMM (73.7 KB) instead of holding the CU for the whole factorisation.  A chunk is
+// [128 rows][32 doubles] UNPADDED (one LDS-DMA instruction = 1 KiB = 4 rows); bank conflicts are avoided by an XOR
+// swizzle applied on the global side: 16-byte slot c of row n holds source slot c ^ (n & 15).
+constexpr int CK = 32;
+constexpr int CHUNK = NB * CK;  // doubles
+constexpr size_t WORKER_LDS = ((size_t)2 * CHUNK + (size_t)SB * LDW) * sizeof(double);  // 82,176 B
+
+__device__ __forceinline__ void chain_stage_chunk(double* __restrict__ Bc, const double* __restrict__ src, long ld, int kc,
+                                                  int wave, int lane) {
+  for (int q = wave; q < NB / 4; q += NW) {
+    const int row = 4 * q + (lane >> 4), cs = (lane & 15) ^ (row & 15);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + (long)row * ld + kc * CK + 2 * cs),
+        (__attribute__((address_space(3))) void*)(Bc + q * (4 * CK)), 16, 0, 0);
+  }
+}
+
+// this wave's 16 x 16 tile of  Arows[16 x 128] (LDS, row stride LDW) * B[n = 16 wave + r][128]^T, B streamed from
+// global (row stride ldb) through the two LDS chunk buffers in two rounds of two chunks
 template <bool NEG>
-__device__ __forceinline__ d4 chain_tile(const double* __restrict__ As, const double* __restrict__ Bs, int wave, int lane,
-                                         d4 acc) {
+__device__ __forceinline__ d4 chain_product(const double* __restrict__ As, double* __restrict__ Bc,
+                                            const double* __restrict__ Bsrc, long ldb, int wave, int lane, d4 acc) {
   const int r = lane & 15, kq = lane >> 4;
-  const double* ap = As + r * LDW + kq;
-  const double* bp = Bs + (16 * wave + r) * LDW + kq;
+  const int row = 16 * wave + r;
   d4 acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
-  for (int kk = 0; kk < 32; kk += 2) {
-    const double a0 = ap[4 * kk], b0 = bp[4 * kk], a1 = ap[4 * kk + 4], b1 = bp[4 * kk + 4];
-    acc = mfma4(NEG ? -a0 : a0, b0, acc);
-    acc2 = mfma4(NEG ? -a1 : a1, b1, acc2);
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (round) __syncthreads();  // every wave is done with both chunk buffers
+    chain_stage_chunk(Bc, Bsrc, ldb, 2 * round, wave, lane);
+    chain_stage_chunk(Bc + CHUNK, Bsrc, ldb, 2 * round + 1, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double* bc = Bc + h * CHUNK + row * CK;
+      const double* ap = As + r * LDW + (2 * round + h) * CK + kq;
+#pragma unroll
+      for (int kk = 0; kk < 8; kk += 2) {
+        const int k0 = 4 * kk + kq, k1 = k0 + 4;
+        const double a0 = ap[4 * kk], a1 = ap[4 * kk + 4];
+        const double b0 = bc[(((k0 >> 1) ^ (row & 15)) << 1) + (k0 & 1)];
+        const double b1 = bc[(((k1 >> 1) ^ (row & 15)) << 1) + (k1 & 1)];
+        acc = mfma4(NEG ? -a0 : a0, b0, acc);
+        acc2 = mfma4(NEG ? -a1 : a1, b1, acc2);
+      }
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
   return acc;
 }
 
-__global__ __launch_bounds__(NT) void chain_kernel(double* __restrict__ A, long lda, int n, double* __restrict__ invd,
-                                                    int* __restrict__ info, int* __restrict__ flags) {
+// ---- workgroup 0's role: all the leaves (its own launch: it needs the leaf's 150 KB of LDS) ---------------------------
+__global__ __launch_bounds__(NT) void chain_leaf_kernel(double* __restrict__ A, long lda, int n, double* __restrict__ invd,
+                                                         int* __restrict__ info, int* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) double S[];
+  const int tid = threadIdx.x;
+  const int np = n / NB;
+  for (int p = 0; p < np; ++p) {
+    if (p > 0) {
+      if (!chain_wait_ge(flags, CF_DG + p, 8, false)) return;          // strip(p-1) reached the diagonal block
+      if (p >= 2 && !chain_wait_ge(flags, CF_RB, p - 1, true)) return;  // rest-updates up to panel p-2 are in
+    }
+    leaf_body<false>(S, A + (long)p * NB * (lda + 1), lda, NB, invd + (long)p * NB * NB, info, p * NB, nullptr);
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&flags[CF_F], p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p == np - 1) __hip_atomic_store(&flags[CF_PP], np, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- row-block owners (blockIdx.x = w - 1) --------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void chain_worker_kernel(double* __restrict__ A, long lda, int n,
+                                                           const double* __restrict__ invd, int* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) double S[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int np = n / NB;
-  if (blockIdx.x == 0) {
-    // ---------------- the leaves -------------------------------------------------------------------------------
-    for (int p = 0; p < np; ++p) {
-      if (p > 0) {
-        if (!chain_wait_ge(flags, CF_DG + p, 8, false)) return;          // strip(p-1) reached the diagonal block
-        if (p >= 2 && !chain_wait_ge(flags, CF_RB, p - 1, true)) return;  // rest-updates up to panel p-2 are in
-      }
-      leaf_body<false>(S, A + (long)p * NB * (lda + 1), lda, NB, invd + (long)p * NB * NB, info, p * NB, nullptr);
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&flags[CF_F], p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p == np - 1) __hip_atomic_store(&flags[CF_PP], np, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      __syncthreads();
-    }
-    return;
-  }
-  // ---------------- row-block owner --------------------------------------------------------------------------------
-  const int rb = 8 + ((int)blockIdx.x - 1);  // 16-row block index
+  const int rb = 8 + (int)blockIdx.x;  // 16-row block index
   const int r0 = rb * SB;
   if (r0 >= n) return;
-  const int pmax = rb / 8 - 1;               // last panel this block takes part in (its rows then join block pmax+1)
-  double* Bs = S;                            // [128][LDW]: inv_p, then X_top
-  double* As = S + NB * LDW;                 // [16][LDW]:  my rows of panel p, then X
+  __builtin_amdgcn_s_setprio(3);  // short bursts of work on a CU shared with a bulk-GEMM workgroup
+  const int pmax = rb / 8 - 1;    // last panel this block takes part in (its rows then join block pmax+1)
+  double* Bc = S;                 // [2][128][32]: chunk buffers
+  double* As = S + 2 * CHUNK;     // [16][LDW]:  my rows of panel p, then X
   const int c = lane & 15, g = lane >> 4;
   for (int p = 0; p <= pmax; ++p) {
     const int cp = p * NB;
     if (!chain_wait_ge(flags, CF_F, p + 1, false)) return;                 // L_pp and inv_p are published
     if (p >= 2 && !chain_wait_ge(flags, CF_RB, p - 1, true)) return;       // my panel-p columns carry rest(<= p-2)
-    chain_stage_rows(Bs, invd + (long)p * NB * NB, NB, NB, wave, lane);
     chain_stage_rows(As, A + (long)r0 * lda + cp, lda, SB, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();
     // ---- solve: X = A_rows inv_p^T ---------------------------------------------------------------------------
-    d4 x = chain_tile<false>(As, Bs, wave, lane, (d4){0.0, 0.0, 0.0, 0.0});
+    d4 x = chain_product<false>(As, Bc, invd + (long)p * NB * NB, NB, wave, lane, (d4){0.0, 0.0, 0.0, 0.0});
     __syncthreads();  // every wave has read As
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -631,20 +667,17 @@ __global__ __launch_bounds__(NT) void chain_kernel(double* __restrict__ A, long 
     // ---- strip: A[rows, panel p+1] -= X X_top^T ----------------------------------------------------------------
     if (!chain_wait_ge(flags, CF_XT + p, 8, false)) return;                // the 8 row blocks of X_top are published
     if (p >= 1 && !chain_wait_ge(flags, CF_RB, p, true)) return;           // rest(p-1) also updates these columns
-    chain_stage_rows(Bs, A + (long)(cp + NB) * lda + cp, lda, NB, wave, lane);  // X_top = solved rows of block p+1
     d4 acc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = A[(long)(r0 + g + 4 * e) * lda + cp + NB + 16 * wave + c];
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();
-    acc = chain_tile<true>(As, Bs, wave, lane, acc);
+    acc = chain_product<true>(As, Bc, A + (long)(cp + NB) * lda + cp, lda, wave, lane, acc);  // X_top = rows of block p+1
 #pragma unroll
     for (int e = 0; e < 4; ++e) A[(long)(r0 + g + 4 * e) * lda + cp + NB + 16 * wave + c] = acc[e];
     if (in_next) {
       (void)chain_publish_add(flags, CF_DG + p + 1);
       return;
     }
-    __syncthreads();  // Bs / As are restaged next
+    __syncthreads();  // chunk buffers / As are restaged next
   }
 }
 
@@ -653,18 +686,26 @@ __global__ __launch_bounds__(NT) void chain_kernel(double* __restrict__ A, long 
 size_t gpk_chain_flag_bytes() { return (size_t)CF_COUNT * sizeof(int); }
 int gpk_chain_flag_index(int which) { return which == 0 ? CF_PP : (which == 1 ? CF_RB : CF_ERR); }
 
-// n <= 2048, n % 128 == 0; flags: device ints (gpk_chain_flag_bytes()), zeroed on the same stream before this call
-int gpk_launch_chain(hipStream_t s, double* A, long lda, int n, double* invd, int* info, int* flags) {
+// n <= 2048, n % 128 == 0; flags: device ints (gpk_chain_flag_bytes()), zeroed before both launches; the leaf role and the
+// row-block owners are separate launches on separate streams (different LDS footprints), coupled only by the flags
+int gpk_launch_chain(hipStream_t s_leaf, hipStream_t s_workers, double* A, long lda, int n, double* invd, int* info,
+                     int* flags) {
   if (n <= 0 || (n % NB) != 0 || n > 2048) return GPK_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)LEAF_LDS));
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_leaf_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_worker_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WORKER_LDS));
     attr_set = true;
   }
-  const int nwg = 1 + (n / SB - 8);
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)nwg), dim3(NT), LEAF_LDS, s, A, lda, n, invd, info, flags);
+  hipLaunchKernelGGL(chain_leaf_kernel, dim3(1), dim3(NT), LEAF_LDS, s_leaf, A, lda, n, invd, info, flags);
   GPK_LAUNCH_CHECK();
+  const int nw = n / SB - 8;
+  if (nw > 0) {
+    hipLaunchKernelGGL(chain_worker_kernel, dim3((unsigned)nw), dim3(NT), WORKER_LDS, s_workers, A, lda, n, invd, flags);
+    GPK_LAUNCH_CHECK();
+  }
   return 0;
 }
 
