@@ -242,3 +242,42 @@ def test_golden_vectors_match_oracle():
     np.testing.assert_allclose(orc.gauss_kl(g["kl_mu"], g["kl_sqrt"], g["kl_K"]), g["kl_K_val"], rtol=1e-10)
     np.testing.assert_allclose(orc.gpr_log_marginal_likelihood(g["c1_X"], g["c1_Y"], variance=1.0, lengthscales=1.0,
                                                                noise_variance=0.1), g["c1_lml"], rtol=1e-13)
+
+
+def test_oracle_vs_torch_cpu_second_opinion():
+    """Independent fp64 restatement with torch-CPU linalg (cholesky / solve_triangular / logdet) of the two headline
+    quantities -- GPR LML and the whitened SVGP ELBO -- on a mid-size problem ('torch-CPU fp64 as a second
+    opinion').  Different code, different BLAS: agreement to 1e-10 relative pins the oracle's arithmetic."""
+    import torch
+    rng = np.random.default_rng(7)
+    N, D, M = 300, 3, 40
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, 1))
+    ls = np.array([0.9, 1.1, 1.3]); var, noise = 1.7, 0.2
+    tX, tY = torch.tensor(X), torch.tensor(Y)
+
+    def k(a, b):
+        a, b = a / torch.tensor(ls), b / torch.tensor(ls)
+        r2 = (a * a).sum(1, keepdim=True) + (b * b).sum(1)[None, :] - 2 * a @ b.T
+        return var * torch.exp(-0.5 * r2)
+
+    # GPR LML (gpr.py:91-107, logdensities.py:139-156)
+    K = k(tX, tX) + noise * torch.eye(N, dtype=torch.float64)
+    L = torch.linalg.cholesky(K)
+    alpha = torch.linalg.solve_triangular(L, tY, upper=False)
+    lml_t = float(-0.5 * (alpha ** 2).sum() - 0.5 * N * np.log(2 * np.pi) - torch.log(torch.diagonal(L)).sum())
+    lml_o = orc.gpr_log_marginal_likelihood(X, Y, variance=var, lengthscales=ls, noise_variance=noise)
+    assert abs(lml_t - lml_o) <= 1e-10 * abs(lml_o)
+    # whitened SVGP ELBO (svgp.py:166-181, conditionals/util.py:84-169, kullback_leiblers.py:59-165)
+    Z = X[:M] + 0.3 * rng.normal(size=(M, D)); tZ = torch.tensor(Z)
+    q_mu = 0.3 * rng.normal(size=(M, 1)); q_sqrt = np.tril(0.1 * rng.normal(size=(M, M))) + 0.5 * np.eye(M)
+    tq, tS = torch.tensor(q_mu), torch.tensor(q_sqrt)
+    Lm = torch.linalg.cholesky(k(tZ, tZ) + 1e-6 * torch.eye(M, dtype=torch.float64))
+    A = torch.linalg.solve_triangular(Lm, k(tZ, tX), upper=False)
+    fmean = A.T @ tq
+    fvar = var - (A * A).sum(0) + ((tS.T @ A) ** 2).sum(0)
+    ve = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(noise) - 0.5 * ((tY[:, 0] - fmean[:, 0]) ** 2 + fvar) / noise
+    kl = 0.5 * ((tq ** 2).sum() - M - torch.log(torch.diagonal(tS) ** 2).sum() + (tS ** 2).sum())
+    elbo_t = float(ve.sum() * (5000.0 / N) - kl)
+    elbo_o = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt[None], variance=var, lengthscales=ls, noise_variance=noise, whiten=True,
+                           num_data=5000)
+    assert abs(elbo_t - elbo_o) <= 1e-10 * abs(elbo_o)
