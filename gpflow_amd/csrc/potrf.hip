@@ -395,9 +395,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
   for (int i = 0; i < nx; ++i) GPK_HIP(hipStreamWaitEvent(Xq[i], evFork, 0));
   // ---- SVGP-sized factorisations: the whole latency chain is ONE persistent kernel (leaf.hip) -----------------------
-  // Opt-in (GPK_CHAIN=1): correct in the test-suite and no faster than the per-step kernels on the SVGP step (A/B 436 vs
-  // 429 steps/s), but bench.py hung once with it (suspected: a launch queued behind a value-wait on a shared hardware
-  // queue).  Until that is understood the default stays the per-step path.
+  // Opt-in (GPK_CHAIN=1), and only with GPU_MAX_HW_QUEUES >= 4: the leaf launch, the row-owner launch and the two
+  // bulk streams (blocked in hipStreamWaitValue32 most of the time) must all be resident hardware queues at once -- with
+  // 2 hardware queues a value-wait occupies a queue for good and the owners' launch is never scheduled (bench.py hung).
+  // Measured 364 steps/s (4 queues) against 440 for the per-step kernels with 2 queues, so the default stays per-step.
   static const bool no_chain = getenv("GPK_CHAIN") == nullptr;
   if (!no_chain && batch == 1 && n % NB == 0 && n >= 2 * NB && n <= 2048 && !ride && aux->chain_flags) {
     const int np = n / NB;
