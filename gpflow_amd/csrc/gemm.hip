@@ -690,7 +690,8 @@ bool small_ok(const GemmArgs& a) {
   if ((a.lda & 1) || (a.ldb & 1) || (a.strideA & 1) || (a.strideB & 1)) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
   if (a.beta != 0.0 && a.alpha == 0.0) return false;
-  return (long)gpk_cdiv(a.m, SM_BM) * gpk_cdiv(a.n, SM_BN) * (a.batch > 0 ? a.batch : 1) <= 512 && a.batch < 65536;
+  static const long max_wgs = getenv("GPK_SMALL_MAX_WGS") ? atol(getenv("GPK_SMALL_MAX_WGS")) : 512;
+  return (long)gpk_cdiv(a.m, SM_BM) * gpk_cdiv(a.n, SM_BN) * (a.batch > 0 ? a.batch : 1) <= max_wgs && a.batch < 65536;
 }
 
 template <int BM, int BN, int WGM, int WGN>
