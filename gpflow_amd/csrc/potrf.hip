@@ -348,7 +348,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
   // outer panel width: 512 for the large GPR factorisations (K = 512 trailing GEMMs), one leaf block for
   // the SVGP-sized ones, where the whole factorisation is a latency chain of leaf -> solve -> strip
-  const int nbo = (n >= 4096) ? NBO : NB;
+  // outer panel width for n >= 4096: A/B at N = 16384 (same box): 384 -> 34.6 ms, 512 -> 33.2, 640 -> 32.6, 768 -> 32.4,
+  // 896 -> 32.3, 1024 -> 32.7
+  static const int nbo_large = getenv("GPK_NBO") ? (atoi(getenv("GPK_NBO")) / NB) * NB : 768;
+  const int nbo = (n >= 4096) ? (nbo_large >= NB ? nbo_large : NBO) : NB;
   const int npanels = gpk_cdiv(n, nbo);
   // Few extra rows (GPR: the P columns of Y) simply ride along through the panel solves and trailing
   // updates of the square part; many extra rows (SVGP: the minibatch) are solved right-looking on their
@@ -502,7 +505,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // first (alone on the chip) and the rest-update overlaps the NEXT panel's chain rather than the strip.
     static const int late_rows = getenv("GPK_LATE_ROWS") ? atoi(getenv("GPK_LATE_ROWS")) : 3072;  // A/B at N = 16384: 3072 -> 32.9 ms, 6144 -> 33.8, off -> 33.1
     const bool strip_first = (n >= 4096) && (n - c1 <= late_rows) && (c1 < n);
-    const bool defer = (nbo == NBO) && (kpend < 2 * NBO) && (n - c2 >= defer_rows) && (c2 + nbo < n);
+    const bool defer = (nbo > NB) && (kpend < 2 * nbo) && (n - c2 >= defer_rows) && (c2 + nbo < n);
     if (c2 < n && !defer) {
       hipStream_t Bp = B;
       if (strip_first) {
@@ -547,7 +550,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // scheme (128-column panels, one-shot LDS-DMA GEMMs for solve and strip) runs it ~2x faster than 512-column panels
     // (opt-in, GPK_TAIL_RECURSION=1: A/B at N = 16384 gave 33.5 ms with it vs 33.25 ms without)
     static const bool tail_recursion = getenv("GPK_TAIL_RECURSION") != nullptr;
-    if (tail_recursion && nbo == NBO && batch == 1 && !useX && c1 < n && n - c1 <= 2048 && n - c1 >= 2 * NBO) {
+    if (tail_recursion && nbo > NB && batch == 1 && !useX && c1 < n && n - c1 <= 2048 && n - c1 >= 2 * NBO) {
       if (r0 != c1) continue;  // (a deferred rest-update is still pending: not at a clean boundary)
       GPK_HIP(hipEventRecord(evJoinP, P));
       GPK_HIP(hipEventRecord(evJoinB, last_bulk));
