@@ -534,7 +534,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // Groups shrink towards the end (.., n-256, n-128, n): whatever is left of the extra-row solve when the LAST leaf
     // finishes is exposed latency, and with one-block groups that is a single short launch instead of seven.
     const bool tail_group = (nbo == NB) && (n >= 8 * NB) && (c1 == n - 2 * NB || c1 == n - NB);
-    const bool full_group = (c1 % NBO) == 0 && !((nbo == NB) && (n >= 8 * NB) && c1 > n - 2 * NB && c1 < n);
+    static const int xgroup = getenv("GPK_XGROUP") ? (atoi(getenv("GPK_XGROUP")) / NB) * NB : NBO;  // A/B knob
+    const bool full_group = (c1 % (xgroup >= NB ? xgroup : NBO)) == 0 && !((nbo == NB) && (n >= 8 * NB) && c1 > n - 2 * NB && c1 < n);
     if (useX && (c1 == n || full_group || tail_group)) {
       const int g0 = xg0;
       xg0 = c1;
