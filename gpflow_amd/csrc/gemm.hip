@@ -503,6 +503,14 @@ template <int EPI, bool PAIR>
 __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int gy, int total, int compact) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if constexpr (!PAIR) {
+    // De-phasing: the two workgroups that share a CU are dispatched together and, with equal tile times, stay in
+    // lock-step -- both in their load/store prologue and epilogue at the same moment, when neither feeds the MFMA
+    // pipes.  In big launches the second resident set (workgroups 256..511 of the dispatch order) therefore starts
+    // half a tile late, once; the offset then persists for the whole kernel.
+    if (p.stagger_ticks > 0 && (int)blockIdx.x >= p.stagger_first && (int)blockIdx.x < 2 * p.stagger_first && blockIdx.y == 0) {
+      const long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+    }
     // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x (used to cap
     // the number of CUs a bulk GEMM may occupy while a latency-critical stream needs free ones)
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
@@ -560,7 +568,17 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   }
   unsigned nwg = (unsigned)total;
   if (a.max_wgs > 0 && (unsigned)a.max_wgs < nwg) nwg = (unsigned)a.max_wgs;
-  hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy, total,
+  GemmArgs b = a;
+  {
+    // half a tile in 100 MHz ticks: a 128x128x16 slab costs ~1.7 us per workgroup when two share a CU
+    // (A/B, 16384^2 x 512, beta = 1: 60.7 -> 63.0 TFLOP/s; lower-only 55.8 -> 58.8; percent of a half tile, 0 = off)
+    static const int stagger_on = getenv("GPK_GEMM_STAGGER") ? atoi(getenv("GPK_GEMM_STAGGER")) : 100;
+    if (b.stagger_first <= 0) b.stagger_first = 256;
+    b.stagger_ticks = (stagger_on && EPI == 0 && !a.b_tri && total >= 1024 && nwg == (unsigned)total)
+                          ? (int)((a.k / 16) * 170 * stagger_on / 200)
+                          : 0;
+  }
+  hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, nb, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total,
                      compact);
   GPK_LAUNCH_CHECK();
   return 0;

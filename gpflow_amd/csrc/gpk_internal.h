@@ -48,6 +48,8 @@ struct GemmArgs {
   double* part; long part_ld; long stridePart;   // [2*tiles_n, m]
   double* C2; long ldc2; long strideC2; int c2_cols;
   int batch;
+  int stagger_first;  // fast path only: number of CUs the launch stream may use (first workgroup of the 2nd resident set), 0 = 256
+  int stagger_ticks;  // fast path only: start delay (100 MHz ticks) of the second resident workgroup set, 0 = none
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);

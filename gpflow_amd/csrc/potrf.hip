@@ -60,6 +60,7 @@ struct Aux {
   hipEvent_t* ev = nullptr;
   int nev = 0;
   int* chain_flags = nullptr;  // device ints of the persistent chain kernel (leaf.hip)
+  int bulk_cus = 0;            // CUs the masked bulk stream B may use
 };
 Aux g_aux[16];
 
@@ -89,6 +90,7 @@ int aux_get(int need, Aux** out) {
     if (ncu > 1024 || xfrom < 0 || xfrom >= ncu) xfrom = 0;
     int rc = masked_stream(&a.B, ncu, reserved, ncu);
     if (rc) return rc;
+    a.bulk_cus = ncu - reserved;
     for (int i = 0; i < 4; ++i) {
       rc = masked_stream(&a.X[i], ncu, xfrom, ncu);
       if (rc) return rc;
@@ -520,6 +522,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       GemmArgs u = gemm_base(R - c2, n - c2, kpend, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
+      if (Bp == aux->B && n >= 4096) u.stagger_first = aux->bulk_cus;
       rc = gpk_launch_gemm(Bp, u);
       if (rc) return rc;
       GPK_HIP(hipEventRecord(evR[p], Bp));
