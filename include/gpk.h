@@ -9,7 +9,8 @@
  *   - every matrix pointer is a DEVICE pointer to row-major fp64 (gpflow default_float,
  *     config/__config__.py:99); leading dimensions are in elements;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work,
- *     they never synchronise and never allocate: scratch comes from the caller's workspace;
+ *     they never synchronise; scratch comes from the caller's workspace (the only internal state is created
+ *     lazily, once per device: the auxiliary streams/events of gpk_potrf and 768 bytes of device sync words);
  *   - small hyper-parameter vectors (lengthscales) are HOST pointers, copied into kernel arguments;
  *   - return value: 0 ok, <0 bad argument (GPK_E_*), >0 HIP runtime error code (hipError_t);
  *   - numerical failure (non-positive pivot) is reported LAPACK-style through a device int
