@@ -79,7 +79,8 @@ int aux_get(int need, Aux** out) {
   if (!a.P) {
     int lo = 0, hi = 0;
     GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    GPK_HIP(hipStreamCreateWithPriority(&a.P, hipStreamNonBlocking, hi));
+    static const bool p_normal = getenv("GPK_P_NORMAL") != nullptr;  // A/B knob: panel stream without priority
+    GPK_HIP(hipStreamCreateWithPriority(&a.P, hipStreamNonBlocking, p_normal ? lo : hi));
     hipDeviceProp_t prop;
     GPK_HIP(hipGetDeviceProperties(&prop, dev));
     const int ncu = prop.multiProcessorCount;
@@ -828,6 +829,22 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   rc = gpk_kernel_matrix((void*)kfu_stream, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0,
                          Kfu, l.ld);
   if (rc) return rc;
+  // Work that depends on neither factorisation nor minibatch solve -- tril(q_sqrt)^T for the projection and the whole
+  // KL term -- also goes to that stream, which idles until the first 512 columns of Lm exist; gpk_potrf joins it.
+  const bool side = kfu_stream != s;
+  int c1 = 0;
+  if (side) {
+    if (!q_diag) {
+      rc = gpk_transpose((void*)kfu_stream, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
+      if (rc) return rc;
+    }
+    rc = gpk_launch_kl_white_stage1(kfu_stream, q_mu, q_sqrt, m, P, q_diag, part1, &c1);
+    if (rc) return rc;
+    const double* p1s[1] = {part1};
+    const double halfs = 0.5;
+    rc = gpk_launch_final(kfu_stream, 1, p1s, &c1, &halfs, -0.5 * (double)m * (double)P, out + 1);
+    if (rc) return rc;
+  }
   // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only
   rc = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter,
                          1, T, l.ld);
@@ -847,14 +864,16 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   if (rc) return rc;
   if (!q_diag) {
     // L = band_part(q_sqrt,-1,0); LTA = L^T A; ssq = sum LTA^2   (util.py:151-164)
-    rc = gpk_transpose(stream, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
-    if (rc) return rc;
+    if (!side) {
+      rc = gpk_transpose(stream, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
+      if (rc) return rc;
+    }
     rc = gpk_project(stream, At, rows, m, l.ld, LqT, l.ld, P, ssq, w + l.off_proj,
                      gpk_project_workspace_bytes(rows, m, P));
     if (rc) return rc;
   }
   // sum_b var_exp_b  (likelihoods/scalar_continuous.py:139-148, svgp.py:174,181)
-  int c0 = 0, c1 = 0;
+  int c0 = 0;
   rc = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean, rows, P, s0, 0, ssq, &variance, 0, noise_variance,
                                 mean_const, nullptr, part0, &c0);
   if (rc) return rc;
@@ -862,6 +881,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   const double one = 1.0;
   rc = gpk_launch_final(s, 1, p0, &c0, &one, 0.0, out);
   if (rc) return rc;
+  if (side) return 0;
   // KL[q || N(0, I)]  (kullback_leiblers.py:45-46, 98-165)
   rc = gpk_launch_kl_white_stage1(s, q_mu, q_sqrt, m, P, q_diag, part1, &c1);
   if (rc) return rc;
