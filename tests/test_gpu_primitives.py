@@ -248,3 +248,25 @@ def test_potrf_ex_out_of_place(gpu):
     np.testing.assert_allclose(Td[:n].cpu().numpy(), Lref, rtol=0, atol=5e-13)
     ref = sla.solve_triangular(Lref, Bm.T, lower=True).T
     np.testing.assert_allclose(Eout.cpu().numpy(), ref, rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("m,n,k,b_tri,c_lower", [(1536, 1280, 272, 0, False), (1408, 1408, 512, 0, True),
+                                                  (1200, 1024, 1024, 1, False), (1100, 896, 896, 2, False)])
+def test_gemm_nt_fast_path(gpu, m, n, k, b_tri, c_lower):
+    """Shapes that select the software-pipelined 128x128x16 kernel (>= 24 tiles, K % 16 == 0, aligned rows): ragged
+    row/column edges, beta != 0 (accumulators preloaded with C), lower-only tile enumeration, triangular K ranges."""
+    from gpflow_amd import ops
+    rng = np.random.default_rng(12)
+    A = rng.normal(size=(m, k))
+    B = rng.normal(size=(n, k))
+    if b_tri == 1:
+        B = np.triu(B)   # B[j, kk] == 0 for kk < j
+    if b_tri == 2:
+        B = np.tril(B)   # B[j, kk] == 0 for kk > j
+    C = rng.normal(size=(m, n))
+    out = ops.gemm_nt(_t(A), _t(B), alpha=-0.9, beta=1.1, C=_t(C), b_tri=b_tri, c_lower=c_lower).cpu().numpy()
+    ref = -0.9 * A @ B.T + 1.1 * C
+    if c_lower:
+        np.testing.assert_allclose(np.tril(out), np.tril(ref), rtol=0, atol=2e-11)
+    else:
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-11)
