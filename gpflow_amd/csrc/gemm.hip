@@ -351,7 +351,8 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   d4 acc[4][4];
   const int row_base = m0 + wm * 64 + (lane >> 4);
   const int col_base = n0 + wn * 64 + (lane & 15);
-  const bool load_c = (EPI == 0) && (p.beta != 0.0);
+  // (EPI = 1 with a C operand: the streamed projection's last group squares C + A B^T without storing it)
+  const bool load_c = (p.beta != 0.0) && (EPI == 0 || p.C != nullptr);
   if (nk > 0) gload(0);
   if (load_c) {
     const double* __restrict__ C = p.C + (long)bz * p.strideC;
@@ -829,6 +830,7 @@ int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
 static int launch_select(hipStream_t s, const GemmArgs& a) {
   const long tiles = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
   if (small_ok(a)) return launch_small(s, a);  // K <= 128, <= 512 workgroups: the latency path
+  if (a.epi == 1 && a.beta != 0.0 && a.C && !fast_ok(a)) return GPK_E_UNSUPPORTED;  // only the fast tile preloads C for epi 1
   if (fast_ok(a) && (a.epi == 1 || (a.n > 64 && (tiles >= 24 || a.m <= 64)))) {
     return a.epi == 1 ? launch_fast<1>(s, a) : launch_fast<0>(s, a);
   }

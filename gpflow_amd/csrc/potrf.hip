@@ -168,7 +168,7 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
 //   E[:,c1:n]  -= E[:,c0:c1] L[c1:n,c0:c1]^T               (one large GEMM, K = c1 - c0)
 int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev_big, double* A, int n, int row0,
                 int extra, int c0, int c1, long lda, int batch, long strideA, const double* invd, long strideInv,
-                double* Eout, long ldeout) {
+                double* Eout, long ldeout, hipEvent_t ev_solved = nullptr) {
   double* E = A + (long)(n + row0) * lda;  // rows [row0, row0 + extra) of the extra block
   // solved panel: in place, or (gpk_potrf_ex) in the separate output matrix
   double* So = Eout ? Eout + (long)row0 * ldeout : E;
@@ -207,6 +207,7 @@ int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev
                                (size_t)(c1 - c0) * sizeof(double), (size_t)extra, hipMemcpyDeviceToDevice, s));
     }
   }
+  if (ev_solved) GPK_HIP(hipEventRecord(ev_solved, s));  // columns [c0,c1) of the extra rows are final
   if (c1 < n) {
     // the one large GEMM of the group: E[:, c1:n] -= S[:, c0:c1] L[c1:n, c0:c1]^T
     if (sbig != s) {
@@ -226,6 +227,62 @@ int extra_panel(hipStream_t s, hipStream_t sbig, hipEvent_t ev_in, hipEvent_t ev
       GPK_HIP(hipStreamWaitEvent(s, ev_big, 0));
     }
   }
+  return 0;
+}
+
+// ---- streamed projection (SVGP step) -----------------------------------------------------------------------------
+// LTA = tril(q_sqrt)^T A needs, for output row i, the rows k >= i of A = Lm^-1 Kuf -- the LAST rows the factorisation
+// produces -- so as one GEMM it can only start when everything else is over (0.55 ms of the 2.2 ms step, alone on the
+// chip).  Right-looking instead: as soon as the extra-row solve has finished columns [g0,g1) of A^T, their
+// contribution to ALL outputs i < g1 is added,
+//     C[b, i] (+)= sum_{k in [max(i,g0), g1)} At[b,k] LqT[i,k]        (rectangle i < g0: beta = 1; triangle: beta = 0)
+// on the extra-row stream, which otherwise idles until the panel chain delivers the next group.  The last group
+// runs with the row-sum-of-squares epilogue (C + A B^T is squared, not stored).  Set by gpk_svgp_elbo_shard around
+// its factorisation call only.
+struct ProjStream {
+  bool on = false;
+  const double* LqT = nullptr; long ldl = 0, strideL = 0;   // [P][m, ldl]  LqT[i,k] = q_sqrt[k,i], zero for k < i
+  double* C = nullptr; long ldc = 0, strideC = 0;           // [P][rows, ldc] running A^T Lq
+  double* part = nullptr; long part_ld = 0, stridePart = 0; // [P][2 * tiles(m), rows] partial row sums of squares
+  int P = 0;
+  int groups = 0;                                           // groups issued (0 afterwards = the hook never ran)
+};
+ProjStream g_proj;
+
+int proj_group(hipStream_t s, const double* At, long ldat, int row0, int nrows, int g0, int g1, int m) {
+  ProjStream& q = g_proj;
+  const bool last = g1 == m;
+  // while the panel chain is still running these GEMMs are capped like the big extra-row update (persistent
+  // workgroups), so that the leaf kernel finds a free CU
+  static const int pwgs = getenv("GPK_PROJ_MAX_WGS") ? atoi(getenv("GPK_PROJ_MAX_WGS")) : 320;
+  const double* Ag = At + (long)row0 * ldat + g0;
+  double* Cg = q.C + (long)row0 * q.ldc;
+  int rc;
+  if (g0 > 0) {
+    GemmArgs r = gemm_base(nrows, g0, g1 - g0, 1.0, Ag, ldat, q.LqT + g0, q.ldl, 1.0, Cg, q.ldc, q.P, 0, q.strideL,
+                           q.strideC);
+    if (!last) r.max_wgs = pwgs;
+    if (last) {
+      r.epi = 1; r.sq_cols = g0; r.c2_cols = 0;
+      r.part = q.part + row0; r.part_ld = q.part_ld; r.stridePart = q.stridePart;
+      r.C2 = q.part; r.ldc2 = 0; r.strideC2 = 0;
+    }
+    rc = gpk_launch_gemm(s, r);
+    if (rc) return rc;
+  }
+  GemmArgs t = gemm_base(nrows, g1 - g0, g1 - g0, 1.0, Ag, ldat, q.LqT + (long)g0 * q.ldl + g0, q.ldl, 0.0, Cg + g0,
+                         q.ldc, q.P, 0, q.strideL, q.strideC);
+  t.b_tri = 1;
+  if (!last) t.max_wgs = pwgs;
+  if (last) {
+    t.C = nullptr;
+    t.epi = 1; t.sq_cols = g1 - g0; t.c2_cols = 0;
+    t.part = q.part + (long)(g0 / NB) * 2 * q.part_ld + row0; t.part_ld = q.part_ld; t.stridePart = q.stridePart;
+    t.C2 = q.part; t.ldc2 = 0; t.strideC2 = 0;
+  }
+  rc = gpk_launch_gemm(s, t);
+  if (rc) return rc;
+  ++q.groups;
   return 0;
 }
 }  // namespace
@@ -477,6 +534,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // Deferred rest-updates: while the trailing matrix is large, the far trailing update is applied once per TWO
   // outer panels, as a K = 1024 GEMM (65 vs 59 TFLOP/s for K = 512 on this chip); the strip of the look-ahead
   // carries whatever panels are still pending for the next panel's columns.  r0 = first pending column.
+  bool proj_side_used = false;
   int r0 = 0, last_rest = -1;  // last_rest: panel index whose evR marks the most recent rest-update
   int xg0 = 0;                 // first column of the current extra-row group
   static const int defer_rows = getenv("GPK_DEFER_ROWS") ? atoi(getenv("GPK_DEFER_ROWS")) : (1 << 30);  // off by default: A/B 33.7 vs 32.7 ms at N = 16384 (the K = 1024 strips starve on the panel stream)
@@ -546,9 +604,24 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       for (int i = 0; i < nx; ++i) {
         if (xrow[i + 1] <= xrow[i]) continue;
         GPK_HIP(hipStreamWaitEvent(Xq[i], evF[p], 0));
+        const bool proj = g_proj.on && batch == 1 && !Eout;
+        // GPK_PROJ_SIDE=1: the projection GEMMs go to a stream of their own (ordered after the group's solve, concurrent
+        // with its big update) instead of following the big update on the extra-row stream
+        const bool proj_side = getenv("GPK_PROJ_SIDE") != nullptr;  // (read per call: the tests toggle it)
+        hipEvent_t evS = (proj && proj_side && nx == 1) ? aux->ev[2 * npanels + 11] : nullptr;
         rc = extra_panel(Xq[i], aux->Xb ? aux->Xb : Xq[i], aux->ev[2 * npanels + 7], aux->ev[2 * npanels + 8], A, n, xrow[i],
-                         xrow[i + 1] - xrow[i], g0, c1, lda, batch, strideA, invd, strideInv, Eout, ldeout);
+                         xrow[i + 1] - xrow[i], g0, c1, lda, batch, strideA, invd, strideInv, Eout, ldeout, evS);
         if (rc) return rc;
+        if (proj) {
+          hipStream_t ps = Xq[i];
+          if (evS) {
+            ps = aux->X[1];
+            GPK_HIP(hipStreamWaitEvent(ps, evS, 0));
+            proj_side_used = true;
+          }
+          rc = proj_group(ps, A + (long)n * lda, lda, xrow[i], xrow[i + 1] - xrow[i], g0, c1, n);
+          if (rc) return rc;
+        }
       }
     }
     // ---- tail of a large factorisation: once <= 2048 columns remain it is a pure latency chain, and the SVGP-sized
@@ -583,6 +656,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     hipEvent_t ej = aux->ev[2 * npanels + 3 + i];
     GPK_HIP(hipEventRecord(ej, Xq[i]));
     GPK_HIP(hipStreamWaitEvent(S, ej, 0));
+  }
+  if (proj_side_used) {
+    GPK_HIP(hipEventRecord(aux->ev[2 * npanels + 12], aux->X[1]));
+    GPK_HIP(hipStreamWaitEvent(S, aux->ev[2 * npanels + 12], 0));
   }
   if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, batch, strideA);
   return 0;
@@ -754,10 +831,13 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
 }
 
 // ---- fused driver: one shard of SVGP.elbo (whitened; shared kernel over the P latents) ----------------
+#ifndef GPK_STREAM_PROJ_DEFAULT
+#define GPK_STREAM_PROJ_DEFAULT 0
+#endif
 namespace {
 struct ElboLayout {
   long ld; int nt;
-  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_At, off_pex, total;
+  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_At, off_pex, off_C, total;
 };
 ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   ElboLayout l{};
@@ -775,6 +855,7 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_At = o; o += gpk_align_up((size_t)rows * l.ld * sizeof(double), 256);   // A^T = Kfu Lm^-T (gpk_potrf_ex output)
   l.off_pex = o; o += gpk_align_up(gpk_potrf_ex_workspace_bytes(), 256);
+  l.off_C = o; o += q_diag ? 0 : gpk_align_up((size_t)P * rows * l.ld * sizeof(double), 256);  // running A^T Lq (streamed projection)
   l.total = o;
   return l;
 }
@@ -851,13 +932,28 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   if (rc) return rc;
   // Lm = chol(Kuu);  A^T = Kfu Lm^-T   (conditionals/util.py:67,125)
   static const bool out_of_place = getenv("GPK_TRSM_GROUP") != nullptr;
+  // streamed projection (see ProjStream): the q_sqrt projection rides along with the extra-row solve, group by group
+  const char* sp_env = getenv("GPK_STREAM_PROJ");
+  const bool stream_proj = (sp_env ? atoi(sp_env) != 0 : GPK_STREAM_PROJ_DEFAULT) && side && !q_diag && !out_of_place &&
+                           (m % GPK_NB) == 0 && getenv("GPK_CHAIN") == nullptr;
   if (out_of_place) {
     rc = gpk_potrf_ex(stream, T, m, rows, l.ld, 1, 0, invd, 0, info, At, l.ld, nullptr, 0);
   } else {
     At = Kfu;  // in place: the extra rows of the trapezoid come back as A^T
+    if (stream_proj) {
+      g_proj = ProjStream{};
+      g_proj.on = true;
+      g_proj.LqT = LqT; g_proj.ldl = l.ld; g_proj.strideL = (long)m * l.ld;
+      g_proj.C = (double*)(w + l.off_C); g_proj.ldc = l.ld; g_proj.strideC = (long)rows * l.ld;
+      g_proj.part = (double*)(w + l.off_proj); g_proj.part_ld = rows; g_proj.stridePart = (long)l.nt * rows;
+      g_proj.P = P;
+    }
     rc = gpk_potrf(stream, T, m, rows, l.ld, 1, 0, invd, 0, info);
+    g_proj.on = false;
   }
   if (rc) return rc;
+  const bool projected = stream_proj && g_proj.groups > 0;
+  g_proj.groups = 0;
   // s0 = sum_k A^2 (util.py:133), fmean = A^T q_mu (util.py:144), q_diag: ssq = sum (A q_sqrt)^2 (:149)
   rc = gpk_row_stats(stream, At, rows, m, l.ld, q_mu, q_diag ? q_sqrt : nullptr, P, 1.0, 0.0, s0, fmean,
                      q_diag ? ssq : nullptr);
@@ -868,8 +964,12 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
       rc = gpk_transpose(stream, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
       if (rc) return rc;
     }
-    rc = gpk_project(stream, At, rows, m, l.ld, LqT, l.ld, P, ssq, w + l.off_proj,
-                     gpk_project_workspace_bytes(rows, m, P));
+    if (projected) {
+      rc = gpk_launch_sum_parts(s, (const double*)(w + l.off_proj), l.nt, rows, (long)l.nt * rows, P, ssq);
+    } else {
+      rc = gpk_project(stream, At, rows, m, l.ld, LqT, l.ld, P, ssq, w + l.off_proj,
+                       gpk_project_workspace_bytes(rows, m, P));
+    }
     if (rc) return rc;
   }
   // sum_b var_exp_b  (likelihoods/scalar_continuous.py:139-148, svgp.py:174,181)

@@ -24,10 +24,12 @@ def _svgp_inputs(M, B, D, seed):
     return X, Y, Z, q_mu, q_sqrt, ls
 
 
-@pytest.mark.parametrize("M", [1024, 2048])
-def test_svgp_step_full_size_vs_oracle(gpu, M):
-    """Configs C3 / Cm: one whitened ELBO step, M inducing points, B = 8192, D = 8, P = 1."""
+@pytest.mark.parametrize("M,stream_proj", [(1024, "1"), (2048, "0"), (2048, "1")])
+def test_svgp_step_full_size_vs_oracle(gpu, monkeypatch, M, stream_proj):
+    """Configs C3 / Cm: one whitened ELBO step, M inducing points, B = 8192, D = 8, P = 1; with the q_sqrt projection
+    as one GEMM (stream_proj 0) and streamed behind the extra-row solve (1)."""
     from gpflow_amd import ops
+    monkeypatch.setenv("GPK_STREAM_PROJ", stream_proj)
     B, D, N = 8192, 8, 1_000_000
     X, Y, Z, q_mu, q_sqrt, ls = _svgp_inputs(M, B, D, 11)
     out, info = ops.svgp_elbo_shard(ops.to_device(Z), ops.to_device(X), ops.to_device(Y), ops.to_device(q_mu),

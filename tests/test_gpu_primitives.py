@@ -227,6 +227,33 @@ def test_fused_svgp_elbo_shard(gpu, m, rows, d, P, q_diag):
     np.testing.assert_allclose(o[1], kl_ref, rtol=1e-12)
 
 
+@pytest.mark.parametrize("m,rows,d,P", [(256, 300, 3, 1), (640, 1000, 8, 2), (1024, 2500, 8, 1), (1152, 777, 4, 3)])
+@pytest.mark.parametrize("mode", ["0", "1", "side"])
+def test_svgp_elbo_shard_streamed_projection(gpu, monkeypatch, m, rows, d, P, mode):
+    """The q_sqrt projection streamed group by group behind the extra-row solve (GPK_STREAM_PROJ=1) and the one-GEMM
+    projection (=0) against the oracle: one group (m = 256), ragged last group (640 = 512 + 128), shrinking tail groups
+    (1024, 1152), several latents, ragged row counts."""
+    from gpflow_amd import ops
+    monkeypatch.setenv("GPK_STREAM_PROJ", "0" if mode == "0" else "1")
+    if mode == "side":
+        monkeypatch.setenv("GPK_PROJ_SIDE", "1")   # projection GEMMs on a stream of their own
+    rng = np.random.default_rng(13)
+    X = rng.normal(size=(rows, d))
+    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(rows, P))
+    Z = rng.normal(size=(m, d))
+    q_mu = 0.1 * rng.normal(size=(m, P))
+    q_sqrt = np.stack([np.tril(0.05 * rng.normal(size=(m, m))) + 0.5 * np.eye(m) for _ in range(P)])
+    kw = dict(variance=1.1, lengthscales=np.sqrt(d) * (0.8 + 0.05 * np.arange(d)), noise_variance=0.1)
+    out, info = ops.svgp_elbo_shard(_t(Z), _t(X), _t(Y), _t(q_mu), _t(q_sqrt), jitter=1e-6, **kw)
+    ops.check_info(info)
+    s_ref, kl_ref = orc.svgp_elbo_terms(X, Y, Z, q_mu, q_sqrt, whiten=True, **kw)
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o[0], s_ref, rtol=1e-9)
+    np.testing.assert_allclose(o[1], kl_ref, rtol=1e-12)
+    out2, _ = ops.svgp_elbo_shard(_t(Z), _t(X), _t(Y), _t(q_mu), _t(q_sqrt), jitter=1e-6, **kw)
+    np.testing.assert_array_equal(out2.cpu().numpy(), o)  # deterministic
+
+
 def test_potrf_ex_out_of_place(gpu):
     """gpk_potrf_ex: same factor, solved extra rows written to a separate matrix (batch 1)."""
     import ctypes
