@@ -92,6 +92,43 @@ def cpu_baseline(budget_s: float = 12.0):
                       f"installable in this image"}
 
 
+def train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, steps: int = 20):
+    """SURVEY 8f row 1 (the caller of the hot path): one TRAINING step = forward + hand-written reverse pass
+    (gpflow_amd/gradients.py) + Adam update, same config Cm, reported beside the headline ELBO metric (not part of it)."""
+    from gpflow_amd import gradients
+    kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, jitter=1e-6, scale=float(N_DATA) / B_ROWS)
+    n_batches = N_DATA // B_ROWS
+    m = {k: torch.zeros_like(v) for k, v in (("Z", Z), ("q_mu", q_mu), ("q_sqrt", q_sqrt))}
+    v2 = {k: torch.zeros_like(v) for k, v in m.items()}
+    par = {"Z": Z.clone(), "q_mu": q_mu.clone(), "q_sqrt": q_sqrt.clone()}
+
+    def one(s):
+        lo = (s % n_batches) * B_ROWS
+        F, g, info = gradients.svgp_elbo_and_grad(par["Z"], X[lo:lo + B_ROWS], Y[lo:lo + B_ROWS], par["q_mu"],
+                                                  par["q_sqrt"], **kw)
+        for k in par:  # Adam (tf.keras defaults) on the device-resident variables
+            m[k].mul_(0.9).add_(g[k], alpha=-0.1)
+            v2[k].mul_(0.999).addcmul_(g[k], g[k], value=0.001)
+            par[k].addcdiv_(m[k], v2[k].sqrt().add_(1e-7), value=-1e-3)
+        small = torch.cat([g["variance"], g["lengthscales"], g["noise_variance"], F]).cpu()  # scalar grads + ELBO to host
+        return float(small[-1]), int(info.cpu()[0])
+
+    for s in range(3):
+        one(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        elbo, info = one(3 + s)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flops = 3.0 * svgp_step_flops(M_IND, B_ROWS, P_LAT)  # forward + ~2x for the reverse pass (same GEMM shapes)
+    return {"workload": "SVGP training step (ELBO + gradients w.r.t. Z, q_mu, q_sqrt, kernel and noise parameters + Adam), "
+                        "config Cm, 8192 rows", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "last_elbo": elbo,
+            "info": info, "approx_tflops": flops / dt / 1e12,
+            "note": "hyper-parameters held fixed in this leg (their gradients are computed and read back); "
+                    "SVGPTrainer updates them on the host"}
+
+
 def gpr_cholesky_leg(ops, lib, device):  # noqa: C901
     """GPR config C2: K(X,X)+noise build + Cholesky + LML tail at N=16384, D=8 (gpr.py:91-107)."""
     n, d = 16384, 8
@@ -155,6 +192,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpr", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,6 +328,8 @@ def main():
         "step_frac_of_fp64_peak": svgp_step_flops(M_IND, B_ROWS, P_LAT) * steps_per_s / 1e12 / FP64_PEAK_TFLOPS,
         "roofline": roof,
     }
+    if world == 1 and not args.no_train:
+        res["train_step"] = train_step_leg(X, Y, Z, q_mu, q_sqrt, ls)
     if world == 1 and not args.no_gpr:
         res["gpr_cholesky"] = gpr_cholesky_leg(ops, lib, device)
     if world == 1 and not args.no_cpu_baseline:

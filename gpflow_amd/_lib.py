@@ -25,6 +25,8 @@ _SIGS = {
     "gpk_version": (C.c_char_p, []),
     "gpk_kernel_matrix": (c_int, [c_void_p, c_int, _dp, c_int, c_long, _dp, c_int, c_long, c_int,
                                   C.POINTER(c_double), c_int, c_double, c_double, c_int, _dp, c_long]),
+    "gpk_kernel_matrix_hadamard": (c_int, [c_void_p, c_int, _dp, c_int, c_long, _dp, c_int, c_long, c_int,
+                                           C.POINTER(c_double), c_int, c_double, _dp, c_long, _dp, c_long]),
     "gpk_invd_elems": (c_size_t, [c_int, c_int]),
     "gpk_potrf": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_int, c_long, _dp, c_int, _dp]),
     "gpk_potrf_ex_workspace_bytes": (c_size_t, []),

@@ -25,12 +25,20 @@ class Bijector:
     def inverse(self, y: np.ndarray) -> np.ndarray:
         raise NotImplementedError
 
+    def forward_grad(self, x: np.ndarray) -> np.ndarray:
+        """Elementwise d forward(x) / dx (the chain-rule factor from constrained to unconstrained gradients; TF
+        autodiff supplies it in the reference, base.py:137-280 + tfp bijectors)."""
+        raise NotImplementedError(f"{self.name} has no elementwise derivative")
+
 
 class Identity(Bijector):
     name = "identity"
 
     def forward(self, x):
         return np.asarray(x, dtype=np.float64)
+
+    def forward_grad(self, x):
+        return np.ones_like(np.asarray(x, dtype=np.float64))
 
     def inverse(self, y):
         return np.asarray(y, dtype=np.float64)
@@ -42,6 +50,10 @@ class Softplus(Bijector):
     def forward(self, x):
         return np.logaddexp(0.0, np.asarray(x, dtype=np.float64))
 
+    def forward_grad(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return np.exp(-np.logaddexp(0.0, -x))  # sigmoid(x)
+
     def inverse(self, y):
         y = np.asarray(y, dtype=np.float64)
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -52,6 +64,9 @@ class Exp(Bijector):
     name = "exp"
 
     def forward(self, x):
+        return np.exp(np.asarray(x, dtype=np.float64))
+
+    def forward_grad(self, x):
         return np.exp(np.asarray(x, dtype=np.float64))
 
     def inverse(self, y):
@@ -68,6 +83,9 @@ class Shift(Bijector):
     def forward(self, x):
         return np.asarray(x, dtype=np.float64) + self.shift
 
+    def forward_grad(self, x):
+        return np.ones_like(np.asarray(x, dtype=np.float64))
+
     def inverse(self, y):
         return np.asarray(y, dtype=np.float64) - self.shift
 
@@ -83,6 +101,13 @@ class Chain(Bijector):
         for b in reversed(self.bijectors):
             x = b.forward(x)
         return x
+
+    def forward_grad(self, x):
+        g = np.ones_like(np.asarray(x, dtype=np.float64))
+        for b in reversed(self.bijectors):
+            g = g * b.forward_grad(x)
+            x = b.forward(x)
+        return g
 
     def inverse(self, y):
         for b in self.bijectors:

@@ -537,9 +537,8 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   if (!attr_set) {
     GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    if constexpr (EPI == 1)
-      GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr_set = true;
   }
   const int gx = gpk_cdiv(a.n, 128), gy = gpk_cdiv(a.m, 128);
@@ -558,8 +557,13 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     if (total <= 0) return 0;
   }
   const unsigned nb = (unsigned)(a.batch > 0 ? a.batch : 1);
-  if constexpr (EPI == 1) {
-    if (a.b_tri == 1 && gx >= 4 && a.b_tri_rows >= a.n) {
+  // triangular-K operands (K range shrinking with the column tile for b_tri 1, growing for b_tri 2): paired column
+  // tiles.  EPI 0 too (the tri-K GEMMs of the reverse pass, gradients.py: 45 -> 60 TFLOP/s class) unless the launch
+  // is lower-only or capped.
+  {
+    const bool pair_ok = (EPI == 1) ? (a.b_tri == 1)
+                                    : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0);
+    if (pair_ok && gx >= 4 && a.b_tri_rows >= a.n) {
       total = ((gx + 1) / 2) * gy;
       hipLaunchKernelGGL((gemm_nt_fast<EPI, true>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy,
                          total, compact);

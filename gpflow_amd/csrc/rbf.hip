@@ -24,6 +24,7 @@ struct RbfArgs {
   double variance, diag_add;
   int family, sym, lower_only, ard;
   double ls[GPK_MAX_D];
+  const double* G; long ldg;  // HAD instantiation only: the output is G .* k(X1, X2)  (kernel backward, gradients.py)
 };
 
 constexpr int T = 64;
@@ -44,7 +45,7 @@ __device__ __forceinline__ double kern_eval(double r2, double variance) {
 // MIRROR (symmetric full build): only tiles on or below the diagonal are computed; each is also written
 // transposed to its mirror position (K(X,X) from the expansion formula is bitwise symmetric: products and the
 // two-term sums commute), which halves the fp64 exp/FMA work of what is otherwise a store-bound kernel.
-template <int FAMILY>
+template <int FAMILY, bool HAD = false>
 __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int d = p.d;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
       const double r2 = (-2.0 * dot[i][j]) + (ni + nr2[tx * 4 + j]);
       double k = kern_eval<FAMILY>(r2, p.variance);
       if (p.sym && gr == gc) k += p.diag_add;
+      if constexpr (HAD) k *= (gr < p.n1 && gc < p.n2) ? p.G[(long)gr * p.ldg + gc] : 0.0;
       v[i][j] = k;
     }
   }
@@ -184,6 +186,39 @@ extern "C" int gpk_kernel_matrix(void* stream, int family, const double* X1, int
     case GPK_KERN_MATERN32: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_MATERN32>, grid, dim3(256), lds, st, a); break;
     default: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_MATERN52>, grid, dim3(256), lds, st, a); break;
   }
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+// out = G .* k(X1, X2): the elementwise factor every kernel-parameter gradient starts from
+// (dF/dtheta = sum_ij Kbar_ij dK_ij/dtheta and dK/dtheta = K .* (...) for the stationary families;
+// SquaredExponential only for now).  k is recomputed from the inputs, not read, so the pass costs one
+// read of G and one write.  No symmetric shortcut, no diagonal term (jitter / noise do not depend on theta).
+extern "C" int gpk_kernel_matrix_hadamard(void* stream, int family, const double* X1, int n1, long ldx1,
+                                          const double* X2, int n2, long ldx2, int d, const double* ls_host,
+                                          int ard, double variance, const double* G, long ldg, double* out,
+                                          long ldo) {
+  if (!X1 || !X2 || !G || !out || !ls_host || n1 < 0 || n2 < 0 || d <= 0 || d > GPK_MAX_D) return GPK_E_ARG;
+  if (family != GPK_KERN_SE) return GPK_E_UNSUPPORTED;
+  RbfArgs a{};
+  a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1;
+  a.sym = 0;
+  a.X2 = X2; a.ldx2 = ldx2; a.n2 = n2;
+  a.d = d; a.K = out; a.ldk = ldo; a.variance = variance; a.diag_add = 0.0;
+  a.family = family; a.lower_only = 0; a.ard = ard;
+  a.G = G; a.ldg = ldg;
+  for (int i = 0; i < (ard ? d : 1); ++i) a.ls[i] = ls_host[i];
+  if (a.n1 == 0 || a.n2 == 0) return 0;
+  const size_t lds = ((size_t)2 * d * T + 2 * T) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_SE, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(((size_t)2 * GPK_MAX_D * T + 2 * T) * sizeof(double))));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)gpk_cdiv(a.n2, T), (unsigned)gpk_cdiv(a.n1, T));
+  hipLaunchKernelGGL((rbf_kernel<GPK_KERN_SE, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
   GPK_LAUNCH_CHECK();
   return 0;
 }

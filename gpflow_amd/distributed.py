@@ -47,3 +47,22 @@ def svgp_elbo_data_parallel(model, data, group=None) -> torch.Tensor:
         return model.elbo_terms((X[lo:hi], Y[lo:hi]))
 
     return sharded_elbo(local, X.shape[0], num_data=model.num_data, group=group)
+
+
+def all_reduce_grads(value: torch.Tensor, grads: dict, group=None):
+    """Data-parallel training step: SUM over ranks of the shard objective and of every gradient in ONE all-reduce of
+    a packed fp64 buffer (|theta| + M P + P M^2 + M D + 1 doubles -- 33.6 MB at M = 2048, P = 1; on the 8-GPU xGMI mesh
+    RCCL runs it as reduce-scatter + all-gather over all links).  Shards must have been evaluated with the global
+    `scale` and kl_weight = 1 / world_size (gradients.svgp_elbo_and_grad) so that the sum is the full-batch value.
+    Returns (value, grads) with the reduced contents (same tensors' shapes; new storage)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value, grads
+    names = sorted(grads)
+    flat = torch.cat([value.reshape(-1)] + [grads[k].reshape(-1) for k in names])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    out, off = {}, value.numel()
+    for k in names:
+        n = grads[k].numel()
+        out[k] = flat[off:off + n].reshape(grads[k].shape)
+        off += n
+    return flat[:value.numel()].reshape(value.shape), out

@@ -1,0 +1,164 @@
+"""Reverse pass of the SVGP hot path (what turns "ELBO steps/s" into "training steps/s").
+
+The reference gets these gradients from TensorFlow autodiff over `SVGP.elbo` (`optimizers/scipy.py:322-331`,
+`models/training_mixins.py:59-78`, the Adam loop of `gps_for_big_data.pct.py:207-228`).  Here the adjoint of each
+stage of the whitened ELBO is written out and executed with the same device primitives as the forward pass --
+the fp64 MFMA GEMM (plain / triangular-K / lower-only), the trapezoidal Cholesky with its fused solve (which also
+delivers Lm^-T from appended identity rows, so no triangular solve is left in the backward), the covariance builder (and its `G .* K` variant) -- so the backward is, like the
+forward, a short list of big GEMM-shaped launches:
+
+    forward   Kuu, Kfu -> Lm, At = Kfu Lm^-T -> fmean = At q_mu, s0 = rowsum(At^2), W_p = At Lq_p, ssq = rowsum(W_p^2)
+              F = scale * sum var_exp(fmean, sigma^2 - s0 + ssq) - KL[q || N(0, I)]
+    backward  At_bar = r q_mu^T - 2 c P At + 2 c sum_p W_p Lq_p^T              r = dF/dfmean, c = dF/dfvar
+              q_mu_bar = At^T r - q_mu,   Lq_bar_p = 2 c tril(At^T W_p) - tril(Lq_p) + diag(1 / Lq_p)
+              Kfu_bar = At_bar Lm^-1,     Lm_bar = -tril(Kfu_bar^T At)
+              Kuu_bar = sym( Lm^-T Phi(Lm^T Lm_bar) Lm^-1 )                    (Cholesky adjoint; Phi = tril, half diagonal)
+              kernel parameters and Z from  G = Kbar .* K  contracted with [1, x, x^2]   (SquaredExponential)
+
+Small O(M^2) / O(B P) elementwise steps (masks, the residual r, the final [M, 2D+1] contractions) are torch
+device ops -- glue between the kernels, never a fallback: every function here needs the HIP library.
+
+All arrays are fp64 device tensors; gradients are returned w.r.t. the CONSTRAINED quantities (variance,
+lengthscales, noise variance, Z, q_mu, q_sqrt); `SVGP.elbo_and_grad` chains them through the parameter transforms.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+LOG2PI = float(np.log(2.0 * np.pi))
+
+
+def _splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 512) -> torch.Tensor:
+    """A Bt^T for a LONG inner dimension and few output tiles (At^T r, At^T W, G [1, x, x^2]): the K range is cut into
+    chunks that run as the batch dimension of one launch (strided views, no copies) and the partial products are summed
+    -- without it a [2048, 2048] lower-only output is 136 workgroups each walking K = 8192 (33 TFLOP/s), and an
+    [M, 17] output is 16 workgroups."""
+    m, k = A.shape
+    n = Bt.shape[0]
+    tiles = -(-m // 128) * -(-n // 128)
+    if c_lower:
+        tiles = max(tiles // 2, 1)
+    chunks = 1
+    while chunks * 2 * tiles <= target_wgs and k % (chunks * 2) == 0 and (k // (chunks * 2)) % 16 == 0 \
+            and k // (chunks * 2) >= 256:
+        chunks *= 2
+    if chunks == 1:
+        return ops.gemm_nt(A, Bt, c_lower=c_lower)
+    kc = k // chunks
+    A3 = torch.as_strided(A, (chunks, m, kc), (kc, A.stride(0), 1), A.storage_offset())
+    B3 = torch.as_strided(Bt, (chunks, n, kc), (kc, Bt.stride(0), 1), Bt.storage_offset())
+    return ops.gemm_nt(A3, B3, c_lower=c_lower).sum(0)
+
+
+def _phi_(T: torch.Tensor) -> torch.Tensor:
+    """Phi(T): lower triangle with the diagonal halved (in place on a fresh tensor)."""
+    P = torch.tril(T)
+    P.diagonal().mul_(0.5)
+    return P
+
+
+def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor) -> torch.Tensor:
+    """Symmetric K_bar with  <K_bar, dK> = <L_bar, dL>  for K = L L^T:  K_bar = sym(L^-T Phi(L^T L_bar) L^-1), with
+    LT = L^T, LinvT = L^-T (both upper, zero below the diagonal) and L_bar lower.  Three triangular-K GEMMs; the
+    explicit inverse comes for free from the factorisation (identity rows appended to the trapezoid)."""
+    # every B operand below is the transpose of a lower-triangular matrix: B[j, kk] = 0 for kk < j  -> b_tri = 1
+    T1 = ops.gemm_nt(LT, ops.transpose(Lbar), b_tri=1)          # L^T L_bar
+    Y = ops.gemm_nt(_phi_(T1), LinvT, b_tri=1)                  # Phi L^-1        (lower)
+    S = ops.gemm_nt(LinvT, ops.transpose(Y, mode=1), b_tri=1)   # L^-T (Phi L^-1)
+    return 0.5 * (S + S.t())
+
+
+def se_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, variance: float, lengthscales,
+                      symmetric: bool):
+    """Adjoint of K = variance * exp(-0.5 r2(A / ls, Bm / ls)) [n1, n2] given Kbar [n1, n2].
+
+    Returns (d/dvariance, d/dlengthscales [D], A_bar [n1, D]); with symmetric=True (Bm is A, Kbar symmetric) A_bar
+    collects both arguments.  B_bar of the non-symmetric case is not needed on this path (B = the minibatch)."""
+    n1, D = A.shape
+    ls = torch.as_tensor(np.broadcast_to(np.asarray(lengthscales, dtype=np.float64), (D,)).copy(), device=A.device)
+    G = ops.kernel_matrix_hadamard(A, Bm, Kbar, variance=variance, lengthscales=lengthscales)   # Kbar .* K
+    V = torch.cat([torch.ones((Bm.shape[0], 1), dtype=torch.float64, device=A.device), Bm, Bm * Bm], dim=1)
+    R = _splitk_gemm_nt(G, V.t().contiguous())        # [n1, 1 + 2D] = G [1, B, B^2]
+    rs, GB, GB2 = R[:, 0:1], R[:, 1:1 + D], R[:, 1 + D:]
+    dvar = rs.sum() / variance
+    if symmetric:
+        Abar = 2.0 * (GB - A * rs) / (ls * ls)
+        dls = (2.0 * (A * A * rs).sum(0) - 2.0 * (A * GB).sum(0)) / ls ** 3
+    else:
+        Abar = (GB - A * rs) / (ls * ls)
+        dls = (GB2 - 2.0 * A * GB + A * A * rs).sum(0) / ls ** 3
+    return dvar, dls, Abar
+
+
+def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor, q_sqrt: torch.Tensor,
+                       *, variance: float, lengthscales, noise_variance: float, jitter: float, scale: float = 1.0,
+                       mean_const: float = 0.0, kl_weight: float = 1.0
+                       ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+    """F = scale * sum_b var_exp_b - kl_weight * KL for the whitened SVGP with a SquaredExponential kernel, a Gaussian likelihood
+    and a full q_sqrt [P, M, M], and dF/d{variance, lengthscales, noise_variance, Z, q_mu, q_sqrt, mean_const}.
+
+    Returns (F [1], grads, info).  `scale` = num_data / minibatch size (svgp.py:176-180).  For a row shard of a
+    data-parallel step pass the GLOBAL scale and kl_weight = 1 / world_size: the SUM over ranks of F and of every
+    gradient is then the full-batch value (one all-reduce of the packed gradient, distributed.all_reduce_grads)."""
+    M, D = Z.shape
+    B = Xb.shape[0]
+    P = q_mu.shape[1]
+    if q_sqrt.dim() != 3 or tuple(q_sqrt.shape) != (P, M, M):
+        raise ValueError("svgp_elbo_and_grad needs the full q_sqrt [P, M, M]")
+    dev = Z.device
+    kw = dict(variance=variance, lengthscales=lengthscales)
+
+    # ---------------------------------------------------------------- forward (intermediates kept)
+    # trapezoid = [Kuu + jitter I ; Kfu ; I]: the factorisation returns Lm, At = Kfu Lm^-T and, from the identity
+    # rows, Lm^-T itself -- the explicit inverse that turns every triangular solve of the backward into one GEMM
+    T = torch.empty((M + B + M, M), dtype=torch.float64, device=dev)
+    ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)       # Kuu + jitter I
+    ops.kernel_matrix(Xb, Z, out=T[M:M + B], **kw)                                      # Kfu
+    T[M + B:] = torch.eye(M, dtype=torch.float64, device=dev)
+    invd, info = ops.potrf_(T, M, zero_upper=True)
+    L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
+    Lq = torch.tril(q_sqrt)                                                             # band_part(q_sqrt, -1, 0)
+    LqT = ops.transpose(q_sqrt, mode=1)                                                 # [P, M, M] = tril(q_sqrt)^T
+    s0, fmean, _ = ops.row_stats(At, V=q_mu)                                            # rowsum(At^2), At q_mu
+    W = ops.gemm_nt(At, LqT, b_tri=1)                                                   # [P, B, M]: W_p = At Lq_p
+    ssq = torch.stack([ops.row_stats(W[p])[0] for p in range(P)])                       # [P, B]
+    ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
+                                    mean_const=mean_const)
+    kl = ops.gauss_kl_white(q_mu, q_sqrt)
+    F = scale * ve - kl_weight * kl
+
+    # ---------------------------------------------------------------- backward
+    c = -0.5 * scale / noise_variance                                                   # dF/dfvar (every b, p)
+    r = (scale / noise_variance) * (Yb - fmean - mean_const)                            # dF/dfmean [B, P]
+    Atb = ops.gemm_nt(r, q_mu)                                                          # r q_mu^T  [B, M]
+    for p in range(P):                                                                  # + 2c W_p Lq_p^T (Lq_p lower: b_tri 2)
+        ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=Atb, b_tri=2)
+    Atb.add_(At, alpha=-2.0 * c * P)                                                    # - 2 c P At
+    A = ops.transpose(At)                                                               # [M, B]
+    Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)                                          # At_bar Lm^-1  [B, M]
+    Kuf_bar = ops.transpose(Kfu_bar)                                                    # [M, B]
+    g_qmu = _splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                   # At^T r - q_mu
+    g_qs = torch.stack([torch.tril(_splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True)) for p in range(P)])
+    g_qs *= 2.0 * c                                                                     # 2c tril(At^T W_p)
+    g_qs.sub_(Lq, alpha=kl_weight)
+    g_qs.diagonal(dim1=1, dim2=2).add_(kl_weight / Lq.diagonal(dim1=1, dim2=2))
+    Lbar = -torch.tril(_splitk_gemm_nt(Kuf_bar, A, c_lower=True))                       # -tril(Kfu_bar^T At)
+    Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
+    dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
+    dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+    g_var = dv1 + dv2 + c * B * P                                                       # Knn = variance in every fvar
+    g_ls = dl1 + dl2
+    if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
+        g_ls = g_ls.sum().reshape(1)
+    # sum_bp ((y - f)^2 + fvar) recovered from the forward value:  ve = B P k0 - Q / (2 s2)
+    k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
+    Q = 2.0 * noise_variance * (B * P * k0 - ve)
+    g_noise = scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)
+    grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
+             "Z": Zb1 + Zb2, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
+    return F, grads, info

@@ -104,6 +104,30 @@ def kernel_matrix(X1: torch.Tensor, X2: Optional[torch.Tensor], *, variance: flo
     return out
 
 
+def kernel_matrix_hadamard(X1: torch.Tensor, X2: torch.Tensor, G: torch.Tensor, *, variance: float, lengthscales,
+                           family: str = "SquaredExponential", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """G .* K(X1, X2) with K recomputed on the fly -> [n1, n2] (the elementwise factor of the kernel backward)."""
+    lib = _lib.load()
+    _chk(X1, "X1", 2)
+    _chk(X2, "X2", 2)
+    _chk(G, "G", 2)
+    n1, d = X1.shape
+    n2 = X2.shape[0]
+    if X2.shape[1] != d or tuple(G.shape) != (n1, n2):
+        raise ValueError("inconsistent shapes")
+    if d < 1 or d > MAX_D:
+        raise ValueError(f"input dimension {d} outside [1, {MAX_D}]")
+    if out is None:
+        out = torch.empty((n1, n2), dtype=torch.float64, device=X1.device)
+    _chk(out, "out", 2)
+    ls, ard = _ls_host(lengthscales, d)
+    rc = lib.gpk_kernel_matrix_hadamard(_stream(), KERNEL_FAMILIES[family], X1.data_ptr(), n1, _rowmajor(X1, "X1"),
+                                        X2.data_ptr(), n2, _rowmajor(X2, "X2"), d, ls, ard, float(variance),
+                                        G.data_ptr(), _rowmajor(G, "G"), out.data_ptr(), _rowmajor(out, "out"))
+    _lib.check(rc, "gpk_kernel_matrix_hadamard")
+    return out
+
+
 def invd_alloc(n: int, batch: int = 1) -> torch.Tensor:
     lib = _lib.load()
     return torch.empty(int(lib.gpk_invd_elems(n, batch)), dtype=torch.float64, device=device())

@@ -1,0 +1,126 @@
+"""Device-resident training loop for the whitened SVGP (SquaredExponential kernel, Gaussian likelihood) -- the caller
+of the hot path that SURVEY 8f row 1 names: the Adam loop of `gps_for_big_data.pct.py:207-228`
+(`tf.optimizers.Adam().minimize(model.training_loss_closure(iter), model.trainable_variables)`).
+
+The reference keeps variables in TF and differentiates through them; here the big variables (q_mu, q_sqrt, Z) and their
+Adam moments stay in HBM, the handful of scalar hyper-parameters live on the host in unconstrained form (their
+constrained values are C-ABI arguments), and one step is
+    gradients.svgp_elbo_and_grad  ->  (multi-GPU: one all-reduce of the packed gradient)  ->  Adam update.
+The update rule and defaults are tf.keras Adam's (lr 1e-3, beta 0.9 / 0.999, epsilon 1e-7, bias-corrected step size).
+The elementwise Adam arithmetic on the device tensors is torch glue.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import config, distributed, gradients, ops
+from .inducing_variables import InducingPoints
+from .kernels.stationaries import SquaredExponential
+from .likelihoods import Gaussian
+
+
+class _Adam:
+    def __init__(self, lr: float, b1: float, b2: float, eps: float):
+        self.lr, self.b1, self.b2, self.eps, self.t = lr, b1, b2, eps, 0
+        self.m: Dict[str, object] = {}
+        self.v: Dict[str, object] = {}
+
+    def step_size(self) -> float:
+        return self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+
+    def update_device(self, name: str, p: torch.Tensor, g: torch.Tensor) -> None:
+        if name not in self.m:
+            self.m[name], self.v[name] = torch.zeros_like(p), torch.zeros_like(p)
+        m, v = self.m[name], self.v[name]
+        m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+        v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+        p.addcdiv_(m, v.sqrt().add_(self.eps), value=-self.step_size())
+
+    def update_host(self, name: str, p: np.ndarray, g: np.ndarray) -> np.ndarray:
+        if name not in self.m:
+            self.m[name], self.v[name] = np.zeros_like(p), np.zeros_like(p)
+        self.m[name] = self.b1 * self.m[name] + (1.0 - self.b1) * g
+        self.v[name] = self.b2 * self.v[name] + (1.0 - self.b2) * g * g
+        return p - self.step_size() * self.m[name] / (np.sqrt(self.v[name]) + self.eps)
+
+
+class SVGPTrainer:
+    """Adam on -ELBO for `model` (SVGP: whitened, full q_sqrt, SquaredExponential kernel, Gaussian likelihood with a
+    constant variance, InducingPoints, constant or zero mean).  Honours `Parameter.trainable`.
+
+        trainer = SVGPTrainer(model, learning_rate=1e-3)
+        for Xb, Yb in batches:            # device or host arrays; with torch.distributed initialised each rank passes
+            elbo = trainer.step((Xb, Yb))  # ITS row shard of the global minibatch (global_batch = total rows)
+        trainer.sync_to_model()           # write the trained values back into the model's Parameters
+    """
+
+    def __init__(self, model, *, learning_rate: float = 1e-3, beta_1: float = 0.9, beta_2: float = 0.999,
+                 epsilon: float = 1e-7, group=None):
+        k, lik, iv = model.kernel, model.likelihood, model.inducing_variable
+        if not (model.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian)
+                and lik.variance is not None and isinstance(iv, InducingPoints) and model.q_sqrt.numpy().ndim == 3):
+            raise NotImplementedError("SVGPTrainer covers the whitened SVGP with a SquaredExponential kernel, a Gaussian "
+                                      "likelihood (variance parameter), InducingPoints and a full q_sqrt")
+        if k.active_dims != slice(None, None, None):
+            raise NotImplementedError("active_dims are not supported by the trainer")
+        c = model.mean_function.constant_value()
+        if c is None:
+            raise NotImplementedError("only zero / constant mean functions")
+        for p in (k.variance, k.lengthscales, lik.variance, iv.Z, model.q_mu, model.q_sqrt):
+            if p.prior is not None:
+                raise NotImplementedError("parameter priors are not part of the trainer's objective")
+        self.model, self.group = model, group
+        self.mean_const = float(c)
+        self.opt = _Adam(learning_rate, beta_1, beta_2, epsilon)
+        # host side: unconstrained scalars (their constrained values are host arguments of the C-ABI)
+        self.host = {"variance": k.variance, "lengthscales": k.lengthscales, "noise_variance": lik.variance}
+        self.u = {n: np.array(p.unconstrained_variable, dtype=np.float64, copy=True) for n, p in self.host.items()}
+        # device side (identity / fill-triangular transforms: the constrained array IS the variable)
+        self.dev = {"Z": ops.to_device(iv.Z.numpy()).clone(), "q_mu": ops.to_device(model.q_mu.numpy()).clone(),
+                    "q_sqrt": ops.to_device(model.q_sqrt.numpy()).clone()}
+        self.dev_params = {"Z": iv.Z, "q_mu": model.q_mu, "q_sqrt": model.q_sqrt}
+        self.last_info: Optional[torch.Tensor] = None
+
+    def constrained(self, name: str) -> np.ndarray:
+        return np.asarray(self.host[name].transform.forward(self.u[name]), dtype=np.float64)
+
+    def step(self, data, *, global_batch: Optional[int] = None) -> torch.Tensor:
+        """One Adam step on the minibatch (or this rank's shard of it); returns the ELBO estimate BEFORE the update as
+        a device tensor [1] (no host synchronisation beyond the scalar-gradient read-back)."""
+        import torch.distributed as dist
+        Xb, Yb = ops.to_device(data[0]), ops.to_device(data[1])
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        rows = int(global_batch) if global_batch is not None else Xb.shape[0] * world
+        scale = 1.0 if self.model.num_data is None else float(self.model.num_data) / float(rows)
+        var = float(self.constrained("variance"))
+        ls = self.constrained("lengthscales")
+        noise = float(self.constrained("noise_variance"))
+        F, g, info = gradients.svgp_elbo_and_grad(
+            self.dev["Z"], Xb, Yb, self.dev["q_mu"], self.dev["q_sqrt"], variance=var, lengthscales=ls,
+            noise_variance=noise, jitter=config.default_jitter(), scale=scale, mean_const=self.mean_const,
+            kl_weight=1.0 / world)
+        F, g = distributed.all_reduce_grads(F, g, self.group)
+        self.last_info = info
+        self.opt.t += 1
+        for name in ("Z", "q_mu", "q_sqrt"):                     # minimise -F
+            if self.dev_params[name].trainable:
+                self.opt.update_device(name, self.dev[name], -g[name])
+        small = torch.cat([g["variance"].reshape(-1), g["lengthscales"].reshape(-1), g["noise_variance"].reshape(-1)])
+        small = small.cpu().numpy()                              # the step's one read-back: 2 + |lengthscales| doubles
+        parts = {"variance": small[0:1], "lengthscales": small[1:-1], "noise_variance": small[-1:]}
+        for name, p in self.host.items():
+            if not p.trainable:
+                continue
+            gu = -parts[name].reshape(self.u[name].shape) * p.transform.forward_grad(self.u[name])
+            self.u[name] = self.opt.update_host(name, self.u[name], gu)
+        return F
+
+    def sync_to_model(self) -> None:
+        for name, p in self.host.items():
+            p.assign_unconstrained(self.u[name])
+        for name, p in self.dev_params.items():
+            v = self.dev[name].cpu().numpy()
+            p.assign(np.tril(v) if name == "q_sqrt" else v)

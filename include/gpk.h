@@ -55,6 +55,14 @@ int gpk_kernel_matrix(void* stream, int family, const double* X1, int n1, long l
                       const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
                       double variance, double diag_add, int lower_only, double* K, long ldk);
 
+/* out = G .* k(X1, X2) with k recomputed from the inputs (one read of G, one write): the elementwise factor of
+ * every kernel-parameter gradient, dF/dtheta = sum_ij Kbar_ij dK_ij/dtheta with dK/dtheta = K .* (...) for the
+ * stationary kernels -- the reverse pass of Stationary.K (stationaries.py:103-116, 209-210) that TF autodiff
+ * builds for optimizers/scipy.py:322-331.  SquaredExponential only; X2 must be given. */
+int gpk_kernel_matrix_hadamard(void* stream, int family, const double* X1, int n1, long ldx1,
+                               const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
+                               double variance, const double* G, long ldg, double* out, long ldo);
+
 /* ---- trapezoidal Cholesky ---------------------------------------------------------------------
  * A is [(n + extra) x n] row-major.  Top n x n block (lower triangle read): K -> L in place,
  * K = L L^T (tf.linalg.cholesky call sites: gpr.py:102, posteriors.py:422,703, conditionals/util.py:67,

@@ -1,0 +1,63 @@
+"""CPU oracle for the GRADIENTS of the SVGP hot path: a torch-CPU fp64 restatement of the same reference
+formulas as oracle/gp_oracle.py, differentiated by torch autograd -- the stand-in for the TensorFlow autodiff
+the reference uses (`optimizers/scipy.py:322-331`, `models/training_mixins.py:59-78`).
+
+TEST INFRASTRUCTURE ONLY (same rules as gp_oracle.py: imported by tests/ only, never by gpflow_amd/).
+Pinned by tests/test_oracle.py: the VALUE equals gp_oracle.svgp_elbo (the NumPy restatement, itself pinned by the
+reference's in-test restatements) to 1e-12, and every gradient agrees with central finite differences of
+gp_oracle.svgp_elbo.  "Absolute values vs TensorFlow" remain unpinned, as for the forward oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+LOG2PI = float(np.log(2 * np.pi))
+
+
+def _sqdist(X, X2):
+    """gpflow/utilities/ops.py:105-122 (expansion formula)."""
+    Xs = (X * X).sum(-1)
+    X2s = (X2 * X2).sum(-1)
+    return -2.0 * X @ X2.T + Xs[:, None] + X2s[None, :]
+
+
+def _rbf(X, X2, variance, ls):
+    """stationaries.py:77-79, 103-116, 209-210"""
+    return variance * torch.exp(-0.5 * _sqdist(X / ls, X2 / ls))
+
+
+def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_variance, *, num_data=None, jitter=1e-6,
+                    mean=0.0):
+    """Whitened SVGP.elbo (svgp.py:166-181) on torch fp64 tensors; q_sqrt [P, M, M]."""
+    M = Z.shape[0]
+    B = X.shape[0]
+    Kmm = _rbf(Z, Z, variance, lengthscales) + jitter * torch.eye(M, dtype=torch.float64)   # covariances/kuus.py:29-34
+    Kmn = _rbf(Z, X, variance, lengthscales)                                                # kufs.py:31-34
+    Lm = torch.linalg.cholesky(Kmm)                                                         # conditionals/util.py:67
+    A = torch.linalg.solve_triangular(Lm, Kmn, upper=False)                                 # :125
+    fvar = variance - (A * A).sum(0)                                                        # :133 (Knn = K_diag)
+    fmean = A.T @ q_mu + mean                                                               # :144
+    Lq = torch.tril(q_sqrt)                                                                 # :151
+    LTA = Lq.transpose(1, 2) @ A                                                            # :157  [P, M, B]
+    fvar = fvar[None, :] + (LTA * LTA).sum(1)                                               # :164  [P, B]
+    fvar = fvar.T                                                                           # [B, P]
+    ve = -0.5 * LOG2PI - 0.5 * torch.log(noise_variance) - 0.5 * ((Y - fmean) ** 2 + fvar) / noise_variance
+    # gauss_kl, white (kullback_leiblers.py:98-165): 0.5 (mahalanobis - M P - sum log diag(Lq)^2 + trace)
+    kl = 0.5 * ((q_mu * q_mu).sum() - M * q_mu.shape[1]
+                - torch.log(torch.diagonal(Lq, dim1=1, dim2=2) ** 2).sum() + (Lq * Lq).sum())
+    scale = 1.0 if num_data is None else float(num_data) / B
+    return ve.sum() * scale - kl
+
+
+def svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, *, variance, lengthscales, noise_variance, num_data=None,
+                              jitter=1e-6, mean=0.0):
+    """NumPy in, (value, dict of NumPy gradients w.r.t. the constrained quantities) out."""
+    t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
+    Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
+    var, ls, nv, mc = t(variance, True), t(np.atleast_1d(lengthscales), True), t(noise_variance, True), t(mean, True)
+    F = svgp_elbo_torch(t(X), t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=mc)
+    F.backward()
+    g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "Z": Zt.grad, "q_mu": qm.grad,
+         "q_sqrt": qs.grad, "mean_const": mc.grad}
+    return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}

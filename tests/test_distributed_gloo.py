@@ -62,3 +62,59 @@ def test_sharded_elbo_single_process():
     from gpflow_amd.distributed import sharded_elbo
     out = sharded_elbo(lambda lo, hi: torch.tensor([float(hi - lo), 2.0], dtype=torch.float64), 10, num_data=100)
     assert float(out) == pytest.approx(10 * 10.0 - 2.0)
+
+
+def _train_worker(rank, world, port, q):
+    """Data-parallel TRAINING step: each rank evaluates value + gradient on its row shard (emulated primitives: no GPU
+    here), one all-reduce of the packed gradient, identical Adam update everywhere."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fake_ops
+        import gpflow_amd as gpflow
+        from gpflow_amd import gradients, training
+        from gpflow_amd.distributed import shard_bounds
+        from oracle import gp_oracle_grad as orcg
+        gradients.ops = fake_ops
+        training.ops = fake_ops
+        rng = np.random.default_rng(21)  # identical on every rank
+        B, M, D, P = 90, 24, 2, 1
+        X = rng.normal(size=(B, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(B, P))
+        Z = rng.normal(size=(M, D)); q_mu = 0.2 * rng.normal(size=(M, P))
+        q_sqrt = np.tril(0.05 * rng.normal(size=(P, M, M))) + 0.7 * np.eye(M)
+        model = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=1.2, lengthscales=[0.9, 1.1]),
+                                   gpflow.likelihoods.Gaussian(0.3), Z.copy(), q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(),
+                                   num_data=4000)
+        v, g = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, variance=1.2, lengthscales=[0.9, 1.1],
+                                              noise_variance=0.3, num_data=4000)
+        tr = training.SVGPTrainer(model, learning_rate=1e-2)
+        lo, hi = shard_bounds(B, world, rank)
+        F = tr.step((X[lo:hi], Y[lo:hi]), global_batch=B)
+        tr.sync_to_model()
+        lr_t = 1e-2 * np.sqrt(1 - 0.999) / (1 - 0.9)
+        gl = -g["q_mu"]
+        expect_qmu = q_mu - lr_t * (0.1 * gl) / (np.sqrt(0.001 * gl ** 2) + 1e-7)
+        q.put((rank, float(F[0]), v, float(np.abs(model.q_mu.numpy() - expect_qmu).max()),
+               model.kernel.lengthscales.numpy().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_training_step_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort()
+    (_, f0, v0, err0, ls0), (_, f1, v1, err1, ls1) = results
+    assert f0 == f1 and ls0 == ls1                 # every rank holds the same objective and parameters afterwards
+    assert abs(f0 - v0) <= 1e-10 * abs(v0)          # sum of the shard objectives == full-batch ELBO (oracle)
+    assert err0 <= 1e-9 and err1 <= 1e-9            # Adam step on the all-reduced gradient == step on the full gradient
