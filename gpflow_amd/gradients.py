@@ -162,3 +162,40 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
              "Z": Zb1 + Zb2, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
     return F, grads, info
+
+
+def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
+                     mean_const: float = 0.0) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+    """GPR.log_marginal_likelihood (gpr.py:91-107) and its gradient w.r.t. {variance, lengthscales, noise_variance,
+    mean_const} for a SquaredExponential kernel -- what `optimizers/scipy.py:322-331` asks TF autodiff for.
+
+        L = chol(K + s2 I),  alpha = L^-1 (Y - m),  LML = -0.5 |alpha|^2 - 0.5 N P log 2pi - P sum log diag L
+        K_bar = 0.5 (beta beta^T - P K^-1),  beta = K^-1 (Y - m)        d/ds2 = tr K_bar,   d/dm = sum beta
+
+    The trapezoid is [K + s2 I ; (Y - m)^T ; I]: the identity rows return L^-T, so K^-1 = L^-T L^-1 and beta are GEMMs
+    (no triangular solve), and the kernel-parameter contraction is the same G = K_bar .* K pass as for the SVGP."""
+    N, D = X.shape
+    P = Y.shape[1]
+    dev = X.device
+    kw = dict(variance=variance, lengthscales=lengthscales)
+    T = torch.empty((N + P + N, N), dtype=torch.float64, device=dev)
+    ops.kernel_matrix(X, None, diag_add=noise_variance, lower_only=False, out=T[:N], **kw)
+    T[N:N + P] = (Y - mean_const).t()
+    T[N + P:] = torch.eye(N, dtype=torch.float64, device=dev)
+    invd, info = ops.potrf_(T, N, zero_upper=True)
+    L, alphat, LinvT = T[:N], T[N:N + P], T[N + P:]
+    a2 = ops.row_stats(alphat)[0].sum()
+    lml = -0.5 * a2 - 0.5 * N * P * LOG2PI - P * torch.log(torch.diagonal(L)).sum()
+    # beta^T = alpha^T L^-1  [P, N];  K^-1 = L^-T (L^-T)^T, lower tiles only
+    betat = ops.gemm_nt(alphat, LinvT, b_tri=1)
+    Kbar = ops.gemm_nt(LinvT, LinvT, b_tri=1, c_lower=True)
+    beta = betat.t().contiguous()                                                       # [N, P]
+    ops.gemm_nt(beta, beta, alpha=0.5, beta=-0.5 * P, C=Kbar, c_lower=True)             # 0.5 beta beta^T - 0.5 P K^-1
+    low = torch.tril(Kbar)
+    Kbar = low + torch.tril(low, -1).t()                                                # symmetric, full
+    dvar, dls, _ = se_kernel_adjoint(X, X, Kbar, symmetric=True, **kw)
+    if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
+        dls = dls.sum().reshape(1)
+    grads = {"variance": dvar.reshape(1), "lengthscales": dls, "noise_variance": torch.diagonal(Kbar).sum().reshape(1),
+             "mean_const": betat.sum().reshape(1)}
+    return lml.reshape(1), grads, info

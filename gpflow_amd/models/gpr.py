@@ -57,6 +57,38 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
         m = self.mean_function(X)
         return multivariate_normal(Y, m, K).sum()
 
+    def log_marginal_likelihood_and_grad(self):
+        """(LML as a float, {Parameter: dLML/d(unconstrained value) as NumPy}) for the trainable parameters -- what
+        `optimizers/scipy.py:322-331` obtains from TF autodiff.  SquaredExponential kernel, constant / zero mean,
+        constant noise variance (gradients.gpr_lml_and_grad); anything else raises NotImplementedError."""
+        import numpy as np
+        from .. import gradients
+        from ..kernels.stationaries import SquaredExponential
+        from ..mean_functions import Constant
+        k, lik, mf = self.kernel, self.likelihood, self.mean_function
+        c = mf.constant_value()
+        if not isinstance(k, SquaredExponential) or c is None or lik.variance is None \
+                or k.active_dims != slice(None, None, None):
+            raise NotImplementedError("gradients: SquaredExponential kernel (no active_dims), constant mean, Gaussian "
+                                      "likelihood with a variance parameter")
+        X, Y = self.data
+        _, var, ls = k.hyper()
+        lml, g, info = gradients.gpr_lml_and_grad(X, Y, variance=var, lengthscales=ls,
+                                                  noise_variance=lik.noise_variance(), mean_const=c)
+        ops.check_info(info)
+        host = {n: t.cpu().numpy() for n, t in g.items()}
+        pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (lik.variance, host["noise_variance"])]
+        if isinstance(mf, Constant):
+            pairs.append((mf.c, host["mean_const"]))
+        out = {}
+        for par, gc in pairs:
+            if par.trainable:
+                u = par.unconstrained_variable
+                out[par] = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+        if any(p.prior is not None for p in out):
+            raise NotImplementedError("parameter priors are not differentiated here")
+        return float(lml.cpu()[0]), out
+
     def posterior(self, precompute_cache=posteriors.PrecomputeCacheType.TENSOR) -> posteriors.GPRPosterior:
         """gpr.py:146-175"""
         return posteriors.GPRPosterior(kernel=self.kernel, data=self.data, likelihood=self.likelihood,

@@ -61,3 +61,22 @@ def svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, *, variance, lengthscales, 
     g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "Z": Zt.grad, "q_mu": qm.grad,
          "q_sqrt": qs.grad, "mean_const": mc.grad}
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}
+
+
+def gpr_lml_torch(X, Y, variance, lengthscales, noise_variance, mean=0.0):
+    """GPR.log_marginal_likelihood (gpr.py:91-107; logdensities.py:139-156) on torch fp64 tensors."""
+    N = X.shape[0]
+    K = _rbf(X, X, variance, lengthscales) + noise_variance * torch.eye(N, dtype=torch.float64)   # gpr.py:100-101
+    L = torch.linalg.cholesky(K)                                                                 # :102
+    alpha = torch.linalg.solve_triangular(L, Y - mean, upper=False)                              # logdensities.py:150
+    P = Y.shape[1]
+    return -0.5 * (alpha * alpha).sum() - 0.5 * N * P * LOG2PI - P * torch.log(torch.diagonal(L)).sum()
+
+
+def gpr_lml_value_and_grads(X, Y, *, variance, lengthscales, noise_variance, mean=0.0):
+    t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
+    var, ls, nv, mc = t(variance, True), t(np.atleast_1d(lengthscales), True), t(noise_variance, True), t(mean, True)
+    F = gpr_lml_torch(t(X), t(Y), var, ls, nv, mc)
+    F.backward()
+    g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "mean_const": mc.grad}
+    return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}

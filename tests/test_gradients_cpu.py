@@ -142,3 +142,69 @@ def test_trainer_improves_the_elbo_and_respects_trainable(monkeypatch):
     tr.sync_to_model()
     np.testing.assert_array_equal(m.inducing_variable.Z.numpy(), Z0)
     assert np.all(np.triu(m.q_sqrt.numpy()[0], 1) == 0.0)
+
+
+def test_gpr_autograd_oracle_matches_numpy_oracle_and_fd():
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(40, 2)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(40, 2))
+    kw = dict(variance=1.4, lengthscales=np.array([0.8, 1.2]), noise_variance=0.15)
+    v, g = orcg.gpr_lml_value_and_grads(X, Y, mean=0.2, **kw)
+    ref = orc.gpr_log_marginal_likelihood(X, Y, mean=0.2, **kw)
+    assert abs(v - float(np.sum(ref))) <= 1e-12 * abs(v)
+    h = 1e-6
+    for name in ("variance", "noise_variance"):
+        up, dn = dict(kw), dict(kw)
+        up[name] += h; dn[name] -= h
+        fd = (np.sum(orc.gpr_log_marginal_likelihood(X, Y, mean=0.2, **up))
+              - np.sum(orc.gpr_log_marginal_likelihood(X, Y, mean=0.2, **dn))) / (2 * h)
+        assert abs(float(g[name]) - fd) <= 2e-6 * max(1.0, abs(fd)), name
+
+
+@pytest.mark.parametrize("N,D,P,ard", [(200, 3, 2, True), (130, 2, 1, False)])
+def test_gpr_adjoint_composition_on_emulated_primitives(monkeypatch, N, D, P, ard):
+    import torch
+    from gpflow_amd import gradients
+    import fake_ops
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P))
+    ls = np.sqrt(D) * (0.8 + 0.05 * np.arange(D)) if ard else 1.1
+    kw = dict(variance=1.4, lengthscales=ls, noise_variance=0.15)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    F, g, info = gradients.gpr_lml_and_grad(t(X), t(Y), mean_const=0.2, **kw)
+    v, go = orcg.gpr_lml_value_and_grads(X, Y, mean=0.2, **kw)
+    assert abs(float(F[0]) - v) <= 1e-10 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "mean_const"):
+        got, ref = g[name].numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=1e-8 * max(1.0, np.abs(ref).max()), err_msg=name)
+
+
+def test_scipy_optimizer_fits_gpr_on_emulated_primitives(monkeypatch):
+    """gpflow.optimizers.Scipy().minimize on a GPR: packs the unconstrained trainables, L-BFGS-B with the device gradient
+    (emulated primitives here).  The optimum must match scipy run directly on the autograd oracle."""
+    import scipy.optimize
+    import fake_ops
+    import gpflow_amd as gpflow
+    from gpflow_amd import gradients
+    from gpflow_amd.models import gpr as gpr_mod
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    monkeypatch.setattr(gpr_mod, "ops", fake_ops)
+    rng = np.random.default_rng(6)
+    X = rng.uniform(-2, 2, size=(60, 1)); Y = np.sin(2 * X) + 0.1 * rng.normal(size=(60, 1))
+    m = gpflow.models.GPR((X, Y), gpflow.kernels.SquaredExponential(), noise_variance=0.5)
+    v0, g = m.log_marginal_likelihood_and_grad()
+    assert set(g) == {m.kernel.variance, m.kernel.lengthscales, m.likelihood.variance}
+    res = gpflow.optimizers.Scipy().minimize(m, options=dict(maxiter=200))
+    assert res.success and -res.fun > v0 + 10
+
+    sp = gpflow.base.positive()
+    def f(u):   # the same objective from the oracle, in unconstrained space (all three use the default positive transform)
+        var, ls, nv = sp.forward(u[0]), sp.forward(u[1]), m.likelihood.variance.transform.forward(u[2])
+        v, go = orcg.gpr_lml_value_and_grads(X, Y, variance=var, lengthscales=ls, noise_variance=nv)
+        gu = np.array([go["variance"].item() * sp.forward_grad(u[0]), go["lengthscales"].item() * sp.forward_grad(u[1]),
+                       go["noise_variance"].item() * m.likelihood.variance.transform.forward_grad(u[2])])
+        return -v, -gu
+    ref = scipy.optimize.minimize(f, np.array([sp.inverse(1.0), sp.inverse(1.0), m.likelihood.variance.transform.inverse(0.5)]),
+                                  jac=True, method="L-BFGS-B", options=dict(maxiter=200))
+    assert abs(res.fun - ref.fun) <= 1e-6 * abs(ref.fun)
+    np.testing.assert_allclose(m.kernel.lengthscales.numpy(), sp.forward(ref.x[1]), rtol=1e-4)
