@@ -33,7 +33,7 @@ from . import ops
 LOG2PI = float(np.log(2.0 * np.pi))
 
 
-def _splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 512) -> torch.Tensor:
+def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 512) -> torch.Tensor:
     """A Bt^T for a LONG inner dimension and few output tiles (At^T r, At^T W, G [1, x, x^2]): the K range is cut into
     chunks that run as the batch dimension of one launch (strided views, no copies) and the partial products are summed
     -- without it a [2048, 2048] lower-only output is 136 workgroups each walking K = 8192 (33 TFLOP/s), and an
@@ -83,7 +83,7 @@ def se_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, 
     ls = torch.as_tensor(np.broadcast_to(np.asarray(lengthscales, dtype=np.float64), (D,)).copy(), device=A.device)
     G = ops.kernel_matrix_hadamard(A, Bm, Kbar, variance=variance, lengthscales=lengthscales)   # Kbar .* K
     V = torch.cat([torch.ones((Bm.shape[0], 1), dtype=torch.float64, device=A.device), Bm, Bm * Bm], dim=1)
-    R = _splitk_gemm_nt(G, V.t().contiguous())        # [n1, 1 + 2D] = G [1, B, B^2]
+    R = splitk_gemm_nt(G, V.t().contiguous())        # [n1, 1 + 2D] = G [1, B, B^2]
     rs, GB, GB2 = R[:, 0:1], R[:, 1:1 + D], R[:, 1 + D:]
     dvar = rs.sum() / variance
     if symmetric:
@@ -142,12 +142,12 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     A = ops.transpose(At)                                                               # [M, B]
     Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)                                          # At_bar Lm^-1  [B, M]
     Kuf_bar = ops.transpose(Kfu_bar)                                                    # [M, B]
-    g_qmu = _splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                   # At^T r - q_mu
-    g_qs = torch.stack([torch.tril(_splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True)) for p in range(P)])
+    g_qmu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                   # At^T r - q_mu
+    g_qs = torch.stack([torch.tril(splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True)) for p in range(P)])
     g_qs *= 2.0 * c                                                                     # 2c tril(At^T W_p)
     g_qs.sub_(Lq, alpha=kl_weight)
     g_qs.diagonal(dim1=1, dim2=2).add_(kl_weight / Lq.diagonal(dim1=1, dim2=2))
-    Lbar = -torch.tril(_splitk_gemm_nt(Kuf_bar, A, c_lower=True))                       # -tril(Kfu_bar^T At)
+    Lbar = -torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True))                       # -tril(Kfu_bar^T At)
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
     dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
     dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)

@@ -1,0 +1,205 @@
+"""SGPR -- sparse GP regression, Titsias 2009 (gpflow/models/sgpr.py:36-384), SURVEY 8f row 3: the same three device
+primitives as the SVGP step (covariance builder, trapezoidal Cholesky with fused solve, fp64 MFMA GEMM), but the data
+axis is the WHOLE data set and the exchange between row shards is a matrix, not a scalar.
+
+With the rows of (X, Y) sharded over ranks, a rank computes from its shard
+
+    At = Kfu Lm^-T [n, M]        (Lm = chol(Kuu + jitter I), replicated;  the reference's A is At^T / sigma)
+    S  = At^T At [M, M],   a = At^T (Y - m) [M, P],   e2 = |Y - m|^2,   q = |At|_F^2
+
+and ONE all-reduce of the packed (S lower tiles as a full block, a, e2, q) -- M^2 + M P + 2 doubles, 33.6 MB at M = 2048
+-- gives every rank the statistics of the full data set; the M x M tail (B = I + S / s2, its Cholesky with the fused
+solve for c) is replicated.  Single-process use needs no collective.  Constant noise variance, stationary kernel,
+constant / zero mean (anything else raises NotImplementedError: not on the path of this row).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import config, gradients, ops, posteriors  # noqa: F401
+from ..inducing_variables import InducingPoints, inducingpoint_wrapper
+from ..kernels import Kernel
+from ..kernels.stationaries import Stationary
+from ..likelihoods import Gaussian
+from ..mean_functions import MeanFunction
+from ..posteriors import assert_params_false
+from .model import GPModel
+from .training_mixins import InternalDataTrainingLossMixin
+
+LOG2PI = float(np.log(2.0 * np.pi))
+
+
+def shard_statistics(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, family: str,
+                     jitter: float, mean_const: float):
+    """(L [M,M] lower with zero upper, invd, packed statistics [M*M + M*P + 2]) of one row shard (see module doc)."""
+    M, n, P = Z.shape[0], X.shape[0], Y.shape[1]
+    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+    T = torch.empty((M + n, M), dtype=torch.float64, device=Z.device)
+    ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)      # Kuu + jitter I  (sgpr.py:200)
+    if n:
+        ops.kernel_matrix(X, Z, out=T[M:], **kw)                                       # Kfu             (:199)
+    invd, info = ops.potrf_(T, M, zero_upper=True)                                      # L (:201); At = Kfu L^-T (:204)
+    ops.check_info(info)
+    L, At = T[:M], T[M:]
+    packed = torch.zeros(M * M + M * P + 2, dtype=torch.float64, device=Z.device)
+    if n:
+        err = (Y - mean_const).contiguous()
+        A = ops.transpose(At)                                                           # [M, n]
+        S = gradients.splitk_gemm_nt(A, A, c_lower=True)                                # At^T At, lower tiles (:205)
+        packed[:M * M] = torch.tril(S).reshape(-1)
+        packed[M * M:M * M + M * P] = gradients.splitk_gemm_nt(A, err.t().contiguous()).reshape(-1)   # At^T err (:268)
+        packed[-2] = ops.sumsq(err)[0]
+        packed[-1] = ops.sumsq(At)[0]
+    return L, invd, packed
+
+
+def tail_factor(packed: torch.Tensor, M: int, P: int, scale: float):
+    """LB = chol(I + S * scale) with the fused solve  c^T = (a * scale)^T LB^-T  (sgpr.py:206-207, 268-269 with
+    scale = 1 / s2; the upper bound reuses it with 1 / cn_var).  Returns (LB, invdB, c^T [P, M])."""
+    S = packed[:M * M].reshape(M, M)
+    T2 = torch.empty((M + P, M), dtype=torch.float64, device=packed.device)
+    T2[:M] = S * scale
+    T2[:M].diagonal().add_(1.0)                                                         # add_noise_cov(AAT, 1)
+    T2[M:] = packed[M * M:M * M + M * P].reshape(M, P).t() * scale
+    invdB, info = ops.potrf_(T2, M, zero_upper=True)
+    ops.check_info(info)
+    return T2[:M], invdB, T2[M:]
+
+
+def elbo_from_statistics(packed: torch.Tensor, M: int, P: int, N: int, *, variance: float, noise_variance: float):
+    """sgpr.py:214-290 from the (all-reduced) statistics; the reference's A carries 1/sigma, here it is explicit."""
+    s2 = noise_variance
+    LB, _, ct = tail_factor(packed, M, P, 1.0 / s2)
+    half_logdet_b = ops.sum_log_diag(LB)[0]                                             # :245
+    trace = N * variance / s2 - packed[-1] / s2                                         # :236-242
+    logdet = -P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * trace)           # :248-251
+    # the reference's c = LB^-1 A err with A = At^T / sigma and err / sigma: both sigma factors sit in a / s2, so ct IS c^T
+    quad = -0.5 * (packed[-2] / s2 - ops.sumsq(ct)[0])                                   # :272-276
+    return -0.5 * N * P * LOG2PI + logdet + quad                                        # :287-290
+
+
+def upper_bound_from_statistics(packed: torch.Tensor, M: int, N: int, *, variance: float, noise_variance: float):
+    """sgpr.py:85-148 (single-output form, as written in the reference)."""
+    s2 = noise_variance
+    LB, _, _ = tail_factor(packed, M, 1, 1.0 / s2)
+    c_tr = N * variance - packed[-1]                                                    # :121
+    cn_var = float(s2 + c_tr)                                                           # :124 (host scalar: one read-back)
+    _, _, vt = tail_factor(packed, M, 1, 1.0 / cn_var)                                  # LC, v (:130-137)
+    const = -0.5 * N * float(np.log(2 * np.pi * s2))
+    logdet = -ops.sum_log_diag(LB)[0]
+    quad = -0.5 * packed[-2] / cn_var + 0.5 * ops.sumsq(vt)[0]
+    return const + logdet + quad
+
+
+class SGPR(GPModel, InternalDataTrainingLossMixin):
+    def __init__(self, data, kernel: Kernel, inducing_variable, *, mean_function: Optional[MeanFunction] = None,
+                 num_latent_gps: Optional[int] = None, noise_variance=None, likelihood: Optional[Gaussian] = None,
+                 sharded: bool = False, group=None):
+        """sgpr.py:46-81.  `sharded=True` (NEW: the reference is single process): `data` is THIS rank's row shard and
+        the sufficient statistics are summed over the ranks of `group` (torch.distributed; RCCL on the GPUs)."""
+        assert (noise_variance is None) or (likelihood is None), "Cannot set both `noise_variance` and `likelihood`."
+        if likelihood is None:
+            likelihood = Gaussian(1.0 if noise_variance is None else noise_variance)
+        X, Y = data
+        self.data = (ops.to_device(X), ops.to_device(Y))
+        if self.data[0].dim() != 2 or self.data[1].dim() != 2 or self.data[0].shape[0] != self.data[1].shape[0]:
+            raise ValueError("data must be (X [N,D], Y [N,P])")
+        P = self.data[1].shape[-1] if num_latent_gps is None else num_latent_gps
+        super().__init__(kernel, likelihood, mean_function, num_latent_gps=P)
+        self.inducing_variable = inducingpoint_wrapper(inducing_variable)
+        self.sharded, self.group = bool(sharded), group
+        self.num_data = self._global_rows()
+
+    # ---- plumbing --------------------------------------------------------------------------------
+    def _global_rows(self) -> int:
+        n = int(self.data[0].shape[0])
+        if self.sharded:
+            import torch.distributed as dist
+            t = torch.tensor([float(n)], dtype=torch.float64, device=self.data[0].device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            n = int(round(float(t.cpu()[0])))
+        return n
+
+    def _config(self):
+        k, iv, lik = self.kernel, self.inducing_variable, self.likelihood
+        c = self.mean_function.constant_value()
+        if not (isinstance(k, Stationary) and isinstance(iv, InducingPoints) and isinstance(lik, Gaussian)
+                and lik.variance is not None and c is not None):
+            raise NotImplementedError("SGPR here: stationary kernel, InducingPoints, constant noise variance, constant mean")
+        family, var, ls = k.hyper()
+        X, Z = k.slice(self.data[0], iv.Z.device_value())
+        return dict(variance=var, lengthscales=ls, family=family), X, Z, float(c), lik.noise_variance()
+
+    def _statistics(self):
+        kw, X, Z, c, s2 = self._config()
+        L, invd, packed = shard_statistics(Z, X, self.data[1], jitter=config.default_jitter(), mean_const=c, **kw)
+        if self.sharded:
+            import torch.distributed as dist
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+        return kw, Z, c, s2, L, invd, packed
+
+    # ---- objectives ------------------------------------------------------------------------------
+    def maximum_log_likelihood_objective(self):
+        return self.elbo()
+
+    def elbo(self) -> torch.Tensor:
+        """sgpr.py:279-290"""
+        kw, Z, c, s2, L, invd, packed = self._statistics()
+        return elbo_from_statistics(packed, Z.shape[0], self.data[1].shape[1], self.num_data, variance=kw["variance"],
+                                    noise_variance=s2)
+
+    def upper_bound(self) -> torch.Tensor:
+        """sgpr.py:85-148"""
+        if self.data[1].shape[1] != 1:
+            raise NotImplementedError("upper_bound is written for a single output column in the reference (sgpr.py:126)")
+        kw, Z, c, s2, L, invd, packed = self._statistics()
+        return upper_bound_from_statistics(packed, Z.shape[0], self.num_data, variance=kw["variance"], noise_variance=s2)
+
+    # ---- prediction ------------------------------------------------------------------------------
+    def predict_f(self, Xnew, full_cov: bool = False, full_output_cov: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """sgpr.py:292-345"""
+        assert_params_false(self.predict_f, full_output_cov=full_output_cov)
+        kw, Z, c, s2, L, invd, packed = self._statistics()
+        M, P = Z.shape[0], self.data[1].shape[1]
+        LB, invdB, ct = tail_factor(packed, M, P, 1.0 / s2)
+        # the reference's c carries one factor sigma more than ct (A = At^T / sigma, err / sigma): mean = tmp2^T c with
+        # tmp2 free of sigma, so mean = tmp2^T ct  exactly as below
+        Xn = ops.to_device(Xnew)
+        lead = Xn.shape[:-1]
+        Xn2, _ = self.kernel.slice(Xn.reshape(-1, Xn.shape[-1]), None)
+        t1 = ops.kernel_matrix(Xn2, Z, **kw)                                            # Kus^T [T, M]
+        ops.trsm_(t1, L, invd, trans=0)                                                 # tmp1^T = Kus^T L^-T
+        t2 = t1.clone()
+        ops.trsm_(t2, LB, invdB, trans=0)                                               # tmp2^T
+        mean = ops.gemm_nt(t2, ct.contiguous()) + c                                     # [T, P]
+        if full_cov:
+            var = ops.kernel_matrix(Xn2, None, **kw)
+            ops.gemm_nt(t2, t2, alpha=1.0, beta=1.0, C=var)
+            ops.gemm_nt(t1, t1, alpha=-1.0, beta=1.0, C=var)
+            var = var[None].expand(self.num_latent_gps, -1, -1).contiguous()
+            return mean.reshape(lead + (P,)), var
+        v = kw["variance"] + ops.row_stats(t2)[0] - ops.row_stats(t1)[0]
+        var = v[:, None].expand(-1, self.num_latent_gps).contiguous()
+        return mean.reshape(lead + (P,)), var.reshape(lead + (self.num_latent_gps,))
+
+    def compute_qu(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """sgpr.py:351-384: mean [M, P] and covariance [M, M] of q(u) (single process)."""
+        if self.sharded:
+            raise NotImplementedError("compute_qu on a sharded model")
+        kw, X, Z, c, s2 = self._config()
+        M, P = Z.shape[0], self.data[1].shape[1]
+        Kfu = ops.kernel_matrix(X, Z, **kw)
+        Kuf = ops.transpose(Kfu)                                                        # [M, N]
+        err = (self.data[1] - c).contiguous()
+        T = torch.empty((M + M + P, M), dtype=torch.float64, device=Z.device)
+        kuu = ops.kernel_matrix(Z, None, diag_add=config.default_jitter(), **kw)
+        T[:M] = kuu + torch.tril(gradients.splitk_gemm_nt(Kuf, Kuf, c_lower=True)) / s2   # sig (lower triangle is read)
+        T[M:2 * M] = kuu                                                                # rows -> kuu sig_sqrt^-T
+        T[2 * M:] = gradients.splitk_gemm_nt(Kuf, err.t().contiguous()).t() / s2         # (scaled_kuf scaled_err)^T
+        _, info = ops.potrf_(T, M, zero_upper=True)
+        ops.check_info(info)
+        Sm, vt = T[M:2 * M].contiguous(), T[2 * M:].contiguous()                        # sig_sqrt_kuu^T, v^T
+        return ops.gemm_nt(Sm, vt), ops.gemm_nt(Sm, Sm)

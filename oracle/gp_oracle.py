@@ -360,6 +360,89 @@ def svgp_elbo_separate(X, Y, Zs, q_mu, q_sqrt, *, variances, lengthscales_list, 
     return np.sum(var_exp) * scale_ - kl
 
 
+# ----------------------------------------------------------------------------- SGPR
+def sgpr_common(X, Z, *, variance, lengthscales, noise_variance, jitter=DEFAULT_JITTER):
+    """gpflow/models/sgpr.py:181-213 (_common_calculation), constant noise variance."""
+    sigma = np.sqrt(noise_variance)
+    kuf = Kuf(Z, X, variance=variance, lengthscales=lengthscales)
+    kuu = Kuu(Z, variance=variance, lengthscales=lengthscales, jitter=jitter)
+    L = np.linalg.cholesky(kuu)
+    A = sla.solve_triangular(L, kuf / sigma, lower=True)
+    AAT = A @ A.T
+    B = AAT + np.eye(AAT.shape[0])
+    LB = np.linalg.cholesky(B)
+    return A, AAT, LB, L
+
+
+def sgpr_elbo(X, Y, Z, *, variance, lengthscales, noise_variance, mean=0.0, jitter=DEFAULT_JITTER):
+    """gpflow/models/sgpr.py:214-290 (logdet_term, quad_term, elbo)."""
+    N, P = Y.shape
+    A, AAT, LB, _ = sgpr_common(X, Z, variance=variance, lengthscales=lengthscales, noise_variance=noise_variance,
+                                jitter=jitter)
+    trace_k = N * variance / noise_variance                      # :236-238  (K_diag = variance)
+    trace_q = np.trace(AAT)                                      # :240
+    half_logdet_b = np.sum(np.log(np.diag(LB)))                  # :245
+    logdet = -P * (half_logdet_b + 0.5 * N * np.log(noise_variance) + 0.5 * (trace_k - trace_q))   # :248-251
+    err = (Y - mean) / np.sqrt(noise_variance)                   # :266
+    c = sla.solve_triangular(LB, A @ err, lower=True)            # :268-269
+    quad = -0.5 * (np.sum(err * err) - np.sum(c * c))            # :272-276
+    const = -0.5 * N * P * LOG2PI                                # :287
+    return const + logdet + quad
+
+
+def sgpr_predict_f(X, Y, Z, Xnew, *, variance, lengthscales, noise_variance, mean=0.0, full_cov=False,
+                   jitter=DEFAULT_JITTER):
+    """gpflow/models/sgpr.py:292-345"""
+    sigma = np.sqrt(noise_variance)
+    A, _, LB, L = sgpr_common(X, Z, variance=variance, lengthscales=lengthscales, noise_variance=noise_variance,
+                              jitter=jitter)
+    Kus = Kuf(Z, Xnew, variance=variance, lengthscales=lengthscales)
+    c = sla.solve_triangular(LB, A @ ((Y - mean) / sigma), lower=True)
+    tmp1 = sla.solve_triangular(L, Kus, lower=True)
+    tmp2 = sla.solve_triangular(LB, tmp1, lower=True)
+    fmean = tmp2.T @ c + mean
+    P = Y.shape[1]
+    if full_cov:
+        var = rbf_K(Xnew, variance=variance, lengthscales=lengthscales) + tmp2.T @ tmp2 - tmp1.T @ tmp1
+        return fmean, np.tile(var[None], [P, 1, 1])
+    var = variance + np.sum(tmp2 * tmp2, 0) - np.sum(tmp1 * tmp1, 0)
+    return fmean, np.tile(var[:, None], [1, P])
+
+
+def sgpr_compute_qu(X, Y, Z, *, variance, lengthscales, noise_variance, mean=0.0, jitter=DEFAULT_JITTER):
+    """gpflow/models/sgpr.py:351-384: q(u) = N(mu, cov)."""
+    std = np.sqrt(noise_variance)
+    kuf = Kuf(Z, X, variance=variance, lengthscales=lengthscales)
+    kuu = Kuu(Z, variance=variance, lengthscales=lengthscales, jitter=jitter)
+    skuf = kuf / std
+    sig_sqrt = np.linalg.cholesky(kuu + skuf @ skuf.T)
+    sig_sqrt_kuu = sla.solve_triangular(sig_sqrt, kuu, lower=True)
+    cov = sig_sqrt_kuu.T @ sig_sqrt_kuu
+    mu = sig_sqrt_kuu.T @ sla.solve_triangular(sig_sqrt, skuf @ ((Y - mean) / std), lower=True)
+    return mu, cov
+
+
+def sgpr_upper_bound(X, Y, Z, *, variance, lengthscales, noise_variance, mean=0.0, jitter=DEFAULT_JITTER):
+    """gpflow/models/sgpr.py:85-148 (Titsias 2014 upper bound), constant noise variance, P = 1 semantics as written."""
+    N = X.shape[0]
+    kuu = Kuu(Z, variance=variance, lengthscales=lengthscales, jitter=jitter)
+    kuf = Kuf(Z, X, variance=variance, lengthscales=lengthscales)
+    L = np.linalg.cholesky(kuu)
+    A = sla.solve_triangular(L, kuf, lower=True)
+    A_sigma = A / np.sqrt(noise_variance)
+    LB = np.linalg.cholesky(np.eye(len(Z)) + A_sigma @ A_sigma.T)
+    c = N * variance - np.sum(A * A)
+    cn_var = noise_variance + c
+    const = -0.5 * N * np.log(2 * np.pi * noise_variance)
+    logdet = -np.sum(np.log(np.diag(LB)))
+    A_cn = A / np.sqrt(cn_var)
+    err = Y - mean
+    LC = np.linalg.cholesky(np.eye(len(Z)) + A_cn @ A_cn.T)
+    v = sla.solve_triangular(LC, A_cn @ (err / np.sqrt(cn_var)), lower=True)
+    quad = -0.5 * np.sum((err / np.sqrt(cn_var)) ** 2) + 0.5 * np.sum(v * v)
+    return const + logdet + quad
+
+
 # ----------------------------------------------------------------------------- posteriors cache
 def svgp_precompute(Z, q_mu, q_sqrt, *, variance, lengthscales, whiten=True,
                     kernel="SquaredExponential"):

@@ -171,3 +171,15 @@ def gauss_kl_white(q_mu, q_sqrt):
     M, P = q_mu.shape
     kl = 0.5 * ((_np(q_mu) ** 2).sum() - M * P - np.log(np.diagonal(Lq, axis1=1, axis2=2) ** 2).sum() + (Lq * Lq).sum())
     return torch.tensor([kl], dtype=torch.float64)
+
+
+def sumsq(A, *, upper_only=False):
+    a = _np(A)
+    if upper_only:
+        a = np.triu(a)
+    return torch.tensor([(a * a).sum()], dtype=torch.float64)
+
+
+def sum_log_diag(L):
+    L3 = L if L.dim() == 3 else L.unsqueeze(0)
+    return torch.from_numpy(np.log(np.diagonal(_np(L3), axis1=1, axis2=2)).sum(1))

@@ -118,3 +118,49 @@ def test_data_parallel_training_step_world2_gloo():
     assert f0 == f1 and ls0 == ls1                 # every rank holds the same objective and parameters afterwards
     assert abs(f0 - v0) <= 1e-10 * abs(v0)          # sum of the shard objectives == full-batch ELBO (oracle)
     assert err0 <= 1e-9 and err1 <= 1e-9            # Adam step on the all-reduced gradient == step on the full gradient
+
+
+def _sgpr_worker(rank, world, port, q):
+    """SGPR over row shards: per-shard statistics (emulated primitives), ONE all-reduce of the packed M x M + M x P + 2
+    buffer, replicated tail."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fake_ops
+        from gpflow_amd import gradients
+        from gpflow_amd.distributed import shard_bounds
+        from gpflow_amd.models import sgpr
+        from oracle import gp_oracle as orc
+        gradients.ops = fake_ops
+        sgpr.ops = fake_ops
+        rng = np.random.default_rng(31)
+        N, M, D, P = 301, 40, 2, 2
+        X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P)); Z = rng.normal(size=(M, D))
+        t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+        lo, hi = shard_bounds(N, world, rank)
+        _, _, packed = sgpr.shard_statistics(t(Z), t(X[lo:hi]), t(Y[lo:hi]), variance=1.1, lengthscales=0.8,
+                                             family="SquaredExponential", jitter=1e-6, mean_const=0.0)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        elbo = float(sgpr.elbo_from_statistics(packed, M, P, N, variance=1.1, noise_variance=0.3))
+        ref = orc.sgpr_elbo(X, Y, Z, variance=1.1, lengthscales=0.8, noise_variance=0.3)
+        q.put((rank, elbo, ref))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sgpr_row_sharded_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sgpr_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, e0, ref0), (_, e1, _) = results
+    assert e0 == e1
+    assert abs(e0 - ref0) <= 1e-10 * abs(ref0)

@@ -1,0 +1,73 @@
+"""GPU parity of SGPR (gpflow/models/sgpr.py) against the oracle, plus the reference's own relational
+tests (tests/gpflow/models/test_sgpr.py:29-80)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as orc  # noqa: E402  (checker only)
+
+
+def _data(N, M, D, P, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.2 * rng.normal(size=(N, P)); Z = rng.normal(size=(M, D))
+    ls = 0.8 + 0.1 * np.arange(D)
+    return X, Y, Z, dict(variance=1.3, lengthscales=ls, noise_variance=0.25)
+
+
+def _model(X, Y, Z, kw, mean=None):
+    import gpflow_amd as gpflow
+    mf = gpflow.mean_functions.Constant(np.array([mean])) if mean is not None else None
+    return gpflow.models.SGPR((X, Y), gpflow.kernels.SquaredExponential(variance=kw["variance"], lengthscales=kw["lengthscales"]),
+                              Z, noise_variance=kw["noise_variance"], mean_function=mf)
+
+
+@pytest.mark.parametrize("N,M,D,P,mean", [(500, 60, 2, 1, None), (3000, 384, 4, 2, 0.3), (8192, 1024, 8, 1, None)])
+def test_sgpr_elbo_and_predict_vs_oracle(gpu, N, M, D, P, mean):
+    X, Y, Z, kw = _data(N, M, D, P, 1)
+    m = _model(X, Y, Z, kw, mean)
+    mo = 0.0 if mean is None else mean
+    ref = orc.sgpr_elbo(X, Y, Z, mean=mo, **kw)
+    got = float(m.elbo().cpu())
+    assert abs(got - ref) <= 1e-8 * abs(ref), (got, ref)
+    assert float(m.training_loss().cpu()) == -got or abs(float(m.training_loss().cpu()) + got) <= 1e-12 * abs(got)
+    Xn = np.random.default_rng(2).normal(size=(257, D))
+    fm, fv = m.predict_f(Xn)
+    rm, rv = orc.sgpr_predict_f(X, Y, Z, Xn, mean=mo, **kw)
+    np.testing.assert_allclose(fm.cpu().numpy(), rm, rtol=0, atol=1e-8 * max(1.0, np.abs(rm).max()))
+    np.testing.assert_allclose(fv.cpu().numpy(), rv, rtol=0, atol=1e-8)
+    if M <= 384:
+        fm2, fc = m.predict_f(Xn[:100], full_cov=True)
+        _, rc = orc.sgpr_predict_f(X, Y, Z, Xn[:100], mean=mo, full_cov=True, **kw)
+        np.testing.assert_allclose(fc.cpu().numpy(), rc, rtol=0, atol=1e-8)
+        with pytest.raises(NotImplementedError):
+            m.predict_f(Xn, full_output_cov=True)
+    if P == 1:
+        ub = float(m.upper_bound().cpu())
+        rub = orc.sgpr_upper_bound(X, Y, Z, mean=mo, **kw)
+        assert abs(ub - rub) <= 1e-8 * abs(rub)
+        assert got <= ub
+
+
+def test_sgpr_qu_and_svgp_equivalence(gpu):
+    """tests/gpflow/models/test_sgpr.py:29-80: q(u) from compute_qu == predict_f at Z; an un-whitened SVGP carrying that
+    q(u) predicts like the SGPR."""
+    import gpflow_amd as gpflow
+    rng = np.random.RandomState(0)
+    X = rng.randn(100, 2); Y = rng.randn(100, 1); Z = rng.randn(20, 2)
+    kw = dict(variance=1.0, lengthscales=1.0, noise_variance=1.0)
+    m = _model(X, Y, Z, kw)
+    mu, cov = m.compute_qu()
+    rmu, rcov = orc.sgpr_compute_qu(X, Y, Z, **kw)
+    np.testing.assert_allclose(mu.cpu().numpy(), rmu, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(cov.cpu().numpy(), rcov, rtol=0, atol=1e-9)
+    fz, fzc = m.predict_f(Z, full_cov=True)
+    np.testing.assert_allclose(mu.cpu().numpy(), fz.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(cov.cpu().numpy()[None], fzc.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    q_sqrt = np.linalg.cholesky(cov.cpu().numpy())[None]
+    svgp = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), gpflow.likelihoods.Gaussian(1.0), Z,
+                              q_mu=mu.cpu().numpy(), q_sqrt=q_sqrt, whiten=False)
+    Xnew = np.random.RandomState(2).randn(100, 2)
+    a, b = m.predict_f(Xnew), svgp.predict_f(Xnew)
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), atol=1e-4)
+    np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), atol=1e-4)

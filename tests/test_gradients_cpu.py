@@ -208,3 +208,32 @@ def test_scipy_optimizer_fits_gpr_on_emulated_primitives(monkeypatch):
                                   jac=True, method="L-BFGS-B", options=dict(maxiter=200))
     assert abs(res.fun - ref.fun) <= 1e-6 * abs(ref.fun)
     np.testing.assert_allclose(m.kernel.lengthscales.numpy(), sp.forward(ref.x[1]), rtol=1e-4)
+
+
+def test_sgpr_statistics_composition_on_emulated_primitives(monkeypatch):
+    """SGPR: shard statistics -> sum -> replicated tail, against the oracle; two row shards summed by
+    hand stand in for the all-reduce (the gloo test runs the real collective)."""
+    import torch
+    import fake_ops
+    from gpflow_amd import gradients
+    from gpflow_amd.models import sgpr
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    monkeypatch.setattr(sgpr, "ops", fake_ops)
+    rng = np.random.default_rng(8)
+    N, M, D, P = 700, 150, 3, 2
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P)); Z = rng.normal(size=(M, D))
+    ls = np.array([0.9, 1.1, 1.3])
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    kw = dict(variance=1.2, lengthscales=ls, family="SquaredExponential", jitter=1e-6, mean_const=0.3)
+    packed = None
+    for lo, hi in [(0, 401), (401, 700)]:
+        L, invd, pk = sgpr.shard_statistics(t(Z), t(X[lo:hi]), t(Y[lo:hi]), **kw)
+        packed = pk if packed is None else packed + pk
+    elbo = sgpr.elbo_from_statistics(packed, M, P, N, variance=1.2, noise_variance=0.25)
+    ref = orc.sgpr_elbo(X, Y, Z, variance=1.2, lengthscales=ls, noise_variance=0.25, mean=0.3)
+    assert abs(float(elbo) - ref) <= 1e-10 * abs(ref)
+    # single output: the upper bound
+    L, invd, pk1 = sgpr.shard_statistics(t(Z), t(X), t(Y[:, :1]), **kw)
+    ub = sgpr.upper_bound_from_statistics(pk1, M, N, variance=1.2, noise_variance=0.25)
+    ref_ub = orc.sgpr_upper_bound(X, Y[:, :1], Z, variance=1.2, lengthscales=ls, noise_variance=0.25, mean=0.3)
+    assert abs(float(ub) - ref_ub) <= 1e-10 * abs(ref_ub)

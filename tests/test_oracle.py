@@ -281,3 +281,43 @@ def test_oracle_vs_torch_cpu_second_opinion():
     elbo_o = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt[None], variance=var, lengthscales=ls, noise_variance=noise, whiten=True,
                            num_data=5000)
     assert abs(elbo_t - elbo_o) <= 1e-10 * abs(elbo_o)
+
+
+# ----------------------------------------------------------------------------- SGPR
+def _sgpr_data(seed=0, N=100, M=20):
+    rng = np.random.RandomState(seed)   # tests/gpflow/models/test_sgpr.py:22-26 (Datum)
+    X = rng.randn(N, 2); Y = np.sin(X @ np.array([[-1.4], [0.5]])) + 0.5 * rng.randn(N, 1); Z = rng.randn(M, 2)
+    return X, Y, Z, dict(variance=1.3, lengthscales=0.9, noise_variance=0.4)
+
+
+def test_sgpr_compute_qu_equals_predict_at_Z():
+    """tests/gpflow/models/test_sgpr.py:29-44 (test_sgpr_qu), without the optimisation step."""
+    X, Y, Z, kw = _sgpr_data()
+    # (the two routes differ by O(jitter * cond): Kus = k(Z, Z) carries no jitter, kuu does -- 5e-5 at the default 1e-6
+    #  for these un-optimised hyper-parameters, so the identity is checked at a smaller jitter)
+    kw = dict(kw, jitter=1e-9)
+    mu, cov = orc.sgpr_compute_qu(X, Y, Z, **kw)
+    fm, fc = orc.sgpr_predict_f(X, Y, Z, Z, full_cov=True, **kw)
+    np.testing.assert_allclose(mu, fm, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cov[None], fc, rtol=1e-5, atol=1e-5)
+
+
+def test_sgpr_predicts_like_unwhitened_svgp_with_its_qu():
+    """tests/gpflow/models/test_sgpr.py:47-80 (test_sgpr_svgp_qu_equivivalent), constant noise."""
+    X, Y, Z, kw = _sgpr_data(2)
+    mu, cov = orc.sgpr_compute_qu(X, Y, Z, **kw)
+    q_sqrt = np.linalg.cholesky(cov)[None]
+    Xnew = np.random.RandomState(3).randn(100, 2)
+    fm, fv = orc.sgpr_predict_f(X, Y, Z, Xnew, **kw)
+    sm, sv = orc.svgp_predict_f(Xnew, Z, mu, q_sqrt, variance=kw["variance"], lengthscales=kw["lengthscales"], whiten=False)
+    np.testing.assert_allclose(fm, sm, atol=1e-4)
+    np.testing.assert_allclose(fv, sv, atol=1e-4)
+
+
+def test_sgpr_bounds_sandwich_the_exact_lml_and_are_tight_at_Z_equals_X():
+    """elbo <= exact LML <= upper_bound (Titsias 2009 / 2014), with equality of the ELBO when Z = X."""
+    X, Y, Z, kw = _sgpr_data(4, N=80, M=15)
+    lml = float(orc.gpr_log_marginal_likelihood(X, Y, **kw))
+    lo, hi = orc.sgpr_elbo(X, Y, Z, **kw), orc.sgpr_upper_bound(X, Y, Z, **kw)
+    assert lo <= lml <= hi
+    assert abs(orc.sgpr_elbo(X, Y, X, jitter=1e-10, **kw) - lml) <= 1e-5 * abs(lml)
