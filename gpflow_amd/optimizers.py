@@ -40,3 +40,37 @@ class Scipy:
         res = scipy.optimize.minimize(fun, x0, jac=True, method=method, options=options or {}, **scipy_kwargs)
         unpack(res.x)
         return res
+
+
+class NaturalGradient:
+    """`gpflow.optimizers.NaturalGradient(gamma)` (natgrad.py:155-368) for the (q_mu, q_sqrt) of an SVGP, natural
+    parametrisation.  The reference takes a loss closure and differentiates it with TF; here the loss is the model's
+    -ELBO on `data` and its gradient comes from the device reverse pass (gradients.svgp_elbo_and_grad), so the call is
+
+        NaturalGradient(gamma=1.0).minimize(model, data)      # one step; updates model.q_mu / model.q_sqrt
+
+    (whitened SVGP, SquaredExponential kernel, Gaussian likelihood, full q_sqrt -- the scope of the reverse pass)."""
+
+    def __init__(self, gamma: float = 1.0):
+        self.gamma = float(gamma)
+
+    def minimize(self, model, data) -> None:
+        from . import config, gradients, natgrad, ops
+        from .kernels.stationaries import SquaredExponential
+        from .likelihoods import Gaussian
+        k, lik, iv = model.kernel, model.likelihood, model.inducing_variable
+        c = model.mean_function.constant_value()
+        if not (model.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
+                and c is not None and model.q_sqrt.numpy().ndim == 3 and k.active_dims == slice(None, None, None)):
+            raise NotImplementedError("NaturalGradient here: whitened SVGP, SquaredExponential, Gaussian likelihood, full q_sqrt")
+        X, Y = ops.to_device(data[0]), ops.to_device(data[1])
+        scale = 1.0 if model.num_data is None else float(model.num_data) / float(X.shape[0])
+        _, var, ls = k.hyper()
+        q_mu, q_sqrt = model.q_mu.device_value(), model.q_sqrt.device_value()
+        _, g, info = gradients.svgp_elbo_and_grad(iv.Z.device_value(), X, Y, q_mu, q_sqrt, variance=var, lengthscales=ls,
+                                                  noise_variance=lik.noise_variance(), jitter=config.default_jitter(),
+                                                  scale=scale, mean_const=float(c))
+        ops.check_info(info)
+        mu, sq = natgrad.natgrad_update(q_mu, q_sqrt, -g["q_mu"], -g["q_sqrt"], self.gamma)   # loss = -ELBO
+        model.q_mu.assign(mu.cpu().numpy())
+        model.q_sqrt.assign(sq.cpu().numpy())

@@ -80,3 +80,29 @@ def gpr_lml_value_and_grads(X, Y, *, variance, lengthscales, noise_variance, mea
     F.backward()
     g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "mean_const": mc.grad}
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}
+
+
+# ----------------------------------------------------------------------------- natural gradient
+def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma):
+    """One XiNat step of gpflow/optimizers/natgrad.py:280-368, restated literally with torch autograd standing in for
+    the TF tapes: dL/deta through expectation_to_meanvarsqrt (:484-487), theta <- theta - gamma dL/deta (:341-343),
+    natural_to_meanvarsqrt (:429-441).  q_mu [M, P], q_sqrt [P, M, M]; g_* = loss gradients w.r.t. them."""
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64)  # noqa: E731
+    mu = t(q_mu).T[:, :, None]                               # [P, M, 1]   (swap_dimensions :385-420)
+    Ls = torch.tril(t(q_sqrt))
+    gm = t(g_mu).T[:, :, None]
+    gL = torch.tril(t(g_sqrt))
+    eta1 = mu.clone().requires_grad_(True)
+    eta2 = (Ls @ Ls.transpose(1, 2) + mu @ mu.transpose(1, 2)).requires_grad_(True)       # :496-498
+    var = eta2 - eta1 @ eta1.transpose(1, 2)                                             # :485
+    m_out, s_out = eta1, torch.linalg.cholesky(var)                                      # :486-487
+    dL_deta1, dL_deta2 = torch.autograd.grad([m_out, s_out], [eta1, eta2], grad_outputs=[gm, gL])   # :327-329
+    Linv = torch.linalg.solve_triangular(Ls, torch.eye(Ls.shape[1], dtype=torch.float64).expand_as(Ls), upper=False)
+    s_inv = Linv.transpose(1, 2) @ Linv                                                  # :452-454
+    nat1, nat2 = s_inv @ mu, -0.5 * s_inv
+    nat1n, nat2n = nat1 - gamma * dL_deta1, nat2 - gamma * dL_deta2                      # :341-343
+    vsi = torch.linalg.cholesky(-2 * nat2n)                                              # :435
+    vs = torch.linalg.solve_triangular(vsi, torch.eye(vsi.shape[1], dtype=torch.float64).expand_as(vsi), upper=False)
+    S = vs.transpose(1, 2) @ vs                                                          # :437
+    mun = S @ nat1n                                                                      # :438
+    return mun[:, :, 0].T.numpy().copy(), torch.linalg.cholesky(S).numpy().copy()        # :441

@@ -237,3 +237,27 @@ def test_sgpr_statistics_composition_on_emulated_primitives(monkeypatch):
     ub = sgpr.upper_bound_from_statistics(pk1, M, N, variance=1.2, noise_variance=0.25)
     ref_ub = orc.sgpr_upper_bound(X, Y[:, :1], Z, variance=1.2, lengthscales=ls, noise_variance=0.25, mean=0.3)
     assert abs(float(ub) - ref_ub) <= 1e-10 * abs(ref_ub)
+
+
+def test_natgrad_update_on_emulated_primitives_and_svgp_vs_sgpr(monkeypatch):
+    """(i) the written-out natural-gradient step == the literal restatement of natgrad.py with autograd through the
+    parameter conversions; (ii) tests/gpflow/optimizers/test_natural_gradient.py:171 (test_svgp_vs_sgpr): with a Gaussian
+    likelihood ONE step of size 1 takes the SVGP bound to the SGPR bound."""
+    import torch
+    import fake_ops
+    from gpflow_amd import gradients, natgrad
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    monkeypatch.setattr(natgrad, "ops", fake_ops)
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(140, 400, 2, 2, 9)
+    N = X.shape[0]
+    v, g = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=N, **kw)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    for gamma in (0.1, 1.0):
+        mu_n, sq_n = natgrad.natgrad_update(t(q_mu), t(q_sqrt), t(-g["q_mu"]), t(-g["q_sqrt"]), gamma)
+        mu_r, sq_r = orcg.natgrad_step(q_mu, q_sqrt, -g["q_mu"], -g["q_sqrt"], gamma)
+        np.testing.assert_allclose(mu_n.numpy(), mu_r, rtol=0, atol=1e-9 * max(1.0, np.abs(mu_r).max()))
+        np.testing.assert_allclose(sq_n.numpy(), sq_r, rtol=0, atol=1e-9)
+    after = orc.svgp_elbo(X, Y, Z, mu_n.numpy(), sq_n.numpy(), whiten=True, num_data=N, **kw)
+    sgpr = orc.sgpr_elbo(X, Y, Z, **kw)
+    assert abs(v - sgpr) > 1.0                   # different before
+    assert abs(after - sgpr) <= 1e-4             # equal after one step of size 1
