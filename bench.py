@@ -163,6 +163,9 @@ def gpr_cholesky_leg(ops, lib, device):  # noqa: C901
     ops.gpr_lml(X, Y, **kw)
     ms_t, n_t, fl_t = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
     lib.gpk_profile_gemm_collect_min(ctypes.c_double(2e10), 1, ctypes.byref(ms_t), ctypes.byref(n_t), ctypes.byref(fl_t))
+    win_ms, win_all, win_match, win_n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+    lib.gpk_profile_gemm_window(ctypes.c_double(2e10), ctypes.byref(win_ms), ctypes.byref(win_all), ctypes.byref(win_match),
+                                ctypes.byref(win_n))
     ms_g, n_g, fl_g = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
     lib.gpk_profile_gemm_collect_min(ctypes.c_double(0.0), 0, ctypes.byref(ms_g), ctypes.byref(n_g), ctypes.byref(fl_g))
     lib.gpk_profile_gemm_enable(0)
@@ -172,6 +175,15 @@ def gpr_cholesky_leg(ops, lib, device):  # noqa: C901
                 "launches": int(n_t.value), "algorithmic_gflop": fl_t.value / 1e9,
                 "share_of_factorisation_flops": fl_t.value / flops, "summed_launch_ms": ms_t.value,
                 "all_gemm_launches": int(n_g.value), "all_gemm_gflop": fl_g.value / 1e9,
+                "phase_chipwide": {
+                    "window_ms": win_ms.value, "gemm_launches_in_window": int(win_n.value),
+                    "algorithmic_gflop_in_window": win_all.value / 1e9,
+                    "achieved": win_all.value / (win_ms.value * 1e-3) / 1e12 if win_ms.value > 0 else 0.0,
+                    "frac": (win_all.value / (win_ms.value * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if win_ms.value > 0 else 0.0,
+                    "unit": "TFLOP/s",
+                    "note": "first start .. last end of those launches (HIP events) and the algorithmic flops of EVERY GEMM "
+                            "issued in between -- the trailing updates plus the look-ahead panel (solves, inner updates, "
+                            "strips) that shares the chip with them; leaf kernels not counted"},
                 "note": "sum of algorithmic flops / sum of HIP-event durations of these launches, recorded on the bulk "
                         "stream (CU-masked: 240 of 256 CUs; the look-ahead panel runs beside them on the other 16)"}
     return {"workload": "GPR RBF N=16384 D=8 fp64: K build + Cholesky + LML (one gpk_gpr_lml call)",

@@ -803,6 +803,33 @@ extern "C" int gpk_profile_gemm_collect_min(double min_flops, int keep, double* 
   if (!keep) g_prof_n = 0;
   return 0;
 }
+// The phase spanned by the launches with >= min_flops (first such launch's start .. last such launch's end, by HIP
+// events) and the algorithmic flops of EVERY recorded launch issued in between, whatever its stream: the chip-wide
+// rate of e.g. the trailing-update phase of a factorisation, where the bulk stream's big GEMMs and the look-ahead
+// panel's smaller ones share the machine.  Records are kept.
+extern "C" int gpk_profile_gemm_window(double min_flops, double* window_ms, double* flops_all, double* flops_matching,
+                                       long* launches_all) {
+  GPK_HIP(hipDeviceSynchronize());
+  int first = -1, last = -1;
+  for (int i = 0; i < g_prof_n; ++i)
+    if (g_prof[i].flops >= min_flops) { if (first < 0) first = i; last = i; }
+  double fa = 0.0, fm = 0.0;
+  float t = 0.f;
+  long cnt = 0;
+  if (first >= 0) {
+    GPK_HIP(hipEventElapsedTime(&t, g_prof[first].e0, g_prof[last].e1));
+    for (int i = first; i <= last; ++i) {
+      fa += g_prof[i].flops;
+      if (g_prof[i].flops >= min_flops) fm += g_prof[i].flops;
+      ++cnt;
+    }
+  }
+  if (window_ms) *window_ms = t;
+  if (flops_all) *flops_all = fa;
+  if (flops_matching) *flops_matching = fm;
+  if (launches_all) *launches_all = cnt;
+  return 0;
+}
 extern "C" int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops) {
   return gpk_profile_gemm_collect_min(0.0, 0, total_ms, launches, flops);
 }

@@ -628,7 +628,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // scheme (128-column panels, one-shot LDS-DMA GEMMs for solve and strip) runs it ~2x faster than 512-column panels
     // (opt-in, GPK_TAIL_RECURSION=1: A/B at N = 16384 gave 33.5 ms with it vs 33.25 ms without)
     static const bool tail_recursion = getenv("GPK_TAIL_RECURSION") != nullptr;
-    if (tail_recursion && nbo > NB && batch == 1 && !useX && c1 < n && n - c1 <= 2048 && n - c1 >= 2 * NBO) {
+    static const int tail_rows = getenv("GPK_TAIL_ROWS") ? atoi(getenv("GPK_TAIL_ROWS")) : 2048;  // (< 4096: the inner call must take the 128-column scheme)
+    if (tail_recursion && nbo > NB && batch == 1 && !useX && c1 < n && n - c1 <= tail_rows && n - c1 < 4096 && n - c1 >= 2 * NBO) {
       if (r0 != c1) continue;  // (a deferred rest-update is still pending: not at a clean boundary)
       GPK_HIP(hipEventRecord(evJoinP, P));
       GPK_HIP(hipEventRecord(evJoinB, last_bulk));

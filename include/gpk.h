@@ -196,6 +196,10 @@ void gpk_profile_gemm_enable(int on);
 int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops);
 /* same, restricted to launches with at least min_flops algorithmic flops; keep != 0 keeps the records */
 int gpk_profile_gemm_collect_min(double min_flops, int keep, double* total_ms, long* launches, double* flops);
+/* phase spanned by the launches with >= min_flops (first start .. last end) and the algorithmic flops of ALL recorded
+ * launches issued in between, on any stream: chip-wide rate of a phase in which several streams share the machine */
+int gpk_profile_gemm_window(double min_flops, double* window_ms, double* flops_all, double* flops_matching,
+                            long* launches_all);
 
 /* micro-benchmarks used by bench.py / profiles (fp64 MFMA issue rate, HBM write stream) */
 int gpk_bench_mfma_f64(void* stream, int blocks, int iters, double* sink);
