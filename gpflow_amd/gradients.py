@@ -199,3 +199,70 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
     grads = {"variance": dvar.reshape(1), "lengthscales": dls, "noise_variance": torch.diagonal(Kbar).sum().reshape(1),
              "mean_const": betat.sum().reshape(1)}
     return lml.reshape(1), grads, info
+
+
+def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales,
+                       noise_variance: float, jitter: float, mean_const: float = 0.0
+                       ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+    """SGPR.elbo (sgpr.py:181-290) and its gradient w.r.t. {variance, lengthscales, noise_variance, Z, mean_const}
+    (single process; SquaredExponential).  With At = Kfu Lm^-T, S = At^T At, a = At^T err, q = |At|^2, e2 = |err|^2,
+    B = I + S / s2, w = B^-1 a / s2:
+
+        F     = -N P log(2 pi)/2 - P (logdet B / 2 + N log(s2)/2 + (N var - q) / (2 s2)) - e2 / (2 s2) + a^T w / (2 s2)
+        B_bar = -(P B^-1 + w w^T) / 2,   S_bar = B_bar / s2,   a_bar = w / s2,   q_bar = P / (2 s2)
+        At_bar = At (2 S_bar + 2 q_bar I) + err a_bar^T        -> then exactly the SVGP chain: Kfu_bar, Lm_bar, Kuu_bar, kernel
+    """
+    M, D = Z.shape
+    N, P = Y.shape
+    dev = Z.device
+    s2 = float(noise_variance)
+    kw = dict(variance=variance, lengthscales=lengthscales)
+    eye = torch.eye(M, dtype=torch.float64, device=dev)
+    T = torch.empty((M + N + M, M), dtype=torch.float64, device=dev)
+    ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
+    ops.kernel_matrix(X, Z, out=T[M:M + N], **kw)
+    T[M + N:] = eye
+    _, info = ops.potrf_(T, M, zero_upper=True)
+    L, At, LinvT = T[:M], T[M:M + N], T[M + N:]
+    err = (Y - mean_const).contiguous()
+    A = ops.transpose(At)                                                               # [M, N]
+    Slow = torch.tril(splitk_gemm_nt(A, A, c_lower=True))
+    S = Slow + torch.tril(Slow, -1).t()
+    a = splitk_gemm_nt(A, err.t().contiguous())                                         # [M, P]
+    e2, q = ops.sumsq(err)[0], ops.sumsq(At)[0]
+    T2 = torch.empty((2 * M + P, M), dtype=torch.float64, device=dev)
+    T2[:M] = S / s2 + eye
+    T2[M:2 * M] = eye
+    T2[2 * M:] = a.t() / s2
+    _, info2 = ops.potrf_(T2, M, zero_upper=True)
+    LB, LBinvT, ct = T2[:M], T2[M:2 * M], T2[2 * M:]
+    half_logdet_b = ops.sum_log_diag(LB)[0]
+    F = (-0.5 * N * P * LOG2PI - P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * (N * variance - q) / s2)
+         - 0.5 * (e2 / s2 - ops.sumsq(ct)[0]))
+    # ---- backward
+    Binv = ops.gemm_nt(LBinvT, LBinvT, b_tri=1)                                         # B^-1 = LB^-T LB^-1
+    wt = ops.gemm_nt(ct.contiguous(), LBinvT, b_tri=1)                                  # w^T = c^T LB^-1  [P, M]
+    w = wt.t().contiguous()                                                             # [M, P]
+    Bbar = -0.5 * P * Binv
+    ops.gemm_nt(w, w, alpha=-0.5, beta=1.0, C=Bbar)                                     # - w w^T / 2
+    Ssym = (2.0 / s2) * Bbar + (P / s2) * eye                                           # 2 S_bar + 2 q_bar I
+    abar = w / s2
+    Atb = ops.gemm_nt(err, abar)                                                        # err a_bar^T  [N, M]
+    ops.gemm_nt(At, Ssym, alpha=1.0, beta=1.0, C=Atb)                                   # + At (2 S_bar + 2 q_bar I)
+    Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)
+    Kuf_bar = ops.transpose(Kfu_bar)
+    Lbar = -torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True))
+    Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
+    dv1, dl1, Zb1 = se_kernel_adjoint(Z, X, Kuf_bar, symmetric=False, **kw)
+    dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+    g_var = dv1 + dv2 - 0.5 * P * N / s2
+    g_ls = dl1 + dl2
+    if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
+        g_ls = g_ls.sum().reshape(1)
+    wa, ww = (w * a).sum(), (w * w).sum()
+    g_noise = (-P * (-0.5 * (M - torch.diagonal(Binv).sum()) / s2 + 0.5 * N / s2 - 0.5 * (N * variance - q) / s2 ** 2)
+               + 0.5 * e2 / s2 ** 2 - 0.5 * wa / s2 ** 2 - 0.5 * ww / s2)
+    g_mean = (err / s2 - ops.gemm_nt(At, abar.t().contiguous())).sum()
+    grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1), "Z": Zb1 + Zb2,
+             "mean_const": g_mean.reshape(1)}
+    return F.reshape(1), grads, torch.maximum(info, info2)

@@ -89,6 +89,8 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
             raise NotImplementedError("parameter priors are not differentiated here")
         return float(lml.cpu()[0]), out
 
+    objective_and_grad = log_marginal_likelihood_and_grad   # what optimizers.Scipy calls
+
     def posterior(self, precompute_cache=posteriors.PrecomputeCacheType.TENSOR) -> posteriors.GPRPosterior:
         """gpr.py:146-175"""
         return posteriors.GPRPosterior(kernel=self.kernel, data=self.data, likelihood=self.likelihood,

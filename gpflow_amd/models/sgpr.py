@@ -158,6 +158,34 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         kw, Z, c, s2, L, invd, packed = self._statistics()
         return upper_bound_from_statistics(packed, Z.shape[0], self.num_data, variance=kw["variance"], noise_variance=s2)
 
+    def objective_and_grad(self):
+        """(ELBO as a float, {Parameter: dELBO/d(unconstrained value)}) for the trainable parameters among kernel variance,
+        lengthscales, noise variance, Z and a Constant mean -- the gradient `optimizers/scipy.py:322-331` takes from TF
+        (gradients.sgpr_elbo_and_grad; single process, SquaredExponential kernel)."""
+        from ..kernels.stationaries import SquaredExponential
+        from ..mean_functions import Constant
+        if self.sharded:
+            raise NotImplementedError("gradients of a row-sharded SGPR")
+        kw, X, Z, c, s2 = self._config()
+        if not isinstance(self.kernel, SquaredExponential) or self.kernel.active_dims != slice(None, None, None):
+            raise NotImplementedError("gradients: SquaredExponential kernel without active_dims")
+        F, g, info = gradients.sgpr_elbo_and_grad(Z, X, self.data[1], variance=kw["variance"], lengthscales=kw["lengthscales"],
+                                                  noise_variance=s2, jitter=config.default_jitter(), mean_const=c)
+        ops.check_info(info)
+        host = {n: t.cpu().numpy() for n, t in g.items()}
+        pairs = [(self.kernel.variance, host["variance"]), (self.kernel.lengthscales, host["lengthscales"]),
+                 (self.likelihood.variance, host["noise_variance"]), (self.inducing_variable.Z, host["Z"])]
+        if isinstance(self.mean_function, Constant):
+            pairs.append((self.mean_function.c, host["mean_const"]))
+        out = {}
+        for par, gc in pairs:
+            if par.trainable:
+                if par.prior is not None:
+                    raise NotImplementedError("parameter priors are not differentiated here")
+                u = par.unconstrained_variable
+                out[par] = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+        return float(F.cpu()[0]), out
+
     # ---- prediction ------------------------------------------------------------------------------
     def predict_f(self, Xnew, full_cov: bool = False, full_output_cov: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """sgpr.py:292-345"""

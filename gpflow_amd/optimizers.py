@@ -1,7 +1,7 @@
 """`gpflow.optimizers.Scipy` (gpflow/optimizers/scipy.py:45-331) for the models whose objective has a hand-written
 gradient on the device: the reference packs the trainable variables' UNCONSTRAINED values into one vector
 (`scipy.py:289-305`), evaluates loss and gradient with TF (`:322-331`) and hands both to `scipy.optimize.minimize`;
-here loss and gradient come from `model.log_marginal_likelihood_and_grad()` (gpflow_amd/gradients.py)."""
+here loss and gradient come from `model.objective_and_grad()` (GPR, SGPR; gpflow_amd/gradients.py)."""
 from __future__ import annotations
 
 from typing import Any, Dict, Optional
@@ -13,10 +13,11 @@ import scipy.optimize
 class Scipy:
     def minimize(self, model, *, method: str = "L-BFGS-B", options: Optional[Dict[str, Any]] = None,
                  **scipy_kwargs) -> scipy.optimize.OptimizeResult:
-        """Minimise -LML of `model` (a GPR) over its trainable parameters; the model holds the optimum afterwards."""
-        if not hasattr(model, "log_marginal_likelihood_and_grad"):
+        """Minimise the training loss (-LML of a GPR, -ELBO of an SGPR) over the model's trainable parameters; the model
+        holds the optimum afterwards."""
+        if not hasattr(model, "objective_and_grad"):
             raise NotImplementedError(f"{type(model).__name__} has no device gradient; use training.SVGPTrainer for SVGP")
-        _, g0 = model.log_marginal_likelihood_and_grad()
+        _, g0 = model.objective_and_grad()
         params = list(g0)
         sizes = [int(np.size(p.unconstrained_variable)) for p in params]
 
@@ -29,7 +30,7 @@ class Scipy:
         def fun(x):
             unpack(x)
             try:
-                v, g = model.log_marginal_likelihood_and_grad()
+                v, g = model.objective_and_grad()
             except Exception as e:  # a failed factorisation during a line search: reject the point, as scipy expects
                 if "not successful" not in str(e):
                     raise

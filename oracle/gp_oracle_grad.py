@@ -106,3 +106,33 @@ def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma):
     S = vs.transpose(1, 2) @ vs                                                          # :437
     mun = S @ nat1n                                                                      # :438
     return mun[:, :, 0].T.numpy().copy(), torch.linalg.cholesky(S).numpy().copy()        # :441
+
+
+# ----------------------------------------------------------------------------- SGPR gradients (SURVEY 8f rows 1 + 3)
+def sgpr_elbo_torch(X, Y, Z, variance, lengthscales, noise_variance, *, jitter=1e-6, mean=0.0):
+    """SGPR.elbo (gpflow/models/sgpr.py:181-290) on torch fp64 tensors, constant noise variance."""
+    N, P = Y.shape
+    M = Z.shape[0]
+    sigma = torch.sqrt(noise_variance)
+    kuf = _rbf(Z, X, variance, lengthscales)
+    kuu = _rbf(Z, Z, variance, lengthscales) + jitter * torch.eye(M, dtype=torch.float64)
+    L = torch.linalg.cholesky(kuu)
+    A = torch.linalg.solve_triangular(L, kuf / sigma, upper=False)
+    AAT = A @ A.T
+    LB = torch.linalg.cholesky(AAT + torch.eye(M, dtype=torch.float64))
+    trace = N * variance / noise_variance - torch.trace(AAT)
+    logdet = -P * (torch.log(torch.diagonal(LB)).sum() + 0.5 * N * torch.log(noise_variance) + 0.5 * trace)
+    err = (Y - mean) / sigma
+    c = torch.linalg.solve_triangular(LB, A @ err, upper=False)
+    quad = -0.5 * ((err * err).sum() - (c * c).sum())
+    return -0.5 * N * P * LOG2PI + logdet + quad
+
+
+def sgpr_elbo_value_and_grads(X, Y, Z, *, variance, lengthscales, noise_variance, jitter=1e-6, mean=0.0):
+    t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
+    Zt = t(Z, True)
+    var, ls, nv, mc = t(variance, True), t(np.atleast_1d(lengthscales), True), t(noise_variance, True), t(mean, True)
+    F = sgpr_elbo_torch(t(X), t(Y), Zt, var, ls, nv, jitter=jitter, mean=mc)
+    F.backward()
+    g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "Z": Zt.grad, "mean_const": mc.grad}
+    return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}

@@ -102,3 +102,30 @@ def test_natural_gradient_step_and_svgp_vs_sgpr(gpu):
     mu_r, sq_r = orcg.natgrad_step(q_mu, q_sqrt, -g["q_mu"], -g["q_sqrt"], 0.1)
     np.testing.assert_allclose(m2.q_mu.numpy(), mu_r, rtol=0, atol=1e-8 * max(1.0, np.abs(mu_r).max()))
     np.testing.assert_allclose(m2.q_sqrt.numpy(), sq_r, rtol=0, atol=1e-8)
+
+
+def test_sgpr_gradients_and_scipy_fit(gpu):
+    """SGPR.objective_and_grad vs the autograd oracle (chained to the unconstrained parameters), then the reference's
+    test_sgpr_qu recipe (tests/gpflow/models/test_sgpr.py:29-44): optimise with Scipy, then q(u) == predict_f at Z."""
+    import gpflow_amd as gpflow
+    from oracle import gp_oracle_grad as orcg
+    rng = np.random.RandomState(1)
+    X = np.random.RandomState(0).randn(100, 2); Z = np.random.RandomState(0).randn(20, 2)
+    Y = np.sin(X @ np.array([[-1.4], [0.5]])) + 0.5 * rng.randn(len(X), 1)
+    m = gpflow.models.SGPR((X, Y), gpflow.kernels.SquaredExponential(), Z.copy())
+    v, g = m.objective_and_grad()
+    rv, rg = orcg.sgpr_elbo_value_and_grads(X, Y, Z, variance=1.0, lengthscales=1.0, noise_variance=1.0)
+    assert abs(v - rv) <= 1e-9 * abs(rv)
+    sp = gpflow.base.positive()
+    u1 = sp.inverse(1.0)
+    np.testing.assert_allclose(g[m.kernel.variance], rg["variance"] * sp.forward_grad(u1), rtol=1e-8)
+    np.testing.assert_allclose(g[m.kernel.lengthscales], rg["lengthscales"].reshape(()) * sp.forward_grad(u1), rtol=1e-8)
+    np.testing.assert_allclose(g[m.inducing_variable.Z], rg["Z"], rtol=0, atol=1e-8 * np.abs(rg["Z"]).max())
+    tn = m.likelihood.variance.transform
+    np.testing.assert_allclose(g[m.likelihood.variance], rg["noise_variance"] * tn.forward_grad(tn.inverse(1.0)), rtol=1e-8)
+    res = gpflow.optimizers.Scipy().minimize(m, options=dict(maxiter=200))
+    assert -res.fun > v + 5.0
+    qu_mean, qu_cov = m.compute_qu()
+    fz, fzc = m.predict_f(m.inducing_variable.Z.numpy(), full_cov=True)
+    np.testing.assert_allclose(qu_mean.cpu().numpy(), fz.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(qu_cov.cpu().numpy().reshape(1, 20, 20), fzc.cpu().numpy(), rtol=1e-5, atol=1e-5)

@@ -261,3 +261,23 @@ def test_natgrad_update_on_emulated_primitives_and_svgp_vs_sgpr(monkeypatch):
     sgpr = orc.sgpr_elbo(X, Y, Z, **kw)
     assert abs(v - sgpr) > 1.0                   # different before
     assert abs(after - sgpr) <= 1e-4             # equal after one step of size 1
+
+
+@pytest.mark.parametrize("N,M,D,P,ard", [(400, 150, 3, 2, True), (300, 64, 2, 1, False)])
+def test_sgpr_adjoint_composition_on_emulated_primitives(monkeypatch, N, M, D, P, ard):
+    import torch
+    import fake_ops
+    from gpflow_amd import gradients
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    rng = np.random.default_rng(12)
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P)); Z = rng.normal(size=(M, D))
+    ls = 0.8 + 0.1 * np.arange(D) if ard else 1.1
+    kw = dict(variance=1.2, lengthscales=ls, noise_variance=0.3)
+    v, go = orcg.sgpr_elbo_value_and_grads(X, Y, Z, mean=0.2, **kw)
+    assert abs(v - orc.sgpr_elbo(X, Y, Z, mean=0.2, **kw)) <= 1e-11 * abs(v)      # the autograd oracle is the NumPy oracle
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    F, g, info = gradients.sgpr_elbo_and_grad(t(Z), t(X), t(Y), jitter=1e-6, mean_const=0.2, **kw)
+    assert abs(float(F[0]) - v) <= 1e-10 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "mean_const"):
+        got, ref = g[name].numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=1e-8 * max(1.0, np.abs(ref).max()), err_msg=name)
