@@ -340,6 +340,28 @@ def main():
         "step_frac_of_fp64_peak": svgp_step_flops(M_IND, B_ROWS, P_LAT) * steps_per_s / 1e12 / FP64_PEAK_TFLOPS,
         "roofline": roof,
     }
+    if world == 1:
+        # PCIe-inclusive rate (never `value`): the same step when the minibatch arrives in (pinned) HOST memory, as it
+        # does for a caller handing NumPy arrays to the Python mirror -- 8192 x (8 + 1) doubles = 0.59 MB per step
+        hX = [X[i * B_ROWS:(i + 1) * B_ROWS].cpu().pin_memory() for i in range(4)]
+        hY = [Y[i * B_ROWS:(i + 1) * B_ROWS].cpu().pin_memory() for i in range(4)]
+        dX, dY = torch.empty_like(X[:B_ROWS]), torch.empty_like(Y[:B_ROWS])
+
+        def host_step(s):
+            dX.copy_(hX[s % 4], non_blocking=True)
+            dY.copy_(hY[s % 4], non_blocking=True)
+            ops.svgp_elbo_shard(Z, dX, dY, q_mu, q_sqrt, variance=1.0, lengthscales=ls, noise_variance=0.1, jitter=1e-6,
+                                ws=ws, out=out, info=info)
+            h_out.copy_(out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        for s in range(3):
+            host_step(s)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s in range(30):
+            host_step(s)
+        torch.cuda.synchronize()
+        res["pcie_inclusive_steps_per_s"] = 30.0 / (time.perf_counter() - t1)
     if world == 1 and not args.no_train:
         res["train_step"] = train_step_leg(X, Y, Z, q_mu, q_sqrt, ls)
     if world == 1 and not args.no_gpr:

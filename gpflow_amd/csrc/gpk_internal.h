@@ -50,6 +50,7 @@ struct GemmArgs {
   int batch;
   int stagger_first;  // fast path only: number of CUs the launch stream may use (first workgroup of the 2nd resident set), 0 = 256
   int stagger_ticks;  // fast path only: start delay (100 MHz ticks) of the second resident workgroup set, 0 = none
+  int no_small;     // never take the one-shot LDS-DMA latency kernel (150 KB of LDS per workgroup: needs a CU free of GEMM workgroups)
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);

@@ -581,6 +581,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       GemmArgs u = gemm_base(R - c2, n - c2, kpend, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
+      // A/B knob: with many extra rows in flight (SVGP step) the rest-update's one-shot kernel (150 KB LDS per workgroup)
+      // only fits on CUs free of extra-row GEMM workgroups; the tiled kernel can share a CU
+      static const int rest_no_small = getenv("GPK_REST_NO_SMALL") ? atoi(getenv("GPK_REST_NO_SMALL")) : 0;
+      if (rest_no_small && useX && nbo == NB) u.no_small = 1;
       if (Bp == aux->B && n >= 4096) u.stagger_first = aux->bulk_cus;
       rc = gpk_launch_gemm(Bp, u);
       if (rc) return rc;
