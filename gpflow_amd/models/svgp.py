@@ -112,6 +112,48 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             scale = 1.0
         return terms[0] * scale - terms[1]
 
+    def elbo_and_grad(self, data):
+        """(ELBO on `data` as a float, {Parameter: dELBO/d(unconstrained value) as NumPy}) for the trainable parameters
+        -- the pair `optimizers/scipy.py:322-331` gets from TF autodiff over `training_loss_closure(data)`.  Whitened,
+        SquaredExponential kernel, Gaussian likelihood, InducingPoints, full q_sqrt (gradients.svgp_elbo_and_grad).
+        For minibatch training keep the variables on the device instead: training.SVGPTrainer."""
+        from .. import gradients
+        from ..base import FillTriangular
+        from ..kernels.stationaries import SquaredExponential
+        from ..mean_functions import Constant
+        k, lik, iv, mf = self.kernel, self.likelihood, self.inducing_variable, self.mean_function
+        c = mf.constant_value()
+        if not (self.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
+                and isinstance(iv, InducingPoints) and c is not None and self.q_sqrt.numpy().ndim == 3
+                and k.active_dims == slice(None, None, None)):
+            raise NotImplementedError("gradients: whitened SVGP, SquaredExponential (no active_dims), Gaussian likelihood, "
+                                      "InducingPoints, full q_sqrt, constant mean")
+        X, Y = ops.to_device(data[0]), ops.to_device(data[1])
+        scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
+        _, var, ls = k.hyper()
+        F, g, info = gradients.svgp_elbo_and_grad(iv.Z.device_value(), X, Y, self.q_mu.device_value(),
+                                                  self.q_sqrt.device_value(), variance=var, lengthscales=ls,
+                                                  noise_variance=lik.noise_variance(), jitter=config.default_jitter(),
+                                                  scale=scale, mean_const=float(c))
+        ops.check_info(info)
+        host = {n: t.cpu().numpy() for n, t in g.items()}
+        pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (lik.variance, host["noise_variance"]),
+                 (iv.Z, host["Z"]), (self.q_mu, host["q_mu"]), (self.q_sqrt, host["q_sqrt"])]
+        if isinstance(mf, Constant):
+            pairs.append((mf.c, host["mean_const"]))
+        out = {}
+        for par, gc in pairs:
+            if not par.trainable:
+                continue
+            if par.prior is not None:
+                raise NotImplementedError("parameter priors are not differentiated here")
+            u = par.unconstrained_variable
+            if isinstance(par.transform, FillTriangular):   # linear embedding: the vector entries are the lower-triangular ones
+                out[par] = par.transform.inverse(np.asarray(gc, dtype=np.float64)).reshape(u.shape)
+            else:
+                out[par] = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+        return float(F.cpu()[0]), out
+
     def posterior(self, precompute_cache=posteriors.PrecomputeCacheType.TENSOR):
         """svgp.py:210-240"""
         return posteriors.create_posterior(self.kernel, self.inducing_variable, self.q_mu, self.q_sqrt,

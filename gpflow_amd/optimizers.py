@@ -11,13 +11,17 @@ import scipy.optimize
 
 
 class Scipy:
-    def minimize(self, model, *, method: str = "L-BFGS-B", options: Optional[Dict[str, Any]] = None,
+    def minimize(self, model, data=None, *, method: str = "L-BFGS-B", options: Optional[Dict[str, Any]] = None,
                  **scipy_kwargs) -> scipy.optimize.OptimizeResult:
-        """Minimise the training loss (-LML of a GPR, -ELBO of an SGPR) over the model's trainable parameters; the model
-        holds the optimum afterwards."""
-        if not hasattr(model, "objective_and_grad"):
-            raise NotImplementedError(f"{type(model).__name__} has no device gradient; use training.SVGPTrainer for SVGP")
-        _, g0 = model.objective_and_grad()
+        """Minimise the training loss (-LML of a GPR, -ELBO of an SGPR, -ELBO of an SVGP on the fixed batch `data`) over
+        the model's trainable parameters; the model holds the optimum afterwards."""
+        if data is not None and hasattr(model, "elbo_and_grad"):
+            objective = lambda: model.elbo_and_grad(data)  # noqa: E731
+        elif hasattr(model, "objective_and_grad"):
+            objective = model.objective_and_grad
+        else:
+            raise NotImplementedError(f"{type(model).__name__} has no device gradient (SVGP needs `data`)")
+        _, g0 = objective()
         params = list(g0)
         sizes = [int(np.size(p.unconstrained_variable)) for p in params]
 
@@ -30,7 +34,7 @@ class Scipy:
         def fun(x):
             unpack(x)
             try:
-                v, g = model.objective_and_grad()
+                v, g = objective()
             except Exception as e:  # a failed factorisation during a line search: reject the point, as scipy expects
                 if "not successful" not in str(e):
                     raise

@@ -146,3 +146,30 @@ def test_scipy_optimizer_fits_gpr(gpu):
     ref = scipy.optimize.minimize(f, x0, jac=True, method="L-BFGS-B", options=dict(maxiter=300))
     assert abs(res.fun - ref.fun) <= 1e-6 * abs(ref.fun), (res.fun, ref.fun)
     np.testing.assert_allclose(m.kernel.lengthscales.numpy(), sp.forward(ref.x[1:3]), rtol=1e-3)
+
+
+def test_svgp_elbo_and_grad_chained_to_unconstrained_and_scipy(gpu):
+    """SVGP.elbo_and_grad: gradients in the UNCONSTRAINED space of every trainable parameter (softplus for the positive
+    ones, fill-triangular for q_sqrt) against finite differences of the model's own fused ELBO; then Scipy on a fixed
+    batch raises the ELBO."""
+    import gpflow_amd as gpflow
+    m, X, Y = _small_model(40, 300, 2, 1, 11)
+    v, g = m.elbo_and_grad((X, Y))
+    assert abs(v - float(m.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+    assert set(g) == {m.kernel.variance, m.kernel.lengthscales, m.likelihood.variance, m.inducing_variable.Z, m.q_mu, m.q_sqrt}
+    h = 1e-5
+    for par, idx in [(m.kernel.variance, ()), (m.kernel.lengthscales, (1,)), (m.likelihood.variance, ()),
+                     (m.q_sqrt, (0, 17)), (m.q_sqrt, (0, 400)), (m.q_mu, (3, 0)), (m.inducing_variable.Z, (5, 1))]:
+        u0 = np.array(par.unconstrained_variable, dtype=np.float64, copy=True)
+        vals = []
+        for d in (h, -h):
+            u = u0.copy()
+            u[idx] += d
+            par.assign_unconstrained(u)
+            vals.append(float(m.elbo((X, Y)).cpu()))
+        par.assign_unconstrained(u0)
+        fd = (vals[0] - vals[1]) / (2 * h)
+        got = float(np.asarray(g[par])[idx])
+        assert abs(got - fd) <= 1e-5 * max(1.0, abs(fd)), (par.name, idx, got, fd)
+    res = gpflow.optimizers.Scipy().minimize(m, (X, Y), options=dict(maxiter=30))
+    assert -res.fun > v + 10.0
