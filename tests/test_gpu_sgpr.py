@@ -129,3 +129,36 @@ def test_sgpr_gradients_and_scipy_fit(gpu):
     fz, fzc = m.predict_f(m.inducing_variable.Z.numpy(), full_cov=True)
     np.testing.assert_allclose(qu_mean.cpu().numpy(), fz.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(qu_cov.cpu().numpy().reshape(1, 20, 20), fzc.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_nextrows_golden_vectors(gpu):
+    """The device paths of the rows built this round against the committed golden fixtures (tests/golden/
+    nextrows_golden.npz: the reference's own SGPR / SVGP test fixtures; generator committed beside it)."""
+    import os
+    import gpflow_amd as gpflow
+    from gpflow_amd import gradients, natgrad, ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nextrows_golden.npz"))
+    kw = dict(variance=1.0, lengthscales=1.0, noise_variance=1.0)
+    m = _model(g["sgpr_X"], g["sgpr_Y"], g["sgpr_Z"], kw)
+    np.testing.assert_allclose(float(m.elbo().cpu()), g["sgpr_elbo"], rtol=1e-9)
+    np.testing.assert_allclose(float(m.upper_bound().cpu()), g["sgpr_upper"], rtol=1e-9)
+    fm, fv = m.predict_f(g["sgpr_Xnew"])
+    np.testing.assert_allclose(fm.cpu().numpy(), g["sgpr_mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fv.cpu().numpy(), g["sgpr_var"], rtol=0, atol=1e-9)
+    mu, cov = m.compute_qu()
+    np.testing.assert_allclose(mu.cpu().numpy(), g["sgpr_qu_mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(cov.cpu().numpy(), g["sgpr_qu_cov"], rtol=0, atol=1e-9)
+    _, gs, _ = gradients.sgpr_elbo_and_grad(ops.to_device(g["sgpr_Z"]), ops.to_device(g["sgpr_X"]), ops.to_device(g["sgpr_Y"]),
+                                            jitter=1e-6, **kw)
+    np.testing.assert_allclose(gs["Z"].cpu().numpy(), g["sgpr_g_Z"], rtol=0, atol=1e-8 * np.abs(g["sgpr_g_Z"]).max())
+    np.testing.assert_allclose(gs["noise_variance"].cpu().numpy().reshape(()), g["sgpr_g_noise"], rtol=1e-8)
+    t = ops.to_device
+    F, gr, _ = gradients.svgp_elbo_and_grad(t(g["grad_Z"]), t(g["grad_X"]), t(g["grad_Y"]), t(g["grad_q_mu"]), t(g["grad_q_sqrt"]),
+                                            jitter=1e-6, scale=200 / 20, **kw)
+    np.testing.assert_allclose(float(F.cpu()[0]), g["grad_elbo"], rtol=1e-9)
+    for k in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt"):
+        ref = g[f"grad_g_{k}"]
+        np.testing.assert_allclose(gr[k].cpu().numpy().reshape(ref.shape), ref, rtol=0, atol=1e-8 * max(1.0, np.abs(ref).max()))
+    mu_n, sq_n = natgrad.natgrad_update(t(g["grad_q_mu"]), t(g["grad_q_sqrt"]), -gr["q_mu"], -gr["q_sqrt"], 0.3)
+    np.testing.assert_allclose(mu_n.cpu().numpy(), g["nat_q_mu"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(sq_n.cpu().numpy(), g["nat_q_sqrt"], rtol=0, atol=1e-8)

@@ -321,3 +321,25 @@ def test_sgpr_bounds_sandwich_the_exact_lml_and_are_tight_at_Z_equals_X():
     lo, hi = orc.sgpr_elbo(X, Y, Z, **kw), orc.sgpr_upper_bound(X, Y, Z, **kw)
     assert lo <= lml <= hi
     assert abs(orc.sgpr_elbo(X, Y, X, jitter=1e-10, **kw) - lml) <= 1e-5 * abs(lml)
+
+
+def test_nextrows_golden_vectors_match_oracles():
+    """tests/golden/nextrows_golden.npz (SGPR, gradients, natural gradient; generated by make_golden_next.py on the
+    reference's test fixtures) is reproduced by the oracles -- a pin against silent drift of the checkers themselves."""
+    from oracle import gp_oracle_grad as orcg
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nextrows_golden.npz"))
+    kw = dict(variance=1.0, lengthscales=1.0, noise_variance=1.0)
+    X, Y, Z = g["sgpr_X"], g["sgpr_Y"], g["sgpr_Z"]
+    np.testing.assert_allclose(orc.sgpr_elbo(X, Y, Z, **kw), g["sgpr_elbo"], rtol=1e-12)
+    np.testing.assert_allclose(orc.sgpr_upper_bound(X, Y, Z, **kw), g["sgpr_upper"], rtol=1e-12)
+    fm, fv = orc.sgpr_predict_f(X, Y, Z, g["sgpr_Xnew"], **kw)
+    np.testing.assert_allclose(fm, g["sgpr_mean"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(fv, g["sgpr_var"], rtol=0, atol=1e-12)
+    v, gr = orcg.svgp_elbo_value_and_grads(g["grad_X"], g["grad_Y"], g["grad_Z"], g["grad_q_mu"], g["grad_q_sqrt"],
+                                           num_data=200, **kw)
+    np.testing.assert_allclose(v, g["grad_elbo"], rtol=1e-12)
+    for k, val in gr.items():
+        np.testing.assert_allclose(val, g[f"grad_g_{k}"], rtol=0, atol=1e-10 * max(1.0, np.abs(val).max()))
+    mu_n, sq_n = orcg.natgrad_step(g["grad_q_mu"], g["grad_q_sqrt"], -gr["q_mu"], -gr["q_sqrt"], 0.3)
+    np.testing.assert_allclose(mu_n, g["nat_q_mu"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(sq_n, g["nat_q_sqrt"], rtol=0, atol=1e-10)
