@@ -167,3 +167,53 @@ def test_shard_bounds():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+# ---------------------------------------------------------------- host logic of the rows added for SURVEY 8f
+def test_bijector_forward_grad_matches_finite_differences():
+    from gpflow_amd.base import Chain, Exp, Identity, Shift, Softplus, positive
+    x = np.array([-4.0, -0.3, 0.0, 0.7, 6.0])
+    h = 1e-6
+    for b in (Identity(), Softplus(), Exp(), Shift(0.5), Chain([Shift(1e-3), Softplus()]), positive(lower=1e-6),
+              positive(base="exp")):
+        fd = (b.forward(x + h) - b.forward(x - h)) / (2 * h)
+        np.testing.assert_allclose(b.forward_grad(x), fd, rtol=1e-6, atol=1e-9, err_msg=b.name)
+    from gpflow_amd.base import FillTriangular
+    with pytest.raises(NotImplementedError):
+        FillTriangular().forward_grad(np.zeros(3))
+
+
+def test_gradient_entry_points_refuse_unsupported_models_before_touching_the_device():
+    """The reverse pass covers the whitened SVGP / GPR / SGPR with a SquaredExponential kernel and a Gaussian likelihood;
+    everything else must say so (NotImplementedError), not silently compute something else."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import training
+    Z = np.random.default_rng(0).normal(size=(5, 2))
+    lik = gpflow.likelihoods.Gaussian(0.1)
+    unwhitened = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), lik, Z, whiten=False)
+    matern = gpflow.models.SVGP(gpflow.kernels.Matern32(), lik, Z)
+    qdiag = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), lik, Z, q_diag=True)
+    sliced = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(active_dims=[0]), lik, Z)
+    data = (np.zeros((4, 2)), np.zeros((4, 1)))
+    for m in (unwhitened, matern, qdiag, sliced):
+        with pytest.raises(NotImplementedError):
+            training.SVGPTrainer(m)
+        with pytest.raises(NotImplementedError):
+            m.elbo_and_grad(data)
+        with pytest.raises(NotImplementedError):
+            gpflow.optimizers.NaturalGradient(1.0).minimize(m, data)
+    with pytest.raises(NotImplementedError):
+        gpflow.optimizers.Scipy().minimize(object())
+
+
+def test_adam_state_matches_tf_keras_rule():
+    from gpflow_amd.training import _Adam
+    opt = _Adam(1e-2, 0.9, 0.999, 1e-7)
+    p = np.array([1.0, -2.0]); m = np.zeros(2); v = np.zeros(2)
+    for t, g in enumerate([np.array([0.3, -0.1]), np.array([0.2, 0.4]), np.array([-0.5, 0.1])], start=1):
+        opt.t = t
+        p_new = opt.update_host("p", p, g)
+        m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
+        lr_t = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        np.testing.assert_allclose(p_new, p - lr_t * m / (np.sqrt(v) + 1e-7), rtol=1e-14)
+        p = p_new
