@@ -23,6 +23,7 @@ lengthscales, noise variance, Z, q_mu, q_sqrt); `SVGP.elbo_and_grad` chains them
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import numpy as np
@@ -33,16 +34,19 @@ from . import ops
 LOG2PI = float(np.log(2.0 * np.pi))
 
 
-def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 512) -> torch.Tensor:
+def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 1100) -> torch.Tensor:
     """A Bt^T for a LONG inner dimension and few output tiles (At^T r, At^T W, G [1, x, x^2]): the K range is cut into
     chunks that run as the batch dimension of one launch (strided views, no copies) and the partial products are summed
     -- without it a [2048, 2048] lower-only output is 136 workgroups each walking K = 8192 (33 TFLOP/s), and an
-    [M, 17] output is 16 workgroups."""
+    [M, 17] output is 16 workgroups.  target_wgs ~ two full rounds of the 512 resident workgroups (A/B on the training
+    step: 272 workgroups 8.08 ms, 544 7.9, 1088 7.65, 2176 7.78)."""
     m, k = A.shape
     n = Bt.shape[0]
-    tiles = -(-m // 128) * -(-n // 128)
-    if c_lower:
-        tiles = max(tiles // 2, 1)
+    tm, tn = -(-m // 128), -(-n // 128)
+    tiles = tm * tn
+    if c_lower:   # tiles on or below the diagonal
+        tiles = sum(min(tn, i + 1) for i in range(tm))
+    target_wgs = int(os.environ.get("GPK_SPLITK_TARGET", target_wgs))
     chunks = 1
     while chunks * 2 * tiles <= target_wgs and k % (chunks * 2) == 0 and (k // (chunks * 2)) % 16 == 0 \
             and k // (chunks * 2) >= 256:
