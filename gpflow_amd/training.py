@@ -58,7 +58,10 @@ class SVGPTrainer:
     """
 
     def __init__(self, model, *, learning_rate: float = 1e-3, beta_1: float = 0.9, beta_2: float = 0.999,
-                 epsilon: float = 1e-7, group=None):
+                 epsilon: float = 1e-7, natgrad_gamma: Optional[float] = None, group=None):
+        """natgrad_gamma: if given, (q_mu, q_sqrt) take a natural-gradient step of that size per iteration
+        (optimizers/natgrad.py; natgrad.natgrad_update on the device) and Adam handles the remaining parameters -- the
+        hybrid recipe of the reference's natural-gradient notebook, from ONE gradient evaluation per step."""
         k, lik, iv = model.kernel, model.likelihood, model.inducing_variable
         if not (model.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian)
                 and lik.variance is not None and isinstance(iv, InducingPoints) and model.q_sqrt.numpy().ndim == 3):
@@ -73,6 +76,7 @@ class SVGPTrainer:
             if p.prior is not None:
                 raise NotImplementedError("parameter priors are not part of the trainer's objective")
         self.model, self.group = model, group
+        self.natgrad_gamma = None if natgrad_gamma is None else float(natgrad_gamma)
         self.mean_const = float(c)
         self.opt = _Adam(learning_rate, beta_1, beta_2, epsilon)
         # host side: unconstrained scalars (their constrained values are host arguments of the C-ABI)
@@ -105,7 +109,14 @@ class SVGPTrainer:
         F, g = distributed.all_reduce_grads(F, g, self.group)
         self.last_info = info
         self.opt.t += 1
-        for name in ("Z", "q_mu", "q_sqrt"):                     # minimise -F
+        adam_names = ("Z", "q_mu", "q_sqrt")
+        if self.natgrad_gamma is not None:
+            from . import natgrad
+            adam_names = ("Z",)
+            mu, sq = natgrad.natgrad_update(self.dev["q_mu"], self.dev["q_sqrt"], -g["q_mu"], -g["q_sqrt"], self.natgrad_gamma)
+            self.dev["q_mu"].copy_(mu)
+            self.dev["q_sqrt"].copy_(sq)
+        for name in adam_names:                                  # minimise -F
             if self.dev_params[name].trainable:
                 self.opt.update_device(name, self.dev[name], -g[name])
         small = torch.cat([g["variance"].reshape(-1), g["lengthscales"].reshape(-1), g["noise_variance"].reshape(-1)])

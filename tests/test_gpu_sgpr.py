@@ -162,3 +162,27 @@ def test_nextrows_golden_vectors(gpu):
     mu_n, sq_n = natgrad.natgrad_update(t(g["grad_q_mu"]), t(g["grad_q_sqrt"]), -gr["q_mu"], -gr["q_sqrt"], 0.3)
     np.testing.assert_allclose(mu_n.cpu().numpy(), g["nat_q_mu"], rtol=0, atol=1e-8)
     np.testing.assert_allclose(sq_n.cpu().numpy(), g["nat_q_sqrt"], rtol=0, atol=1e-8)
+
+
+def test_trainer_natgrad_hybrid(gpu):
+    """SVGPTrainer(natgrad_gamma=1) with frozen hyper-parameters: one step takes the device-resident q(u) to the optimum
+    (next ELBO == SGPR bound); with trainable hyper-parameters 25 hybrid steps beat 25 plain Adam steps."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import training
+    X, Y, Z, kw = _data(1500, 128, 3, 1, 9)
+
+    def svgp():
+        return gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=kw["variance"], lengthscales=kw["lengthscales"]),
+                                  gpflow.likelihoods.Gaussian(kw["noise_variance"]), Z.copy(), num_data=X.shape[0])
+    m = svgp()
+    for p in (m.kernel.variance, m.kernel.lengthscales, m.likelihood.variance, m.inducing_variable.Z):
+        gpflow.set_trainable(p, False) if hasattr(p, "_walk") else setattr(p, "_trainable", False)
+    tr = training.SVGPTrainer(m, natgrad_gamma=1.0)
+    tr.step((X, Y))
+    f1 = float(tr.step((X, Y)).cpu()[0])
+    target = float(_model(X, Y, Z, kw).elbo().cpu())
+    assert abs(f1 - target) <= 1e-4, (f1, target)
+    a, b = training.SVGPTrainer(svgp(), learning_rate=1e-2, natgrad_gamma=0.5), training.SVGPTrainer(svgp(), learning_rate=1e-2)
+    for _ in range(25):
+        fa, fb = a.step((X, Y)), b.step((X, Y))
+    assert float(fa.cpu()[0]) > float(fb.cpu()[0])

@@ -281,3 +281,22 @@ def test_sgpr_adjoint_composition_on_emulated_primitives(monkeypatch, N, M, D, P
     for name in ("variance", "lengthscales", "noise_variance", "Z", "mean_const"):
         got, ref = g[name].numpy(), np.asarray(go[name])
         np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=1e-8 * max(1.0, np.abs(ref).max()), err_msg=name)
+
+
+def test_trainer_natgrad_hybrid_reaches_the_sgpr_bound_in_one_step(monkeypatch):
+    """SVGPTrainer(natgrad_gamma=1): (q_mu, q_sqrt) by a natural-gradient step, the rest by Adam.  With the hyper-parameters
+    and Z frozen, one step puts q(u) at the optimum: the next ELBO evaluation equals the SGPR bound (oracle)."""
+    import fake_ops
+    from gpflow_amd import natgrad, training
+    _patch_ops(monkeypatch)
+    monkeypatch.setattr(natgrad, "ops", fake_ops)
+    m, X, Y = _small_model(M=30, B=150, P=1, seed=15)
+    for p in (m.kernel.variance, m.kernel.lengthscales, m.likelihood.variance, m.inducing_variable.Z):
+        p._trainable = False
+    m.num_data = X.shape[0]
+    tr = training.SVGPTrainer(m, natgrad_gamma=1.0)
+    f0 = float(tr.step((X, Y))[0])
+    f1 = float(tr.step((X, Y))[0])
+    ref = orc.sgpr_elbo(X, Y, m.inducing_variable.Z.numpy(), variance=float(m.kernel.variance.numpy()),
+                        lengthscales=m.kernel.lengthscales.numpy(), noise_variance=float(m.likelihood.variance.numpy()))
+    assert abs(f0 - ref) > 1.0 and abs(f1 - ref) <= 1e-4, (f0, f1, ref)
