@@ -112,6 +112,23 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             scale = 1.0
         return terms[0] * scale - terms[1]
 
+    def gradient_config(self):
+        """(SquaredExponential kernel, InducingPoints, mean constant) if the hand-written reverse pass covers this model:
+        whitened, Gaussian likelihood with a variance parameter, full q_sqrt, constant mean, and ONE SquaredExponential
+        kernel (no active_dims) over InducingPoints -- either directly or as SharedIndependent +
+        SharedIndependentInducingVariables (BASELINE config C5: P latents share Kuu / Kuf).  Raises NotImplementedError."""
+        from ..kernels.stationaries import SquaredExponential
+        k, iv, lik = self.kernel, self.inducing_variable, self.likelihood
+        if isinstance(k, SharedIndependent) and isinstance(iv, SharedIndependentInducingVariables):
+            k, iv = k.kernel, iv.inducing_variable
+        c = self.mean_function.constant_value()
+        if not (self.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
+                and isinstance(iv, InducingPoints) and c is not None and self.q_sqrt.numpy().ndim == 3
+                and k.active_dims == slice(None, None, None)):
+            raise NotImplementedError("gradients: whitened SVGP, SquaredExponential (no active_dims; optionally shared by "
+                                      "independent latents), Gaussian likelihood, InducingPoints, full q_sqrt, constant mean")
+        return k, iv, float(c)
+
     def elbo_and_grad(self, data):
         """(ELBO on `data` as a float, {Parameter: dELBO/d(unconstrained value) as NumPy}) for the trainable parameters
         -- the pair `optimizers/scipy.py:322-331` gets from TF autodiff over `training_loss_closure(data)`.  Whitened,
@@ -119,15 +136,9 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         For minibatch training keep the variables on the device instead: training.SVGPTrainer."""
         from .. import gradients
         from ..base import FillTriangular
-        from ..kernels.stationaries import SquaredExponential
         from ..mean_functions import Constant
-        k, lik, iv, mf = self.kernel, self.likelihood, self.inducing_variable, self.mean_function
-        c = mf.constant_value()
-        if not (self.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
-                and isinstance(iv, InducingPoints) and c is not None and self.q_sqrt.numpy().ndim == 3
-                and k.active_dims == slice(None, None, None)):
-            raise NotImplementedError("gradients: whitened SVGP, SquaredExponential (no active_dims), Gaussian likelihood, "
-                                      "InducingPoints, full q_sqrt, constant mean")
+        k, iv, c = self.gradient_config()
+        lik, mf = self.likelihood, self.mean_function
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
         _, var, ls = k.hyper()

@@ -61,13 +61,8 @@ class NaturalGradient:
 
     def minimize(self, model, data) -> None:
         from . import config, gradients, natgrad, ops
-        from .kernels.stationaries import SquaredExponential
-        from .likelihoods import Gaussian
-        k, lik, iv = model.kernel, model.likelihood, model.inducing_variable
-        c = model.mean_function.constant_value()
-        if not (model.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
-                and c is not None and model.q_sqrt.numpy().ndim == 3 and k.active_dims == slice(None, None, None)):
-            raise NotImplementedError("NaturalGradient here: whitened SVGP, SquaredExponential, Gaussian likelihood, full q_sqrt")
+        k, iv, c = model.gradient_config()
+        lik = model.likelihood
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if model.num_data is None else float(model.num_data) / float(X.shape[0])
         _, var, ls = k.hyper()

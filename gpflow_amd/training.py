@@ -62,16 +62,8 @@ class SVGPTrainer:
         """natgrad_gamma: if given, (q_mu, q_sqrt) take a natural-gradient step of that size per iteration
         (optimizers/natgrad.py; natgrad.natgrad_update on the device) and Adam handles the remaining parameters -- the
         hybrid recipe of the reference's natural-gradient notebook, from ONE gradient evaluation per step."""
-        k, lik, iv = model.kernel, model.likelihood, model.inducing_variable
-        if not (model.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian)
-                and lik.variance is not None and isinstance(iv, InducingPoints) and model.q_sqrt.numpy().ndim == 3):
-            raise NotImplementedError("SVGPTrainer covers the whitened SVGP with a SquaredExponential kernel, a Gaussian "
-                                      "likelihood (variance parameter), InducingPoints and a full q_sqrt")
-        if k.active_dims != slice(None, None, None):
-            raise NotImplementedError("active_dims are not supported by the trainer")
-        c = model.mean_function.constant_value()
-        if c is None:
-            raise NotImplementedError("only zero / constant mean functions")
+        k, iv, c = model.gradient_config()      # NotImplementedError outside the scope of the reverse pass
+        lik = model.likelihood
         for p in (k.variance, k.lengthscales, lik.variance, iv.Z, model.q_mu, model.q_sqrt):
             if p.prior is not None:
                 raise NotImplementedError("parameter priors are not part of the trainer's objective")

@@ -173,3 +173,25 @@ def test_svgp_elbo_and_grad_chained_to_unconstrained_and_scipy(gpu):
         assert abs(got - fd) <= 1e-5 * max(1.0, abs(fd)), (par.name, idx, got, fd)
     res = gpflow.optimizers.Scipy().minimize(m, (X, Y), options=dict(maxiter=30))
     assert -res.fun > v + 10.0
+
+
+def test_shared_independent_svgp_gradients_and_trainer(gpu):
+    """BASELINE config C5's structure (SharedIndependent kernel + SharedIndependentInducingVariables, P latents sharing
+    Kuu / Kuf): elbo_and_grad against the autograd oracle, agreement with the fused forward, and the trainer."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import training
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(60, 300, 2, 3, 21)
+    k = gpflow.kernels.SharedIndependent(gpflow.kernels.SquaredExponential(variance=kw["variance"], lengthscales=kw["lengthscales"]),
+                                         output_dim=3)
+    iv = gpflow.inducing_variables.SharedIndependentInducingVariables(gpflow.inducing_variables.InducingPoints(Z.copy()))
+    m = gpflow.models.SVGP(k, gpflow.likelihoods.Gaussian(kw["noise_variance"]), iv, q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(),
+                           num_data=3000)
+    v, g = m.elbo_and_grad((X, Y))
+    rv, rg = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=3000, **kw)
+    assert abs(v - rv) <= 1e-9 * abs(rv)
+    assert abs(v - float(m.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+    np.testing.assert_allclose(g[m.q_mu], rg["q_mu"], rtol=0, atol=1e-8 * np.abs(rg["q_mu"]).max())
+    np.testing.assert_allclose(g[iv.inducing_variable.Z], rg["Z"], rtol=0, atol=1e-8 * np.abs(rg["Z"]).max())
+    tr = training.SVGPTrainer(m, learning_rate=2e-2)
+    vals = [float(tr.step((X, Y)).cpu()[0]) for _ in range(15)]
+    assert abs(vals[0] - rv) <= 1e-9 * abs(rv) and vals[-1] > vals[0]
