@@ -19,7 +19,7 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from .. import config, gradients, ops, posteriors  # noqa: F401
+from .. import config, gradients, ops
 from ..inducing_variables import InducingPoints, inducingpoint_wrapper
 from ..kernels import Kernel
 from ..kernels.stationaries import Stationary

@@ -17,9 +17,6 @@ import numpy as np
 import torch
 
 from . import config, distributed, gradients, ops
-from .inducing_variables import InducingPoints
-from .kernels.stationaries import SquaredExponential
-from .likelihoods import Gaussian
 
 
 class _Adam:
