@@ -270,3 +270,93 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1), "Z": Zb1 + Zb2,
              "mean_const": g_mean.reshape(1)}
     return F.reshape(1), grads, torch.maximum(info, info2)
+
+
+def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor,
+                                  q_sqrt: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
+                                  jitter: float, scale: float = 1.0, mean_const: float = 0.0, kl_weight: float = 1.0
+                                  ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+    """The `whiten=False` SVGP: q(u) = N(q_mu, Lq Lq^T) on u itself (conditionals/util.py:137-139, kullback_leiblers.py:
+    98-165 with K = Kuu).  With Linv = Lm^-1 (from the identity rows of the trapezoid):
+
+        forward   A2t = At Linv,  fmean = A2t q_mu,  W_p = A2t Lq_p,  fvar = var - rowsum(At^2) + rowsum(W_p^2)
+                  KL = 0.5 sum_p (|Linv q_mu_p|^2 - M - log|Lq_p|^2 + |Linv Lq_p|_F^2) + P sum log diag Lm
+        backward  A2t_bar = r q_mu^T + 2c sum_p W_p Lq_p^T,   At_bar = -2cP At + A2t_bar Linv^T,
+                  Linv_bar = tril(At^T A2t_bar) - k (alpha q_mu^T + sum_p V_p Lq_p^T)      (alpha = Linv q_mu, V_p = Linv Lq_p)
+                  Lm_bar   = -tril(Kfu_bar^T At) - tril(Linv^T Linv_bar Linv^T) - k P diag(1 / Lm)
+    and then the same Cholesky / kernel adjoints as the whitened path.  VALIDATED ON THE EMULATED PRIMITIVES ONLY
+    (tests/test_gradients_cpu.py) -- written after this round's GPU budget was spent; it composes primitives whose
+    device behaviour the whitened path already exercises."""
+    M, D = Z.shape
+    B = Xb.shape[0]
+    P = q_mu.shape[1]
+    if q_sqrt.dim() != 3 or tuple(q_sqrt.shape) != (P, M, M):
+        raise ValueError("needs the full q_sqrt [P, M, M]")
+    dev = Z.device
+    kw = dict(variance=variance, lengthscales=lengthscales)
+    k = float(kl_weight)
+    T = torch.empty((M + B + M, M), dtype=torch.float64, device=dev)
+    ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
+    ops.kernel_matrix(Xb, Z, out=T[M:M + B], **kw)
+    T[M + B:] = torch.eye(M, dtype=torch.float64, device=dev)
+    _, info = ops.potrf_(T, M, zero_upper=True)
+    L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
+    Linv = ops.transpose(LinvT)                                                         # lower
+    Lq = torch.tril(q_sqrt)
+    LqT = ops.transpose(q_sqrt, mode=1)
+    A2t = ops.gemm_nt(At, LinvT, b_tri=1)                                               # At Linv   (util.py:139)
+    s0 = ops.row_stats(At)[0]
+    _, fmean, _ = ops.row_stats(A2t, V=q_mu, want_sumsq=False)
+    W = ops.gemm_nt(A2t, LqT, b_tri=1)                                                  # [P, B, M]
+    ssq = torch.stack([ops.row_stats(W[p])[0] for p in range(P)])
+    ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
+                                    mean_const=mean_const)
+    alphat = ops.gemm_nt(q_mu.t().contiguous(), Linv, b_tri=2)                          # (Linv q_mu)^T  [P, M]
+    V = ops.gemm_nt(Linv, LqT, b_tri=1)                                                 # [P, M, M]: V_p = Linv Lq_p
+    if V.dim() == 2:
+        V = V.unsqueeze(0)
+    kl = 0.5 * (ops.sumsq(alphat)[0] - M * P - torch.log(Lq.diagonal(dim1=1, dim2=2) ** 2).sum()
+                + sum(ops.sumsq(V[p])[0] for p in range(P))) + P * ops.sum_log_diag(L)[0]
+    F = scale * ve - k * kl
+    # ---- backward
+    c = -0.5 * scale / noise_variance
+    r = (scale / noise_variance) * (Yb - fmean - mean_const)
+    A2tb = ops.gemm_nt(r, q_mu)
+    for p in range(P):
+        ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=A2tb, b_tri=2)
+    Atb = ops.gemm_nt(A2tb, Linv, b_tri=2)                                              # A2t_bar Linv^T
+    Atb.add_(At, alpha=-2.0 * c * P)
+    A = ops.transpose(At)
+    A2 = ops.transpose(A2t)
+    Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)
+    Kuf_bar = ops.transpose(Kfu_bar)
+    # q(u) gradients: data part through A2t, KL part through Kuu^-1
+    Kinv_qmu_t = ops.gemm_nt(alphat, LinvT, b_tri=1)                                    # (Linv^T alpha)^T  [P, M]
+    g_qmu = splitk_gemm_nt(A2, r.t().contiguous()) - k * Kinv_qmu_t.t()
+    g_qs = torch.stack([torch.tril(splitk_gemm_nt(A2, ops.transpose(W[p]), c_lower=True)) for p in range(P)]) * (2.0 * c)
+    for p in range(P):
+        KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p]))                               # Linv^T V_p = Kuu^-1 Lq_p
+        g_qs[p] -= k * torch.tril(KinvLq)
+    g_qs.diagonal(dim1=1, dim2=2).add_(k / Lq.diagonal(dim1=1, dim2=2))
+    # Linv_bar (lower) and its pull-back to Lm
+    Linv_bar = torch.tril(splitk_gemm_nt(A, ops.transpose(A2tb), c_lower=True))         # tril(At^T A2t_bar)
+    Linv_bar -= k * torch.tril(ops.gemm_nt(alphat.t().contiguous(), q_mu))              # alpha q_mu^T
+    for p in range(P):
+        Linv_bar -= k * torch.tril(ops.gemm_nt(V[p], Lq[p], b_tri=2))                   # V_p Lq_p^T
+    X1 = ops.gemm_nt(LinvT, ops.transpose(Linv_bar))                                    # Linv^T Linv_bar
+    X2 = ops.gemm_nt(X1, Linv, b_tri=2)                                                 # (.) Linv^T
+    Lbar = -torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True)) - torch.tril(X2)
+    Lbar.diagonal().sub_(k * P / L.diagonal())
+    Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
+    dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
+    dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+    g_var = dv1 + dv2 + c * B * P
+    g_ls = dl1 + dl2
+    if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
+        g_ls = g_ls.sum().reshape(1)
+    k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
+    Q = 2.0 * noise_variance * (B * P * k0 - ve)
+    g_noise = scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)
+    grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
+             "Z": Zb1 + Zb2, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
+    return F, grads, info

@@ -28,8 +28,8 @@ def _rbf(X, X2, variance, ls):
 
 
 def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_variance, *, num_data=None, jitter=1e-6,
-                    mean=0.0):
-    """Whitened SVGP.elbo (svgp.py:166-181) on torch fp64 tensors; q_sqrt [P, M, M]."""
+                    mean=0.0, whiten=True):
+    """SVGP.elbo (svgp.py:166-181) on torch fp64 tensors; q_sqrt [P, M, M]; whiten as in the reference."""
     M = Z.shape[0]
     B = X.shape[0]
     Kmm = _rbf(Z, Z, variance, lengthscales) + jitter * torch.eye(M, dtype=torch.float64)   # covariances/kuus.py:29-34
@@ -37,6 +37,8 @@ def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_varianc
     Lm = torch.linalg.cholesky(Kmm)                                                         # conditionals/util.py:67
     A = torch.linalg.solve_triangular(Lm, Kmn, upper=False)                                 # :125
     fvar = variance - (A * A).sum(0)                                                        # :133 (Knn = K_diag)
+    if not whiten:
+        A = torch.linalg.solve_triangular(Lm.T, A, upper=True)                              # :137-139
     fmean = A.T @ q_mu + mean                                                               # :144
     Lq = torch.tril(q_sqrt)                                                                 # :151
     LTA = Lq.transpose(1, 2) @ A                                                            # :157  [P, M, B]
@@ -44,19 +46,25 @@ def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_varianc
     fvar = fvar.T                                                                           # [B, P]
     ve = -0.5 * LOG2PI - 0.5 * torch.log(noise_variance) - 0.5 * ((Y - fmean) ** 2 + fvar) / noise_variance
     # gauss_kl, white (kullback_leiblers.py:98-165): 0.5 (mahalanobis - M P - sum log diag(Lq)^2 + trace)
-    kl = 0.5 * ((q_mu * q_mu).sum() - M * q_mu.shape[1]
-                - torch.log(torch.diagonal(Lq, dim1=1, dim2=2) ** 2).sum() + (Lq * Lq).sum())
+    if whiten:
+        kl = 0.5 * ((q_mu * q_mu).sum() - M * q_mu.shape[1]
+                    - torch.log(torch.diagonal(Lq, dim1=1, dim2=2) ** 2).sum() + (Lq * Lq).sum())
+    else:   # K = Kuu (kullback_leiblers.py:107-165, prior_kl :48-49)
+        alpha = torch.linalg.solve_triangular(Lm, q_mu, upper=False)
+        LpiLq = torch.linalg.solve_triangular(Lm.expand(Lq.shape[0], M, M), Lq, upper=False)
+        kl = 0.5 * ((alpha * alpha).sum() - M * q_mu.shape[1] - torch.log(torch.diagonal(Lq, dim1=1, dim2=2) ** 2).sum()
+                    + (LpiLq * LpiLq).sum() + q_mu.shape[1] * torch.log(torch.diagonal(Lm) ** 2).sum())
     scale = 1.0 if num_data is None else float(num_data) / B
     return ve.sum() * scale - kl
 
 
 def svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, *, variance, lengthscales, noise_variance, num_data=None,
-                              jitter=1e-6, mean=0.0):
+                              jitter=1e-6, mean=0.0, whiten=True):
     """NumPy in, (value, dict of NumPy gradients w.r.t. the constrained quantities) out."""
     t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
     Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
     var, ls, nv, mc = t(variance, True), t(np.atleast_1d(lengthscales), True), t(noise_variance, True), t(mean, True)
-    F = svgp_elbo_torch(t(X), t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=mc)
+    F = svgp_elbo_torch(t(X), t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=mc, whiten=whiten)
     F.backward()
     g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "Z": Zt.grad, "q_mu": qm.grad,
          "q_sqrt": qs.grad, "mean_const": mc.grad}

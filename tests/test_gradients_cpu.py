@@ -300,3 +300,24 @@ def test_trainer_natgrad_hybrid_reaches_the_sgpr_bound_in_one_step(monkeypatch):
     ref = orc.sgpr_elbo(X, Y, m.inducing_variable.Z.numpy(), variance=float(m.kernel.variance.numpy()),
                         lengthscales=m.kernel.lengthscales.numpy(), noise_variance=float(m.likelihood.variance.numpy()))
     assert abs(f0 - ref) > 1.0 and abs(f1 - ref) <= 1e-4, (f0, f1, ref)
+
+
+@pytest.mark.parametrize("M,B,D,P,ard", [(150, 300, 3, 2, True), (64, 200, 2, 1, False)])
+def test_unwhitened_adjoint_on_emulated_primitives(monkeypatch, M, B, D, P, ard):
+    """whiten=False: autograd oracle == NumPy oracle (value), then the hand-written adjoint on the emulated primitives."""
+    import torch
+    import fake_ops
+    from gpflow_amd import gradients
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(M, B, D, P, 17, ard)
+    v, go = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=1000, mean=0.1, whiten=False, **kw)
+    ref = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt, whiten=False, num_data=1000, mean=0.1, **kw)
+    assert abs(v - ref) <= 1e-10 * abs(ref)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    F, g, info = gradients.svgp_elbo_and_grad_unwhitened(t(Z), t(X), t(Y), t(q_mu), t(q_sqrt), jitter=1e-6, scale=1000.0 / B,
+                                                         mean_const=0.1, **kw)
+    assert abs(float(F[0]) - v) <= 1e-9 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt", "mean_const"):
+        got, ref_g = g[name].numpy(), np.asarray(go[name])
+        tol = 1e-7 * max(1.0, np.abs(ref_g).max())
+        np.testing.assert_allclose(got.reshape(ref_g.shape), ref_g, rtol=0, atol=tol, err_msg=name)
