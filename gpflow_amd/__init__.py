@@ -7,12 +7,6 @@
 Device work is hand-written HIP (gfx950) in libgpk.so behind the C-ABI of include/gpk.h; tensors are
 fp64 torch tensors on the HIP device.  There is no CPU fallback.
 """
-import os as _os
-
-# see bench.py / DESIGN.md: fewer HIP hardware queues serve the panel/bulk stream mix better (takes effect only if
-# the HIP runtime has not been initialised yet; an explicit setting in the environment wins)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
-
 from . import config  # noqa: F401,E402
 from .base import Module, Parameter, set_trainable  # noqa: F401
 from .config import default_float, default_int, default_jitter  # noqa: F401

@@ -11,7 +11,9 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgpk.so")
+# GPK_LIBRARY: an explicit path to the shared library -- used by the same-box A/B tooling (tools/ab*.sh) to load the
+# experimental build (libgpk_exp.so, environment tunables); unset, the product library next to this file is loaded.
+_LIB_PATH = os.environ.get("GPK_LIBRARY") or os.path.join(_HERE, "libgpk.so")
 
 c_void_p, c_int, c_long, c_double, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_size_t
 _dp = C.c_void_p  # device pointers travel as integers
@@ -27,10 +29,10 @@ _SIGS = {
                                   C.POINTER(c_double), c_int, c_double, c_double, c_int, _dp, c_long]),
     "gpk_kernel_matrix_hadamard": (c_int, [c_void_p, c_int, _dp, c_int, c_long, _dp, c_int, c_long, c_int,
                                            C.POINTER(c_double), c_int, c_double, _dp, c_long, _dp, c_long]),
+    "gpk_kernel_matrix_combine": (c_int, [c_void_p, c_int, c_int, _dp, c_int, c_long, _dp, c_int, c_long, c_int,
+                                          C.POINTER(c_double), c_int, c_double, c_double, _dp, c_long, _dp, c_long]),
     "gpk_invd_elems": (c_size_t, [c_int, c_int]),
     "gpk_potrf": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_int, c_long, _dp, c_int, _dp]),
-    "gpk_potrf_ex_workspace_bytes": (c_size_t, []),
-    "gpk_potrf_ex": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_int, c_long, _dp, c_int, _dp, _dp, c_long, c_void_p, c_size_t]),
     "gpk_trtri_blocks": (c_int, [c_void_p, _dp, c_int, c_long, c_int, c_long, _dp]),
     "gpk_trsm": (c_int, [c_void_p, c_int, _dp, c_long, _dp, c_int, _dp, c_int, c_long, c_int, c_long,
                          c_long]),

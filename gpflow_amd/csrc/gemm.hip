@@ -496,6 +496,73 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   }
 }
 
+// ---- ticketed tiles + software CU reservation ---------------------------------------------------------------------
+// A bulk GEMM that runs BESIDE the latency chain of a factorisation must not sit on every CU: the chain's kernels need
+// whole CUs (the leaf: 133 KB of LDS; the one-shot solve / strip kernels: 150 KB) and a resident 128x128x16 workgroup
+// holds 256 VGPRs per lane, so two of them leave a CU no room for anything.  CU-masked HIP queues solve that in
+// hardware but were measured to dispatch short kernels slowly; here it is done in software: the launch is a set of
+// persistent workgroups that DRAW tiles (atomic tickets) and a workgroup that finds itself on a reserved CU
+// (HW_REG_HW_ID / HW_REG_XCC_ID looked up in a table built from a census of the chip) draws none and exits, leaving
+// that CU to the chain for good.  Tickets are per XCD (own range first = the XCD-contiguous L2 order of tile_order,
+// then stealing), so load balance no longer depends on which workgroups survived.
+// Guarantee: if NO workgroup survives (every non-reserved CU was busy with other kernels while the grid was placed),
+// the last workgroup to leave processes the whole tile list itself -- slow, never wrong.  Counters reset themselves:
+// ctr[0..7] tickets per XCD, ctr[8] workgroups that left, ctr[9] workgroups that took part.
+__device__ __forceinline__ unsigned cu_key() {
+  const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);    // HW_REG_HW_ID[15:8]: SE_ID, SH_ID, CU_ID
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
+  return (xcc << 8) | hw;
+}
+
+template <int EPI>
+__device__ __forceinline__ void ticketed_tiles(const GemmArgs& p, int gx, int gy, int total, int compact, double* smem) {
+  __shared__ int s_lin, s_flag;
+  const int tid = threadIdx.x;
+  const unsigned key = cu_key();
+  const bool survivor = !(p.resv != nullptr && p.resv[key & (GPK_CU_KEYS - 1)] != 0);
+  const int x = (int)(key >> 8) & 7;
+  const int q = total >> 3, r = total & 7;
+  unsigned* ctr = p.ctr;
+  auto run = [&]() {
+    int k0 = 0;  // (thread 0) XCD offsets below k0 are known to be exhausted
+    for (;;) {
+      if (tid == 0) {
+        int lin = -1;
+        for (int k = k0; k < 8; ++k) {
+          const int xx = (x + k) & 7;
+          const int cnt = q + (xx < r ? 1 : 0);
+          const int local = (int)__hip_atomic_fetch_add(&ctr[xx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (local < cnt) { lin = local * 8 + xx; k0 = k; break; }
+          k0 = k + 1;
+        }
+        s_lin = lin;
+      }
+      __syncthreads();
+      const int lin = s_lin;
+      if (lin < 0) break;
+      int tile_m, tile_n;
+      tile_order(lin, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+      fast_tile<EPI>(p, tile_m, tile_n, smem);
+      __syncthreads();  // both LDS buffers (and s_lin) are about to be rewritten
+    }
+  };
+  if (survivor) {
+    if (tid == 0) __hip_atomic_fetch_add(&ctr[9], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    run();
+  }
+  if (tid == 0) {
+    const unsigned left = __hip_atomic_fetch_add(&ctr[8], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    int flag = 0;
+    if (left == gridDim.x - 1)  // every other workgroup has left
+      flag = (__hip_atomic_load(&ctr[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 2;
+    s_flag = flag;
+  }
+  __syncthreads();
+  const int flag = s_flag;
+  if (flag == 2) run();  // nobody took part: this last workgroup does the whole launch, wherever it sits
+  if (flag != 0 && tid < 10) __hip_atomic_store(&ctr[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // pair = 0: one tile per workgroup, XCD-contiguous / column-grouped order.
 // pair = 1 (triangular-K operand, b_tri = 1): the K range of column tile j shrinks with j, so a workgroup
 // takes column tiles j and gx-1-j back to back -- every workgroup then carries the same number of K slabs
@@ -512,8 +579,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
       const long long t0 = wall_clock64();
       while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
     }
-    // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x (used to cap
-    // the number of CUs a bulk GEMM may occupy while a latency-critical stream needs free ones)
+    if (p.ctr != nullptr) {
+      ticketed_tiles<EPI>(p, gx, gy, total, compact, smem);
+      return;
+    }
+    // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
       int tile_m, tile_n;
       tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
@@ -533,14 +603,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
 template <int EPI>
 int launch_fast(hipStream_t s, const GemmArgs& a) {
   constexpr size_t LDS_BYTES = 2 * (size_t)256 * LDSS * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    attr_set = true;
-  }
+  // (function-local statics: initialised once, thread-safe)
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+  GPK_HIP(attr0);
+  GPK_HIP(attr1);
   const int gx = gpk_cdiv(a.n, 128), gy = gpk_cdiv(a.m, 128);
   if (gx <= 0 || gy <= 0) return 0;
   int total = gx * gy, compact = 0;
@@ -562,7 +631,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   // is lower-only or capped.
   {
     const bool pair_ok = (EPI == 1) ? (a.b_tri == 1)
-                                    : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0);
+                                    : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0 && a.ctr == nullptr);
     if (pair_ok && gx >= 4 && a.b_tri_rows >= a.n) {
       total = ((gx + 1) / 2) * gy;
       hipLaunchKernelGGL((gemm_nt_fast<EPI, true>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy,
@@ -574,10 +643,20 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   unsigned nwg = (unsigned)total;
   if (a.max_wgs > 0 && (unsigned)a.max_wgs < nwg) nwg = (unsigned)a.max_wgs;
   GemmArgs b = a;
+  if (a.ctr != nullptr && nb == 1) {
+    // ticketed: one resident set (2 workgroups per CU by LDS and VGPRs) unless capped; reserved-CU workgroups exit
+    const unsigned cap = a.max_wgs > 0 ? (unsigned)a.max_wgs : 512u;
+    nwg = (unsigned)total < cap ? (unsigned)total : cap;
+    b.stagger_ticks = 0;
+    hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, 1, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total, compact);
+    GPK_LAUNCH_CHECK();
+    return 0;
+  }
+  b.ctr = nullptr;
   {
     // half a tile in 100 MHz ticks: a 128x128x16 slab costs ~1.7 us per workgroup when two share a CU
     // (A/B, 16384^2 x 512, beta = 1: 60.7 -> 63.0 TFLOP/s; lower-only 55.8 -> 58.8; percent of a half tile, 0 = off)
-    static const int stagger_on = getenv("GPK_GEMM_STAGGER") ? atoi(getenv("GPK_GEMM_STAGGER")) : 100;
+    const int stagger_on = GPK_TUNE(GEMM_STAGGER, 100);
     if (b.stagger_first <= 0) b.stagger_first = 256;
     b.stagger_ticks = (stagger_on && EPI == 0 && !a.b_tri && total >= 1024 && nwg == (unsigned)total)
                           ? (int)((a.k / 16) * 170 * stagger_on / 200)
@@ -591,8 +670,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
 
 // 16-byte aligned rows and K ranges that are multiples of 16 everywhere (per-tile b_tri ranges too)
 bool fast_ok(const GemmArgs& a) {
-  static const bool disabled = getenv("GPK_GEMM_NO_FAST") != nullptr;
-  if (disabled) return false;
+  if (GPK_TUNE(GEMM_NO_FAST, 0)) return false;
   if (a.k <= 0 || (a.k & 15) || (a.b_tri && (a.b_tri_off & 15))) return false;
   if ((a.lda & 1) || (a.ldb & 1) || (a.strideA & 1) || (a.strideB & 1)) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
@@ -692,13 +770,10 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk)
 int launch_small(hipStream_t s, const GemmArgs& a) {
   const int ldk = a.k + 2;
   const size_t lds = (size_t)(SM_BM + SM_BN) * ldk * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((SM_BM + SM_BN) * 130 * sizeof(double))));
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)((SM_BM + SM_BN) * 130 * sizeof(double)));
+  GPK_HIP(attr);
   dim3 grid((unsigned)gpk_cdiv(a.n, SM_BN), (unsigned)gpk_cdiv(a.m, SM_BM), (unsigned)(a.batch > 0 ? a.batch : 1));
   hipLaunchKernelGGL(gemm_nt_small, grid, dim3(SM_THREADS), lds, s, a, ldk);
   GPK_LAUNCH_CHECK();
@@ -707,25 +782,21 @@ int launch_small(hipStream_t s, const GemmArgs& a) {
 
 // small-K latency path: K <= 128 in whole 16-slabs, 16-byte aligned rows, modest row count
 bool small_ok(const GemmArgs& a) {
-  static const bool disabled = getenv("GPK_GEMM_NO_SMALL") != nullptr;
-  if (disabled || a.epi != 0) return false;
+  if (GPK_TUNE(GEMM_NO_SMALL, 0) || a.epi != 0) return false;
   if (a.k <= 0 || a.k > 128 || (a.k & 15) || (a.b_tri && (a.b_tri_off & 15))) return false;
   if ((a.lda & 1) || (a.ldb & 1) || (a.strideA & 1) || (a.strideB & 1)) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
   if (a.beta != 0.0 && a.alpha == 0.0) return false;
-  static const long max_wgs = getenv("GPK_SMALL_MAX_WGS") ? atol(getenv("GPK_SMALL_MAX_WGS")) : 512;
+  const long max_wgs = GPK_TUNE(SMALL_MAX_WGS, 512);
   return (long)gpk_cdiv(a.m, SM_BM) * gpk_cdiv(a.n, SM_BN) * (a.batch > 0 ? a.batch : 1) <= max_wgs && a.batch < 65536;
 }
 
 template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(hipStream_t s, const GemmArgs& a) {
   using Cfg = TileCfg<BM, BN, WGM, WGN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, WGM, WGN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, WGM, WGN>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+  GPK_HIP(attr);
   const int gx = gpk_cdiv(a.n, BN), gy = gpk_cdiv(a.m, BM);
   if (gx <= 0 || gy <= 0) return 0;
   int total = gx * gy, compact = 0;
@@ -871,6 +942,27 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
   const long tiles128 = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
   if (tiles128 < 192 && a.m > 64) return launch_cfg<64, 128, 1, 4>(s, a);
   return launch_cfg<128, 128, 2, 2>(s, a);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void cu_census_kernel(unsigned* keys) {
+  extern __shared__ double pad[];  // 80 KB per workgroup: exactly two fit a CU, so 512 resident workgroups cover the chip
+  if (threadIdx.x == 0) {
+    keys[blockIdx.x] = cu_key();
+    pad[0] = 0.0;
+  }
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(8);  // 20 us: keep the workgroup resident while the grid is placed
+}
+}  // namespace
+
+int gpk_cu_census(hipStream_t s, unsigned* keys_dev, int n) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(cu_census_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  GPK_HIP(attr);
+  hipLaunchKernelGGL(cu_census_kernel, dim3((unsigned)n), dim3(256), 80 * 1024, s, keys_dev);
+  GPK_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, const double* A,

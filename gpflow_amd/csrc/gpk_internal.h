@@ -10,11 +10,30 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 #include <stdio.h>
 #include <stdlib.h>
+
+// Tunables.  The PRODUCT build (libgpk.so) has none at run time: every GPK_TUNE is its compile-time default and the
+// library never reads the environment.  Only the A/B build (`make exp` -> libgpk_exp.so, -DGPK_EXPERIMENTAL, used by
+// tools/ab*.sh on the GPU box and never loaded by the package unless GPK_LIBRARY points at it) reads GPK_<NAME> once.
+#ifdef GPK_EXPERIMENTAL
+#define GPK_TUNE(name, def)                                                                      \
+  ([]() -> int {                                                                                 \
+    static const int v__ = getenv("GPK_" #name) ? atoi(getenv("GPK_" #name)) : (int)(def);       \
+    return v__;                                                                                  \
+  }())
+#define GPK_TRACE(...)                                        \
+  do {                                                        \
+    if (GPK_TUNE(DEBUG, 0)) fprintf(stderr, "[gpk] " __VA_ARGS__); \
+  } while (0)
+#else
+#define GPK_TUNE(name, def) ((int)(def))
+#define GPK_TRACE(...) do { } while (0)
+#endif
+
 #define GPK_HIP(call)                                                                                   \
   do {                                                                                                  \
     hipError_t e__ = (call);                                                                            \
     if (e__ != hipSuccess) {                                                                            \
-      if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] %s:%d: %s -> %d\n", __FILE__, __LINE__, #call, (int)e__); \
+      GPK_TRACE("%s:%d: %s -> %d\n", __FILE__, __LINE__, #call, (int)e__);                              \
       return (int)e__;                                                                                  \
     }                                                                                                   \
   } while (0)
@@ -22,7 +41,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
   do {                                                                                                  \
     hipError_t e__ = hipGetLastError();                                                                 \
     if (e__ != hipSuccess) {                                                                            \
-      if (getenv("GPK_DEBUG")) fprintf(stderr, "[gpk] %s:%d: kernel launch -> %d\n", __FILE__, __LINE__, (int)e__); \
+      GPK_TRACE("%s:%d: kernel launch -> %d\n", __FILE__, __LINE__, (int)e__);                          \
       return (int)e__;                                                                                  \
     }                                                                                                   \
   } while (0)
@@ -52,25 +71,24 @@ struct GemmArgs {
   int stagger_ticks;  // fast path only: start delay (100 MHz ticks) of the second resident workgroup set, 0 = none
   int no_small;     // never take the one-shot LDS-DMA latency kernel (150 KB of LDS per workgroup: needs a CU free of GEMM workgroups)
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
+  // Ticketed launch (fast path, batch 1): workgroups draw tiles from per-XCD counters instead of owning a fixed tile
+  // list, and a workgroup that finds itself on a compute unit listed in `resv` takes none and exits -- the SOFTWARE
+  // CU reservation that keeps the latency chain of a factorisation (leaf / panel solve / strip) dispatchable while a
+  // bulk GEMM owns the rest of the chip.  ctr: 16 zeroed device words owned by the launch stream (self-resetting).
+  unsigned* ctr;
+  const unsigned char* resv;   // [GPK_CU_KEYS] 1 = reserved, or NULL
 };
+#define GPK_CU_KEYS 4096   // key = XCC_ID << 8 | HW_ID[15:8] (SE_ID, SH_ID, CU_ID)
+// census of the physical compute units (gemm.hip): fills keys[0..n) with the key of the CU each of n workgroups ran on
+int gpk_cu_census(hipStream_t s, unsigned* keys_dev, int n);
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
-int gpk_gemm_tiles_n(int n);
-int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg): graph capture is bypassed  // number of column tiles the launcher will use for n columns
+int gpk_gemm_tiles_n(int n);   // number of column tiles the launcher will use for n columns
+int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg)
 
 // ---- leaf (leaf.hip): NB x NB Cholesky + inverse of the diagonal block --------------------------
 // A: pointer to the diagonal block (row-major, lda); nb <= NB valid rows/cols.
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
                     long strideInv, int* info, int col0, int batch, int already_factored);
-
-// persistent chain kernel (leaf.hip): whole latency chain of an n <= 2048 factorisation in one launch
-size_t gpk_chain_flag_bytes();
-int gpk_chain_flag_index(int which);  // 0: PP (panels published), 1: RB (rest-updates done), 2: ERR
-int gpk_launch_chain(hipStream_t s_leaf, hipStream_t s_workers, double* A, long lda, int n, double* invd, int* info,
-                     int* flags);
-
-// ---- trsm.hip: Eout[:, 0:128 nb] = Ein[:, 0:128 nb] L_gg^-T in one launch (16 rows per workgroup) ----------
-int gpk_launch_trsm_group(hipStream_t s, const double* Ein, long ldein, double* Eout, long ldeout, int rows,
-                          const double* Lgg, long lda, const double* invg, int nb);
 
 // ---- rbf.hip ---------------------------------------------------------------------------------
 // (entry point gpk_kernel_matrix is defined there)

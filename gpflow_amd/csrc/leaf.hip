@@ -278,7 +278,7 @@ __device__ __forceinline__ d4 inv_level3_X(const double* __restrict__ S, int a, 
 }
 
 // The leaf as a device function (one workgroup of NT threads, LDS block S of LEAF_LDS bytes): used by the
-// stand-alone kernel below and by the persistent chain kernel (chain.hip part of this file).
+// stand-alone kernel below.
 template <bool FACTORED>
 __device__ __forceinline__ void leaf_body(double* __restrict__ S, double* __restrict__ A, long lda, int nb,
                                           double* __restrict__ inv, int* __restrict__ info, int col0,
@@ -480,259 +480,25 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
 }
 
 
-// =====================================================================================================================
-// Persistent chain kernel: the WHOLE latency chain of an SVGP-sized factorisation (n <= 2048, n % 128 == 0) in one
-// launch.  With one kernel per step (leaf -> panel solve -> strip) the chain paid, per 128 columns, two kernel
-// boundaries, the dispatch of a one-workgroup kernel that needs an entire CU's LDS (and therefore queued behind
-// any bulk GEMM occupying the chip), and host issue time.  Here workgroup 0 keeps a CU for all the leaves and
-// workgroup w >= 1 OWNS the 16-row block  rb = 8 + (w - 1)  for the whole factorisation:
-//   WG 0      for p:  wait DG[p] == 8 (its diagonal block has its last update)  ->  leaf(p)  ->  F = p + 1
-//   WG w      for p:  wait F > p        ->  X = A[rows, panel p] inv_p^T                (panel solve, written in place)
-//                     publish PS[p]++ (last arriver: PP = p + 1, which the host-enqueued bulk streams wait on with
-//                     hipStreamWaitValue32), and XT[p]++ if the rows lie in block p + 1
-//                     wait XT[p] == 8, RB >= p  ->  A[rows, panel p+1] -= X X_top^T           (strip)
-//                     rows in block p + 1: DG[p+1]++ and retire
-// The rest of each trailing update (columns from panel p + 2 on) stays a bulk GEMM on the bulk stream, ordered by
-// PP (wait) and RB (hipStreamWriteValue32 after it).  Every hand-off follows the producer-release / flag /
-// consumer-acquire recipe (plain stores -> __syncthreads -> lane-0 agent release -> s_waitcnt -> relaxed flag;
-// relaxed poll -> agent acquire -> __syncthreads -> plain loads); every spin is bounded and sets CF_ERR.
-// Dependencies only ever point to work that is already resident or needs no CU (stream waits), so a partially
-// resident grid cannot deadlock; the grid (<= 121 workgroups) fits the chip beside the bulk GEMMs.
-enum { CF_F = 0, CF_ERR = 1, CF_RB = 32, CF_PP = 64, CF_PS = 96, CF_XT = 128, CF_DG = 160, CF_COUNT = 192 };
-constexpr int LDW = NB + 2;
-constexpr long CHAIN_SPIN_LIMIT = 1500L * 1000;  // ~1-2 s; a healthy wait is microseconds
-
-__device__ __forceinline__ bool chain_wait_ge(int* __restrict__ flags, int idx, int v, bool system_scope) {
-  __shared__ int st;
-  if (threadIdx.x == 0) {
-    int ok = 1;
-    long it = 0;
-    for (;;) {
-      const int cur = system_scope ? __hip_atomic_load(&flags[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                   : __hip_atomic_load(&flags[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (cur >= v) break;
-      __builtin_amdgcn_s_sleep(2);
-      if ((++it & 255) == 0) {
-        if (__hip_atomic_load(&flags[CF_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
-        if (it > CHAIN_SPIN_LIMIT) {
-          __hip_atomic_store(&flags[CF_ERR], 1 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = 0;
-          break;
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    st = ok;
-  }
-  __syncthreads();
-  const bool r = st != 0;
-  __syncthreads();  // st may be rewritten by the next wait
-  return r;
-}
-
-// all threads' earlier global stores become visible at agent scope, then flags[idx] += 1; returns the old value (lane 0)
-__device__ __forceinline__ int chain_publish_add(int* __restrict__ flags, int idx) {
-  __syncthreads();
-  int old = -1;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    old = __hip_atomic_fetch_add(&flags[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return old;
-}
-
-// stage `nrows` rows of 128 doubles (global row stride ld) into LDS rows of LDW doubles by LDS-DMA, 8 waves
-__device__ __forceinline__ void chain_stage_rows(double* __restrict__ dst, const double* __restrict__ src, long ld,
-                                                 int nrows, int wave, int lane) {
-  for (int q = wave; q < nrows; q += NW) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)q * ld + 2 * lane),
-                                     (__attribute__((address_space(3))) void*)(dst + q * LDW), 16, 0, 0);
-  }
-}
-
-// B operands are staged in K chunks of 32 so that a row-block owner needs only 82 KB of LDS and shares its CU with
-// one workgroup of the bulk GEMM (73.7 KB) instead of holding the CU for the whole factorisation.  A chunk is
-// [128 rows][32 doubles] UNPADDED (one LDS-DMA instruction = 1 KiB = 4 rows); bank conflicts are avoided by an XOR
-// swizzle applied on the global side: 16-byte slot c of row n holds source slot c ^ (n & 15).
-constexpr int CK = 32;
-constexpr int CHUNK = NB * CK;  // doubles
-constexpr size_t WORKER_LDS = ((size_t)2 * CHUNK + (size_t)SB * LDW) * sizeof(double);  // 82,176 B
-
-__device__ __forceinline__ void chain_stage_chunk(double* __restrict__ Bc, const double* __restrict__ src, long ld, int kc,
-                                                  int wave, int lane) {
-  for (int q = wave; q < NB / 4; q += NW) {
-    const int row = 4 * q + (lane >> 4), cs = (lane & 15) ^ (row & 15);
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + (long)row * ld + kc * CK + 2 * cs),
-        (__attribute__((address_space(3))) void*)(Bc + q * (4 * CK)), 16, 0, 0);
-  }
-}
-
-// this wave's 16 x 16 tile of  Arows[16 x 128] (LDS, row stride LDW) * B[n = 16 wave + r][128]^T, B streamed from
-// global (row stride ldb) through the two LDS chunk buffers in two rounds of two chunks
-template <bool NEG>
-__device__ __forceinline__ d4 chain_product(const double* __restrict__ As, double* __restrict__ Bc,
-                                            const double* __restrict__ Bsrc, long ldb, int wave, int lane, d4 acc) {
-  const int r = lane & 15, kq = lane >> 4;
-  const int row = 16 * wave + r;
-  d4 acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    if (round) __syncthreads();  // every wave is done with both chunk buffers
-    chain_stage_chunk(Bc, Bsrc, ldb, 2 * round, wave, lane);
-    chain_stage_chunk(Bc + CHUNK, Bsrc, ldb, 2 * round + 1, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const double* bc = Bc + h * CHUNK + row * CK;
-      const double* ap = As + r * LDW + (2 * round + h) * CK + kq;
-#pragma unroll
-      for (int kk = 0; kk < 8; kk += 2) {
-        const int k0 = 4 * kk + kq, k1 = k0 + 4;
-        const double a0 = ap[4 * kk], a1 = ap[4 * kk + 4];
-        const double b0 = bc[(((k0 >> 1) ^ (row & 15)) << 1) + (k0 & 1)];
-        const double b1 = bc[(((k1 >> 1) ^ (row & 15)) << 1) + (k1 & 1)];
-        acc = mfma4(NEG ? -a0 : a0, b0, acc);
-        acc2 = mfma4(NEG ? -a1 : a1, b1, acc2);
-      }
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
-  return acc;
-}
-
-// ---- workgroup 0's role: all the leaves (its own launch: it needs the leaf's 150 KB of LDS) ---------------------------
-__global__ __launch_bounds__(NT) void chain_leaf_kernel(double* __restrict__ A, long lda, int n, double* __restrict__ invd,
-                                                         int* __restrict__ info, int* __restrict__ flags) {
-  extern __shared__ __attribute__((aligned(16))) double S[];
-  const int tid = threadIdx.x;
-  const int np = n / NB;
-  for (int p = 0; p < np; ++p) {
-    if (p > 0) {
-      if (!chain_wait_ge(flags, CF_DG + p, 8, false)) return;          // strip(p-1) reached the diagonal block
-      if (p >= 2 && !chain_wait_ge(flags, CF_RB, p - 1, true)) return;  // rest-updates up to panel p-2 are in
-    }
-    leaf_body<false>(S, A + (long)p * NB * (lda + 1), lda, NB, invd + (long)p * NB * NB, info, p * NB, nullptr);
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&flags[CF_F], p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (p == np - 1) __hip_atomic_store(&flags[CF_PP], np, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __syncthreads();
-  }
-}
-
-// ---- row-block owners (blockIdx.x = w - 1) --------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void chain_worker_kernel(double* __restrict__ A, long lda, int n,
-                                                           const double* __restrict__ invd, int* __restrict__ flags) {
-  extern __shared__ __attribute__((aligned(16))) double S[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int np = n / NB;
-  const int rb = 8 + (int)blockIdx.x;  // 16-row block index
-  const int r0 = rb * SB;
-  if (r0 >= n) return;
-  __builtin_amdgcn_s_setprio(3);  // short bursts of work on a CU shared with a bulk-GEMM workgroup
-  const int pmax = rb / 8 - 1;    // last panel this block takes part in (its rows then join block pmax+1)
-  double* Bc = S;                 // [2][128][32]: chunk buffers
-  double* As = S + 2 * CHUNK;     // [16][LDW]:  my rows of panel p, then X
-  const int c = lane & 15, g = lane >> 4;
-  for (int p = 0; p <= pmax; ++p) {
-    const int cp = p * NB;
-    if (!chain_wait_ge(flags, CF_F, p + 1, false)) return;                 // L_pp and inv_p are published
-    if (p >= 2 && !chain_wait_ge(flags, CF_RB, p - 1, true)) return;       // my panel-p columns carry rest(<= p-2)
-    chain_stage_rows(As, A + (long)r0 * lda + cp, lda, SB, wave, lane);
-    // ---- solve: X = A_rows inv_p^T ---------------------------------------------------------------------------
-    d4 x = chain_product<false>(As, Bc, invd + (long)p * NB * NB, NB, wave, lane, (d4){0.0, 0.0, 0.0, 0.0});
-    __syncthreads();  // every wave has read As
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      As[(g + 4 * e) * LDW + 16 * wave + c] = x[e];
-      A[(long)(r0 + g + 4 * e) * lda + cp + 16 * wave + c] = x[e];
-    }
-    const bool in_next = (rb >= 8 * (p + 1)) && (rb < 8 * (p + 2));  // my rows belong to diagonal block p + 1
-    {
-      const int old = chain_publish_add(flags, CF_PS + p);
-      if (tid == 0) {
-        if (in_next) __hip_atomic_fetch_add(&flags[CF_XT + p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 8 * (np - 1 - p) - 1)  // last row block of panel p: the bulk streams may consume it
-          __hip_atomic_store(&flags[CF_PP], p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-    // ---- strip: A[rows, panel p+1] -= X X_top^T ----------------------------------------------------------------
-    if (!chain_wait_ge(flags, CF_XT + p, 8, false)) return;                // the 8 row blocks of X_top are published
-    if (p >= 1 && !chain_wait_ge(flags, CF_RB, p, true)) return;           // rest(p-1) also updates these columns
-    d4 acc;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = A[(long)(r0 + g + 4 * e) * lda + cp + NB + 16 * wave + c];
-    acc = chain_product<true>(As, Bc, A + (long)(cp + NB) * lda + cp, lda, wave, lane, acc);  // X_top = rows of block p+1
-#pragma unroll
-    for (int e = 0; e < 4; ++e) A[(long)(r0 + g + 4 * e) * lda + cp + NB + 16 * wave + c] = acc[e];
-    if (in_next) {
-      (void)chain_publish_add(flags, CF_DG + p + 1);
-      return;
-    }
-    __syncthreads();  // chunk buffers / As are restaged next
-  }
-}
-
 }  // namespace
-
-size_t gpk_chain_flag_bytes() { return (size_t)CF_COUNT * sizeof(int); }
-int gpk_chain_flag_index(int which) { return which == 0 ? CF_PP : (which == 1 ? CF_RB : CF_ERR); }
-
-// n <= 2048, n % 128 == 0; flags: device ints (gpk_chain_flag_bytes()), zeroed before both launches; the leaf role and the
-// row-block owners are separate launches on separate streams (different LDS footprints), coupled only by the flags
-int gpk_launch_chain(hipStream_t s_leaf, hipStream_t s_workers, double* A, long lda, int n, double* invd, int* info,
-                     int* flags) {
-  if (n <= 0 || (n % NB) != 0 || n > 2048) return GPK_E_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_leaf_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_worker_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WORKER_LDS));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(chain_leaf_kernel, dim3(1), dim3(NT), LEAF_LDS, s_leaf, A, lda, n, invd, info, flags);
-  GPK_LAUNCH_CHECK();
-  const int nw = n / SB - 8;
-  if (nw > 0) {
-    hipLaunchKernelGGL(chain_worker_kernel, dim3((unsigned)nw), dim3(NT), WORKER_LDS, s_workers, A, lda, n, invd, flags);
-    GPK_LAUNCH_CHECK();
-  }
-  return 0;
-}
-
-namespace {
-}  // namespace
-
-static long long* g_leaf_dbg = nullptr;
-extern "C" void gpk_debug_set_leaf_timing(long long* dev_buf) { g_leaf_dbg = dev_buf; }
 
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
                     long strideInv, int* info, int col0, int batch, int already_factored) {
   if (nb <= 0 || nb > NB) return GPK_E_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
-    attr_set = true;
-  }
+  // (function-local statics: initialised once, thread-safe)
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_kernel<true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_kernel<false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+  GPK_HIP(attr1);
+  GPK_HIP(attr0);
   dim3 grid((unsigned)(batch > 0 ? batch : 1));
   if (already_factored)
     hipLaunchKernelGGL((leaf_kernel<true>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd,
-                       strideInv, info, col0, g_leaf_dbg);
+                       strideInv, info, col0, nullptr);
   else
     hipLaunchKernelGGL((leaf_kernel<false>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd,
-                       strideInv, info, col0, g_leaf_dbg);
+                       strideInv, info, col0, nullptr);
   GPK_LAUNCH_CHECK();
   return 0;
 }

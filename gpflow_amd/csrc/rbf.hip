@@ -24,7 +24,8 @@ struct RbfArgs {
   double variance, diag_add;
   int family, sym, lower_only, ard;
   double ls[GPK_MAX_D];
-  const double* G; long ldg;  // HAD instantiation only: the output is G .* k(X1, X2)  (kernel backward, gradients.py)
+  const double* G; long ldg;  // COMB instantiations only: the output is G .* k(X1, X2) (1) or G + k(X1, X2) (2)
+  int comb_diag;              // COMB: X2 is X1 and diag_add goes onto the diagonal of the combined result
 };
 
 constexpr int T = 64;
@@ -45,7 +46,10 @@ __device__ __forceinline__ double kern_eval(double r2, double variance) {
 // MIRROR (symmetric full build): only tiles on or below the diagonal are computed; each is also written
 // transposed to its mirror position (K(X,X) from the expansion formula is bitwise symmetric: products and the
 // two-term sums commute), which halves the fp64 exp/FMA work of what is otherwise a store-bound kernel.
-template <int FAMILY, bool HAD = false>
+// COMB = 0: plain build.  COMB = 1 / 2: out = G .* k / G + k, the other factor / term G read from memory (may alias
+// the output: every element is read and written by the same thread) -- kernel products and sums (kernels/base.py:216-
+// 329) and the elementwise factor of the kernel backward, without materialising the second matrix.
+template <int FAMILY, int COMB = 0>
 __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int d = p.d;
@@ -110,7 +114,11 @@ __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
       const double r2 = (-2.0 * dot[i][j]) + (ni + nr2[tx * 4 + j]);
       double k = kern_eval<FAMILY>(r2, p.variance);
       if (p.sym && gr == gc) k += p.diag_add;
-      if constexpr (HAD) k *= (gr < p.n1 && gc < p.n2) ? p.G[(long)gr * p.ldg + gc] : 0.0;
+      if constexpr (COMB != 0) {
+        const double g = (gr < p.n1 && gc < p.n2) ? p.G[(long)gr * p.ldg + gc] : 0.0;
+        k = (COMB == 1) ? k * g : k + g;
+        if (p.comb_diag && gr == gc) k += p.diag_add;
+      }
       v[i][j] = k;
     }
   }
@@ -150,6 +158,30 @@ __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
 
 }  // namespace
 
+namespace {
+template <int COMB>
+int launch_combine(hipStream_t st, int family, const RbfArgs& a, dim3 grid, size_t lds) {
+  static const int max_lds = (int)(((size_t)2 * GPK_MAX_D * T + 2 * T) * sizeof(double));
+  static const hipError_t at0 = hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_SE, COMB>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  static const hipError_t at1 = hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN12, COMB>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  static const hipError_t at2 = hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN32, COMB>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  static const hipError_t at3 = hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN52, COMB>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  GPK_HIP(at0); GPK_HIP(at1); GPK_HIP(at2); GPK_HIP(at3);
+  switch (family) {
+    case GPK_KERN_SE: hipLaunchKernelGGL((rbf_kernel<GPK_KERN_SE, COMB>), grid, dim3(256), lds, st, a); break;
+    case GPK_KERN_MATERN12: hipLaunchKernelGGL((rbf_kernel<GPK_KERN_MATERN12, COMB>), grid, dim3(256), lds, st, a); break;
+    case GPK_KERN_MATERN32: hipLaunchKernelGGL((rbf_kernel<GPK_KERN_MATERN32, COMB>), grid, dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL((rbf_kernel<GPK_KERN_MATERN52, COMB>), grid, dim3(256), lds, st, a); break;
+  }
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
 extern "C" int gpk_kernel_matrix(void* stream, int family, const double* X1, int n1, long ldx1,
                                  const double* X2, int n2, long ldx2, int d, const double* ls_host,
                                  int ard, double variance, double diag_add, int lower_only,
@@ -165,60 +197,44 @@ extern "C" int gpk_kernel_matrix(void* stream, int family, const double* X1, int
   for (int i = 0; i < (ard ? d : 1); ++i) a.ls[i] = ls_host[i];
   if (a.n1 == 0 || a.n2 == 0) return 0;
   const size_t lds = ((size_t)2 * d * T + 2 * T) * sizeof(double);
-  static bool attr_set = false;
-  const int max_lds = (int)(((size_t)2 * GPK_MAX_D * T + 2 * T) * sizeof(double));
-  if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_SE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN12>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN32>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_MATERN52>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    attr_set = true;
-  }
   dim3 grid((unsigned)gpk_cdiv(a.n2, T), (unsigned)gpk_cdiv(a.n1, T));
-  hipStream_t st = (hipStream_t)stream;
-  switch (family) {
-    case GPK_KERN_SE: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_SE>, grid, dim3(256), lds, st, a); break;
-    case GPK_KERN_MATERN12: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_MATERN12>, grid, dim3(256), lds, st, a); break;
-    case GPK_KERN_MATERN32: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_MATERN32>, grid, dim3(256), lds, st, a); break;
-    default: hipLaunchKernelGGL(rbf_kernel<GPK_KERN_MATERN52>, grid, dim3(256), lds, st, a); break;
-  }
-  GPK_LAUNCH_CHECK();
-  return 0;
+  return launch_combine<0>((hipStream_t)stream, family, a, grid, lds);
 }
 
-// out = G .* k(X1, X2): the elementwise factor every kernel-parameter gradient starts from
-// (dF/dtheta = sum_ij Kbar_ij dK_ij/dtheta and dK/dtheta = K .* (...) for the stationary families;
-// SquaredExponential only for now).  k is recomputed from the inputs, not read, so the pass costs one
-// read of G and one write.  No symmetric shortcut, no diagonal term (jitter / noise do not depend on theta).
-extern "C" int gpk_kernel_matrix_hadamard(void* stream, int family, const double* X1, int n1, long ldx1,
-                                          const double* X2, int n2, long ldx2, int d, const double* ls_host,
-                                          int ard, double variance, const double* G, long ldg, double* out,
-                                          long ldo) {
-  if (!X1 || !X2 || !G || !out || !ls_host || n1 < 0 || n2 < 0 || d <= 0 || d > GPK_MAX_D) return GPK_E_ARG;
-  if (family != GPK_KERN_SE) return GPK_E_UNSUPPORTED;
+// out = G .* k(X1, X2) (op 1) or G + k(X1, X2) (op 2), k recomputed from the inputs, not read: one read of G and one
+// write.  Used for (a) the elementwise factor every kernel-parameter gradient starts from (dF/dtheta = sum_ij Kbar_ij
+// dK_ij/dtheta and dK/dtheta = K .* (...) for the stationary families) and (b) Product / Sum kernels
+// (gpflow/kernels/base.py:216-220, 283-329): the second factor / term is folded into the first matrix in place.
+// X2 == NULL means K(X1, X1); diag_add is then added to the diagonal of the COMBINED result.  No symmetric shortcut.
+
+extern "C" int gpk_kernel_matrix_combine(void* stream, int family, int op, const double* X1, int n1, long ldx1,
+                                         const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
+                                         double variance, double diag_add, const double* G, long ldg, double* out,
+                                         long ldo) {
+  if (!X1 || !G || !out || !ls_host || n1 < 0 || n2 < 0 || d <= 0 || d > GPK_MAX_D) return GPK_E_ARG;
+  if (family < GPK_KERN_SE || family > GPK_KERN_MATERN52) return GPK_E_UNSUPPORTED;
+  if (op != 1 && op != 2) return GPK_E_ARG;
   RbfArgs a{};
   a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1;
   a.sym = 0;
-  a.X2 = X2; a.ldx2 = ldx2; a.n2 = n2;
-  a.d = d; a.K = out; a.ldk = ldo; a.variance = variance; a.diag_add = 0.0;
+  a.comb_diag = (X2 == nullptr);
+  a.X2 = X2 ? X2 : X1; a.ldx2 = X2 ? ldx2 : ldx1; a.n2 = X2 ? n2 : n1;
+  a.d = d; a.K = out; a.ldk = ldo; a.variance = variance; a.diag_add = a.comb_diag ? diag_add : 0.0;
   a.family = family; a.lower_only = 0; a.ard = ard;
   a.G = G; a.ldg = ldg;
   for (int i = 0; i < (ard ? d : 1); ++i) a.ls[i] = ls_host[i];
   if (a.n1 == 0 || a.n2 == 0) return 0;
   const size_t lds = ((size_t)2 * d * T + 2 * T) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kernel<GPK_KERN_SE, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(((size_t)2 * GPK_MAX_D * T + 2 * T) * sizeof(double))));
-    attr_set = true;
-  }
   dim3 grid((unsigned)gpk_cdiv(a.n2, T), (unsigned)gpk_cdiv(a.n1, T));
-  hipLaunchKernelGGL((rbf_kernel<GPK_KERN_SE, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
-  GPK_LAUNCH_CHECK();
-  return 0;
+  return op == 1 ? launch_combine<1>((hipStream_t)stream, family, a, grid, lds)
+                 : launch_combine<2>((hipStream_t)stream, family, a, grid, lds);
+}
+
+extern "C" int gpk_kernel_matrix_hadamard(void* stream, int family, const double* X1, int n1, long ldx1,
+                                          const double* X2, int n2, long ldx2, int d, const double* ls_host,
+                                          int ard, double variance, const double* G, long ldg, double* out,
+                                          long ldo) {
+  if (!X2) return GPK_E_ARG;
+  return gpk_kernel_matrix_combine(stream, family, 1, X1, n1, ldx1, X2, n2, ldx2, d, ls_host, ard, variance, 0.0, G, ldg,
+                                   out, ldo);
 }

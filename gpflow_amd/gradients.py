@@ -23,7 +23,6 @@ lengthscales, noise variance, Z, q_mu, q_sqrt); `SVGP.elbo_and_grad` chains them
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, Tuple
 
 import numpy as np
@@ -46,7 +45,6 @@ def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, 
     tiles = tm * tn
     if c_lower:   # tiles on or below the diagonal
         tiles = sum(min(tn, i + 1) for i in range(tm))
-    target_wgs = int(os.environ.get("GPK_SPLITK_TARGET", target_wgs))
     chunks = 1
     while chunks * 2 * tiles <= target_wgs and k % (chunks * 2) == 0 and (k // (chunks * 2)) % 16 == 0 \
             and k // (chunks * 2) >= 256:
@@ -284,9 +282,9 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
         backward  A2t_bar = r q_mu^T + 2c sum_p W_p Lq_p^T,   At_bar = -2cP At + A2t_bar Linv^T,
                   Linv_bar = tril(At^T A2t_bar) - k (alpha q_mu^T + sum_p V_p Lq_p^T)      (alpha = Linv q_mu, V_p = Linv Lq_p)
                   Lm_bar   = -tril(Kfu_bar^T At) - tril(Linv^T Linv_bar Linv^T) - k P diag(1 / Lm)
-    and then the same Cholesky / kernel adjoints as the whitened path.  VALIDATED ON THE EMULATED PRIMITIVES ONLY
-    (tests/test_gradients_cpu.py) -- written after this round's GPU budget was spent; it composes primitives whose
-    device behaviour the whitened path already exercises."""
+    and then the same Cholesky / kernel adjoints as the whitened path.  Reached through `SVGP.elbo_and_grad` /
+    `SVGPTrainer` when `whiten=False`; parity vs the autograd oracle on the emulated primitives
+    (tests/test_gradients_cpu.py) and on the GPU (tests/test_gpu_gradients.py)."""
     M, D = Z.shape
     B = Xb.shape[0]
     P = q_mu.shape[1]
@@ -335,7 +333,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     g_qmu = splitk_gemm_nt(A2, r.t().contiguous()) - k * Kinv_qmu_t.t()
     g_qs = torch.stack([torch.tril(splitk_gemm_nt(A2, ops.transpose(W[p]), c_lower=True)) for p in range(P)]) * (2.0 * c)
     for p in range(P):
-        KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p]))                               # Linv^T V_p = Kuu^-1 Lq_p
+        KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p], mode=1), b_tri=1)              # Linv^T V_p = Kuu^-1 Lq_p (V_p lower)
         g_qs[p] -= k * torch.tril(KinvLq)
     g_qs.diagonal(dim1=1, dim2=2).add_(k / Lq.diagonal(dim1=1, dim2=2))
     # Linv_bar (lower) and its pull-back to Lm
@@ -343,7 +341,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     Linv_bar -= k * torch.tril(ops.gemm_nt(alphat.t().contiguous(), q_mu))              # alpha q_mu^T
     for p in range(P):
         Linv_bar -= k * torch.tril(ops.gemm_nt(V[p], Lq[p], b_tri=2))                   # V_p Lq_p^T
-    X1 = ops.gemm_nt(LinvT, ops.transpose(Linv_bar))                                    # Linv^T Linv_bar
+    X1 = ops.gemm_nt(LinvT, ops.transpose(Linv_bar, mode=1), b_tri=1)                   # Linv^T Linv_bar (Linv_bar lower)
     X2 = ops.gemm_nt(X1, Linv, b_tri=2)                                                 # (.) Linv^T
     Lbar = -torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True)) - torch.tril(X2)
     Lbar.diagonal().sub_(k * P / L.diagonal())

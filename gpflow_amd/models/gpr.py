@@ -68,7 +68,7 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
         k, lik, mf = self.kernel, self.likelihood, self.mean_function
         c = mf.constant_value()
         if not isinstance(k, SquaredExponential) or c is None or lik.variance is None \
-                or k.active_dims != slice(None, None, None):
+                or not k.has_default_active_dims:
             raise NotImplementedError("gradients: SquaredExponential kernel (no active_dims), constant mean, Gaussian "
                                       "likelihood with a variance parameter")
         X, Y = self.data

@@ -167,7 +167,7 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         if self.sharded:
             raise NotImplementedError("gradients of a row-sharded SGPR")
         kw, X, Z, c, s2 = self._config()
-        if not isinstance(self.kernel, SquaredExponential) or self.kernel.active_dims != slice(None, None, None):
+        if not isinstance(self.kernel, SquaredExponential) or not self.kernel.has_default_active_dims:
             raise NotImplementedError("gradients: SquaredExponential kernel without active_dims")
         F, g, info = gradients.sgpr_elbo_and_grad(Z, X, self.data[1], variance=kw["variance"], lengthscales=kw["lengthscales"],
                                                   noise_variance=s2, jitter=config.default_jitter(), mean_const=c)

@@ -114,7 +114,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
 
     def gradient_config(self):
         """(SquaredExponential kernel, InducingPoints, mean constant) if the hand-written reverse pass covers this model:
-        whitened, Gaussian likelihood with a variance parameter, full q_sqrt, constant mean, and ONE SquaredExponential
+        whitened or not, Gaussian likelihood with a variance parameter, full q_sqrt, constant mean, and ONE SquaredExponential
         kernel (no active_dims) over InducingPoints -- either directly or as SharedIndependent +
         SharedIndependentInducingVariables (BASELINE config C5: P latents share Kuu / Kuf).  Raises NotImplementedError."""
         from ..kernels.stationaries import SquaredExponential
@@ -122,10 +122,10 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         if isinstance(k, SharedIndependent) and isinstance(iv, SharedIndependentInducingVariables):
             k, iv = k.kernel, iv.inducing_variable
         c = self.mean_function.constant_value()
-        if not (self.whiten and isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
+        if not (isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
                 and isinstance(iv, InducingPoints) and c is not None and self.q_sqrt.numpy().ndim == 3
-                and k.active_dims == slice(None, None, None)):
-            raise NotImplementedError("gradients: whitened SVGP, SquaredExponential (no active_dims; optionally shared by "
+                and k.has_default_active_dims):
+            raise NotImplementedError("gradients: SVGP with a SquaredExponential kernel (no active_dims; optionally shared by "
                                       "independent latents), Gaussian likelihood, InducingPoints, full q_sqrt, constant mean")
         return k, iv, float(c)
 
@@ -142,7 +142,8 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
         _, var, ls = k.hyper()
-        F, g, info = gradients.svgp_elbo_and_grad(iv.Z.device_value(), X, Y, self.q_mu.device_value(),
+        fn = gradients.svgp_elbo_and_grad if self.whiten else gradients.svgp_elbo_and_grad_unwhitened
+        F, g, info = fn(iv.Z.device_value(), X, Y, self.q_mu.device_value(),
                                                   self.q_sqrt.device_value(), variance=var, lengthscales=ls,
                                                   noise_variance=lik.noise_variance(), jitter=config.default_jitter(),
                                                   scale=scale, mean_const=float(c))

@@ -128,6 +128,37 @@ def kernel_matrix_hadamard(X1: torch.Tensor, X2: torch.Tensor, G: torch.Tensor, 
     return out
 
 
+def kernel_matrix_combine(X1: torch.Tensor, X2: Optional[torch.Tensor], G: torch.Tensor, *, op: str, variance: float,
+                          lengthscales, family: str = "SquaredExponential", diag_add: float = 0.0,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = G .* K(X1, X2) (op "mul") or G + K(X1, X2) (op "add"), K recomputed on the fly; `out` may be G itself.
+    X2 None: K(X1, X1) and `diag_add` goes onto the diagonal of the combined result."""
+    lib = _lib.load()
+    _chk(X1, "X1", 2)
+    _chk(G, "G", 2)
+    n1, d = X1.shape
+    if X2 is not None:
+        _chk(X2, "X2", 2)
+        if X2.shape[1] != d:
+            raise ValueError("X1 and X2 must have the same number of columns")
+    n2 = X2.shape[0] if X2 is not None else n1
+    if tuple(G.shape) != (n1, n2):
+        raise ValueError("inconsistent shapes")
+    if d < 1 or d > MAX_D:
+        raise ValueError(f"input dimension {d} outside [1, {MAX_D}]")
+    if out is None:
+        out = torch.empty((n1, n2), dtype=torch.float64, device=X1.device)
+    _chk(out, "out", 2)
+    ls, ard = _ls_host(lengthscales, d)
+    rc = lib.gpk_kernel_matrix_combine(_stream(), KERNEL_FAMILIES[family], {"mul": 1, "add": 2}[op], X1.data_ptr(), n1,
+                                       _rowmajor(X1, "X1"), X2.data_ptr() if X2 is not None else None, n2,
+                                       _rowmajor(X2, "X2") if X2 is not None else 0, d, ls, ard, float(variance),
+                                       float(diag_add), G.data_ptr(), _rowmajor(G, "G"), out.data_ptr(),
+                                       _rowmajor(out, "out"))
+    _lib.check(rc, "gpk_kernel_matrix_combine")
+    return out
+
+
 def invd_alloc(n: int, batch: int = 1) -> torch.Tensor:
     lib = _lib.load()
     return torch.empty(int(lib.gpk_invd_elems(n, batch)), dtype=torch.float64, device=device())

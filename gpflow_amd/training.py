@@ -1,4 +1,4 @@
-"""Device-resident training loop for the whitened SVGP (SquaredExponential kernel, Gaussian likelihood) -- the caller
+"""Device-resident training loop for the SVGP, whitened or not (SquaredExponential kernel, Gaussian likelihood) -- the caller
 of the hot path that SURVEY 8f row 1 names: the Adam loop of `gps_for_big_data.pct.py:207-228`
 (`tf.optimizers.Adam().minimize(model.training_loss_closure(iter), model.trainable_variables)`).
 
@@ -45,8 +45,9 @@ class _Adam:
 
 
 class SVGPTrainer:
-    """Adam on -ELBO for `model` (SVGP: whitened, full q_sqrt, SquaredExponential kernel, Gaussian likelihood with a
-    constant variance, InducingPoints, constant or zero mean).  Honours `Parameter.trainable`.
+    """Adam on -ELBO for `model` (SVGP: whitened or un-whitened, full q_sqrt, SquaredExponential kernel, Gaussian likelihood with a
+    constant variance, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
+    `Constant.c`).  A step whose Kuu factorisation fails raises and leaves variables and Adam moments untouched.
 
         trainer = SVGPTrainer(model, learning_rate=1e-3)
         for Xb, Yb in batches:            # device or host arrays; with torch.distributed initialised each rank passes
@@ -70,12 +71,21 @@ class SVGPTrainer:
         self.opt = _Adam(learning_rate, beta_1, beta_2, epsilon)
         # host side: unconstrained scalars (their constrained values are host arguments of the C-ABI)
         self.host = {"variance": k.variance, "lengthscales": k.lengthscales, "noise_variance": lik.variance}
+        from .mean_functions import Constant
+        mf = model.mean_function
+        if isinstance(mf, Constant):
+            # Constant.c is a trainable Parameter like any other (gpflow/functions.py:173-192): it joins the host set
+            if mf.c.prior is not None:
+                raise NotImplementedError("parameter priors are not part of the trainer's objective")
+            if np.size(mf.c.numpy()) != 1:
+                raise NotImplementedError("the reverse pass covers a scalar Constant mean")
+            self.host["mean_const"] = mf.c
         self.u = {n: np.array(p.unconstrained_variable, dtype=np.float64, copy=True) for n, p in self.host.items()}
         # device side (identity / fill-triangular transforms: the constrained array IS the variable)
         self.dev = {"Z": ops.to_device(iv.Z.numpy()).clone(), "q_mu": ops.to_device(model.q_mu.numpy()).clone(),
                     "q_sqrt": ops.to_device(model.q_sqrt.numpy()).clone()}
         self.dev_params = {"Z": iv.Z, "q_mu": model.q_mu, "q_sqrt": model.q_sqrt}
-        self.last_info: Optional[torch.Tensor] = None
+        self.last_info: Optional[int] = None   # factorisation status of the last step (0 = ok), checked every step
 
     def constrained(self, name: str) -> np.ndarray:
         return np.asarray(self.host[name].transform.forward(self.u[name]), dtype=np.float64)
@@ -91,12 +101,30 @@ class SVGPTrainer:
         var = float(self.constrained("variance"))
         ls = self.constrained("lengthscales")
         noise = float(self.constrained("noise_variance"))
-        F, g, info = gradients.svgp_elbo_and_grad(
+        if "mean_const" in self.host:
+            self.mean_const = float(np.ravel(self.constrained("mean_const"))[0])
+        fn = gradients.svgp_elbo_and_grad if self.model.whiten else gradients.svgp_elbo_and_grad_unwhitened
+        F, g, info = fn(
             self.dev["Z"], Xb, Yb, self.dev["q_mu"], self.dev["q_sqrt"], variance=var, lengthscales=ls,
             noise_variance=noise, jitter=config.default_jitter(), scale=scale, mean_const=self.mean_const,
             kl_weight=1.0 / world)
+        g = dict(g)
+        g["_status"] = info.to(torch.float64).reshape(-1)[:1]   # rides in the packed all-reduce: > 0 iff ANY rank failed
         F, g = distributed.all_reduce_grads(F, g, self.group)
-        self.last_info = info
+        # The factorisation status decides whether this step may be applied at all: after a failed Cholesky of Kuu the
+        # gradients are garbage, and applying them would poison the variables AND the Adam moments for good (the
+        # reference raises from tf.linalg.cholesky at this point).  It rides in the step's one read-back and, with
+        # several ranks, in the packed gradient all-reduce (summed), so every rank takes the same decision.
+        status = g.pop("_status")
+        small = torch.cat([g["variance"].reshape(-1), g["lengthscales"].reshape(-1), g["noise_variance"].reshape(-1),
+                           g["mean_const"].reshape(-1)[:1], status])
+        small = small.cpu().numpy()                              # the step's one read-back: 4 + |lengthscales| doubles
+        self.last_info = int(small[-1])
+        if self.last_info != 0:
+            from ._lib import GpkError
+            raise GpkError("Cholesky decomposition of Kuu was not successful" +
+                           (f" (non-positive pivot at column {self.last_info - 1})" if world == 1 else
+                            " on at least one rank") + "; the step was NOT applied")
         self.opt.t += 1
         adam_names = ("Z", "q_mu", "q_sqrt")
         if self.natgrad_gamma is not None:
@@ -108,9 +136,8 @@ class SVGPTrainer:
         for name in adam_names:                                  # minimise -F
             if self.dev_params[name].trainable:
                 self.opt.update_device(name, self.dev[name], -g[name])
-        small = torch.cat([g["variance"].reshape(-1), g["lengthscales"].reshape(-1), g["noise_variance"].reshape(-1)])
-        small = small.cpu().numpy()                              # the step's one read-back: 2 + |lengthscales| doubles
-        parts = {"variance": small[0:1], "lengthscales": small[1:-1], "noise_variance": small[-1:]}
+        parts = {"variance": small[0:1], "lengthscales": small[1:-3], "noise_variance": small[-3:-2],
+                 "mean_const": small[-2:-1]}
         for name, p in self.host.items():
             if not p.trainable:
                 continue

@@ -9,14 +9,26 @@
  *   - every matrix pointer is a DEVICE pointer to row-major fp64 (gpflow default_float,
  *     config/__config__.py:99); leading dimensions are in elements;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work,
- *     they never synchronise; scratch comes from the caller's workspace (the only internal state is created
- *     lazily, once per device: the auxiliary streams/events of gpk_potrf and 768 bytes of device sync words);
+ *     they never synchronise; scratch comes from the caller's workspace;
  *   - small hyper-parameter vectors (lengthscales) are HOST pointers, copied into kernel arguments;
  *   - return value: 0 ok, <0 bad argument (GPK_E_*), >0 HIP runtime error code (hipError_t);
  *   - numerical failure (non-positive pivot) is reported LAPACK-style through a device int
  *     `info` (0 = ok, j+1 = first bad pivot column) that the caller reads when it next syncs
  *     (TF raises InvalidArgumentError "Cholesky decomposition was not successful" at the same spot);
- *   - thread-safe per stream; no global mutable state besides a one-time kernel-attribute setup.
+ *
+ * Internal state and threading (the complete list; nothing else in the library is mutable)
+ *   - gpk_potrf with n > 128 (and the two fused drivers, which call it) uses per-device state created lazily on the
+ *     first such call: five internal HIP streams (panel / bulk / bulk-small / bulk-late / extra-rows), a pool of
+ *     timing-disabled events that grows to 2 * panels + 8, a 4 KiB device table of the compute units reserved for the
+ *     latency chain (filled once from a census kernel: THIS FIRST CALL synchronises its panel stream once and
+ *     allocates ~4.2 KiB of device memory) and 64 bytes of self-resetting ticket counters.  Work is forked from and
+ *     joined to the caller's stream with events only.
+ *   - One recursive mutex per device serialises the ENQUEUE section of these calls, so they may be issued from any
+ *     number of host threads and on any caller streams; factorisations of one device share the internal streams and
+ *     therefore execute one after the other on the GPU.
+ *   - Every other entry point is stateless and reentrant (kernel attributes are set through thread-safe function-local
+ *     statics).  The library never reads the environment.
+ *   - gpk_profile_gemm_* is a measurement facility for bench.py: process-global, not thread-safe, off by default.
  */
 #ifndef GPK_H
 #define GPK_H
@@ -55,10 +67,18 @@ int gpk_kernel_matrix(void* stream, int family, const double* X1, int n1, long l
                       const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
                       double variance, double diag_add, int lower_only, double* K, long ldk);
 
-/* out = G .* k(X1, X2) with k recomputed from the inputs (one read of G, one write): the elementwise factor of
- * every kernel-parameter gradient, dF/dtheta = sum_ij Kbar_ij dK_ij/dtheta with dK/dtheta = K .* (...) for the
- * stationary kernels -- the reverse pass of Stationary.K (stationaries.py:103-116, 209-210) that TF autodiff
- * builds for optimizers/scipy.py:322-331.  SquaredExponential only; X2 must be given. */
+/* out = G .* k(X1, X2) (op 1) or G + k(X1, X2) (op 2), k recomputed from the inputs (one read of G, one write; G may
+ * alias out).  Replaces the tf.multiply / tf.add_n reductions of Product / Sum kernels (kernels/base.py:216-220,
+ * 283-329): the second factor / term is folded into the first matrix in place instead of being materialised.
+ * X2 == NULL: K(X1, X1), and diag_add goes onto the diagonal of the COMBINED result (noise / jitter). */
+int gpk_kernel_matrix_combine(void* stream, int family, int op, const double* X1, int n1, long ldx1,
+                              const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
+                              double variance, double diag_add, const double* G, long ldg, double* out, long ldo);
+
+/* = gpk_kernel_matrix_combine(op 1) with X2 given: the elementwise factor of every kernel-parameter gradient,
+ * dF/dtheta = sum_ij Kbar_ij dK_ij/dtheta with dK/dtheta = K .* (...) for the stationary kernels -- the reverse pass
+ * of Stationary.K (stationaries.py:103-116, 209-210) that TF autodiff builds for optimizers/scipy.py:322-331
+ * (SURVEY 8f row 1). */
 int gpk_kernel_matrix_hadamard(void* stream, int family, const double* X1, int n1, long ldx1,
                                const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
                                double variance, const double* G, long ldg, double* out, long ldo);
@@ -77,14 +97,6 @@ int gpk_kernel_matrix_hadamard(void* stream, int family, const double* X1, int n
 size_t gpk_invd_elems(int n, int batch);
 int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch, long strideA,
               double* invd, int zero_upper, int* info);
-
-/* gpk_potrf with the solved extra rows  B L^-T  written to Eout [extra, n] (ldeout) instead of in place (the
- * extra rows of A are consumed).  With ws_bytes >= gpk_potrf_ex_workspace_bytes(), n a multiple of 512 below
- * 4096, batch 1 and more than 256 extra rows (the SVGP minibatch), each 512-column group of the extra rows is
- * solved with one GEMM against the explicit inverse of the group's diagonal block. */
-size_t gpk_potrf_ex_workspace_bytes(void);
-int gpk_potrf_ex(void* stream, double* A, int n, int extra, long lda, int batch, long strideA, double* invd,
-                 int zero_upper, int* info, double* Eout, long ldeout, void* ws, size_t ws_bytes);
 
 /* inverses of the diagonal NB-blocks of an existing lower factor L [n,n] (for gpk_trsm on a cached
  * L: GPRPosterior cache (err, Lm), posteriors.py:415-432). invd [batch, ceil(n/NB), NB, NB]. */

@@ -77,6 +77,18 @@ def kernel_matrix_hadamard(X1, X2, G, *, variance, lengthscales, family="Squared
     return out
 
 
+def kernel_matrix_combine(X1, X2, G, *, op, variance, lengthscales, family="SquaredExponential", diag_add=0.0, out=None):
+    K = _k(X1, X1 if X2 is None else X2, variance, lengthscales, family)
+    R = K * _np(G) if op == "mul" else K + _np(G)
+    if X2 is None:
+        R = R + diag_add * np.eye(R.shape[0])
+    Rt = torch.from_numpy(R)
+    if out is None:
+        return Rt
+    out.copy_(Rt)
+    return out
+
+
 def _invd(n, batch, mark):
     """Stand-in for the diagonal-block inverses: the emulation solves with L itself, the tensor only carries a marker
     (+1: belongs to L, -1: to L^T from transpose_factor) so that a wrong pairing is caught."""

@@ -48,6 +48,61 @@ def test_svgp_elbo_and_grad_vs_autograd_oracle(gpu, M, B, D, P, ard):
         np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=tol, err_msg=name)
 
 
+@pytest.mark.parametrize("M,B,D,P,ard", [(150, 300, 3, 2, True), (64, 200, 2, 1, False), (384, 1024, 8, 1, True)])
+def test_unwhitened_svgp_elbo_and_grad_vs_autograd_oracle(gpu, M, B, D, P, ard):
+    """whiten=False (conditionals/util.py:137-139, kullback_leiblers.py:98-165 with K = Kuu): value and every gradient
+    of the hand-written adjoint against the autograd oracle; tolerance 1e-7 of the largest entry (the un-whitened
+    chain goes through the explicit Lm^-1 twice, one more kappa(Lm) than the whitened path)."""
+    from gpflow_amd import gradients, ops
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(M, B, D, P, 17, ard)
+    t = ops.to_device
+    F, g, info = gradients.svgp_elbo_and_grad_unwhitened(t(Z), t(X), t(Y), t(q_mu), t(q_sqrt), jitter=1e-6,
+                                                         scale=1000.0 / B, mean_const=0.1, **kw)
+    ops.check_info(info)
+    v, go = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=1000, mean=0.1, whiten=False, **kw)
+    assert abs(float(F.reshape(-1).cpu()[0]) - v) <= 1e-9 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt", "mean_const"):
+        got, ref = g[name].cpu().numpy(), np.asarray(go[name])
+        tol = 1e-7 * max(1.0, np.abs(ref).max())
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=tol, err_msg=name)
+
+
+def test_unwhitened_model_gradients_and_trainer(gpu):
+    """SVGP(whiten=False).elbo_and_grad reaches the un-whitened adjoint (value == the model's own composed forward,
+    gradients vs the autograd oracle); SVGPTrainer steps it, trains a Constant mean, and refuses a failed step."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import training
+    from gpflow_amd._lib import GpkError
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(48, 256, 2, 1, 23)
+    k = gpflow.kernels.SquaredExponential(variance=kw["variance"], lengthscales=kw["lengthscales"])
+    m = gpflow.models.SVGP(k, gpflow.likelihoods.Gaussian(kw["noise_variance"]), Z.copy(), q_mu=q_mu.copy(),
+                           q_sqrt=q_sqrt.copy(), num_data=2000, whiten=False,
+                           mean_function=gpflow.mean_functions.Constant(0.25))
+    v, g = m.elbo_and_grad((X, Y))
+    rv, rg = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=2000, mean=0.25, whiten=False, **kw)
+    assert abs(v - rv) <= 1e-9 * abs(rv)
+    assert abs(v - float(m.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+    np.testing.assert_allclose(g[m.q_mu], rg["q_mu"], rtol=0, atol=1e-7 * np.abs(rg["q_mu"]).max())
+    np.testing.assert_allclose(g[m.inducing_variable.Z], rg["Z"], rtol=0, atol=1e-7 * np.abs(rg["Z"]).max())
+    assert m.mean_function.c in g                      # Constant.c is trainable by default
+    np.testing.assert_allclose(np.ravel(g[m.mean_function.c]), np.ravel(rg["mean_const"]), rtol=1e-7)
+    tr = training.SVGPTrainer(m, learning_rate=2e-2)
+    vals = [float(tr.step((X, Y)).cpu()[0]) for _ in range(12)]
+    assert abs(vals[0] - rv) <= 1e-9 * abs(rv) and vals[-1] > vals[0]
+    assert tr.last_info == 0
+    tr.sync_to_model()
+    assert abs(float(np.ravel(m.mean_function.c.numpy())[0]) - 0.25) > 1e-3   # the mean constant was trained
+    # a step whose Kuu is not positive definite must raise and leave the variables untouched
+    m2 = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=1e13, lengthscales=1.0),
+                            gpflow.likelihoods.Gaussian(0.1), np.zeros((40, 2)), num_data=2000)
+    tr2 = training.SVGPTrainer(m2)
+    before = tr2.dev["q_mu"].clone()
+    with pytest.raises(GpkError):
+        tr2.step((X, Y))
+    assert tr2.last_info != 0 and tr2.opt.t == 0
+    np.testing.assert_array_equal(tr2.dev["q_mu"].cpu().numpy(), before.cpu().numpy())
+
+
 def _small_model(M, B, D, P, seed):
     import gpflow_amd as gpflow
     X, Y, Z, q_mu, q_sqrt, kw = _problem(M, B, D, P, seed)

@@ -85,16 +85,176 @@ def test_gpr_batched_xnew_and_mean_function(gp):
 
 
 def test_gpr_not_pd_raises(gp):
+    """A covariance that is not positive definite in fp64 must surface as an error carrying the LAPACK-style pivot
+    index (TF raises InvalidArgumentError from tf.linalg.cholesky, gpr.py:102), never as a silent NaN.
+    K = 1e13 * ones + 2e-6 I: the noise is far below one ulp of the entries (0.002), so K is exactly rank one in fp64
+    and the second or third pivot is <= 0."""
+    from gpflow_amd import ops
     from gpflow_amd._lib import GpkError
     X = np.zeros((20, 1)); Y = np.zeros((20, 1))
     lik = gp.likelihoods.Gaussian(variance=2e-6)
-    m = gp.models.GPR((X, Y), gp.kernels.RBF(), likelihood=lik)
-    # K = ones + 2e-6 I is numerically singular in fp64 -> must raise or give a finite value; a silent NaN is a bug
-    try:
-        v = float(m.log_marginal_likelihood())
-        assert np.isfinite(v)
-    except GpkError:
-        pass
+    m = gp.models.GPR((X, Y), gp.kernels.RBF(variance=1e13), likelihood=lik)
+    with pytest.raises(GpkError, match="not successful"):
+        m.log_marginal_likelihood()
+    # the device status itself: info = index + 1 of the first non-positive pivot, within the first few columns
+    _, info = ops.gpr_lml(ops.to_device(X), ops.to_device(Y), variance=1e13, lengthscales=1.0, noise_variance=2e-6)
+    assert 1 <= int(info.cpu()[0]) <= 20
+    with pytest.raises(np.linalg.LinAlgError):      # the oracle's factorisation (LAPACK) refuses the same matrix
+        np.linalg.cholesky(orc.rbf_K(X, variance=1e13, lengthscales=1.0) + 2e-6 * np.eye(20))
+    # a well-conditioned relative (same data, variance 1, noise 2e-6: condition 1e7) must still factor
+    ok = gp.models.GPR((X, Y), gp.kernels.RBF(), likelihood=gp.likelihoods.Gaussian(variance=2e-6))
+    assert np.isfinite(float(ok.log_marginal_likelihood()))
+
+
+@pytest.mark.parametrize("dims", [slice(1, 4), [3, 0, 2], slice(0, 5, 2)])
+def test_active_dims_through_models(gp, dims):
+    """Kernel.slice (kernels/base.py:90-109): a slice or an index list of active columns, through GPR (LML, predict,
+    cached posterior) and SVGP (fused ELBO shard, predict) == the oracle on the explicitly sliced inputs."""
+    rng = np.random.default_rng(12)
+    N, D, M = 260, 5, 130
+    X = rng.normal(size=(N, D))
+    Y = np.sin(X[:, :3].sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, 1))
+    sel = np.arange(D)[dims] if isinstance(dims, slice) else np.asarray(dims)
+    ls = 0.8 + 0.1 * np.arange(len(sel))
+    kw = dict(variance=1.2, lengthscales=ls, noise_variance=0.1)
+    Xnew = rng.normal(size=(33, D))
+    m = gp.models.GPR((X, Y), gp.kernels.RBF(variance=1.2, lengthscales=ls, active_dims=dims), noise_variance=0.1)
+    np.testing.assert_allclose(float(m.log_marginal_likelihood()), orc.gpr_log_marginal_likelihood(X[:, sel], Y, **kw),
+                               rtol=1e-10)
+    mu, var = m.predict_f(Xnew)
+    mu_r, var_r = orc.gpr_predict_f(X[:, sel], Y, Xnew[:, sel], **kw)
+    np.testing.assert_allclose(_np(mu), mu_r, atol=1e-9)
+    np.testing.assert_allclose(_np(var), var_r, atol=1e-9)
+    mu2, var2 = m.posterior().predict_f(Xnew)
+    np.testing.assert_allclose(_np(mu2), mu_r, atol=1e-9)
+    np.testing.assert_allclose(_np(var2), var_r, atol=1e-9)
+    Z = X[:M] + 0.01 * rng.normal(size=(M, D))
+    q_mu = 0.3 * rng.normal(size=(M, 1))
+    q_sqrt = (np.tril(0.1 * rng.normal(size=(M, M))) + 0.5 * np.eye(M))[None]
+    for whiten in (True, False):
+        s = gp.models.SVGP(gp.kernels.RBF(variance=1.2, lengthscales=ls, active_dims=dims), gp.likelihoods.Gaussian(0.1),
+                           Z, q_mu=q_mu, q_sqrt=q_sqrt, whiten=whiten, num_data=5000)
+        ref = orc.svgp_elbo(X[:, sel], Y, Z[:, sel], q_mu, q_sqrt, whiten=whiten, num_data=5000, **kw)
+        np.testing.assert_allclose(float(s.elbo((X, Y))), ref, rtol=1e-9)
+        mu, var = s.predict_f(Xnew)
+        mu_r, var_r = orc.svgp_predict_f(Xnew[:, sel], Z[:, sel], q_mu, q_sqrt, variance=1.2, lengthscales=ls,
+                                         whiten=whiten)
+        np.testing.assert_allclose(_np(mu), mu_r, atol=1e-9)
+        np.testing.assert_allclose(_np(var), var_r, atol=1e-9)
+    # the gradient entry points refuse active_dims with NotImplementedError (not an unrelated ValueError)
+    with pytest.raises(NotImplementedError):
+        s.elbo_and_grad((X, Y))
+    with pytest.raises(NotImplementedError):
+        m.log_marginal_likelihood_and_grad()
+
+
+def test_kernel_sum_and_product(gp):
+    """`+` / `*` (kernels/base.py:216-220): Sum / Product of stationary kernels with their own active_dims, flattened
+    nesting (:247-255), K / K_diag vs the oracle, and a GPR on a combined kernel (composed path: kernel -> potrf ->
+    multivariate_normal) vs a dense NumPy restatement.  (Matern12 only appears in a cross-covariance check: on the
+    diagonal of K(X, X) its sqrt(max(r2, 1e-36)) turns the 1e-16 rounding noise of the expansion formula into 1e-8, in
+    the reference as here, so two correct implementations differ there by 1e-8.)"""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(13)
+    X = rng.normal(size=(150, 3)); X2 = rng.normal(size=(37, 3))
+    k1 = gp.kernels.RBF(variance=1.3, lengthscales=0.7, active_dims=[0, 2])
+    k2 = gp.kernels.Matern32(variance=0.5, lengthscales=[1.0, 2.0, 0.5])
+    k3 = gp.kernels.Matern52(lengthscales=1.5, active_dims=slice(1, 3))
+    ks = k1 + k2 * k3 + gp.kernels.Matern52(variance=0.2)
+    assert isinstance(ks, gp.kernels.Sum) and [type(k).__name__ for k in ks.kernels] == \
+        ["SquaredExponential", "Product", "Matern52"]
+    assert len((k1 * k2 * k3).kernels) == 3 and len(ks.parameters) == 8
+
+    def ref(A, B):
+        r1 = orc.stationary_K("SquaredExponential", A[:, [0, 2]], None if B is None else B[:, [0, 2]], variance=1.3,
+                              lengthscales=0.7)
+        r2 = orc.stationary_K("Matern32", A, B, variance=0.5, lengthscales=np.array([1.0, 2.0, 0.5]))
+        r3 = orc.stationary_K("Matern52", A[:, 1:3], None if B is None else B[:, 1:3], variance=1.0, lengthscales=1.5)
+        r4 = orc.stationary_K("Matern52", A, B, variance=0.2, lengthscales=1.0)
+        return r1 + r2 * r3 + r4
+    np.testing.assert_allclose(_np(ks(X, X2)), ref(X, X2), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(_np(ks(X)), ref(X, None), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(_np(ks(X, full_cov=False)), np.full(150, 1.3 + 0.5 * 1.0 + 0.2), rtol=1e-15)
+    kx = gp.kernels.Matern12(variance=0.7, lengthscales=1.1, active_dims=[1]) * k1 + k2
+    rx = orc.stationary_K("Matern12", X[:, [1]], X2[:, [1]], variance=0.7, lengthscales=1.1) * \
+        orc.stationary_K("SquaredExponential", X[:, [0, 2]], X2[:, [0, 2]], variance=1.3, lengthscales=0.7) + \
+        orc.stationary_K("Matern32", X, X2, variance=0.5, lengthscales=np.array([1.0, 2.0, 0.5]))
+    np.testing.assert_allclose(_np(kx(X, X2)), rx, rtol=0, atol=1e-13)
+    with pytest.raises(ValueError):
+        ks(X, X2, full_cov=False)
+    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(150, 2))
+    m = gp.models.GPR((X, Y), ks, noise_variance=0.1)
+    K = ref(X, None) + 0.1 * np.eye(150)
+    L = np.linalg.cholesky(K)
+    a = sla.solve_triangular(L, Y, lower=True)
+    lml = (-0.5 * (a ** 2).sum(0) - 0.5 * 150 * np.log(2 * np.pi) - np.log(np.diag(L)).sum()).sum()
+    np.testing.assert_allclose(float(m.log_marginal_likelihood()), lml, rtol=1e-10)
+    mu, var = m.predict_f(X2)
+    Ks = ref(X, X2)
+    A = sla.solve_triangular(L, Ks, lower=True)
+    np.testing.assert_allclose(_np(mu), A.T @ a, atol=1e-9)
+    np.testing.assert_allclose(_np(var)[:, 0], 2.0 - (A ** 2).sum(0), atol=1e-9)
+    # SVGP over a product kernel: composed (non-fused) ELBO == dense restatement of base_conditional + gauss_kl
+    Z = X[:40].copy()
+    q_mu = 0.2 * rng.normal(size=(40, 2))
+    kp = k1 * k3
+    s = gp.models.SVGP(kp, gp.likelihoods.Gaussian(0.1), Z, q_mu=q_mu, num_latent_gps=2, num_data=1000)
+
+    def refp(A, B):
+        return orc.stationary_K("SquaredExponential", A[:, [0, 2]], None if B is None else B[:, [0, 2]], variance=1.3,
+                                lengthscales=0.7) * \
+            orc.stationary_K("Matern52", A[:, 1:3], None if B is None else B[:, 1:3], variance=1.0, lengthscales=1.5)
+    Kmm = refp(Z, None) + 1e-6 * np.eye(40)
+    fm, fv = orc.base_conditional(refp(Z, X), Kmm, np.full(150, 1.3), q_mu, q_sqrt=np.stack([np.eye(40)] * 2), white=True)
+    ve = orc.gaussian_variational_expectations(fm, fv, Y, 0.1).sum()
+    kl = orc.gauss_kl(q_mu, np.stack([np.eye(40)] * 2))
+    np.testing.assert_allclose(float(s.elbo((X, Y))), ve * (1000 / 150) - kl, rtol=1e-9)
+
+
+def test_predict_f_samples_and_log_density(gp):
+    """models/model.py:232-280, 327-343 (+ sample_mvn, conditionals/util.py:179-211): shapes, the rejected
+    combinations, first / second moments of the draws against the predictive distribution, and
+    predict_log_density against the oracle."""
+    import torch
+    rng = np.random.default_rng(14)
+    X = rng.normal(size=(60, 2))
+    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(60, 2))
+    kw = dict(variance=1.1, lengthscales=0.9, noise_variance=0.15)
+    m = gp.models.GPR((X, Y), gp.kernels.RBF(variance=1.1, lengthscales=0.9), noise_variance=0.15)
+    Xnew = rng.normal(size=(7, 2))
+    mu_r, cov_r = orc.gpr_predict_f(X, Y, Xnew, full_cov=True, **kw)       # [7,2], [2,7,7]
+    _, var_r = orc.gpr_predict_f(X, Y, Xnew, **kw)
+    torch.manual_seed(0)
+    S = 40000
+    s_full = _np(m.predict_f_samples(Xnew, S))                               # full_cov=True default: [S, N, P]
+    assert s_full.shape == (S, 7, 2)
+    assert m.predict_f_samples(Xnew).shape == (7, 2)
+    s_diag = _np(m.predict_f_samples(Xnew, S, full_cov=False))
+    assert s_diag.shape == (S, 7, 2)
+    with pytest.raises(NotImplementedError):
+        m.predict_f_samples(Xnew, 3, full_cov=True, full_output_cov=True)
+    sd = np.sqrt(var_r)
+    assert np.all(np.abs(s_full.mean(0) - mu_r) <= 6.0 * sd / np.sqrt(S) + 1e-3)
+    assert np.all(np.abs(s_diag.mean(0) - mu_r) <= 6.0 * sd / np.sqrt(S) + 1e-3)
+    np.testing.assert_allclose(s_diag.var(0), var_r, rtol=0.05, atol=1e-6)
+    for p in range(2):
+        c = np.cov(s_full[:, :, p].T)
+        scale = np.sqrt(np.outer(np.diag(cov_r[p]), np.diag(cov_r[p]))) + 1e-6
+        assert np.abs(c - cov_r[p]).max() <= 0.05 * scale.max(), np.abs(c - cov_r[p]).max()
+    # predict_log_density (scalar_continuous.py:132-136): log N(y | mu, var + noise) summed over outputs
+    Ynew = rng.normal(size=(7, 2))
+    ld = m.predict_log_density((Xnew, Ynew))
+    ref = orc.gaussian_predict_log_density(mu_r, var_r, Ynew, 0.15)
+    np.testing.assert_allclose(_np(ld), np.asarray(ref).reshape(_np(ld).shape), rtol=1e-9, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        m.predict_log_density((Xnew, Ynew), full_cov=True)
+    # SVGP samples: diag draws have the predictive variance
+    Z = X[:20].copy()
+    s = gp.models.SVGP(gp.kernels.RBF(variance=1.1, lengthscales=0.9), gp.likelihoods.Gaussian(0.15), Z,
+                       q_mu=0.3 * rng.normal(size=(20, 1)))
+    mu, var = s.predict_f(Xnew)
+    dr = _np(s.predict_f_samples(Xnew, S, full_cov=False))
+    np.testing.assert_allclose(dr.var(0), _np(var), rtol=0.05, atol=1e-6)
 
 
 # ---------------------------------------------------------------------------------------- SVGP

@@ -228,15 +228,12 @@ def test_fused_svgp_elbo_shard(gpu, m, rows, d, P, q_diag):
 
 
 @pytest.mark.parametrize("m,rows,d,P", [(256, 300, 3, 1), (640, 1000, 8, 2), (1024, 2500, 8, 1), (1152, 777, 4, 3)])
-@pytest.mark.parametrize("mode", ["0", "1", "side"])
-def test_svgp_elbo_shard_streamed_projection(gpu, monkeypatch, m, rows, d, P, mode):
-    """The q_sqrt projection streamed group by group behind the extra-row solve (GPK_STREAM_PROJ=1) and the one-GEMM
-    projection (=0) against the oracle: one group (m = 256), ragged last group (640 = 512 + 128), shrinking tail groups
-    (1024, 1152), several latents, ragged row counts."""
+def test_svgp_elbo_shard_column_groups(gpu, m, rows, d, P):
+    """The fused shard over the column-group shapes of the extra-row solve / q_sqrt projection, against the oracle: one
+    group (m = 256), ragged last group (640 = 512 + 128), shrinking tail groups (1024, 1152), several latents, ragged
+    row counts; bulk GEMMs ticketed under the software CU reservation.  (With the A/B library, GPK_LIBRARY=libgpk_exp.so,
+    the same test covers GPK_STREAM_PROJ=0/1 and GPK_SOFT_RESERVE=0/1 from the environment: tools/ab.sh.)"""
     from gpflow_amd import ops
-    monkeypatch.setenv("GPK_STREAM_PROJ", "0" if mode == "0" else "1")
-    if mode == "side":
-        monkeypatch.setenv("GPK_PROJ_SIDE", "1")   # projection GEMMs on a stream of their own
     rng = np.random.default_rng(13)
     X = rng.normal(size=(rows, d))
     Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(rows, P))
@@ -252,29 +249,6 @@ def test_svgp_elbo_shard_streamed_projection(gpu, monkeypatch, m, rows, d, P, mo
     np.testing.assert_allclose(o[1], kl_ref, rtol=1e-12)
     out2, _ = ops.svgp_elbo_shard(_t(Z), _t(X), _t(Y), _t(q_mu), _t(q_sqrt), jitter=1e-6, **kw)
     np.testing.assert_array_equal(out2.cpu().numpy(), o)  # deterministic
-
-
-def test_potrf_ex_out_of_place(gpu):
-    """gpk_potrf_ex: same factor, solved extra rows written to a separate matrix (batch 1)."""
-    import ctypes
-    import torch
-    from gpflow_amd import _lib, ops
-    lib = _lib.load()
-    rng = np.random.default_rng(11)
-    n, extra = 640, 300
-    _, K = _spd(rng, n)
-    Bm = rng.normal(size=(extra, n))
-    Td = _t(np.vstack([K, Bm]))
-    Eout = torch.zeros((extra, n), dtype=torch.float64, device=Td.device)
-    invd = ops.invd_alloc(n)
-    info = torch.zeros(1, dtype=torch.int32, device=Td.device)
-    rc = lib.gpk_potrf_ex(torch.cuda.current_stream().cuda_stream, Td.data_ptr(), n, extra, n, 1, 0, invd.data_ptr(), 1,
-                          info.data_ptr(), Eout.data_ptr(), n, None, 0)
-    assert rc == 0 and int(info[0]) == 0
-    Lref = np.linalg.cholesky(K)
-    np.testing.assert_allclose(Td[:n].cpu().numpy(), Lref, rtol=0, atol=5e-13)
-    ref = sla.solve_triangular(Lref, Bm.T, lower=True).T
-    np.testing.assert_allclose(Eout.cpu().numpy(), ref, rtol=0, atol=1e-11)
 
 
 @pytest.mark.parametrize("m,n,k,b_tri,c_lower", [(1536, 1280, 272, 0, False), (1408, 1408, 512, 0, True),

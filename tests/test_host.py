@@ -184,18 +184,17 @@ def test_bijector_forward_grad_matches_finite_differences():
 
 
 def test_gradient_entry_points_refuse_unsupported_models_before_touching_the_device():
-    """The reverse pass covers the whitened SVGP / GPR / SGPR with a SquaredExponential kernel and a Gaussian likelihood;
-    everything else must say so (NotImplementedError), not silently compute something else."""
+    """The reverse pass covers the SVGP (whitened or not) / GPR / SGPR with a SquaredExponential kernel and a Gaussian
+    likelihood; everything else must say so (NotImplementedError), not silently compute something else."""
     import gpflow_amd as gpflow
     from gpflow_amd import training
     Z = np.random.default_rng(0).normal(size=(5, 2))
     lik = gpflow.likelihoods.Gaussian(0.1)
-    unwhitened = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), lik, Z, whiten=False)
     matern = gpflow.models.SVGP(gpflow.kernels.Matern32(), lik, Z)
     qdiag = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), lik, Z, q_diag=True)
     sliced = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(active_dims=[0]), lik, Z)
     data = (np.zeros((4, 2)), np.zeros((4, 1)))
-    for m in (unwhitened, matern, qdiag, sliced):
+    for m in (matern, qdiag, sliced):
         with pytest.raises(NotImplementedError):
             training.SVGPTrainer(m)
         with pytest.raises(NotImplementedError):
