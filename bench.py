@@ -1,17 +1,25 @@
 """bench.py -- headline benchmark of the dense-GP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cm|c3|c4-weak|c4-strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Metric (BASELINE.json): SVGP ELBO steps/s at N=1e6, M=2048, D=8 (config "Cm"), with the GPR Cholesky at
-N=16384 (GF/s vs fp64 peak) reported alongside in the same JSON line (key "gpr_cholesky", N=1 only).
+Metric (BASELINE.json): SVGP ELBO steps/s at N=1e6, M=2048, D=8 (config "Cm", the default workload), with the GPR
+config C2 (N=16384: K build + Cholesky + predict, GF/s vs fp64 peak) reported alongside in the same JSON line (key
+"gpr_cholesky", N=1 only).
 
-A "step" = one forward minibatch ELBO evaluation (SVGP.elbo, gpflow/models/svgp.py:166-181) over
-B = 8192 rows per GPU: Kuu / Kuf builds, Cholesky of Kuu, the triangular solves, the q_sqrt projection,
-the variational expectations, KL, the (multi-GPU) all-reduce of the per-shard data term and the scalar
-landing in host memory.  Weak scaling: every rank keeps the same 8192-row shard size, so a global step
-covers 8192*N rows and `value` = N * (global steps / s) = 8192-row minibatch evaluations per second
-over the whole job.  Inputs (the 1e6 x 8 data matrix, Z, q) are resident in HBM before the timed region.
+A "step" = one forward minibatch ELBO evaluation (SVGP.elbo, gpflow/models/svgp.py:166-181): Kuu / Kuf builds,
+Cholesky of Kuu, the triangular solves, the q_sqrt projection, the variational expectations, KL, the (multi-GPU)
+all-reduce of the per-shard data term and the scalar landing in host memory.  Inputs (the data matrix, Z, q) are
+resident in HBM before the timed region.
+
+Workloads:
+  cm         N=1e6, M=2048, D=8,  8192 rows per GPU (weak scaling: a global step covers 8192*G rows)     [headline]
+  c3         N=1e6, M=1024, D=8,  8192 rows per GPU (weak)
+  c4-weak    N=1e7, M=2048, D=16, 8192 rows per GPU (weak)
+  c4-strong  N=1e7, M=2048, D=16, global minibatch 8192 rows, 8192/G rows per GPU (strong scaling)
+`value` = 8192-row minibatch evaluations per second over the whole job for the weak workloads, global steps per second
+for c4-strong.  The last step's ELBO is checked against the CPU oracle ON THE SAME ARRAYS (`parity_rel_err`), and that
+oracle call is what `cpu_baseline` times.
 """
 from __future__ import annotations
 
@@ -23,9 +31,12 @@ import sys
 import time
 
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The factorisation runs a latency-critical
-# panel stream next to bulk streams; with 2 hardware queues the SVGP step measured 415 steps/s vs 380 with 4 and
-# 350 with 8 (A/B on one MI355X, tools/ab.sh).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# panel stream next to bulk streams; with 2 hardware queues the SVGP step measured faster than with 4 or 8 (same-box
+# A/B, tools/ab.sh; numbers in DESIGN.md).  Must be set before the HIP runtime initialises; an explicit setting wins.
+# Single-process runs only: with RCCL in the process (WORLD_SIZE > 1) the runtime default is kept -- the all-reduce
+# needs a hardware queue of its own and that combination could not be measured on a 1-GPU box.
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import numpy as np
 import torch
@@ -34,8 +45,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_DATA, M_IND, D_IN, B_ROWS, P_LAT = 1_000_000, 2048, 8, 8192, 1
 FP64_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, FP64 matrix (= FP64 vector); the in-image guide lists no fp64 row
+WORKLOADS = {
+    # name: (N, M, D, rows per global step, strong?, data seed)
+    "cm": (1_000_000, 2048, 8, 8192, False, 4),
+    "c3": (1_000_000, 1024, 8, 8192, False, 4),
+    "c4-weak": (10_000_000, 2048, 16, 8192, False, 6),
+    "c4-strong": (10_000_000, 2048, 16, 8192, True, 6),
+}
+P_LAT = 1
 
 
 def svgp_step_flops(m: int, b: int, p: int) -> float:
@@ -43,42 +61,33 @@ def svgp_step_flops(m: int, b: int, p: int) -> float:
     return m ** 3 / 3.0 + float(m) * m * b * (1 + p)
 
 
-def make_inputs(rank: int, device):
-    """SURVEY 8d config Cm: X ~ N(0,1) seed 4, Y = sin(sum x) + 0.1 eps, Z = first M rows + 0.01 noise,
-    q_mu ~ 0.1 N(0,1), q_sqrt = tril(0.05 N(0,1)) + 0.5 I, ARD lengthscales sqrt(D)(0.8 + 0.05 d), noise 0.1.
-    The data are pre-shuffled once (seed 5) so minibatch s of rank r is a contiguous slice."""
-    g = torch.Generator(device="cpu").manual_seed(4)
-    X = torch.randn((N_DATA, D_IN), generator=g, dtype=torch.float64)
-    Y = torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn((N_DATA, P_LAT), generator=g, dtype=torch.float64)
-    Z = X[:M_IND] + 0.01 * torch.randn((M_IND, D_IN), generator=g, dtype=torch.float64)
-    q_mu = 0.1 * torch.randn((M_IND, P_LAT), generator=g, dtype=torch.float64)
-    q_sqrt = torch.tril(0.05 * torch.randn((P_LAT, M_IND, M_IND), generator=g, dtype=torch.float64)) \
-        + 0.5 * torch.eye(M_IND, dtype=torch.float64)
-    perm = torch.randperm(N_DATA, generator=torch.Generator(device="cpu").manual_seed(5))
-    X, Y = X[perm], Y[perm]
-    ls = np.sqrt(D_IN) * (0.8 + 0.05 * np.arange(D_IN))
-    return (X.to(device), Y.to(device), Z.to(device).contiguous(), q_mu.to(device).contiguous(),
-            q_sqrt.to(device).contiguous(), ls)
+def make_inputs(n_data, m_ind, d_in, seed, device):
+    """X ~ N(0,1), Y = sin(sum x) + 0.1 eps, Z = first M rows + 0.01 noise, q_mu ~ 0.1 N(0,1),
+    q_sqrt = tril(0.05 N(0,1)) + 0.5 I, ARD lengthscales sqrt(D)(0.8 + 0.05 d), noise 0.1.  The rows are i.i.d., so
+    minibatch s of rank r is simply a contiguous slice (a fixed permutation of i.i.d. rows changes nothing).
+    Generated on the device (identical on every rank: same seed)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    X = torch.randn((n_data, d_in), generator=g, dtype=torch.float64, device=device)
+    Y = torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn((n_data, P_LAT), generator=g, dtype=torch.float64, device=device)
+    Z = (X[:m_ind] + 0.01 * torch.randn((m_ind, d_in), generator=g, dtype=torch.float64, device=device)).contiguous()
+    q_mu = (0.1 * torch.randn((m_ind, P_LAT), generator=g, dtype=torch.float64, device=device)).contiguous()
+    q_sqrt = (torch.tril(0.05 * torch.randn((P_LAT, m_ind, m_ind), generator=g, dtype=torch.float64, device=device))
+              + 0.5 * torch.eye(m_ind, dtype=torch.float64, device=device)).contiguous()
+    ls = np.sqrt(d_in) * (0.8 + 0.05 * np.arange(d_in))
+    return X, Y, Z, q_mu, q_sqrt, ls
 
 
-def cpu_baseline(budget_s: float = 12.0):
-    """The oracle (NumPy/SciPy restatement of GPflow's algorithm; TensorFlow itself is not installable
-    here) timed on this box's host cores on the SAME step: M=2048, B=8192, D=8, whitened, P=1."""
+def cpu_baseline_and_parity(Xb, Yb, Z, q_mu, q_sqrt, ls, n_data, gpu_elbo, budget_s: float = 14.0):
+    """The oracle (NumPy/SciPy restatement of GPflow's algorithm; TensorFlow itself is not installable here) evaluated
+    on the host cores on EXACTLY the arrays of the last timed step: its value is the parity check of `last_elbo`, its
+    wall-clock the CPU baseline (warm-up 1 call + median, benchmark/run.py:71 convention)."""
     from oracle import gp_oracle as orc
-    rng = np.random.default_rng(4)
-    X = rng.normal(size=(B_ROWS * 2, D_IN))
-    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(B_ROWS * 2, 1))
-    Z = X[:M_IND] + 0.01 * rng.normal(size=(M_IND, D_IN))
-    q_mu = 0.1 * rng.normal(size=(M_IND, 1))
-    q_sqrt = (np.tril(0.05 * rng.normal(size=(M_IND, M_IND))) + 0.5 * np.eye(M_IND))[None]
-    ls = np.sqrt(D_IN) * (0.8 + 0.05 * np.arange(D_IN))
-    kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, whiten=True, num_data=N_DATA)
-    orc.svgp_elbo(X[:B_ROWS], Y[:B_ROWS], Z, q_mu, q_sqrt, **kw)  # warm-up (benchmark/run.py:71 convention)
+    kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, whiten=True, num_data=n_data)
+    ref = orc.svgp_elbo(Xb, Yb, Z, q_mu, q_sqrt, **kw)  # warm-up call = the parity value
     times, t_start = [], time.perf_counter()
-    while time.perf_counter() - t_start < budget_s and len(times) < 50:
-        s = len(times) % 2
+    while time.perf_counter() - t_start < budget_s and len(times) < 5:
         t0 = time.perf_counter()
-        orc.svgp_elbo(X[s * B_ROWS:(s + 1) * B_ROWS], Y[s * B_ROWS:(s + 1) * B_ROWS], Z, q_mu, q_sqrt, **kw)
+        orc.svgp_elbo(Xb, Yb, Z, q_mu, q_sqrt, **kw)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     try:
@@ -86,25 +95,28 @@ def cpu_baseline(budget_s: float = 12.0):
         threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    return {"value": 1.0 / med, "unit": "steps/s", "cores": int(threads), "kind": "port",
-            "sample": f"{len(times)} ELBO steps of the workload (M={M_IND}, B={B_ROWS}, D={D_IN}, P=1, whitened), "
+    m, b, d = Z.shape[0], Xb.shape[0], Xb.shape[1]
+    base = {"value": 1.0 / med, "unit": "steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"{len(times)} ELBO steps on the arrays of the last timed GPU step (M={m}, B={b}, D={d}, P=1, whitened), "
                       f"median {med * 1e3:.1f} ms/step, NumPy/SciPy (OpenBLAS) oracle; GPflow+TensorFlow is not "
                       f"installable in this image"}
+    return base, float(ref), abs(gpu_elbo - ref) / abs(ref)
 
 
-def train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, steps: int = 20):
+def train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, n_data, b_rows, steps: int = 20):
     """SURVEY 8f row 1 (the caller of the hot path): one TRAINING step = forward + hand-written reverse pass
-    (gpflow_amd/gradients.py) + Adam update, same config Cm, reported beside the headline ELBO metric (not part of it)."""
+    (gpflow_amd/gradients.py) + Adam update, reported beside the headline ELBO metric (not part of it)."""
     from gpflow_amd import gradients
-    kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, jitter=1e-6, scale=float(N_DATA) / B_ROWS)
-    n_batches = N_DATA // B_ROWS
+    m_ind = Z.shape[0]
+    kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, jitter=1e-6, scale=float(n_data) / b_rows)
+    n_batches = n_data // b_rows
     m = {k: torch.zeros_like(v) for k, v in (("Z", Z), ("q_mu", q_mu), ("q_sqrt", q_sqrt))}
     v2 = {k: torch.zeros_like(v) for k, v in m.items()}
     par = {"Z": Z.clone(), "q_mu": q_mu.clone(), "q_sqrt": q_sqrt.clone()}
 
     def one(s):
-        lo = (s % n_batches) * B_ROWS
-        F, g, info = gradients.svgp_elbo_and_grad(par["Z"], X[lo:lo + B_ROWS], Y[lo:lo + B_ROWS], par["q_mu"],
+        lo = (s % n_batches) * b_rows
+        F, g, info = gradients.svgp_elbo_and_grad(par["Z"], X[lo:lo + b_rows], Y[lo:lo + b_rows], par["q_mu"],
                                                   par["q_sqrt"], **kw)
         for k in par:  # Adam (tf.keras defaults) on the device-resident variables
             m[k].mul_(0.9).add_(g[k], alpha=-0.1)
@@ -121,39 +133,52 @@ def train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, steps: int = 20):
         elbo, info = one(3 + s)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    flops = 3.0 * svgp_step_flops(M_IND, B_ROWS, P_LAT)  # forward + ~2x for the reverse pass (same GEMM shapes)
+    flops = 3.0 * svgp_step_flops(m_ind, b_rows, P_LAT)  # forward + ~2x for the reverse pass (same GEMM shapes)
     return {"workload": "SVGP training step (ELBO + gradients w.r.t. Z, q_mu, q_sqrt, kernel and noise parameters + Adam), "
-                        "config Cm, 8192 rows", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "last_elbo": elbo,
+                        f"M={m_ind}, {b_rows} rows", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "last_elbo": elbo,
             "info": info, "approx_tflops": flops / dt / 1e12,
             "note": "hyper-parameters held fixed in this leg (their gradients are computed and read back); "
                     "SVGPTrainer updates them on the host"}
 
 
-def gpr_cholesky_leg(ops, lib, device):  # noqa: C901
-    """GPR config C2: K(X,X)+noise build + Cholesky + LML tail at N=16384, D=8 (gpr.py:91-107)."""
-    n, d = 16384, 8
-    g = torch.Generator(device="cpu").manual_seed(2)
-    X = torch.randn((n, d), generator=g, dtype=torch.float64).to(device)
-    Y = (torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn((n, 1), dtype=torch.float64, device=device))
+def _event_time(fn, reps: int, warm: int = 1):
+    """median device time of fn() over reps, by HIP events on the current stream (the caller's stream: the library
+    forks from / joins to it, so the interval covers all internal streams)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
+    """GPR config C2: N=16384, D=8, ARD lengthscales, noise 0.1:
+    (i) K(X,X)+noise build + Cholesky + LML tail, one gpk_gpr_lml call (gpr.py:91-107);
+    (ii) predict_f at T=4096 fresh rows, fused route (posteriors.py:435-443): factorisation with the test rows and
+         (Y-m)^T riding along + reductions (the alpha-form of SURVEY 8d: N^3/3 + N^2 T flops)."""
+    import gpflow_amd as gpflow
+    n, d, T = 16384, 8, 4096
+    rng = np.random.default_rng(2)
+    Xh = rng.normal(size=(n, d))
+    Yh = np.sin(Xh.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(n, 1))
+    Xnew = ops.to_device(np.random.default_rng(3).normal(size=(T, d)))
+    X, Y = ops.to_device(Xh), ops.to_device(Yh)
     ls = np.sqrt(d) * (0.8 + 0.05 * np.arange(d))
     ws = torch.empty(int(lib.gpk_gpr_lml_workspace_bytes(n, d, 1)) // 8 + 1, dtype=torch.float64, device=device)
     kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, ws=ws)
-    for _ in range(2):
-        out, info = ops.gpr_lml(X, Y, **kw)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); out, info = ops.gpr_lml(X, Y, **kw); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e-3)
-    t = float(np.median(ts))
+    res = {}
+
+    def lml_call():
+        res["out"], res["info"] = ops.gpr_lml(X, Y, **kw)
+    t, _ = _event_time(lml_call, 5, warm=2)
+    out, info = res["out"], res["info"]
     K = torch.empty((n, n), dtype=torch.float64, device=device)
-    tk = []
-    for _ in range(4):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); ops.kernel_matrix(X, None, variance=1.0, lengthscales=ls, diag_add=0.1, out=K); e1.record()
-        torch.cuda.synchronize(); tk.append(e0.elapsed_time(e1) * 1e-3)
-    tkb = float(np.min(tk[1:]))
+    _, tkb = _event_time(lambda: ops.kernel_matrix(X, None, variance=1.0, lengthscales=ls, diag_add=0.1, out=K), 4)
+    del K
     flops = n ** 3 / 3.0
     kb_alg = n * n * 8 + n * d * 8  # algorithmic bytes: the full N x N fp64 write + the N x D read (SURVEY 8d)
     # the trailing update on its own (north_star: ">= 60 % of fp64 MFMA peak on the N=16384 Cholesky trailing update"):
@@ -170,8 +195,17 @@ def gpr_cholesky_leg(ops, lib, device):  # noqa: C901
     lib.gpk_profile_gemm_collect_min(ctypes.c_double(0.0), 0, ctypes.byref(ms_g), ctypes.byref(n_g), ctypes.byref(fl_g))
     lib.gpk_profile_gemm_enable(0)
     tu_tf = fl_t.value / (ms_t.value * 1e-3) / 1e12 if ms_t.value > 0 else 0.0
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pj = json.load(f)
+        kb_traffic = float(pj["rbf_kernel<0> full 16384^2"]["hbm_bytes_per_launch"])
+        traffic = float(pj["gemm_nt_fast<0,false> trailing update"]["hbm_bytes_per_launch"])
+    except Exception:
+        kb_traffic = None
     trailing = {"bound": "mfma", "kernel": "gemm_nt_fast<0,false>, lower tiles, K = 768 (outer trailing updates)",
                 "achieved": tu_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tu_tf / FP64_PEAK_TFLOPS,
+                "traffic": traffic,
                 "launches": int(n_t.value), "algorithmic_gflop": fl_t.value / 1e9,
                 "share_of_factorisation_flops": fl_t.value / flops, "summed_launch_ms": ms_t.value,
                 "all_gemm_launches": int(n_g.value), "all_gemm_gflop": fl_g.value / 1e9,
@@ -186,25 +220,63 @@ def gpr_cholesky_leg(ops, lib, device):  # noqa: C901
                             "strips) that shares the chip with them; leaf kernels not counted"},
                 "note": "sum of algorithmic flops / sum of HIP-event durations of these launches, recorded on the bulk "
                         "stream (CU-masked: 240 of 256 CUs; the look-ahead panel runs beside them on the other 16)"}
-    return {"workload": "GPR RBF N=16384 D=8 fp64: K build + Cholesky + LML (one gpk_gpr_lml call)",
-            "kernel_build_roofline": {"bound": "hbm", "kernel": "rbf_kernel (full N x N)", "achieved": kb_alg / tkb / 1e9,
-                                      "peak": 8000.0, "unit": "GB/s", "frac": kb_alg / tkb / 8e12, "traffic": None},
-            "trailing_update_roofline": trailing,
-            "lml": float(out.cpu()[0]), "info": int(info.cpu()[0]), "ms_total": t * 1e3,
-            "cholesky_gflops_incl_build_and_tail": flops / t / 1e9,
-            "frac_of_fp64_peak": flops / t / 1e12 / FP64_PEAK_TFLOPS,
-            "kernel_build_full_ms": tkb * 1e3, "kernel_build_full_GBps": n * n * 8 / tkb / 1e9,
-            "kernel_build_frac_of_8TBps": n * n * 8 / tkb / 8e12}
+    # (ii) predict_f at T = 4096 through the model surface (fused route), then the cached posterior
+    m = gpflow.models.GPR((X, Y), gpflow.kernels.SquaredExponential(variance=1.0, lengthscales=ls), noise_variance=0.1)
+    pred = {}
+
+    def fused():
+        pred["mu"], pred["var"] = m.predict_f(Xnew)
+    t_pred, _ = _event_time(fused, 3)
+    post = m.posterior()
+    torch.cuda.synchronize()
+    cached = {}
+
+    def cached_call():
+        cached["mu"], cached["var"] = post.predict_f(Xnew)
+    t_cached, _ = _event_time(cached_call, 3)
+    pred_flops = n ** 3 / 3.0 + float(n) * n * T
+    predict = {"workload": f"GPR.predict_f(Xnew [{T},{d}]) fused: K build + Cholesky with the test rows riding along + "
+                           "reductions (alpha-form mean, SURVEY 8d)",
+               "ms_total": t_pred * 1e3, "algorithmic_gflop": pred_flops / 1e9,
+               "roofline": {"bound": "mfma", "achieved": pred_flops / t_pred / 1e12, "peak": FP64_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": pred_flops / t_pred / 1e12 / FP64_PEAK_TFLOPS,
+                            "kernel": "whole call (gemm_nt_fast launches carry > 97 % of the flops)", "traffic": None},
+               "cached_posterior_ms": t_cached * 1e3, "cached_posterior_gflop": float(n) * n * T / 1e9,
+               "cached_posterior_tflops": float(n) * n * T / t_cached / 1e12,
+               "routes_max_abs_diff": {"mean": float((pred["mu"] - cached["mu"]).abs().max()),
+                                       "var": float((pred["var"] - cached["var"]).abs().max())}}
+    res = {"workload": "GPR RBF N=16384 D=8 fp64: K build + Cholesky + LML (one gpk_gpr_lml call) and predict_f at T=4096",
+           "kernel_build_roofline": {"bound": "hbm", "kernel": "rbf_kernel (full N x N)", "achieved": kb_alg / tkb / 1e9,
+                                     "peak": 8000.0, "unit": "GB/s", "frac": kb_alg / tkb / 8e12, "traffic": kb_traffic},
+           "trailing_update_roofline": trailing, "predict": predict,
+           "lml": float(out.cpu()[0]), "info": int(info.cpu()[0]), "ms_total": t * 1e3,
+           "cholesky_gflops_incl_build_and_tail": flops / t / 1e9,
+           "frac_of_fp64_peak": flops / t / 1e12 / FP64_PEAK_TFLOPS,
+           "kernel_build_full_ms": tkb * 1e3, "kernel_build_full_GBps": n * n * 8 / tkb / 1e9,
+           "kernel_build_frac_of_8TBps": n * n * 8 / tkb / 8e12}
+    if with_oracle:
+        from oracle import gp_oracle as orc
+        t0 = time.perf_counter()
+        ref = orc.gpr_log_marginal_likelihood(Xh, Yh, variance=1.0, lengthscales=ls, noise_variance=0.1)
+        t_cpu = time.perf_counter() - t0
+        res["parity_rel_err"] = abs(res["lml"] - ref) / abs(ref)
+        res["oracle_lml"] = float(ref)
+        res["cpu_baseline"] = {"value": flops / t_cpu / 1e9, "unit": "GF/s", "cores": os.cpu_count() or 1, "kind": "port",
+                               "sample": f"one oracle GPR.log_marginal_likelihood at N={n} on the same arrays "
+                                         f"({t_cpu:.1f} s: K build + LAPACK dpotrf + solve, NumPy/SciPy OpenBLAS)"}
+    return res
 
 
-def main():
+def main():  # noqa: C901
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpr", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and Python-mirror legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,29 +293,38 @@ def main():
 
     from gpflow_amd import _lib, ops
     lib = _lib.load()
-    X, Y, Z, q_mu, q_sqrt, ls = make_inputs(rank, device)
-    ws = ops.svgp_elbo_workspace(M_IND, B_ROWS, D_IN, P_LAT, False)
+    n_data, m_ind, d_in, global_rows, strong, seed = WORKLOADS[args.workload]
+    if strong and global_rows % world:
+        raise SystemExit("c4-strong needs a GPU count that divides 8192")
+    b_rows = global_rows // world if strong else global_rows      # rows per rank per step
+    rows_per_step = b_rows * world                                # rows of one global minibatch
+    X, Y, Z, q_mu, q_sqrt, ls = make_inputs(n_data, m_ind, d_in, seed, device)
+    ws = ops.svgp_elbo_workspace(m_ind, b_rows, d_in, P_LAT, False)
     out = torch.empty(2, dtype=torch.float64, device=device)
     info = torch.zeros(1, dtype=torch.int32, device=device)
-    n_batches = N_DATA // (B_ROWS * world)
-    scale = float(N_DATA) / float(B_ROWS * world)
+    n_batches = n_data // rows_per_step
+    scale = float(n_data) / float(rows_per_step)
     last = {}
 
     # the step's scalars land in pinned host memory by two async copies + one stream synchronise
     h_out = torch.empty(2, dtype=torch.float64).pin_memory()
     h_info = torch.empty(1, dtype=torch.int32).pin_memory()
 
+    def shard_lo(s: int, r: int) -> int:
+        return ((s % n_batches) * world + r) * b_rows  # rank r's shard of global minibatch s
+
     def step(s: int) -> float:
-        lo = ((s % n_batches) * world + rank) * B_ROWS  # this rank's shard of global minibatch s
-        ops.svgp_elbo_shard(Z, X[lo:lo + B_ROWS], Y[lo:lo + B_ROWS], q_mu, q_sqrt, variance=1.0, lengthscales=ls,
+        lo = shard_lo(s, rank)
+        ops.svgp_elbo_shard(Z, X[lo:lo + b_rows], Y[lo:lo + b_rows], q_mu, q_sqrt, variance=1.0, lengthscales=ls,
                             noise_variance=0.1, jitter=1e-6, ws=ws, out=out, info=info)
         if world > 1:
-            dist.all_reduce(out[0:1], op=dist.ReduceOp.SUM)  # RCCL over xGMI: one 8-byte all-reduce per step
+            # RCCL over xGMI: one 8-byte all-reduce per step, enqueued behind the shard (no host sync in between)
+            dist.all_reduce(out[0:1], op=dist.ReduceOp.SUM)
         h_out.copy_(out, non_blocking=True)
         h_info.copy_(info, non_blocking=True)
         torch.cuda.current_stream().synchronize()  # scalar is in host memory
         elbo = float(h_out[0]) * scale - float(h_out[1])
-        last.update(elbo=elbo, info=int(h_info[0]))
+        last.update(elbo=elbo, info=int(h_info[0]), step=s)
         return elbo
 
     def fence():
@@ -264,6 +345,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.cpu()[0])
     assert last["info"] == 0 and np.isfinite(last["elbo"]), last
+    timed_last = dict(last)
 
     # ---- roofline leg (dominant kernel = the fp64 MFMA GEMM): HIP events around every GEMM launch ----
     roof = None
@@ -274,15 +356,31 @@ def main():
         step(args.warmup + args.steps + s)
     fence()
     if rank == 0:
+        def by_kind(kind, min_flops=0.0):
+            ms, n_launch, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+            lib.gpk_profile_gemm_collect_kind(int(kind), ctypes.c_double(min_flops), ctypes.byref(ms), ctypes.byref(n_launch),
+                                              ctypes.byref(fl))
+            return ms.value, n_launch.value, fl.value
+
         def collect(min_flops, keep):
             ms, n_launch, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
             lib.gpk_profile_gemm_collect_min(ctypes.c_double(min_flops), int(keep), ctypes.byref(ms),
                                              ctypes.byref(n_launch), ctypes.byref(fl))
             return ms.value, n_launch.value, fl.value
-        # dominant kernel of a step = the q_sqrt projection launch of gemm_nt_fast (EPI=1, paired triangular-K
-        # tiles): the only launch with >= 3e10 algorithmic flop, one per step, fixed shape -> its HIP-event
-        # duration is directly comparable with rocprofv3's average for `gemm_nt_fast<1, true>` (profiles/).
-        ms_dom, n_dom, fl_dom = collect(3e10, True)
+        kinds = {1: "gemm_nt_small", 2: "gemm_nt_fast<0,false>", 3: "gemm_nt_fast<0,true>", 4: "gemm_nt_fast<1,false>",
+                 5: "gemm_nt_fast<1,true>", 6: "gemm_nt_kernel"}
+        per_kernel = {}
+        for kd, nm in kinds.items():
+            ms_k, n_k, fl_k = by_kind(kd)
+            if n_k:
+                per_kernel[nm] = {"launches_per_step": n_k / nprof, "avg_launch_us": ms_k * 1e3 / n_k,
+                                  "algorithmic_gflop_per_step": fl_k / nprof / 1e9,
+                                  "tflops_over_summed_durations": fl_k / (ms_k * 1e-3) / 1e12 if ms_k > 0 else 0.0}
+        # dominant kernel of a step = the kernel (template instantiation) carrying the most algorithmic flops; its
+        # HIP-event average over ALL its launches is directly comparable with rocprofv3's per-kernel average (profiles/)
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["algorithmic_gflop_per_step"])
+        dom_kind = [k for k, v in kinds.items() if v == dom][0]
+        ms_dom, n_dom, fl_dom = by_kind(dom_kind)
         ms_big, n_big, fl_big = collect(1e9, True)
         ms_all, n_all, fl_all = collect(0.0, False)
         lib.gpk_profile_gemm_enable(0)
@@ -296,13 +394,18 @@ def main():
         traffic = None
         try:  # HBM bytes per launch of this kernel from the committed PMC passes (tools/profile_round.sh)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = float(json.load(f)["gemm_nt_fast<1,true>"]["hbm_bytes_per_launch"])
+                traffic = float(json.load(f)[dom]["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "kernel": "gemm_nt_fast<1,true>: q_sqrt projection, v_mfma_f64_16x16x4_f64, 128x128x16 tiles",
+        step_tf = svgp_step_flops(m_ind, b_rows, P_LAT) * (args.steps / elapsed) / 1e12
+        roof = {"bound": "mfma", "kernel": f"{dom}: v_mfma_f64_16x16x4_f64, 128x128x16 tiles",
                 "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
                 "traffic": traffic, "launches_per_step": n_dom / nprof, "avg_launch_us": ms_dom * 1e3 / max(n_dom, 1),
                 "algorithmic_gflop_per_launch": fl_dom / max(n_dom, 1) / 1e9,
+                "step_level": {"achieved": step_tf, "frac": step_tf / FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "note": "algorithmic flops of the whole step (M^3/3 + 2 M^2 B) / wall-clock of the step "
+                                       "(latency chain, launch gaps, reductions, D2H included)"},
+                "per_kernel": per_kernel,
                 "big_gemm_launches": {"launches_per_step": n_big / nprof, "avg_launch_us": ms_big * 1e3 / max(n_big, 1),
                                       "algorithmic_gflop_per_step": fl_big / nprof / 1e9,
                                       "tflops_over_summed_durations": fl_big / (ms_big * 1e-3) / 1e12 if ms_big > 0 else 0.0},
@@ -311,9 +414,9 @@ def main():
                                       "tflops_over_summed_durations": fl_all / (ms_all * 1e-3) / 1e12 if ms_all > 0 else 0.0},
                 "mfma_f64_issue_ubench_tflops": ubench,
                 "frac_of_measured_mfma_ceiling": ach / ubench if ubench > 0 else None,
-                "note": "achieved = algorithmic flops of the launch (2 * B * sum over column tiles of the non-zero K range: "
-                        "M^2 B with the triangle of q_sqrt counted once) / its HIP-event duration, events recorded on the "
-                        "launch stream; peak = AMD datasheet FP64 matrix (the in-image guide lists no fp64 peak; the "
+                "note": "achieved = algorithmic flops (triangular K ranges counted once) of ALL launches of the dominant "
+                        "kernel in a step / the sum of their HIP-event durations, events recorded on each launch's own "
+                        "stream; peak = AMD datasheet FP64 matrix (the in-image guide lists no fp64 peak; the "
                         "v_mfma_f64_16x16x4 issue rate measured on this chip is next to it); traffic = FETCH_SIZE x2 "
                         "(gfx950 correction for 16-B coalesced loads) + WRITE_SIZE of the same kernel from the PMC passes "
                         "in profiles/ (MALL hits included, so an upper bound on HBM bytes)"}
@@ -326,26 +429,44 @@ def main():
         return
 
     steps_per_s = args.steps / elapsed
-    value = steps_per_s * world
+    value = steps_per_s if strong else steps_per_s * world
+    names = {"cm": "BASELINE metric config Cm", "c3": "BASELINE config C3", "c4-weak": "BASELINE config C4, weak scaling",
+             "c4-strong": "BASELINE config C4, strong scaling"}
     res = {
         "metric": "svgp_elbo_steps_per_s", "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "SVGP RBF(ARD)+Gaussian ELBO, N=1e6 M=2048 D=8 P=1 whitened, minibatch 8192 rows per GPU "
-                               "(BASELINE metric config Cm)", "rows_per_gpu_per_step": B_ROWS,
-                   "global_batch": B_ROWS * world, "parallelism": f"dp{world} (minibatch rows sharded, Z/q replicated, "
-                                                                  f"one 8-byte RCCL all-reduce per step)"},
-        "global_steps_per_s": steps_per_s, "last_elbo": last["elbo"],
-        "step_tflops_per_gpu": svgp_step_flops(M_IND, B_ROWS, P_LAT) * steps_per_s / 1e12,
-        "step_frac_of_fp64_peak": svgp_step_flops(M_IND, B_ROWS, P_LAT) * steps_per_s / 1e12 / FP64_PEAK_TFLOPS,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"SVGP RBF(ARD)+Gaussian ELBO, N={n_data:.0e} M={m_ind} D={d_in} P=1 whitened, "
+                               f"{b_rows} minibatch rows per GPU per step ({names[args.workload]})",
+                   "name": args.workload, "rows_per_gpu_per_step": b_rows, "global_batch": rows_per_step,
+                   "parallelism": f"dp{world} (minibatch rows sharded, Z/q replicated, one 8-byte RCCL all-reduce per step)",
+                   "value_counts": "global steps/s" if strong else "8192-row minibatch evaluations/s over the whole job"},
+        "global_steps_per_s": steps_per_s, "last_elbo": timed_last["elbo"],
+        "step_tflops_per_gpu": svgp_step_flops(m_ind, b_rows, P_LAT) * steps_per_s / 1e12,
+        "step_frac_of_fp64_peak": svgp_step_flops(m_ind, b_rows, P_LAT) * steps_per_s / 1e12 / FP64_PEAK_TFLOPS,
+        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
+        "library": lib.gpk_version().decode(),
         "roofline": roof,
     }
-    if world == 1:
+    if not args.no_cpu_baseline:
+        # parity of the LAST TIMED step against the oracle on the same arrays (all shards of that global minibatch; the
+        # data are replicated on every rank), and the oracle's own wall-clock as the CPU baseline
+        s_last = timed_last["step"]
+        idx = torch.cat([torch.arange(shard_lo(s_last, r), shard_lo(s_last, r) + b_rows, device=device) for r in range(world)])
+        base, ref, err = cpu_baseline_and_parity(X[idx].cpu().numpy(), Y[idx].cpu().numpy(), Z.cpu().numpy(),
+                                                 q_mu.cpu().numpy(), q_sqrt.cpu().numpy(), ls, n_data, timed_last["elbo"])
+        if strong or world > 1:
+            base["sample"] += f" (global minibatch of {rows_per_step} rows)"
+        res["cpu_baseline"] = base
+        res["oracle_elbo"] = ref
+        res["parity_rel_err"] = err
+        res["parity_ok"] = bool(err <= 1e-8)
+    if world == 1 and not args.no_extras:
         # PCIe-inclusive rate (never `value`): the same step when the minibatch arrives in (pinned) HOST memory, as it
-        # does for a caller handing NumPy arrays to the Python mirror -- 8192 x (8 + 1) doubles = 0.59 MB per step
-        hX = [X[i * B_ROWS:(i + 1) * B_ROWS].cpu().pin_memory() for i in range(4)]
-        hY = [Y[i * B_ROWS:(i + 1) * B_ROWS].cpu().pin_memory() for i in range(4)]
-        dX, dY = torch.empty_like(X[:B_ROWS]), torch.empty_like(Y[:B_ROWS])
+        # does for a caller handing NumPy arrays to the Python mirror -- rows x (D + 1) doubles per step
+        hX = [X[i * b_rows:(i + 1) * b_rows].cpu().pin_memory() for i in range(4)]
+        hY = [Y[i * b_rows:(i + 1) * b_rows].cpu().pin_memory() for i in range(4)]
+        dX, dY = torch.empty_like(X[:b_rows]), torch.empty_like(Y[:b_rows])
 
         def host_step(s):
             dX.copy_(hX[s % 4], non_blocking=True)
@@ -362,12 +483,27 @@ def main():
             host_step(s)
         torch.cuda.synchronize()
         res["pcie_inclusive_steps_per_s"] = 30.0 / (time.perf_counter() - t1)
+        # the same step through the Python mirror (gpflow_amd.models.SVGP.elbo: Parameters with cached device values,
+        # hyper-parameters converted on the host every call, ctypes into the same fused driver, float() of the result)
+        import gpflow_amd as gpflow
+        model = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=1.0, lengthscales=ls),
+                                   gpflow.likelihoods.Gaussian(0.1), Z.cpu().numpy(), q_mu=q_mu.cpu().numpy(),
+                                   q_sqrt=q_sqrt.cpu().numpy(), num_data=n_data)
+        for s in range(3):
+            v = float(model.elbo((X[s * b_rows:(s + 1) * b_rows], Y[s * b_rows:(s + 1) * b_rows])))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s in range(30):
+            lo = (s % n_batches) * b_rows
+            v = float(model.elbo((X[lo:lo + b_rows], Y[lo:lo + b_rows])))
+        res["python_mirror_steps_per_s"] = 30.0 / (time.perf_counter() - t1)
+        res["python_mirror_last_elbo"] = v
     if world == 1 and not args.no_train:
-        res["train_step"] = train_step_leg(X, Y, Z, q_mu, q_sqrt, ls)
+        res["train_step"] = train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, n_data, b_rows)
     if world == 1 and not args.no_gpr:
-        res["gpr_cholesky"] = gpr_cholesky_leg(ops, lib, device)
-    if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline()
+        del X, Y
+        torch.cuda.empty_cache()
+        res["gpr_cholesky"] = gpr_leg(ops, lib, device, with_oracle=not args.no_cpu_baseline)
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

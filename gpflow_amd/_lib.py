@@ -65,6 +65,7 @@ _SIGS = {
     "gpk_profile_gemm_enable": (None, [c_int]),
     "gpk_profile_gemm_collect": (c_int, [C.POINTER(c_double), C.POINTER(c_long), C.POINTER(c_double)]),
     "gpk_profile_gemm_collect_min": (c_int, [c_double, c_int, C.POINTER(c_double), C.POINTER(c_long), C.POINTER(c_double)]),
+    "gpk_profile_gemm_collect_kind": (c_int, [c_int, c_double, C.POINTER(c_double), C.POINTER(c_long), C.POINTER(c_double)]),
     "gpk_profile_gemm_window": (c_int, [c_double, C.POINTER(c_double), C.POINTER(c_double), C.POINTER(c_double),
                                         C.POINTER(c_long)]),
     "gpk_bench_mfma_f64": (c_int, [c_void_p, c_int, c_int, _dp]),

@@ -55,13 +55,19 @@ def _as_rows(Kmn: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, ...]]:
 
 
 def conditional_tail(At: torch.Tensor, fac: Factor, Knn: torch.Tensor, f: torch.Tensor, *,
-                     full_cov: bool, q_sqrt: Optional[torch.Tensor], white: bool):
+                     full_cov: bool, q_sqrt: Optional[torch.Tensor], white: bool,
+                     Linv_f: Optional[torch.Tensor] = None):
     """Everything of base_conditional_with_lm after A = Lm^-1 Kmn (util.py:128-167).
     At [N,M] (overwritten when not white); Knn [N] or [N,N]; f [M,R]; returns fmean [N,R] and
-    fvar [N,R] / [R,N,N]."""
+    fvar [N,R] / [R,N,N].
+    Linv_f [M,R] = Lm^-1 f, if the caller has it (it rides through the factorisation as R extra rows): with no q_sqrt
+    the un-whitened mean  (Lm^-T A)^T f = A^T (Lm^-1 f)  then needs no second triangular solve of the N columns of A
+    (util.py:139 costs M^2 N flops; this form costs M N) -- the equivalent alpha-form SURVEY 8d names for GPR predict."""
     N, M = At.shape
     R = f.shape[1]
     f = f.contiguous()
+    if not white and q_sqrt is None and Linv_f is not None:
+        white, f = True, Linv_f.contiguous()
     if full_cov:
         fvar0 = Knn - ops.gemm_nt(At, At)  # Knn - A^T A           (util.py:129)
         s0 = None

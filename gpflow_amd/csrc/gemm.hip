@@ -22,6 +22,9 @@ namespace {
 
 constexpr int BK = 16;
 constexpr int LDSS = BK + 2;
+// kernel the launcher picked last (bench profiling facility only; see gpk_profile_gemm_collect_kind):
+// 1 gemm_nt_small, 2 + 2 EPI + PAIR gemm_nt_fast<EPI, PAIR>, 6 gemm_nt_kernel
+int g_last_kind = 0;
 constexpr int GROUP_N = 8;
 
 template <int BM, int BN, int WGM, int WGN>
@@ -634,6 +637,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
                                     : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0 && a.ctr == nullptr);
     if (pair_ok && gx >= 4 && a.b_tri_rows >= a.n) {
       total = ((gx + 1) / 2) * gy;
+      g_last_kind = 2 + 2 * EPI + 1;
       hipLaunchKernelGGL((gemm_nt_fast<EPI, true>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy,
                          total, compact);
       GPK_LAUNCH_CHECK();
@@ -643,10 +647,14 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   unsigned nwg = (unsigned)total;
   if (a.max_wgs > 0 && (unsigned)a.max_wgs < nwg) nwg = (unsigned)a.max_wgs;
   GemmArgs b = a;
+  g_last_kind = 2 + 2 * EPI;
   if (a.ctr != nullptr && nb == 1) {
     // ticketed: one resident set (2 workgroups per CU by LDS and VGPRs) unless capped; reserved-CU workgroups exit
+    // (a quarter more workgroups than tiles when there are few tiles: the ones that land on reserved CUs leave at once,
+    //  and the survivors should still be able to take one tile each)
     const unsigned cap = a.max_wgs > 0 ? (unsigned)a.max_wgs : 512u;
-    nwg = (unsigned)total < cap ? (unsigned)total : cap;
+    const unsigned want = (unsigned)total + (unsigned)total / 4u + 16u;
+    nwg = want < cap ? want : cap;
     b.stagger_ticks = 0;
     hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, 1, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total, compact);
     GPK_LAUNCH_CHECK();
@@ -775,6 +783,7 @@ int launch_small(hipStream_t s, const GemmArgs& a) {
                                                      (int)((SM_BM + SM_BN) * 130 * sizeof(double)));
   GPK_HIP(attr);
   dim3 grid((unsigned)gpk_cdiv(a.n, SM_BN), (unsigned)gpk_cdiv(a.m, SM_BM), (unsigned)(a.batch > 0 ? a.batch : 1));
+  g_last_kind = 1;
   hipLaunchKernelGGL(gemm_nt_small, grid, dim3(SM_THREADS), lds, s, a, ldk);
   GPK_LAUNCH_CHECK();
   return 0;
@@ -813,6 +822,7 @@ int launch_cfg(hipStream_t s, const GemmArgs& a) {
     if (total <= 0) return 0;
   }
   dim3 grid((unsigned)total, (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  g_last_kind = 6;
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN>), grid, dim3(256), Cfg::LDS_BYTES, s, a, gx, gy, total,
                      compact);
   GPK_LAUNCH_CHECK();
@@ -826,7 +836,7 @@ int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
 // ---- optional per-launch timing (bench.py roofline leg): HIP events around every GEMM launch, on the
 // stream the kernel is launched on.  Off by default; adds two event records per launch when on. -------
 namespace {
-struct ProfRec { hipEvent_t e0, e1; double flops; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int kind; };
 bool g_prof_on = false;
 ProfRec* g_prof = nullptr;
 int g_prof_n = 0, g_prof_cap = 0;
@@ -901,6 +911,25 @@ extern "C" int gpk_profile_gemm_window(double min_flops, double* window_ms, doub
   if (launches_all) *launches_all = cnt;
   return 0;
 }
+// the same, restricted to launches of ONE kernel (kind: 1 gemm_nt_small, 2 gemm_nt_fast<0,false>, 3 <0,true>, 4 <1,false>,
+// 5 <1,true>, 6 gemm_nt_kernel) -- directly comparable with rocprofv3's per-kernel average.  Records are kept.
+extern "C" int gpk_profile_gemm_collect_kind(int kind, double min_flops, double* total_ms, long* launches, double* flops) {
+  GPK_HIP(hipDeviceSynchronize());
+  double ms = 0.0, fl = 0.0;
+  long cnt = 0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    if (g_prof[i].kind != kind || g_prof[i].flops < min_flops) continue;
+    float t = 0.f;
+    GPK_HIP(hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1));
+    ms += t;
+    fl += g_prof[i].flops;
+    ++cnt;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = cnt;
+  if (flops) *flops = fl;
+  return 0;
+}
 extern "C" int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops) {
   return gpk_profile_gemm_collect_min(0.0, 0, total_ms, launches, flops);
 }
@@ -925,6 +954,7 @@ int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
   r.flops = algorithmic_flops(a);
   GPK_HIP(hipEventRecord(r.e0, s));
   const int rc = launch_select(s, a);
+  r.kind = g_last_kind;
   GPK_HIP(hipEventRecord(r.e1, s));
   return rc;
 }

@@ -37,7 +37,9 @@ inline GemmArgs gemm_base(int m, int n, int k, double alpha, const double* A, lo
 struct Bulk {
   unsigned* ctr = nullptr;
   const unsigned char* resv = nullptr;
+  int cap = 0;  // plain launches only: cap on persistent workgroups of big updates (A/B of the round-1 scheme)
   void apply(GemmArgs& g) const {
+    if (!ctr && cap > 0 && g.k >= 256) g.max_wgs = cap;
     if (ctr && g.batch == 1) {
       g.ctr = ctr;
       g.resv = resv;
@@ -79,7 +81,7 @@ namespace {
 struct Aux {
   std::recursive_mutex mu;
   bool ready = false;
-  hipStream_t P = nullptr, B = nullptr, Bs = nullptr, Bl = nullptr, X = nullptr;
+  hipStream_t P = nullptr, B = nullptr, Bs = nullptr, Bl = nullptr, X = nullptr, pad = nullptr;
   hipEvent_t* ev = nullptr;
   int nev = 0;
   unsigned char* resv = nullptr;  // device [GPK_CU_KEYS]: 1 = compute unit reserved for the latency chain
@@ -147,22 +149,36 @@ int aux_get(int dev, int need, Aux** out) {
   if (!a.ready) {
     int lo = 0, hi = 0;
     GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    GPK_HIP(hipStreamCreateWithPriority(&a.P, hipStreamNonBlocking, hi));
     hipDeviceProp_t prop;
     GPK_HIP(hipGetDeviceProperties(&prop, dev));
     const int ncu = prop.multiProcessorCount;
     a.ncu = ncu;
+    // Stream -> hardware queue -> microengine pipe.  Two facts measured on MI355X (rocprofv3 kernel timelines of the
+    // SVGP step, profiles/r02_*): (1) HIP keeps a pool of GPU_MAX_HW_QUEUES hardware queues per priority level: a new
+    // stream opens a new queue while the pool is not full, afterwards it shares the queue with the fewest streams
+    // (ties: the most recently opened queue); CU-masked and non-default-priority streams get queues of their own.
+    // (2) Hardware queues are spread round-robin over FOUR pipes in creation order, and two queues of one pipe that
+    // are active at the same time slow each other down badly: every kernel start / cross-queue event hand-off on them
+    // then takes ~50 us instead of ~5 (queues 1 and 5, or 2 and 6: the step went from 2.2 to 3.3 - 4.4 ms).
+    // Hence this creation order -- default stream = queue 1 (pipe 0) exists already:
+    //   P -> queue 2 (pipe 1);  X -> queue 3 (pipe 2);  one unused stream, then Bs: with the usual pool of 2 the unused
+    //   one shares X's queue and Bs lands on the default stream's (idle) queue 1, with a pool of 4 they open queues 4
+    //   and 5 (pipes 3 and 0);  then the masked B -> pipe 3 (or 1) and Bl -> pipe 0 (or 2).
+    // The chain (P), its rest-updates (Bs) and the bulk stream (X or B) are then always on three different pipes.
+    GPK_HIP(hipStreamCreateWithPriority(&a.P, hipStreamNonBlocking, hi));
+    GPK_HIP(hipStreamCreateWithFlags(&a.X, hipStreamNonBlocking));
+    GPK_HIP(hipStreamCreateWithFlags(&a.pad, hipStreamNonBlocking));
+    GPK_HIP(hipStreamCreateWithFlags(&a.Bs, hipStreamNonBlocking));
     int reserved = GPK_TUNE(RESERVED_CUS, 16);
     if (ncu > 1024 || reserved < 0 || reserved >= ncu) reserved = 0;
     int rc = masked_stream(&a.B, ncu, reserved, ncu);
     if (rc) return rc;
     a.bulk_cus = ncu - reserved;
-    int late_res = GPK_TUNE(LATE_RESERVED_CUS, ncu / 2);
-    if (ncu > 1024 || late_res < 0 || late_res >= ncu) late_res = 0;
+    int late_res = GPK_TUNE(LATE_RESERVED_CUS, -1);
+    if (late_res < 0) late_res = ncu / 2;
+    if (ncu > 1024 || late_res >= ncu) late_res = 0;
     rc = masked_stream(&a.Bl, ncu, late_res, ncu);
     if (rc) return rc;
-    GPK_HIP(hipStreamCreateWithFlags(&a.Bs, hipStreamNonBlocking));
-    GPK_HIP(hipStreamCreateWithFlags(&a.X, hipStreamNonBlocking));
     rc = build_reservation(a, GPK_TUNE(SOFT_RESERVED_CUS, 32));
     if (rc) return rc;
     a.ready = true;
@@ -217,40 +233,70 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
   return 0;
 }
 
-// Rows E [rows, n] (leading dimension lde) against the finished columns [c0,c1) of the factor L (ldl), right-looking:
-//   E[:,c0:c1] <- E[:,c0:c1] L[c0:c1,c0:c1]^-T            (NB-blocked, diagonal-block inverses; after block j is solved
+// Rows E [rows, n] against the finished columns [c0,c1) of the factor L (ldl), right-looking:
+//   S[:,c0:c1] = E[:,c0:c1] L[c0:c1,c0:c1]^-T             (NB-blocked, diagonal-block inverses; after block j is solved
 //                                                          ALL remaining columns of the group get one K = 128 update --
 //                                                          the left-looking form was latency-bound at 44 / 58 / 74 us)
-//   E[:,c1:n]  -= E[:,c0:c1] L[c1:n,c0:c1]^T               (one large GEMM, K = c1 - c0)
-// Used for the extra rows of the factorisation and, group after group, by gpk_trsm(trans = 0).
-int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, int rows, const double* L, long ldl,
-                    const double* invd, long strideInv, int n, int c0, int c1, int batch, long strideE, long strideL) {
+//   E[:,c1:n] -= S[:,c0:c1] L[c1:n,c0:c1]^T                (one large GEMM, K = c1 - c0)
+// The solved columns S are written to Eo (ldeo) -- the same matrix as E for the in-place form, a separate one when the
+// caller wants A^T apart from the consumed input rows.  Used for the extra rows of the factorisation and, group after
+// group, by gpk_trsm(trans = 0).
+// With `ginv` (the explicit inverse of the group's 512 x 512 diagonal block, lower, leading dimension 512; Eo != E
+// required: several column tiles read what others write) the seven short dependent launches of the in-group phase --
+// 64 to 192 tiles each on a 256-CU chip -- become ONE triangular-K GEMM  S = E[:,c0:c1] ginv^T.
+int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, double* Eo, long ldeo, int rows, const double* L,
+                    long ldl, const double* invd, long strideInv, int n, int c0, int c1, int batch, long strideE,
+                    long strideEo, long strideL, const double* ginv = nullptr) {
   int rc;
-  for (int j0 = c0; j0 < c1; j0 += NB) {
-    const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
-    const int nb = j1 - j0;
-    GemmArgs g = gemm_base(rows, nb, nb, 1.0, E + j0, lde, invd + (long)(j0 / NB) * NB * NB, NB, 0.0,
-                           E + j0, lde, batch, strideE, strideInv, strideE);
+  if (ginv != nullptr) {
+    GemmArgs g = gemm_base(rows, c1 - c0, c1 - c0, 1.0, E + c0, lde, ginv, c1 - c0, 0.0, Eo + c0, ldeo, batch, strideE, 0,
+                           strideEo);
     g.b_tri = 2;
     bulk.apply(g);
     rc = gpk_launch_gemm(s, g);
     if (rc) return rc;
-    if (j1 < c1) {
-      GemmArgs u = gemm_base(rows, c1 - j1, nb, -1.0, E + j0, lde, L + (long)j1 * ldl + j0, ldl, 1.0,
-                             E + j1, lde, batch, strideE, strideL, strideE);
-      bulk.apply(u);
-      rc = gpk_launch_gemm(s, u);
+  } else {
+    for (int j0 = c0; j0 < c1; j0 += NB) {
+      const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
+      const int nb = j1 - j0;
+      GemmArgs g = gemm_base(rows, nb, nb, 1.0, E + j0, lde, invd + (long)(j0 / NB) * NB * NB, NB, 0.0,
+                             Eo + j0, ldeo, batch, strideE, strideInv, strideEo);
+      g.b_tri = 2;
+      bulk.apply(g);
+      rc = gpk_launch_gemm(s, g);
       if (rc) return rc;
+      if (j1 < c1) {
+        GemmArgs u = gemm_base(rows, c1 - j1, nb, -1.0, Eo + j0, ldeo, L + (long)j1 * ldl + j0, ldl, 1.0,
+                               E + j1, lde, batch, strideEo, strideL, strideE);
+        bulk.apply(u);
+        rc = gpk_launch_gemm(s, u);
+        if (rc) return rc;
+      }
     }
   }
   if (c1 < n) {
-    GemmArgs u = gemm_base(rows, n - c1, c1 - c0, -1.0, E + c0, lde, L + (long)c1 * ldl + c0, ldl, 1.0,
-                           E + c1, lde, batch, strideE, strideL, strideE);
+    GemmArgs u = gemm_base(rows, n - c1, c1 - c0, -1.0, Eo + c0, ldeo, L + (long)c1 * ldl + c0, ldl, 1.0,
+                           E + c1, lde, batch, strideEo, strideL, strideE);
     bulk.apply(u);
     rc = gpk_launch_gemm(s, u);
     if (rc) return rc;
   }
   return 0;
+}
+
+// Explicit inverse of the diagonal block L[c0:c1, c0:c1] (c1 - c0 = w <= 512 columns, all panels factored) into
+// ginv [w, w] (lower, leading dimension w), using wT [w, w] as scratch: the right-looking in-group solve applied to the
+// rows of the identity gives L_gg^-T, which is then transposed.  Nine tiny launches (a few workgroups each) on a stream
+// beside the chain; nothing here touches the bulk stream.
+int group_inverse(hipStream_t s, const double* L, long ldl, const double* invd, long strideInv, int c0, int c1, double* wT,
+                  double* ginv) {
+  const int w = c1 - c0;
+  int rc = gpk_launch_set_identity(s, wT, w, w);
+  if (rc) return rc;
+  // (wT - c0: the solver indexes columns globally)
+  rc = solve_group_fwd(s, Bulk{}, wT - c0, w, wT - c0, w, w, L, ldl, invd, strideInv, c1, c0, c1, 1, 0, 0, 0);
+  if (rc) return rc;
+  return gpk_transpose((void*)s, wT, w, w, w, ginv, w, 2, 1, 0, 0);  // keep the upper triangle of L_gg^-T only
 }
 
 // The mirror image for  B <- B L^-1  with LT = L^T (upper, row-major) and the transposed block inverses: columns
@@ -332,8 +378,15 @@ int proj_group(hipStream_t s, const Bulk& bulk, ProjStream& q, const double* At,
   return 0;
 }
 
+// optional separate output of the solved extra rows (batch 1) + scratch for the explicit group inverses
+struct ExtraOut {
+  double* Eout = nullptr; long ldeout = 0;
+  double* gws = nullptr;   // 2 * 512 * 512 doubles per 512-column group of the factor (gpk_ginv_ws_doubles)
+};
+inline size_t ginv_ws_doubles(int n) { return (size_t)gpk_cdiv(n, NBO) * 2 * NBO * NBO; }
+
 int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
-               int* info, ProjStream* proj) {
+               int* info, ProjStream* proj, const ExtraOut* xo = nullptr) {
   if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
   if (batch <= 0) batch = 1;
   if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, S));
@@ -351,12 +404,18 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   const int R = ride ? n + extra : n;  // rows handled together with the square part
   const bool useX = extra > 0 && !ride;
   double* E = A + (long)n * lda;       // the extra rows
+  // solved extra rows: in place, or in the caller's separate matrix (only when they are solved apart from the square part)
+  const bool oop = xo && xo->Eout && useX && batch == 1;
+  double* Eo = oop ? xo->Eout : E;
+  const long ldeo = oop ? xo->ldeout : lda;
+  const long strideEo = oop ? 0 : strideA;
   int rc;
   if (n <= NB) {  // one leaf; nothing to overlap
     rc = factor_panel(S, A, R, 0, n, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
     if (useX) {
-      rc = solve_group_fwd(S, Bulk{}, E, lda, extra, A, lda, invd, strideInv, n, 0, n, batch, strideA, strideA);
+      rc = solve_group_fwd(S, Bulk{}, E, lda, Eo, ldeo, extra, A, lda, invd, strideInv, n, 0, n, batch, strideA, strideEo,
+                           strideA);
       if (rc) return rc;
     }
     return zero_upper ? gpk_launch_zero_upper(S, A, n, lda, batch, strideA) : 0;
@@ -366,7 +425,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> lock(g_aux[dev].mu);
   Aux* aux = nullptr;
-  rc = aux_get(dev, 2 * npanels + 8, &aux);
+  rc = aux_get(dev, 3 * npanels + 8, &aux);
   if (rc) return rc;
   const bool large = n >= 4096;
   hipStream_t P = aux->P, B = large ? aux->B : aux->Bs;
@@ -377,14 +436,18 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   if (!large && batch == 1 && GPK_TUNE(SOFT_RESERVE, 1)) {
     bulk.ctr = aux->ctr;
     bulk.resv = aux->resv_cus > 0 ? aux->resv : nullptr;
+  } else if (!large) {
+    bulk.cap = GPK_TUNE(EXTRA_MAX_WGS, 0);
   }
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
   hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
-  hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1], evJoinB = aux->ev[2 * npanels + 2],
-             evJoinX = aux->ev[2 * npanels + 3], evLate = aux->ev[2 * npanels + 4];
+  hipEvent_t* evG = aux->ev + 2 * npanels;  // [npanels] explicit inverse of the group ending with panel p ready (on B)
+  hipEvent_t evFork = aux->ev[3 * npanels], evJoinP = aux->ev[3 * npanels + 1], evJoinB = aux->ev[3 * npanels + 2],
+             evJoinX = aux->ev[3 * npanels + 3], evLate = aux->ev[3 * npanels + 4];
+  const bool use_ginv = oop && xo->gws && !large && GPK_TUNE(GROUP_INVERSE, 1);
   GPK_HIP(hipEventRecord(evFork, S));  // fork: everything already queued on S comes first
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
-  GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
+  if (B != S) GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
   if (useX && X != B) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
@@ -444,14 +507,28 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     if (useX && (c1 == n || full_group || tail_group)) {
       const int g0 = xg0;
       xg0 = c1;
+      // a full, aligned 512-column group: its explicit inverse is assembled on B (right behind the rest-update of the
+      // group's last panel; a handful of one-to-four-workgroup launches) and the bulk stream solves the group in one GEMM
+      const double* ginv = nullptr;
+      if (use_ginv && c1 - g0 == NBO && (g0 % NBO) == 0) {
+        double* wT = xo->gws + (size_t)(g0 / NBO) * 2 * NBO * NBO;
+        double* gi = wT + (size_t)NBO * NBO;
+        if (c2 >= n) GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));  // (no rest-update was issued for this panel)
+        rc = group_inverse(B, A, lda, invd, strideInv, g0, c1, wT, gi);
+        if (rc) return rc;
+        GPK_HIP(hipEventRecord(evG[p], B));
+        GPK_HIP(hipStreamWaitEvent(X, evG[p], 0));
+        ginv = gi;
+      }
       GPK_HIP(hipStreamWaitEvent(X, evF[p], 0));
       // (columns [g0, c1) may span several 512-groups when the outer panel is wider than a group)
       for (int h0 = g0; h0 < c1; h0 += NBO) {
         const int h1 = std::min(h0 + NBO, c1);
-        rc = solve_group_fwd(X, bulk, E, lda, extra, A, lda, invd, strideInv, n, h0, h1, batch, strideA, strideA);
+        rc = solve_group_fwd(X, bulk, E, lda, Eo, ldeo, extra, A, lda, invd, strideInv, n, h0, h1, batch, strideA,
+                             strideEo, strideA, ginv);
         if (rc) return rc;
         if (proj) {
-          rc = proj_group(X, bulk, *proj, E, lda, extra, h0, h1, n);
+          rc = proj_group(X, bulk, *proj, Eo, ldeo, extra, h0, h1, n);
           if (rc) return rc;
         }
       }
@@ -459,9 +536,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   }
   // join: P has waited for every rest-update it depends on; B's last event covers the rest
   GPK_HIP(hipEventRecord(evJoinP, P));
-  GPK_HIP(hipEventRecord(evJoinB, last_bulk));  // rest-updates are chained through evR, the last one covers all
   GPK_HIP(hipStreamWaitEvent(S, evJoinP, 0));
-  GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
+  if (last_bulk != S) {
+    GPK_HIP(hipEventRecord(evJoinB, last_bulk));  // rest-updates are chained through evR, the last one covers all
+    GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
+  }
   if (useX && X != last_bulk) {
     GPK_HIP(hipEventRecord(evJoinX, X));
     GPK_HIP(hipStreamWaitEvent(S, evJoinX, 0));
@@ -517,8 +596,8 @@ extern "C" int gpk_trsm(void* stream, int trans, const double* L, long ldl, cons
   int rc;
   if (trans == 0) {
     for (int g0 = 0; g0 < n; g0 += NBO) {
-      rc = solve_group_fwd(s, Bulk{}, B, ldb, m, L, ldl, invd, strideInv, n, g0, std::min(g0 + NBO, n), batch, strideB,
-                           strideL);
+      rc = solve_group_fwd(s, Bulk{}, B, ldb, B, ldb, m, L, ldl, invd, strideInv, n, g0, std::min(g0 + NBO, n), batch,
+                           strideB, strideB, strideL);
       if (rc) return rc;
     }
   } else {
@@ -632,7 +711,7 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
 namespace {
 struct ElboLayout {
   long ld; int nt;
-  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_C, total;
+  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_C, off_At, off_gws, total;
 };
 // the q_sqrt projection streamed behind the extra-row solve (1) or as one GEMM after the factorisation (0)
 inline bool stream_proj_on() { return GPK_TUNE(STREAM_PROJ, GPK_STREAM_PROJ_DEFAULT) != 0; }
@@ -651,7 +730,9 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   l.off_proj = o; o += q_diag ? 0 : gpk_align_up(gpk_project_workspace_bytes(rows, m, P), 256);
   l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
-  l.off_C = o; o += q_diag ? 0 : gpk_align_up((size_t)P * rows * l.ld * sizeof(double), 256);  // running A^T Lq (streamed projection)
+  l.off_C = o; o += (q_diag || !stream_proj_on()) ? 0 : gpk_align_up((size_t)P * rows * l.ld * sizeof(double), 256);  // running A^T Lq (streamed projection)
+  l.off_At = o; o += gpk_align_up((size_t)rows * l.ld * sizeof(double), 256);  // A^T = Kfu Lm^-T apart from the consumed Kfu rows
+  l.off_gws = o; o += gpk_align_up(ginv_ws_doubles(m) * sizeof(double), 256);  // explicit inverses of the 512-column groups
   l.total = o;
   return l;
 }
@@ -684,7 +765,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   double* ssq = (double*)(w + l.off_ssq);
   double* part0 = (double*)(w + l.off_part0);
   double* part1 = (double*)(w + l.off_part1);
-  double* At = T + (long)m * l.ld;  // extra rows of the trapezoid: Kfu in, A^T = Kfu Lm^-T out (in place)
+  double* Kfu = T + (long)m * l.ld;  // extra rows of the trapezoid: Kfu, consumed by the factorisation
   int rc;
   // Kuf^T = k(Xb, Z) as the extra rows (posteriors.py:836, covariances/kufs.py:31-34).  Only the bulk stream of the
   // factorisation consumes it, so it is built THERE (ordered after everything already queued on the caller's stream)
@@ -692,6 +773,9 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   // nor minibatch solve -- tril(q_sqrt)^T for the projection and the whole KL term -- goes to that stream too, which
   // idles until the first 512 columns of Lm exist; gpk_potrf joins it.
   const bool side = m > GPK_NB && m < 4096 && rows > 256;
+  // A^T = Kfu Lm^-T: in its own matrix when the extra rows are solved apart from the square part (then whole 512-column
+  // groups are solved with one GEMM against the group's explicit inverse), in place otherwise
+  double* At = side ? (double*)(w + l.off_At) : Kfu;
   int dev = 0;
   rc = current_device(&dev);
   if (rc) return rc;
@@ -707,7 +791,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     kfu_stream = aux->X;
   }
   rc = gpk_kernel_matrix((void*)kfu_stream, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0,
-                         At, l.ld);
+                         Kfu, l.ld);
   if (rc) return rc;
   int c1 = 0;
   if (side) {
@@ -735,7 +819,11 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     ps.part = (double*)(w + l.off_proj); ps.part_ld = rows; ps.stridePart = (long)l.nt * rows;
     ps.P = P;
   }
-  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, stream_proj ? &ps : nullptr);
+  ExtraOut xo;
+  if (side) {
+    xo.Eout = At; xo.ldeout = l.ld; xo.gws = (double*)(w + l.off_gws);
+  }
+  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, stream_proj ? &ps : nullptr, side ? &xo : nullptr);
   if (lock.owns_lock()) lock.unlock();
   if (rc) return rc;
   const bool projected = stream_proj && ps.groups > 0;

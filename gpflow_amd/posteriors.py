@@ -129,6 +129,7 @@ class GPRPosterior(AbstractPosterior):
         self.Y_data = ops.to_device(Y)
         self.likelihood = likelihood
         self._factor: Optional[Factor] = None
+        self._alpha = None
         if precompute_cache is not None:
             self.update_cache(precompute_cache)
 
@@ -136,22 +137,28 @@ class GPRPosterior(AbstractPosterior):
         return self.Y_data - self.mean_function(self.X_data)
 
     def _precompute(self):
-        """cache = (err, Lm) (posteriors.py:415-432); the block inverses stay alongside Lm."""
+        """cache = (err, Lm) (posteriors.py:415-432); the block inverses and alpha = Lm^-1 err (which rides through
+        the factorisation as P extra rows, logdensities.py:150 style) stay alongside Lm."""
         X = self.kernel.slice(self.X_data, None)[0]
         n = X.shape[0]
-        Lm = torch.empty((n, n), dtype=torch.float64, device=X.device)
-        self.kernel.K_into(X, None, Lm, diag_add=self.likelihood.noise_variance(), lower_only=True)
-        invd, info = ops.potrf_(Lm, n, zero_upper=True)
+        err = self._err()
+        P = err.shape[1]
+        T = torch.empty((n + P, n), dtype=torch.float64, device=X.device)
+        self.kernel.K_into(X, None, T[:n], diag_add=self.likelihood.noise_variance(), lower_only=True)
+        T[n:] = err.t()
+        invd, info = ops.potrf_(T, n, zero_upper=True)
         ops.check_info(info)
+        Lm = T[:n]
         self._factor = Factor(Lm, invd)
-        return self._err(), Lm
+        self._alpha = ops.transpose(T[n:])  # [n, P] = Lm^-1 err
+        return err, Lm
 
     def _conditional_with_precompute(self, cache, Xnew, full_cov: bool = False, full_output_cov: bool = False):
         """posteriors.py:384-409"""
         assert_params_false(self._conditional_with_precompute, full_output_cov=full_output_cov)
         err, Lm = cache
-        fac = self._factor if (self._factor is not None and self._factor.L is Lm) else Factor(
-            Lm, ops.trtri_blocks(Lm))
+        own = self._factor is not None and self._factor.L is Lm
+        fac = self._factor if own else Factor(Lm, ops.trtri_blocks(Lm))
         Xf, lead = _flatten_rows(Xnew)
         if full_cov and len(lead) > 1:
             raise NotImplementedError("full_cov with leading batch dimensions")
@@ -159,7 +166,8 @@ class GPRPosterior(AbstractPosterior):
         At = self.kernel.K_into(Xs, Xd, None)  # Kmn^T [T, N]
         ops.trsm_(At, fac.L, fac.invd, trans=0)
         Knn = self.kernel(Xf, full_cov=full_cov)
-        fmean, fvar = conditional_tail(At, fac, Knn, err, full_cov=full_cov, q_sqrt=None, white=False)
+        fmean, fvar = conditional_tail(At, fac, Knn, err, full_cov=full_cov, q_sqrt=None, white=False,
+                                       Linv_f=self._alpha if own else None)
         if len(lead) > 1:
             fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
         return fmean, fvar
@@ -173,15 +181,19 @@ class GPRPosterior(AbstractPosterior):
             raise NotImplementedError("full_cov with leading batch dimensions")
         Xs, Xd = self.kernel.slice(Xf, self.X_data)
         n, t = Xd.shape[0], Xs.shape[0]
-        T = torch.empty((n + t, n), dtype=torch.float64, device=Xd.device)
+        err = self._err()
+        P = err.shape[1]
+        # one trapezoid [K + noise I ; Kxs ; err^T]: the factorisation returns A^T = Kxs Lm^-T and alpha^T = (Lm^-1 err)^T
+        T = torch.empty((n + t + P, n), dtype=torch.float64, device=Xd.device)
         self.kernel.K_into(Xd, None, T[:n], diag_add=self.likelihood.noise_variance(), lower_only=True)
-        self.kernel.K_into(Xs, Xd, T[n:])
+        self.kernel.K_into(Xs, Xd, T[n:n + t])
+        T[n + t:] = err.t()
         invd, info = ops.potrf_(T, n, zero_upper=True)
         ops.check_info(info)
         fac = Factor(T[:n], invd)
         Knn = self.kernel(Xf, full_cov=full_cov)
-        fmean, fvar = conditional_tail(T[n:], fac, Knn, self._err(), full_cov=full_cov, q_sqrt=None,
-                                       white=False)
+        fmean, fvar = conditional_tail(T[n:n + t], fac, Knn, err, full_cov=full_cov, q_sqrt=None,
+                                       white=False, Linv_f=ops.transpose(T[n + t:]))
         if len(lead) > 1:
             fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
         return fmean, fvar

@@ -208,6 +208,10 @@ void gpk_profile_gemm_enable(int on);
 int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops);
 /* same, restricted to launches with at least min_flops algorithmic flops; keep != 0 keeps the records */
 int gpk_profile_gemm_collect_min(double min_flops, int keep, double* total_ms, long* launches, double* flops);
+/* same, restricted to launches of ONE kernel -- kind 1 gemm_nt_small, 2 gemm_nt_fast<0,false>, 3 <0,true>, 4 <1,false>,
+ * 5 <1,true>, 6 gemm_nt_kernel -- so that the HIP-event average can be compared with rocprofv3's per-kernel average;
+ * records are kept */
+int gpk_profile_gemm_collect_kind(int kind, double min_flops, double* total_ms, long* launches, double* flops);
 /* phase spanned by the launches with >= min_flops (first start .. last end) and the algorithmic flops of ALL recorded
  * launches issued in between, on any stream: chip-wide rate of a phase in which several streams share the machine */
 int gpk_profile_gemm_window(double min_flops, double* window_ms, double* flops_all, double* flops_matching,

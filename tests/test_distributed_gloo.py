@@ -164,3 +164,68 @@ def test_sgpr_row_sharded_world2_gloo():
     (_, e0, ref0), (_, e1, _) = results
     assert e0 == e1
     assert abs(e0 - ref0) <= 1e-10 * abs(ref0)
+
+
+def _product_worker(rank, world, port, q, backend):
+    """`distributed.svgp_elbo_data_parallel` on the PRODUCT host code (SVGP model surface -> elbo_terms -> fused shard):
+    gloo + emulated primitives on CPU, nccl (= RCCL) + the HIP library when GPUs are visible."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gpflow_amd as gpflow
+        from gpflow_amd import distributed, ops
+        from oracle import gp_oracle as orc
+        if backend == "gloo":
+            import fake_ops
+            for name in dir(fake_ops):
+                if not name.startswith("_") and callable(getattr(fake_ops, name)) and hasattr(ops, name) \
+                        and name not in ("torch", "np", "sla"):
+                    setattr(ops, name, getattr(fake_ops, name))
+        rng = np.random.default_rng(21)  # identical on every rank
+        B, M, D, P = 301, 140, 3, 2
+        X = rng.normal(size=(B, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(B, P))
+        Z = rng.normal(size=(M, D)); q_mu = 0.2 * rng.normal(size=(M, P))
+        q_sqrt = np.tril(rng.normal(size=(P, M, M))) * 0.05 + 0.5 * np.eye(M)
+        ls = 0.9 * np.sqrt(D)
+        m = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=ls),
+                               gpflow.likelihoods.Gaussian(0.2), Z, q_mu=q_mu, q_sqrt=q_sqrt, num_data=7000)
+        elbo = float(distributed.svgp_elbo_data_parallel(m, (ops.to_device(X), ops.to_device(Y))))
+        ref = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt, variance=1.1, lengthscales=ls, noise_variance=0.2, num_data=7000)
+        q.put((rank, elbo, ref))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_product(backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_product_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, e0, ref0), (_, e1, _) = results
+    assert e0 == e1                                   # the all-reduce leaves every rank with the same ELBO
+    np.testing.assert_allclose(e0, ref0, rtol=1e-9)   # and it is the single-process ELBO of the whole minibatch
+
+
+def test_product_data_parallel_elbo_world2_gloo():
+    _run_product("gloo")
+
+
+@pytest.mark.gpu
+def test_product_data_parallel_elbo_world2_nccl():
+    """The same through RCCL on two MI355X (one process per GPU).  Skipped on boxes with fewer than 2 devices -- the
+    1-GPU gpurun boxes of this build never ran it; it is here for the 8-GPU node."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 HIP devices")
+    _run_product("nccl")

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "r1_ref"))
 from gpflow_amd import ops  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
