@@ -360,6 +360,11 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   if (load_c) {
     const double* __restrict__ C = p.C + (long)bz * p.strideC;
     const double sc = p.beta / p.alpha;
+#ifdef GPK_EXPERIMENTAL
+    const bool bypass = p.c_l1_bypass != 0;  // (workgroup-uniform)
+#else
+    constexpr bool bypass = false;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -370,7 +375,11 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
         for (int j = 0; j < 4; ++j) {
           int col = col_base + j * 16;
           col = col < p.n ? col : p.n - 1;
-          acc[i][j][r] = sc * C[(long)row * p.ldc + col];
+          const double* cp = C + (long)row * p.ldc + col;
+          // device-scope atomic load = `global_load ... sc1`: never served by the CU's L1 (a group-scope sc0 load may
+          // hit it: measured as run-to-run differences of 6e-12), served by the XCD's L2
+          const double cv = bypass ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *cp;
+          acc[i][j][r] = sc * cv;
         }
       }
   } else {
@@ -499,6 +508,7 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   }
 }
 
+#ifdef GPK_EXPERIMENTAL
 // ---- ticketed tiles + software CU reservation ---------------------------------------------------------------------
 // A bulk GEMM that runs BESIDE the latency chain of a factorisation must not sit on every CU: the chain's kernels need
 // whole CUs (the leaf: 133 KB of LDS; the one-shot solve / strip kernels: 150 KB) and a resident 128x128x16 workgroup
@@ -566,6 +576,8 @@ __device__ __forceinline__ void ticketed_tiles(const GemmArgs& p, int gx, int gy
   if (flag != 0 && tid < 10) __hip_atomic_store(&ctr[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#endif  // GPK_EXPERIMENTAL
+
 // pair = 0: one tile per workgroup, XCD-contiguous / column-grouped order.
 // pair = 1 (triangular-K operand, b_tri = 1): the K range of column tile j shrinks with j, so a workgroup
 // takes column tiles j and gx-1-j back to back -- every workgroup then carries the same number of K slabs
@@ -582,10 +594,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
       const long long t0 = wall_clock64();
       while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
     }
+#ifdef GPK_EXPERIMENTAL
     if (p.ctr != nullptr) {
       ticketed_tiles<EPI>(p, gx, gy, total, compact, smem);
       return;
     }
+#endif
     // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
       int tile_m, tile_n;
@@ -648,6 +662,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   if (a.max_wgs > 0 && (unsigned)a.max_wgs < nwg) nwg = (unsigned)a.max_wgs;
   GemmArgs b = a;
   g_last_kind = 2 + 2 * EPI;
+#ifdef GPK_EXPERIMENTAL
   if (a.ctr != nullptr && nb == 1) {
     // ticketed: one resident set (2 workgroups per CU by LDS and VGPRs) unless capped; reserved-CU workgroups exit
     // (a quarter more workgroups than tiles when there are few tiles: the ones that land on reserved CUs leave at once,
@@ -660,6 +675,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     GPK_LAUNCH_CHECK();
     return 0;
   }
+#endif
   b.ctr = nullptr;
   {
     // half a tile in 100 MHz ticks: a 128x128x16 slab costs ~1.7 us per workgroup when two share a CU
@@ -704,8 +720,7 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bz = blockIdx.z;
-  const int m0 = blockIdx.y * SM_BM, n0 = blockIdx.x * SM_BN;
-  if (p.c_lower && n0 > m0 + SM_BM - 1) return;
+  const int n0 = blockIdx.x * SM_BN;
   const double* __restrict__ A = p.A + (long)bz * p.strideA;
   const double* __restrict__ B = p.B + (long)bz * p.strideB;
   int kb = 0, ke = p.k;
@@ -721,57 +736,66 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk)
   const int kc = ke > kb ? ke - kb : 0;  // multiple of 16
   double* As = smem;                  // [16][ldk]
   double* Bs = smem + SM_BM * ldk;    // [128][ldk]
-  // ---- stage: row q of the 144 (16 A rows, 128 B rows), one LDS-DMA instruction each ----------------
-  if (2 * lane < kc) {
-    for (int q = wave; q < SM_BM + SM_BN; q += SM_THREADS / 64) {
-      const double* src;
-      if (q < SM_BM) {
-        int r = m0 + q;
-        r = r < p.m ? r : p.m - 1;
-        src = A + (long)r * p.lda + kb;
-      } else {
-        int r = n0 + q - SM_BM;
-        r = r < p.n ? r : p.n - 1;
-        src = B + (long)r * p.ldb + kb;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * lane),
-                                       (__attribute__((address_space(3))) void*)(smem + q * ldk), 16, 0, 0);
-    }
-  }
-  // ---- this wave's 16x16 output tile: columns n0 + 16 wave .. ------------------------------------------
   const int r = lane & 15, g = lane >> 4;
   const int col = n0 + wave * 16 + r;
-  d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-  if (p.beta != 0.0) {
-    const double* __restrict__ C = p.C + (long)bz * p.strideC;
-    const double sc = p.beta / p.alpha;
-    const int cc = col < p.n ? col : p.n - 1;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int row = m0 + g + 4 * e;
-      row = row < p.m ? row : p.m - 1;
-      acc0[e] = sc * C[(long)row * p.ldc + cc];
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the LDS-DMA rows of this wave have landed
-  __syncthreads();
-  const double* ap = As + r * ldk + g;
-  const double* bp = Bs + (wave * 16 + r) * ldk + g;
-  const int nkk = kc >> 2;
-#pragma unroll 4
-  for (int kk = 0; kk < nkk; kk += 2) {
-    const double a0 = ap[kk * 4], b0 = bp[kk * 4];
-    const double a1 = ap[kk * 4 + 4], b1 = bp[kk * 4 + 4];
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
-  }
   double* __restrict__ C = p.C + (long)bz * p.strideC;
-  if (col < p.n) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = m0 + g + 4 * e;
-      if (row < p.m) C[(long)row * p.ldc + col] = p.alpha * (acc0[e] + acc1[e]);
+  // gridDim.y < number of 16-row blocks: the workgroup walks the row blocks with stride gridDim.y and keeps its B tile
+  // (used when the chain is confined to the reserved compute units: ONE round of workgroups, B staged once per CU)
+  const int nmb = (p.m + SM_BM - 1) / SM_BM;
+  bool first = true;
+  for (int mb = blockIdx.y; mb < nmb; mb += gridDim.y) {
+    const int m0 = mb * SM_BM;
+    if (p.c_lower && n0 > m0 + SM_BM - 1) continue;  // (workgroup-uniform)
+    // ---- stage: row q of the 144 (16 A rows, 128 B rows: first pass only), one LDS-DMA instruction each ----------
+    if (2 * lane < kc) {
+      for (int q = wave; q < (first ? SM_BM + SM_BN : SM_BM); q += SM_THREADS / 64) {
+        const double* src;
+        if (q < SM_BM) {
+          int rr = m0 + q;
+          rr = rr < p.m ? rr : p.m - 1;
+          src = A + (long)rr * p.lda + kb;
+        } else {
+          int rr = n0 + q - SM_BM;
+          rr = rr < p.n ? rr : p.n - 1;
+          src = B + (long)rr * p.ldb + kb;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * lane),
+                                         (__attribute__((address_space(3))) void*)(smem + q * ldk), 16, 0, 0);
+      }
     }
+    first = false;
+    // ---- this wave's 16x16 output tile: columns n0 + 16 wave .. ------------------------------------------
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    if (p.beta != 0.0) {
+      const double sc = p.beta / p.alpha;
+      const int cc = col < p.n ? col : p.n - 1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int row = m0 + g + 4 * e;
+        row = row < p.m ? row : p.m - 1;
+        acc0[e] = sc * C[(long)row * p.ldc + cc];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the LDS-DMA rows of this wave have landed
+    __syncthreads();
+    const double* ap = As + r * ldk + g;
+    const double* bp = Bs + (wave * 16 + r) * ldk + g;
+    const int nkk = kc >> 2;
+#pragma unroll 4
+    for (int kk = 0; kk < nkk; kk += 2) {
+      const double a0 = ap[kk * 4], b0 = bp[kk * 4];
+      const double a1 = ap[kk * 4 + 4], b1 = bp[kk * 4 + 4];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+    }
+    if (col < p.n) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + g + 4 * e;
+        if (row < p.m) C[(long)row * p.ldc + col] = p.alpha * (acc0[e] + acc1[e]);
+      }
+    }
+    if (mb + (int)gridDim.y < nmb) __syncthreads();  // the A rows in LDS are about to be replaced
   }
 }
 
@@ -782,7 +806,10 @@ int launch_small(hipStream_t s, const GemmArgs& a) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)((SM_BM + SM_BN) * 130 * sizeof(double)));
   GPK_HIP(attr);
-  dim3 grid((unsigned)gpk_cdiv(a.n, SM_BN), (unsigned)gpk_cdiv(a.m, SM_BM), (unsigned)(a.batch > 0 ? a.batch : 1));
+  unsigned gy = (unsigned)gpk_cdiv(a.m, SM_BM);
+  const unsigned gxs = (unsigned)gpk_cdiv(a.n, SM_BN);
+  if (a.max_wgs > 0 && gy * gxs > (unsigned)a.max_wgs) gy = ((unsigned)a.max_wgs + gxs - 1) / gxs;  // row blocks walked in-kernel
+  dim3 grid(gxs, gy, (unsigned)(a.batch > 0 ? a.batch : 1));
   g_last_kind = 1;
   hipLaunchKernelGGL(gemm_nt_small, grid, dim3(SM_THREADS), lds, s, a, ldk);
   GPK_LAUNCH_CHECK();
@@ -974,6 +1001,175 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
   return launch_cfg<128, 128, 2, 2>(s, a);
 }
 
+#ifdef GPK_EXPERIMENTAL
+// =====================================================================================================================
+// Tile-dataflow bulk kernel.  The bulk work of an SVGP step (flow_tasks.h) used to be ~30 dependent GEMM launches on one
+// stream: 64 to 768 tiles each on 448 workgroup slots, i.e. every launch boundary left most of the chip idle for the
+// last partial round, and a launch could only start when the chain had delivered what its FIRST tile needed.  Here it is
+// one launch of persistent workgroups (2 per CU, none on the reserved CUs) that draw tiles from the per-XCD ticket lists
+// and spin (s_sleep) on the two things a tile can be waiting for: the chain flag of its column group and the progress
+// counter of its 128-row block.  Dependencies of a ticket are earlier tickets of the same list or chain flags, the chain
+// runs on compute units this kernel never occupies, so it cannot deadlock; if no workgroup survives the reservation check
+// the last one to leave processes every list itself.
+namespace {
+__device__ __forceinline__ GemmArgs flow_gemm(const FlowArgs& f, const FlowTask& t) {
+  GemmArgs g{};
+  const int gi = t.group;
+  const int g0 = f.g0[gi], g1 = f.g1[gi], w = g1 - g0;
+  g.m = f.rows; g.alpha = 1.0; g.beta = 0.0; g.batch = 1;
+  g.c_l1_bypass = (f.coh == 5) ? 0 : 1;
+  switch (t.type) {
+    case FLOW_SOLVE:
+      g.A = f.E + g0; g.lda = f.lde;
+      g.B = f.ginv[gi] ? f.gws + (size_t)gi * 2 * 512 * 512 + (size_t)512 * 512
+                       : f.invd + (size_t)(g0 / GPK_NB) * GPK_NB * GPK_NB;
+      g.ldb = f.ginv[gi] ? w : GPK_NB;
+      g.C = f.Eo + g0; g.ldc = f.ldeo;
+      g.n = w; g.k = w; g.b_tri = 2; g.b_tri_rows = w;
+      break;
+    case FLOW_UPDATE:
+      g.A = f.Eo + g0; g.lda = f.ldeo;
+      g.B = f.L + (long)g1 * f.ldl + g0; g.ldb = f.ldl;
+      g.C = f.E + g1; g.ldc = f.lde;
+      g.n = f.n - g1; g.k = w; g.alpha = -1.0; g.beta = 1.0; g.b_tri_rows = g.n;
+      break;
+    case FLOW_PROJ_RECT:
+      g.A = f.Eo + g0; g.lda = f.ldeo;
+      g.B = f.LqT + (long)t.bz * f.strideQ + g0; g.ldb = f.ldq;
+      g.C = f.Cacc + (long)t.bz * f.strideC; g.ldc = f.ldc;
+      g.n = g0; g.k = w; g.beta = 1.0; g.b_tri_rows = g.n;
+      if (t.last) {
+        g.epi = 1; g.sq_cols = g0;
+        g.part = f.part + (long)t.bz * f.stridePart; g.part_ld = f.part_ld;
+        g.C2 = g.part;
+      }
+      break;
+    default:  // FLOW_PROJ_TRI
+      g.A = f.Eo + g0; g.lda = f.ldeo;
+      g.B = f.LqT + (long)t.bz * f.strideQ + (long)g0 * f.ldq + g0; g.ldb = f.ldq;
+      g.C = f.Cacc + (long)t.bz * f.strideC + g0; g.ldc = f.ldc;
+      g.n = w; g.k = w; g.b_tri = 1; g.b_tri_rows = w;
+      if (t.last) {
+        g.C = nullptr;
+        g.epi = 1; g.sq_cols = w;
+        g.part = f.part + (long)t.bz * f.stridePart + (long)(g0 / GPK_NB) * 2 * f.part_ld; g.part_ld = f.part_ld;
+        g.C2 = g.part;
+      }
+      break;
+  }
+  return g;
+}
+
+// Coherence.  MI355X has one L2 per XCD and they are NOT coherent with each other for ordinary device memory: a
+// device-scope release / acquire is `buffer_wbl2 sc1` / `buffer_inv sc1`, i.e. write back / invalidate the XCD's whole
+// L2 -- done per tile that throws away every shared operand (the first version ran at 21 TFLOP/s: 7 TB/s of operand
+// re-fetches).  The schedule is built so that this is never needed in the normal case:
+//   * a row block's tiles live in ONE list and a workgroup only draws from the list of the XCD it runs on (no stealing),
+//     so producer and consumer of E / S / C tiles share an L2; the producer waits for its stores (vmcnt(0): the vector L1
+//     is write-through).  The consumer's L1 needs no invalidation either: the only tiles that are rewritten after having
+//     been read are the read-modify-write accumulators (E[rb, c] of the updates, C[rb, i] of the projection), and those
+//     are only ever READ through the accumulator preload, which uses L1-bypassing device-scope (sc1) loads (GemmArgs.c_l1_bypass) -- so no
+//     CU ever holds a stale line of them; every other operand enters an L1 only after its final value was written;
+//   * everything that comes from the chain (factor columns, block / group inverses) was written by kernels that finished
+//     before the group's flag was raised and is first touched by this kernel after the flag has been seen (sc1 load).
+// Only the fallback -- the last workgroup mopping up lists whose XCD had no surviving workgroup -- crosses XCDs and uses
+// the device-scope fences.
+__global__ __launch_bounds__(256, 2) void flow_kernel(FlowArgs f) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_task, s_flag;
+  const int tid = threadIdx.x;
+  const unsigned key = cu_key();
+  const bool survivor = !(f.resv != nullptr && f.resv[key & (GPK_CU_KEYS - 1)] != 0);
+  const int x = (int)(key >> 8) & 7;
+  unsigned* ctr = f.ctr;
+  auto run = [&](const bool all_lists) {
+    int k0 = 0;  // (thread 0) lists below this offset are exhausted
+    for (;;) {
+      if (tid == 0) {
+        int t = -1;
+        for (int k = k0; k < (all_lists ? 8 : 1); ++k) {
+          const int xx = (x + k) & 7;
+          const int cnt = f.off[xx + 1] - f.off[xx];
+          const int local = (int)__hip_atomic_fetch_add(&ctr[xx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (local < cnt) { t = f.off[xx] + local; k0 = k; break; }
+          k0 = k + 1;
+        }
+        if (t >= 0) {
+          // Waits are BOUNDED (2 s of the 100 MHz wall clock): if the chain never delivers -- a bug, not a data condition --
+          // the tile proceeds on whatever is there and the factorisation status is set to an impossible column, so the
+          // caller sees a failed factorisation instead of a hung GPU.
+          const FlowTask tk = f.tasks[t];
+          const long long t0 = wall_clock64();
+          bool late = false;
+          if (tk.flag >= 0)
+            while (__hip_atomic_load(&f.flags[tk.flag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.epoch) {
+              __builtin_amdgcn_s_sleep(32);
+              if (wall_clock64() - t0 > 200000000LL) { late = true; break; }
+            }
+          while ((int)__hip_atomic_load(&f.prog[tk.rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tk.need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 200000000LL) { late = true; break; }
+          }
+          if (late && f.info) __hip_atomic_fetch_max(f.info, 0x40000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // protocol 5: ONE lane drops this CU's L1 (buffer_inv sc1 does exactly that on gfx950 and leaves the L2 alone),
+          // everything is then read with ordinary loads from the XCD's L2, which producer and consumer share
+          if (f.coh == 5 && !all_lists) asm volatile("buffer_inv sc1" ::: "memory");
+        }
+        s_task = t;
+      }
+      __syncthreads();
+      const int t = s_task;
+      if (t < 0) break;
+      const FlowTask tk = f.tasks[t];
+      if (all_lists || f.coh == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      else if (f.coh == 3 || (f.coh == 2 && tk.type == FLOW_SOLVE)) asm volatile("buffer_inv sc1" ::: "memory");
+      const GemmArgs g = flow_gemm(f, tk);
+      if (g.epi) fast_tile<1>(g, tk.rb, tk.tn, smem);
+      else fast_tile<0>(g, tk.rb, tk.tn, smem);
+      if (all_lists || f.coh == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's (device-scope) stores are complete
+      __syncthreads();  // (also: both LDS buffers and s_task are about to be rewritten)
+      if (tid == 0) __hip_atomic_fetch_add(&f.prog[tk.rb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if (survivor) {
+    if (tid == 0) __hip_atomic_fetch_add(&ctr[9], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    run(false);
+  }
+  if (tid == 0) {
+    const unsigned left = __hip_atomic_fetch_add(&ctr[8], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_flag = (left == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  // the last workgroup to leave: every other one has finished its own XCD's list; lists of XCDs that had no surviving
+  // workgroup (or the whole launch, if nobody survived the reservation check) are still (partly) untouched
+  if (s_flag) run(true);
+}
+
+__global__ void set_flag_kernel(unsigned* flag, unsigned value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+int gpk_launch_flow(hipStream_t s, const FlowArgs& f) {
+  constexpr size_t LDS_BYTES = 2 * (size_t)256 * LDSS * sizeof(double);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+  GPK_HIP(attr);
+  const int total = f.off[8];
+  if (total <= 0) return 0;
+  const unsigned nwg = total < 512 ? (unsigned)total : 512u;
+  hipLaunchKernelGGL(flow_kernel, dim3(nwg), dim3(256), LDS_BYTES, s, f);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpk_launch_set_flag(hipStream_t s, unsigned* flag, unsigned value) {
+  hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(64), 0, s, flag, value);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
 namespace {
 __global__ __launch_bounds__(256) void cu_census_kernel(unsigned* keys) {
   extern __shared__ double pad[];  // 80 KB per workgroup: exactly two fit a CU, so 512 resident workgroups cover the chip
@@ -994,6 +1190,12 @@ int gpk_cu_census(hipStream_t s, unsigned* keys_dev, int n) {
   GPK_LAUNCH_CHECK();
   return 0;
 }
+
+#else   // product build: no experimental kernels
+int gpk_launch_flow(hipStream_t, const FlowArgs&) { return GPK_E_UNSUPPORTED; }
+int gpk_launch_set_flag(hipStream_t, unsigned*, unsigned) { return GPK_E_UNSUPPORTED; }
+int gpk_cu_census(hipStream_t, unsigned*, int) { return GPK_E_UNSUPPORTED; }
+#endif  // GPK_EXPERIMENTAL
 
 extern "C" int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, const double* A,
                            long lda, const double* B, long ldb, double beta, double* C, long ldc,

@@ -37,10 +37,12 @@ inline GemmArgs gemm_base(int m, int n, int k, double alpha, const double* A, lo
 struct Bulk {
   unsigned* ctr = nullptr;
   const unsigned char* resv = nullptr;
-  int cap = 0;  // plain launches only: cap on persistent workgroups of big updates (A/B of the round-1 scheme)
+  int cap = 0;    // plain launches only: cap on persistent workgroups of big updates (A/B of the round-1 scheme)
+  int min_k = 0;  // ticketing only for launches with K >= min_k: the long ones, which would otherwise hold every CU for
+                  // hundreds of microseconds; the short in-group launches (K = 128) stay one-shot kernels
   void apply(GemmArgs& g) const {
     if (!ctr && cap > 0 && g.k >= 256) g.max_wgs = cap;
-    if (ctr && g.batch == 1) {
+    if (ctr && g.batch == 1 && g.k >= min_k) {
       g.ctr = ctr;
       g.resv = resv;
       g.no_small = 1;  // the one-shot LDS-DMA kernel has no reservation check: everything goes through the tiled kernel
@@ -87,7 +89,16 @@ struct Aux {
   unsigned char* resv = nullptr;  // device [GPK_CU_KEYS]: 1 = compute unit reserved for the latency chain
   unsigned* ctr = nullptr;        // device [16]: ticket counters of stream X (self-resetting)
   int ncu = 0, bulk_cus = 0, resv_cus = 0;
+  // tile-dataflow bulk kernel: state words [16 tickets | FLOW_MAX_RB progress counters] (zeroed before every launch),
+  // chain flags (never reset: they carry the epoch of the factorisation that raised them), cached task lists per shape
+  unsigned* flow_state = nullptr;
+  unsigned* flow_flags = nullptr;
+  unsigned epoch = 0;
+  struct Plan { int n = 0, rows = 0, P = 0, proj = 0; FlowTask* dev = nullptr; int off[9] = {0}; std::vector<FlowGroup> groups; };
+  Plan plans[4];
+  int nplans = 0;
 };
+constexpr int FLOW_MAX_RB = 1024;  // row blocks of 128 rows: minibatches up to 131072 rows
 Aux g_aux[16];
 
 int masked_stream(hipStream_t* out, int ncu, int first, int last) {  // CUs [first, last)
@@ -179,8 +190,10 @@ int aux_get(int dev, int need, Aux** out) {
     if (ncu > 1024 || late_res >= ncu) late_res = 0;
     rc = masked_stream(&a.Bl, ncu, late_res, ncu);
     if (rc) return rc;
-    rc = build_reservation(a, GPK_TUNE(SOFT_RESERVED_CUS, 32));
-    if (rc) return rc;
+    if (kGpkExp) {  // the software CU reservation is an A/B-build experiment (gpk_internal.h)
+      rc = build_reservation(a, GPK_TUNE(SOFT_RESERVED_CUS, 32));
+      if (rc) return rc;
+    }
     a.ready = true;
   }
   if (a.nev < need) {
@@ -203,7 +216,7 @@ int current_device(int* dev) {
 
 // factor the outer panel [c0,c1) of the square part (rows up to `rows`) on stream s
 int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, int batch, long strideA,
-                 double* invd, long strideInv, int* info) {
+                 double* invd, long strideInv, int* info, int chain_cap = 0) {
   int rc;
   for (int j0 = c0; j0 < c1; j0 += NB) {
     const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
@@ -219,6 +232,7 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
     GemmArgs g = gemm_base(below, nb, nb, 1.0, panel, lda, invb, NB, 0.0, panel, lda, batch, strideA,
                            strideInv, strideA);
     g.b_tri = 2;
+    g.max_wgs = chain_cap;
     rc = gpk_launch_gemm(s, g);
     if (rc) return rc;
     const int ncols = c1 - j1;
@@ -378,12 +392,50 @@ int proj_group(hipStream_t s, const Bulk& bulk, ProjStream& q, const double* At,
   return 0;
 }
 
+// cached task lists of the dataflow kernel for one shape (built and uploaded on first use: one hipMalloc + one
+// synchronous hipMemcpy per new shape, at most four shapes kept)
+int flow_plan(Aux& a, int n, int rows, int P, int proj, Aux::Plan** out) {
+  for (int i = 0; i < a.nplans; ++i)
+    if (a.plans[i].n == n && a.plans[i].rows == rows && a.plans[i].P == P && a.plans[i].proj == proj) {
+      *out = &a.plans[i];
+      return 0;
+    }
+  if (!a.flow_state) {
+    GPK_HIP(hipMalloc((void**)&a.flow_state, sizeof(unsigned) * (16 + FLOW_MAX_RB)));
+    GPK_HIP(hipMalloc((void**)&a.flow_flags, sizeof(unsigned) * GPK_FLOW_MAX_GROUPS));
+    GPK_HIP(hipMemset(a.flow_flags, 0, sizeof(unsigned) * GPK_FLOW_MAX_GROUPS));
+  }
+  Aux::Plan* pl = nullptr;
+  if (a.nplans < 4) {
+    pl = &a.plans[a.nplans++];
+  } else {  // evict the oldest (stream-ordered free is not needed: a plan is only replaced under the device mutex after
+            // the work that used it was enqueued; hipFree synchronises the device)
+    pl = &a.plans[0];
+    if (pl->dev) (void)hipFree(pl->dev);
+    pl->dev = nullptr;
+  }
+  pl->n = n; pl->rows = rows; pl->P = P; pl->proj = proj;
+  pl->groups = flow_groups(n);
+  std::vector<FlowTask> lists[8];
+  flow_build(n, rows, P, proj != 0, pl->groups, lists);
+  std::vector<FlowTask> all;
+  pl->off[0] = 0;
+  for (int x = 0; x < 8; ++x) {
+    all.insert(all.end(), lists[x].begin(), lists[x].end());
+    pl->off[x + 1] = (int)all.size();
+  }
+  GPK_HIP(hipMalloc((void**)&pl->dev, sizeof(FlowTask) * (all.size() + 1)));
+  GPK_HIP(hipMemcpy(pl->dev, all.data(), sizeof(FlowTask) * all.size(), hipMemcpyHostToDevice));
+  *out = pl;
+  return 0;
+}
+
 // optional separate output of the solved extra rows (batch 1) + scratch for the explicit group inverses
 struct ExtraOut {
   double* Eout = nullptr; long ldeout = 0;
   double* gws = nullptr;   // 2 * 512 * 512 doubles per 512-column group of the factor (gpk_ginv_ws_doubles)
 };
-inline size_t ginv_ws_doubles(int n) { return (size_t)gpk_cdiv(n, NBO) * 2 * NBO * NBO; }
+inline size_t ginv_ws_doubles(int n) { return ((size_t)gpk_cdiv(n, NBO) + 2) * 2 * NBO * NBO; }  // one slot per group with an inverse
 
 int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
                int* info, ProjStream* proj, const ExtraOut* xo = nullptr) {
@@ -433,22 +485,66 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // trailing updates; for small ones they have stream X, whose GEMMs are ticketed under the software reservation.
   hipStream_t X = large ? aux->B : aux->X;
   Bulk bulk;
-  if (!large && batch == 1 && GPK_TUNE(SOFT_RESERVE, 1)) {
+  if (kGpkExp && !large && batch == 1 && GPK_TUNE(SOFT_RESERVE, 0)) {
     bulk.ctr = aux->ctr;
     bulk.resv = aux->resv_cus > 0 ? aux->resv : nullptr;
+    bulk.min_k = GPK_TUNE(RESERVE_MIN_K, 256);
   } else if (!large) {
-    bulk.cap = GPK_TUNE(EXTRA_MAX_WGS, 0);
+    // cap on the persistent workgroups of the big extra-row updates, so that some CUs stay free for the panel stream's
+    // leaf kernel (A/B on the SVGP step: cap 320 -> 448 steps/s, no cap 435, cap 224 -> 431)
+    bulk.cap = GPK_TUNE(EXTRA_MAX_WGS, 320);
   }
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
   hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
   hipEvent_t* evG = aux->ev + 2 * npanels;  // [npanels] explicit inverse of the group ending with panel p ready (on B)
   hipEvent_t evFork = aux->ev[3 * npanels], evJoinP = aux->ev[3 * npanels + 1], evJoinB = aux->ev[3 * npanels + 2],
              evJoinX = aux->ev[3 * npanels + 3], evLate = aux->ev[3 * npanels + 4];
-  const bool use_ginv = oop && xo->gws && !large && GPK_TUNE(GROUP_INVERSE, 1);
+  const bool use_ginv = kGpkExp && oop && xo->gws && !large && GPK_TUNE(GROUP_INVERSE, 0);
+  // ---- SVGP sizes with a separate output matrix: the whole bulk side is ONE dataflow launch on X ----------------------
+  const bool use_flow = use_ginv && (n % NB) == 0 && n >= 4 * NB && n / NB <= 255 && gpk_cdiv(extra, NB) <= FLOW_MAX_RB &&
+                        (!proj || proj->P <= 255) && GPK_TUNE(FLOW, 0);
+  Aux::Plan* plan = nullptr;
+  // (the streamed projection only pays inside the dataflow launch; as separate K <= 512 read-modify-write launches on
+  //  the bulk stream it measured 3.46 vs 2.59 ms per step, so without a plan the caller projects afterwards)
+  if (proj && !use_flow && !GPK_TUNE(STREAM_PROJ_MULTI, 0)) proj = nullptr;
+  if (use_flow) {
+    rc = flow_plan(*aux, n, extra, proj ? proj->P : 0, proj ? 1 : 0, &plan);
+    if (rc) return rc;
+    if ((int)plan->groups.size() > GPK_FLOW_MAX_GROUPS) plan = nullptr;
+  }
+  unsigned epoch = 0;
+  FlowArgs flow{};
+  if (plan) {
+    epoch = ++aux->epoch;
+    if (epoch == 0) epoch = ++aux->epoch;
+    FlowArgs f{};
+    f.E = E; f.lde = lda; f.Eo = Eo; f.ldeo = ldeo; f.L = A; f.ldl = lda; f.invd = invd; f.gws = xo->gws;
+    if (proj) {
+      f.LqT = proj->LqT; f.ldq = proj->ldl; f.strideQ = proj->strideL;
+      f.Cacc = proj->C; f.ldc = proj->ldc; f.strideC = proj->strideC;
+      f.part = proj->part; f.part_ld = proj->part_ld; f.stridePart = proj->stridePart;
+      f.P = proj->P;
+      proj->groups = (int)plan->groups.size();
+    }
+    f.rows = extra; f.n = n; f.ng = (int)plan->groups.size();
+    for (int i = 0; i < f.ng; ++i) { f.g0[i] = plan->groups[i].g0; f.g1[i] = plan->groups[i].g1; f.ginv[i] = plan->groups[i].ginv; }
+    f.tasks = plan->dev;
+    for (int i = 0; i < 9; ++i) f.off[i] = plan->off[i];
+    f.ctr = aux->flow_state; f.prog = aux->flow_state + 16; f.flags = aux->flow_flags; f.epoch = epoch;
+    f.resv = (GPK_TUNE(SOFT_RESERVE, 0) && aux->resv_cus > 0) ? aux->resv : nullptr;
+    f.info = info;
+    f.coh = GPK_TUNE(FLOW_COH, 2);  // 2: sc1 stores + sc1 accumulator preload + L1 invalidate before solve tasks; 5: ordinary accesses + one L1 invalidate per task
+    flow = f;
+  }
   GPK_HIP(hipEventRecord(evFork, S));  // fork: everything already queued on S comes first
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
   if (B != S) GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
   if (useX && X != B) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
+  // The persistent bulk kernel is launched when the FIRST column group's flag has been raised: until then the chain
+  // has the whole chip for its largest panels, afterwards it is confined to the reserved compute units.
+  bool flow_started = false;
+  const int chain_wgs = std::max(8, GPK_TUNE(CHAIN_WGS, 0) > 0 ? GPK_TUNE(CHAIN_WGS, 0) : aux->resv_cus);
+  if (plan) GPK_HIP(hipMemsetAsync(aux->flow_state, 0, sizeof(unsigned) * (16 + gpk_cdiv(extra, NB)), X));
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
   int xg0 = 0;         // first column of the current extra-row group
@@ -459,7 +555,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     const int c1 = (c0 + nbo < n) ? c0 + nbo : n;
     const int c2 = (c1 + nbo < n) ? c1 + nbo : n;
     // ---- P: the critical path.  Panel p, then the strip = columns of panel p+1 (look-ahead) -----------
-    rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info);
+    // (dataflow mode: once the bulk kernel is resident the chain only finds the reserved compute units free, so its
+    //  one-shot GEMMs are launched as ONE round of workgroups that walk the row blocks)
+    const int chain_cap = (plan && flow_started) ? chain_wgs : 0;
+    rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info, chain_cap);
     if (rc) return rc;
     GPK_HIP(hipEventRecord(evF[p], P));
     const double* Pn = A + (long)c1 * lda + c0;  // rows c1.. of the solved panel
@@ -469,6 +568,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       GemmArgs u = gemm_base(R - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0,
                              A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
+      u.max_wgs = chain_cap;
       rc = gpk_launch_gemm(P, u);
       if (rc) return rc;
     }
@@ -484,6 +584,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
         GPK_HIP(hipEventRecord(evLate, P));
         GPK_HIP(hipStreamWaitEvent(Bp, evLate, 0));
         if (last_rest >= 0) GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
+      } else if (plan && flow_started && GPK_TUNE(REST_AFTER_STRIP, 1)) {
+        // the chain is confined to the reserved CUs: a rest-update that starts together with the strip fights it for
+        // them (strip 15 -> 50 us, rest-update 25 -> 85 us in the timeline); behind the strip it overlaps the next leaf
+        GPK_HIP(hipEventRecord(evLate, P));
+        GPK_HIP(hipStreamWaitEvent(B, evLate, 0));
       } else {
         GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));
       }
@@ -492,6 +597,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
       if (Bp == aux->B && large) u.stagger_first = aux->bulk_cus;
+      if (plan && flow_started) u.no_small = 1;  // (150 KB one-shot workgroups: one per reserved CU -> many rounds)
       rc = gpk_launch_gemm(Bp, u);
       if (rc) return rc;
       GPK_HIP(hipEventRecord(evR[p], Bp));
@@ -504,7 +610,29 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     const bool tail_zone = (nbo == NB) && (n >= 8 * NB);
     const bool tail_group = tail_zone && (c1 == n - 2 * NB || c1 == n - NB);
     const bool full_group = ((c1 - xg0) >= xgroup || (large && c1 - xg0 >= nbo)) && !(tail_zone && c1 > n - 2 * NB && c1 < n);
-    if (useX && (c1 == n || full_group || tail_group)) {
+    if (plan) {
+      // dataflow mode: all this stream code has to do is raise the flag of the column group that ends with this panel,
+      // on B behind the rest-update (and, for a 512-column group, behind the assembly of its explicit inverse)
+      for (size_t gi = 0; gi < plan->groups.size(); ++gi) {
+        const FlowGroup& fg = plan->groups[gi];
+        if (fg.g1 != c1) continue;
+        if (c2 >= n) GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));  // (no rest-update was issued for this panel)
+        if (fg.ginv) {
+          double* wT = xo->gws + gi * 2 * NBO * NBO;
+          rc = group_inverse(B, A, lda, invd, strideInv, fg.g0, fg.g1, wT, wT + (size_t)NBO * NBO);
+          if (rc) return rc;
+        }
+        rc = gpk_launch_set_flag(B, aux->flow_flags + gi, epoch);
+        if (rc) return rc;
+        if (!flow_started) {
+          GPK_HIP(hipEventRecord(evG[p], B));
+          GPK_HIP(hipStreamWaitEvent(X, evG[p], 0));
+          rc = gpk_launch_flow(X, flow);
+          if (rc) return rc;
+          flow_started = true;
+        }
+      }
+    } else if (useX && (c1 == n || full_group || tail_group)) {
       const int g0 = xg0;
       xg0 = c1;
       // a full, aligned 512-column group: its explicit inverse is assembled on B (right behind the rest-update of the
@@ -537,6 +665,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // join: P has waited for every rest-update it depends on; B's last event covers the rest
   GPK_HIP(hipEventRecord(evJoinP, P));
   GPK_HIP(hipStreamWaitEvent(S, evJoinP, 0));
+  if (plan) last_bulk = B;  // (flag kernels follow the last rest-update on B)
   if (last_bulk != S) {
     GPK_HIP(hipEventRecord(evJoinB, last_bulk));  // rest-updates are chained through evR, the last one covers all
     GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
@@ -706,7 +835,7 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
 
 // ---- fused driver: one shard of SVGP.elbo (whitened; shared kernel over the P latents) ----------------
 #ifndef GPK_STREAM_PROJ_DEFAULT
-#define GPK_STREAM_PROJ_DEFAULT 0
+#define GPK_STREAM_PROJ_DEFAULT 0   // (A/B build: 1 makes the projection part of the dataflow launch; ignored without it)
 #endif
 namespace {
 struct ElboLayout {
@@ -714,7 +843,9 @@ struct ElboLayout {
   size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_C, off_At, off_gws, total;
 };
 // the q_sqrt projection streamed behind the extra-row solve (1) or as one GEMM after the factorisation (0)
-inline bool stream_proj_on() { return GPK_TUNE(STREAM_PROJ, GPK_STREAM_PROJ_DEFAULT) != 0; }
+inline bool stream_proj_on() { return kGpkExp && GPK_TUNE(STREAM_PROJ, GPK_STREAM_PROJ_DEFAULT) != 0; }
+// a separate A^T matrix + group-inverse scratch are only needed by the A/B-build schemes that solve whole column groups
+inline bool separate_at_on() { return kGpkExp && (GPK_TUNE(GROUP_INVERSE, 0) || GPK_TUNE(FLOW, 0)); }
 
 ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   ElboLayout l{};
@@ -731,8 +862,8 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_C = o; o += (q_diag || !stream_proj_on()) ? 0 : gpk_align_up((size_t)P * rows * l.ld * sizeof(double), 256);  // running A^T Lq (streamed projection)
-  l.off_At = o; o += gpk_align_up((size_t)rows * l.ld * sizeof(double), 256);  // A^T = Kfu Lm^-T apart from the consumed Kfu rows
-  l.off_gws = o; o += gpk_align_up(ginv_ws_doubles(m) * sizeof(double), 256);  // explicit inverses of the 512-column groups
+  l.off_At = o; o += separate_at_on() ? gpk_align_up((size_t)rows * l.ld * sizeof(double), 256) : 0;  // A^T apart from the consumed Kfu rows
+  l.off_gws = o; o += separate_at_on() ? gpk_align_up(ginv_ws_doubles(m) * sizeof(double), 256) : 0;  // explicit group inverses
   l.total = o;
   return l;
 }
@@ -775,7 +906,8 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   const bool side = m > GPK_NB && m < 4096 && rows > 256;
   // A^T = Kfu Lm^-T: in its own matrix when the extra rows are solved apart from the square part (then whole 512-column
   // groups are solved with one GEMM against the group's explicit inverse), in place otherwise
-  double* At = side ? (double*)(w + l.off_At) : Kfu;
+  const bool sep = side && separate_at_on();
+  double* At = sep ? (double*)(w + l.off_At) : Kfu;
   int dev = 0;
   rc = current_device(&dev);
   if (rc) return rc;
@@ -820,10 +952,10 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     ps.P = P;
   }
   ExtraOut xo;
-  if (side) {
+  if (sep) {
     xo.Eout = At; xo.ldeout = l.ld; xo.gws = (double*)(w + l.off_gws);
   }
-  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, stream_proj ? &ps : nullptr, side ? &xo : nullptr);
+  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, stream_proj ? &ps : nullptr, sep ? &xo : nullptr);
   if (lock.owns_lock()) lock.unlock();
   if (rc) return rc;
   const bool projected = stream_proj && ps.groups > 0;
