@@ -30,13 +30,13 @@ import os
 import sys
 import time
 
-# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The factorisation runs a latency-critical
-# panel stream next to bulk streams; with 2 hardware queues the SVGP step measured faster than with 4 or 8 (same-box
-# A/B, tools/ab.sh; numbers in DESIGN.md).  Must be set before the HIP runtime initialises; an explicit setting wins.
-# Single-process runs only: with RCCL in the process (WORLD_SIZE > 1) the runtime default is kept -- the all-reduce
-# needs a hardware queue of its own and that combination could not be measured on a 1-GPU box.
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues per priority level (default 4).  The factorisation runs a
+# latency-critical panel stream next to bulk streams; with 2 hardware queues the SVGP step measured faster than with 4
+# (same-box A/B, tools/ab.sh: 2.6 vs 3.6 ms in round 2, 415 vs 380 steps/s in round 1).  Must be set before the HIP
+# runtime initialises; an explicit setting in the environment wins.  The same value is used for every rank of a
+# multi-GPU run (RCCL's stream then shares one of the two queues; it could not be measured on the 1-GPU boxes of this
+# build -- set GPU_MAX_HW_QUEUES=4 in the environment if an 8-GPU node shows contention).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import numpy as np
 import torch

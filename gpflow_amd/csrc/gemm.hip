@@ -357,6 +357,22 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   // (EPI = 1 with a C operand: the streamed projection's last group squares C + A B^T without storing it)
   const bool load_c = (p.beta != 0.0) && (EPI == 0 || p.C != nullptr);
   if (nk > 0) gload(0);
+  // C is addressed as  wave-uniform base + a 32-bit offset per accumulator ROW (16 of them, 4 rows apart) + a 32-bit
+  // offset per column step (4 of them, 16 doubles apart), both clamped into the matrix: 20 address registers instead of
+  // 64 address pairs -- the generic row * ldc + col form made the compiler spill 34 VGPRs around the preload (and the
+  // experimental build, whose preload could not be hoisted, ran the N = 16384 factorisation 3 % faster for it)
+  const int c_r0 = wm * 64 + (lane >> 4), c_c0 = wn * 64 + (lane & 15);
+  const int c_rmax = p.m - 1 - m0, c_cmax = p.n - 1 - n0;  // last valid row / column of the matrix, relative to the tile
+  unsigned c_coff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c_c0 + j * 16;
+    c_coff[j] = (unsigned)((c < c_cmax ? c : c_cmax) * 8);
+  }
+  auto c_roff = [&](int q) -> unsigned {  // q = 4 i + r: row c_r0 + 4 q
+    const int rr = c_r0 + 4 * q;
+    return (unsigned)(((long)(rr < c_rmax ? rr : c_rmax) * p.ldc) * 8);
+  };
   if (load_c) {
     const double* __restrict__ C = p.C + (long)bz * p.strideC;
     const double sc = p.beta / p.alpha;
@@ -365,19 +381,16 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
 #else
     constexpr bool bypass = false;
 #endif
+    const char* cb = reinterpret_cast<const char*>(C + (long)m0 * p.ldc + n0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int row = row_base + i * 16 + 4 * r;
-        row = row < p.m ? row : p.m - 1;
+        const char* rowp = cb + c_roff(i * 4 + r);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          int col = col_base + j * 16;
-          col = col < p.n ? col : p.n - 1;
-          const double* cp = C + (long)row * p.ldc + col;
-          // device-scope atomic load = `global_load ... sc1`: never served by the CU's L1 (a group-scope sc0 load may
-          // hit it: measured as run-to-run differences of 6e-12), served by the XCD's L2
+          const double* cp = reinterpret_cast<const double*>(rowp + c_coff[j]);
+          // (experimental dataflow kernel: device-scope atomic load = `global_load ... sc1`, never served by the CU's L1)
           const double cv = bypass ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *cp;
           acc[i][j][r] = sc * cv;
         }
@@ -466,16 +479,26 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   if constexpr (EPI == 0) {
     double* __restrict__ C = p.C + (long)bz * p.strideC;
     const double alpha = p.alpha;
+#ifdef GPK_EXPERIMENTAL
+    const bool through = p.c_l1_bypass != 0;  // (workgroup-uniform)
+#else
+    constexpr bool through = false;
+#endif
+    char* cb = reinterpret_cast<char*>(C + (long)m0 * p.ldc + n0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = row_base + i * 16 + 4 * r;
-        if (row < p.m) {
+        if (c_r0 + 4 * (i * 4 + r) <= c_rmax) {
+          char* rowp = cb + c_roff(i * 4 + r);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int col = col_base + j * 16;
-            if (col < p.n) C[(long)row * p.ldc + col] = alpha * acc[i][j][r];
+            if (c_c0 + j * 16 <= c_cmax) {
+              double* cp = reinterpret_cast<double*>(rowp + c_coff[j]);
+              // (experimental dataflow kernel: device-scope store = `global_store ... sc1`, written through)
+              if (through) __hip_atomic_store(cp, alpha * acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else *cp = alpha * acc[i][j][r];
+            }
           }
         }
       }

@@ -180,7 +180,7 @@ int aux_get(int dev, int need, Aux** out) {
     GPK_HIP(hipStreamCreateWithFlags(&a.X, hipStreamNonBlocking));
     GPK_HIP(hipStreamCreateWithFlags(&a.pad, hipStreamNonBlocking));
     GPK_HIP(hipStreamCreateWithFlags(&a.Bs, hipStreamNonBlocking));
-    int reserved = GPK_TUNE(RESERVED_CUS, 16);
+    int reserved = GPK_TUNE(RESERVED_CUS, 8);
     if (ncu > 1024 || reserved < 0 || reserved >= ncu) reserved = 0;
     int rc = masked_stream(&a.B, ncu, reserved, ncu);
     if (rc) return rc;
@@ -446,7 +446,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
   // outer panel width for n >= 4096: A/B at N = 16384 (same box): 384 -> 34.6 ms, 512 -> 33.2, 640 -> 32.6, 768 -> 32.4,
   // 896 -> 32.3, 1024 -> 32.7; one leaf block for the SVGP sizes, where the whole factorisation is a latency chain
-  const int nbo_large = (GPK_TUNE(NBO, 768) / NB) * NB;
+  const int nbo_large = (GPK_TUNE(NBO, 640) / NB) * NB;
   const int nbo = (n >= 4096) ? (nbo_large >= NB ? nbo_large : NBO) : NB;
   const int npanels = gpk_cdiv(n, nbo);
   // Few extra rows (GPR: the P columns of Y) simply ride along through the panel solves and trailing
