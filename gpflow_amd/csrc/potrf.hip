@@ -267,6 +267,8 @@ int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, double
                            strideEo);
     g.b_tri = 2;
     bulk.apply(g);
+    // (one tile per workgroup: the paired-column-tile form would put 256 tiles on 128 workgroups, half the CUs)
+    if (!g.ctr) g.max_wgs = GPK_TUNE(GINV_SOLVE_WGS, 512);
     rc = gpk_launch_gemm(s, g);
     if (rc) return rc;
   } else {
