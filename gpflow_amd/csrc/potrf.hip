@@ -13,6 +13,7 @@
 // projection onto q_sqrt) runs beside it as bulk work under a SOFTWARE CU reservation (gemm.hip, ticketed tiles).
 #include "gpk_internal.h"
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -439,12 +440,23 @@ struct ExtraOut {
 };
 inline size_t ginv_ws_doubles(int n) { return ((size_t)gpk_cdiv(n, NBO) + 2) * 2 * NBO * NBO; }  // one slot per group with an inverse
 
+// x_prologue: work of the CALLER that belongs on the bulk stream before the first extra-row group (the SVGP driver's Kfu
+// build, transposes, KL).  It is enqueued after the first panel's chain kernels: every host call issued before the first
+// leaf delays the whole step, and nothing on the bulk stream is needed for ~4 panels.
 int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
-               int* info, ProjStream* proj, const ExtraOut* xo = nullptr) {
+               int* info, ProjStream* proj, const ExtraOut* xo = nullptr,
+               const std::function<int(hipStream_t)>* x_prologue = nullptr, int tri = 0) {
   if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
+  if (tri && (tri != n || extra < n || batch > 1)) return GPK_E_ARG;
   if (batch <= 0) batch = 1;
   if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, S));
   if (n == 0) return 0;
+  // tri = n: the LAST n extra rows are the identity (written here) and come back as L^-T.  Row j of that block stays
+  // zero left of column j, so column group [c0, c1) only has to process its first c1 rows: n^3 / 3 flop instead of n^3.
+  if (tri) {
+    const int rci = gpk_launch_set_identity(S, A + (long)(n + extra - tri) * lda, n, lda);
+    if (rci) return rci;
+  }
   const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
   // outer panel width for n >= 4096: A/B at N = 16384 (same box): 384 -> 34.6 ms, 512 -> 33.2, 640 -> 32.6, 768 -> 32.4,
   // 896 -> 32.3, 1024 -> 32.7; one leaf block for the SVGP sizes, where the whole factorisation is a latency chain
@@ -465,6 +477,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   const long strideEo = oop ? 0 : strideA;
   int rc;
   if (n <= NB) {  // one leaf; nothing to overlap
+    if (x_prologue) {
+      rc = (*x_prologue)(S);
+      if (rc) return rc;
+    }
     rc = factor_panel(S, A, R, 0, n, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
     if (useX) {
@@ -538,6 +554,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     f.coh = GPK_TUNE(FLOW_COH, 2);  // 2: sc1 stores + sc1 accumulator preload + L1 invalidate before solve tasks; 5: ordinary accesses + one L1 invalidate per task
     flow = f;
   }
+  if (x_prologue && !useX) {  // the extra rows ride through the panel solves: they must exist before the first one
+    rc = (*x_prologue)(S);
+    if (rc) return rc;
+  }
   GPK_HIP(hipEventRecord(evFork, S));  // fork: everything already queued on S comes first
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
   if (B != S) GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
@@ -606,6 +626,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       last_bulk = Bp;
       last_rest = p;
     }
+    if (p == 0 && x_prologue && useX) {
+      rc = (*x_prologue)(X);
+      if (rc) return rc;
+    }
     // ---- X: the extra rows against the finished columns, in groups of up to 512 columns (so that the big
     // right-looking update is a K = 512 GEMM).  For the small sizes the groups shrink towards the end (.., n-256,
     // n-128, n): whatever is left of the extra-row work when the LAST leaf finishes is exposed latency.
@@ -654,7 +678,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       // (columns [g0, c1) may span several 512-groups when the outer panel is wider than a group)
       for (int h0 = g0; h0 < c1; h0 += NBO) {
         const int h1 = std::min(h0 + NBO, c1);
-        rc = solve_group_fwd(X, bulk, E, lda, Eo, ldeo, extra, A, lda, invd, strideInv, n, h0, h1, batch, strideA,
+        const int xrows = tri ? extra - tri + h1 : extra;  // (identity rows below column h1 are still exactly zero here)
+        rc = solve_group_fwd(X, bulk, E, lda, Eo, ldeo, xrows, A, lda, invd, strideInv, n, h0, h1, batch, strideA,
                              strideEo, strideA, ginv);
         if (rc) return rc;
         if (proj) {
@@ -684,6 +709,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
 extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch,
                          long strideA, double* invd, int zero_upper, int* info) {
   return potrf_core((hipStream_t)stream, A, n, extra, lda, batch, strideA, invd, zero_upper, info, nullptr);
+}
+
+extern "C" int gpk_potrf_inv(void* stream, double* A, int n, int extra, long lda, double* invd, int zero_upper,
+                             int* info) {
+  return potrf_core((hipStream_t)stream, A, n, extra + n, lda, 1, 0, invd, zero_upper, info, nullptr, nullptr, nullptr, n);
 }
 
 extern "C" int gpk_trtri_blocks(void* stream, const double* L, int n, long ldl, int batch,
@@ -913,37 +943,28 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   int dev = 0;
   rc = current_device(&dev);
   if (rc) return rc;
-  std::unique_lock<std::recursive_mutex> lock(g_aux[dev].mu, std::defer_lock);
-  hipStream_t kfu_stream = s;
-  if (side) {
-    lock.lock();  // held until the factorisation has been enqueued: stream X and event slot 0 are shared state
-    Aux* aux = nullptr;
-    rc = aux_get(dev, 8, &aux);
-    if (rc) return rc;
-    GPK_HIP(hipEventRecord(aux->ev[0], s));  // (event slot 0 is re-recorded by the factorisation only after this wait was queued)
-    GPK_HIP(hipStreamWaitEvent(aux->X, aux->ev[0], 0));
-    kfu_stream = aux->X;
-  }
-  rc = gpk_kernel_matrix((void*)kfu_stream, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0,
-                         Kfu, l.ld);
-  if (rc) return rc;
-  int c1 = 0;
-  if (side) {
-    if (!q_diag) {
-      rc = gpk_transpose((void*)kfu_stream, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
-      if (rc) return rc;
-    }
-    rc = gpk_launch_kl_white_stage1(kfu_stream, q_mu, q_sqrt, m, P, q_diag, part1, &c1);
-    if (rc) return rc;
-    const double* p1s[1] = {part1};
-    const double halfs = 0.5;
-    rc = gpk_launch_final(kfu_stream, 1, p1s, &c1, &halfs, -0.5 * (double)m * (double)P, out + 1);
-    if (rc) return rc;
-  }
-  // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only
+  // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only: the chain's first leaf waits for
+  // nothing else, so it is the first thing enqueued
   rc = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter,
                          1, T, l.ld);
   if (rc) return rc;
+  int c1 = 0;
+  // everything else that precedes the minibatch solve, as one closure: enqueued by the factorisation on its bulk stream
+  // (side) or here on the caller's stream
+  const std::function<int(hipStream_t)> prologue = [&](hipStream_t xs) -> int {
+    int r = gpk_kernel_matrix((void*)xs, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0, Kfu, l.ld);
+    if (r) return r;
+    if (!side) return 0;
+    if (!q_diag) {
+      r = gpk_transpose((void*)xs, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
+      if (r) return r;
+    }
+    r = gpk_launch_kl_white_stage1(xs, q_mu, q_sqrt, m, P, q_diag, part1, &c1);
+    if (r) return r;
+    const double* p1s[1] = {part1};
+    const double halfs = 0.5;
+    return gpk_launch_final(xs, 1, p1s, &c1, &halfs, -0.5 * (double)m * (double)P, out + 1);
+  };
   // Lm = chol(Kuu);  A^T = Kfu Lm^-T   (conditionals/util.py:67,125); optionally the projection rides along
   ProjStream ps;
   const bool stream_proj = stream_proj_on() && side && !q_diag && (m % GPK_NB) == 0;
@@ -957,8 +978,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   if (sep) {
     xo.Eout = At; xo.ldeout = l.ld; xo.gws = (double*)(w + l.off_gws);
   }
-  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, stream_proj ? &ps : nullptr, sep ? &xo : nullptr);
-  if (lock.owns_lock()) lock.unlock();
+  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, stream_proj ? &ps : nullptr, sep ? &xo : nullptr, &prologue);
   if (rc) return rc;
   const bool projected = stream_proj && ps.groups > 0;
   // s0 = sum_k A^2 (util.py:133), fmean = A^T q_mu (util.py:144), q_diag: ssq = sum (A q_sqrt)^2 (:149)

@@ -121,8 +121,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     T = torch.empty((M + B + M, M), dtype=torch.float64, device=dev)
     ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)       # Kuu + jitter I
     ops.kernel_matrix(Xb, Z, out=T[M:M + B], **kw)                                      # Kfu
-    T[M + B:] = torch.eye(M, dtype=torch.float64, device=dev)
-    invd, info = ops.potrf_(T, M, zero_upper=True)
+    invd, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)                  # (the last M rows: I -> Lm^-T)
     L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
     Lq = torch.tril(q_sqrt)                                                             # band_part(q_sqrt, -1, 0)
     LqT = ops.transpose(q_sqrt, mode=1)                                                 # [P, M, M] = tril(q_sqrt)^T
@@ -183,8 +182,7 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
     T = torch.empty((N + P + N, N), dtype=torch.float64, device=dev)
     ops.kernel_matrix(X, None, diag_add=noise_variance, lower_only=False, out=T[:N], **kw)
     T[N:N + P] = (Y - mean_const).t()
-    T[N + P:] = torch.eye(N, dtype=torch.float64, device=dev)
-    invd, info = ops.potrf_(T, N, zero_upper=True)
+    invd, info = ops.potrf_(T, N, zero_upper=True, identity_rows=True)                  # (the last N rows: I -> L^-T, N^3/3)
     L, alphat, LinvT = T[:N], T[N:N + P], T[N + P:]
     a2 = ops.row_stats(alphat)[0].sum()
     lml = -0.5 * a2 - 0.5 * N * P * LOG2PI - P * torch.log(torch.diagonal(L)).sum()
@@ -223,8 +221,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     T = torch.empty((M + N + M, M), dtype=torch.float64, device=dev)
     ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
     ops.kernel_matrix(X, Z, out=T[M:M + N], **kw)
-    T[M + N:] = eye
-    _, info = ops.potrf_(T, M, zero_upper=True)
+    _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
     L, At, LinvT = T[:M], T[M:M + N], T[M + N:]
     err = (Y - mean_const).contiguous()
     A = ops.transpose(At)                                                               # [M, N]
@@ -234,10 +231,9 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     e2, q = ops.sumsq(err)[0], ops.sumsq(At)[0]
     T2 = torch.empty((2 * M + P, M), dtype=torch.float64, device=dev)
     T2[:M] = S / s2 + eye
-    T2[M:2 * M] = eye
-    T2[2 * M:] = a.t() / s2
-    _, info2 = ops.potrf_(T2, M, zero_upper=True)
-    LB, LBinvT, ct = T2[:M], T2[M:2 * M], T2[2 * M:]
+    T2[M:M + P] = a.t() / s2
+    _, info2 = ops.potrf_(T2, M, zero_upper=True, identity_rows=True)
+    LB, ct, LBinvT = T2[:M], T2[M:M + P], T2[M + P:]
     half_logdet_b = ops.sum_log_diag(LB)[0]
     F = (-0.5 * N * P * LOG2PI - P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * (N * variance - q) / s2)
          - 0.5 * (e2 / s2 - ops.sumsq(ct)[0]))
@@ -296,8 +292,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     T = torch.empty((M + B + M, M), dtype=torch.float64, device=dev)
     ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
     ops.kernel_matrix(Xb, Z, out=T[M:M + B], **kw)
-    T[M + B:] = torch.eye(M, dtype=torch.float64, device=dev)
-    _, info = ops.potrf_(T, M, zero_upper=True)
+    _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
     L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
     Linv = ops.transpose(LinvT)                                                         # lower
     Lq = torch.tril(q_sqrt)

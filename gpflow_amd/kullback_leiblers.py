@@ -58,7 +58,8 @@ def gauss_kl(q_mu, q_sqrt, K=None, *, K_cholesky=None) -> torch.Tensor:
             n_extra = L + M
             T = torch.empty((M + n_extra, M), dtype=torch.float64, device=dev)
             T[M:M + L] = q_mu.t()
-            T[M + L:] = torch.eye(M, dtype=torch.float64, device=dev)
+            if K is None:   # (with K the factorisation writes the identity rows itself: ops.potrf_(identity_rows=True))
+                T[M + L:] = torch.eye(M, dtype=torch.float64, device=dev)
         else:
             n_extra = L + L * M
             T = torch.empty((M + n_extra, M), dtype=torch.float64, device=dev)
@@ -69,7 +70,7 @@ def gauss_kl(q_mu, q_sqrt, K=None, *, K_cholesky=None) -> torch.Tensor:
             T[:, :M] = Kin
         else:
             T[:M] = Kin
-        _, info = ops.potrf_(T, M)
+        _, info = ops.potrf_(T, M, identity_rows=(is_diag and not is_batched))
         ops.check_info(info)
         Lp = T[:, :M] if is_batched else T[:M]
     else:

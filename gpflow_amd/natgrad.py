@@ -29,12 +29,11 @@ def _factor_with_inverse(Sym: torch.Tensor, extra: torch.Tensor = None):
     e = 0 if extra is None else extra.shape[0]
     T = torch.empty((2 * M + e, M), dtype=torch.float64, device=Sym.device)
     T[:M] = Sym
-    T[M:2 * M] = torch.eye(M, dtype=torch.float64, device=Sym.device)
     if e:
-        T[2 * M:] = extra
-    _, info = ops.potrf_(T, M, zero_upper=True)
+        T[M:M + e] = extra
+    _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
     ops.check_info(info, "natural-gradient precision (step too long?): Cholesky")
-    return T[:M], T[M:2 * M], (T[2 * M:] if e else None)
+    return T[:M], T[M + e:], (T[M:M + e] if e else None)
 
 
 def natgrad_update(q_mu: torch.Tensor, q_sqrt: torch.Tensor, g_mu: torch.Tensor, g_sqrt: torch.Tensor, gamma: float

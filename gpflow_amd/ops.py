@@ -165,9 +165,12 @@ def invd_alloc(n: int, batch: int = 1) -> torch.Tensor:
 
 
 def potrf_(T: torch.Tensor, n: int, *, zero_upper: bool = False,
-           invd: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+           invd: Optional[torch.Tensor] = None, identity_rows: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """In-place trapezoidal Cholesky of T [(n+extra), n] or batched [b, (n+extra), n].
-    Returns (invd, info) -- info is a device int32 tensor (0 ok, j+1 first bad pivot)."""
+    Returns (invd, info) -- info is a device int32 tensor (0 ok, j+1 first bad pivot).
+
+    identity_rows=True (2-D only): the LAST n rows of T are overwritten with the identity by the library and come back
+    as L^-T at a third of the cost of n dense rows (gpk_potrf_inv) -- the caller leaves them uninitialised."""
     lib = _lib.load()
     _chk(T, "T")
     if T.dim() == 2:
@@ -184,6 +187,13 @@ def potrf_(T: torch.Tensor, n: int, *, zero_upper: bool = False,
     if invd is None:
         invd = invd_alloc(n, batch)
     info = torch.zeros(batch, dtype=torch.int32, device=T.device)
+    if identity_rows:
+        if T.dim() != 2 or rows < 2 * n:
+            raise ValueError("identity_rows needs a 2-D T with at least 2 n rows")
+        rc = lib.gpk_potrf_inv(_stream(), T.data_ptr(), n, rows - 2 * n, lda, invd.data_ptr(), int(zero_upper),
+                               info.data_ptr())
+        _lib.check(rc, "gpk_potrf_inv")
+        return invd, info
     rc = lib.gpk_potrf(_stream(), T.data_ptr(), n, rows - n, lda, batch, stride, invd.data_ptr(),
                        int(zero_upper), info.data_ptr())
     _lib.check(rc, "gpk_potrf")

@@ -98,6 +98,14 @@ size_t gpk_invd_elems(int n, int batch);
 int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch, long strideA,
               double* invd, int zero_upper, int* info);
 
+/* gpk_potrf for callers that also need the explicit inverse factor (the reverse pass: gradients.py; the reference
+ * gets the same quantities from the triangular solves inside TF's Cholesky gradient).  A is [n + extra + n, lda]:
+ * the square block, `extra` right-hand-side rows, and n more rows that the CALL overwrites with the identity and
+ * returns as L^-T (upper triangular, exact zeros below the diagonal).  Because row j of that block stays zero left
+ * of column j until its column group is reached, the identity rows cost n^3/3 flop, not the n^3 of n dense rows.
+ * batch 1.  Everything else as gpk_potrf. */
+int gpk_potrf_inv(void* stream, double* A, int n, int extra, long lda, double* invd, int zero_upper, int* info);
+
 /* inverses of the diagonal NB-blocks of an existing lower factor L [n,n] (for gpk_trsm on a cached
  * L: GPRPosterior cache (err, Lm), posteriors.py:415-432). invd [batch, ceil(n/NB), NB, NB]. */
 int gpk_trtri_blocks(void* stream, const double* L, int n, long ldl, int batch, long strideL,

@@ -113,7 +113,10 @@ def _chol_info(K):
         return np.full_like(K, np.nan), n
 
 
-def potrf_(T, n, *, zero_upper=False, invd=None):
+def potrf_(T, n, *, zero_upper=False, invd=None, identity_rows=False):
+    if identity_rows:
+        assert T.dim() == 2 and T.shape[0] >= 2 * n
+        T[T.shape[0] - n:] = torch.eye(n, dtype=T.dtype)
     if T.dim() == 3:
         infos = []
         for b in range(T.shape[0]):

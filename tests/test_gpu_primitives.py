@@ -111,6 +111,35 @@ def test_potrf_trapezoid(gpu, n, extra):
         np.testing.assert_allclose(inv[b][: j1 - j0, : j1 - j0] @ D, np.eye(j1 - j0), rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,extra", [(40, 0), (128, 3), (200, 30), (300, 0), (640, 130), (1152, 700), (2048, 1), (4224, 300)])
+def test_potrf_identity_rows(gpu, n, extra):
+    """gpk_potrf_inv: the library writes the identity rows and returns L^-T, skipping the rows that are still zero.
+    Same values as the dense route (identity rows handed in explicitly; 1e-11: the row count picks the GEMM variant and
+    with it the summation order) and exact zeros below the diagonal; checked against the oracle inverse as well."""
+    import torch
+    from gpflow_amd import ops
+    rng = np.random.default_rng(41)
+    _, K = _spd(rng, n, noise=0.3)
+    Bm = rng.normal(size=(extra, n))
+    Td = torch.full((2 * n + extra, n), float("nan"), dtype=torch.float64, device=_t(K).device)   # identity block: garbage in
+    Td[:n] = _t(K)
+    if extra:
+        Td[n:n + extra] = _t(Bm)
+    _, info = ops.potrf_(Td, n, zero_upper=True, identity_rows=True)
+    ops.check_info(info)
+    Tref = _t(np.vstack([K, Bm, np.eye(n)]))
+    _, info = ops.potrf_(Tref, n, zero_upper=True)
+    ops.check_info(info)
+    out, ref = Td.cpu().numpy(), Tref.cpu().numpy()
+    assert np.array_equal(out[:n], ref[:n])
+    np.testing.assert_allclose(out[n:n + extra], ref[n:n + extra], rtol=0, atol=1e-11)
+    LinvT = out[n + extra:]
+    assert np.all(np.tril(LinvT, -1) == 0)
+    np.testing.assert_allclose(LinvT, ref[n + extra:], rtol=0, atol=1e-11)
+    Lref = np.linalg.cholesky(K)
+    np.testing.assert_allclose(LinvT.T @ Lref, np.eye(n), rtol=0, atol=1e-10)
+
+
 def test_potrf_batched(gpu):
     from gpflow_amd import ops
     rng = np.random.default_rng(5)
