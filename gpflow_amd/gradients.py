@@ -32,6 +32,19 @@ from . import ops
 
 LOG2PI = float(np.log(2.0 * np.pi))
 
+# The reverse pass has two independent branches after Kfu_bar: {q_mu_bar, Lq_bar} (two long-K products, 544 workgroups
+# each) and {Lm_bar -> Cholesky adjoint -> Kuu adjoint} (M^3 products of 256 tiles: one workgroup per CU, time of the
+# longest tile).  On a device they run on two streams so that the under-filled launches share the chip.
+OVERLAP_BRANCHES = True
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev: torch.device):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _side_streams:
+        _side_streams[idx] = torch.cuda.Stream(device=dev)
+    return _side_streams[idx]
+
 
 def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 1100) -> torch.Tensor:
     """A Bt^T for a LONG inner dimension and few output tiles (At^T r, At^T W, G [1, x, x^2]): the K range is cut into
@@ -143,15 +156,31 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     A = ops.transpose(At)                                                               # [M, B]
     Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)                                          # At_bar Lm^-1  [B, M]
     Kuf_bar = ops.transpose(Kfu_bar)                                                    # [M, B]
-    g_qmu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                   # At^T r - q_mu
-    g_qs = torch.stack([torch.tril(splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True)) for p in range(P)])
-    g_qs *= 2.0 * c                                                                     # 2c tril(At^T W_p)
-    g_qs.sub_(Lq, alpha=kl_weight)
-    g_qs.diagonal(dim1=1, dim2=2).add_(kl_weight / Lq.diagonal(dim1=1, dim2=2))
+
+    def branch_q():
+        g_mu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                # At^T r - q_mu
+        g = torch.stack([torch.tril(splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True)) for p in range(P)])
+        g *= 2.0 * c                                                                    # 2c tril(At^T W_p)
+        g.sub_(Lq, alpha=kl_weight)
+        g.diagonal(dim1=1, dim2=2).add_(kl_weight / Lq.diagonal(dim1=1, dim2=2))
+        return g_mu, g
+
+    side = _side_stream(dev) if (OVERLAP_BRANCHES and Z.is_cuda) else None
+    if side is not None:
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            g_qmu, g_qs = branch_q()
     Lbar = -torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True))                       # -tril(Kfu_bar^T At)
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
     dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
     dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+    if side is not None:
+        main.wait_stream(side)
+        g_qmu.record_stream(main)
+        g_qs.record_stream(main)
+    else:
+        g_qmu, g_qs = branch_q()
     g_var = dv1 + dv2 + c * B * P                                                       # Knn = variance in every fvar
     g_ls = dl1 + dl2
     if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
