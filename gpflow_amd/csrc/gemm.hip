@@ -1013,10 +1013,12 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
   const long tiles = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
   if (!a.no_small && small_ok(a)) return launch_small(s, a);  // K <= 128, <= 512 workgroups: the latency path
   if (a.epi == 1 && a.beta != 0.0 && a.C && !fast_ok(a)) return GPK_E_UNSUPPORTED;  // only the fast tile preloads C for epi 1
-  if (kGpkExp && a.epi == 0 && a.k >= 512 && a.m > 64 && a.n > 64 && !a.ctr) {
-    // (experiment: under-filled long-K launches -- the M^3 products of the reverse pass -- on 64 x 128 tiles)
+  if (a.epi == 0 && a.k >= 1024 && a.m > 64 && a.n > 64 && !a.ctr) {
+    // under-filled long-K launches (the M^3 triangular products of the reverse pass: 256 tiles of 128 x 128 = ONE
+    // workgroup per CU, so the launch lasts as long as its longest tile, 283 us at M = 2048) go to 64 x 128 tiles:
+    // twice the workgroups, half the longest tile.  Training step 7.15 -> 6.90 ms (same box, 300; 600: 7.00).
     const long eff = a.c_lower ? tiles / 2 : tiles;
-    if (eff < GPK_TUNE(HALF_TILE_BELOW, 0)) return launch_cfg<64, 128, 1, 4>(s, a);
+    if (eff < GPK_TUNE(HALF_TILE_BELOW, 300)) return launch_cfg<64, 128, 1, 4>(s, a);
   }
   if (fast_ok(a) && (a.epi == 1 || (a.n > 64 && (tiles >= 24 || a.m <= 64)))) {
     return a.epi == 1 ? launch_fast<1>(s, a) : launch_fast<0>(s, a);
