@@ -46,7 +46,8 @@ def _side_stream(dev: torch.device):
     return _side_streams[idx]
 
 
-def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 1100) -> torch.Tensor:
+def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 1100,
+                   alpha: float = 1.0) -> torch.Tensor:
     """A Bt^T for a LONG inner dimension and few output tiles (At^T r, At^T W, G [1, x, x^2]): the K range is cut into
     chunks that run as the batch dimension of one launch (strided views, no copies) and the partial products are summed
     -- without it a [2048, 2048] lower-only output is 136 workgroups each walking K = 8192 (33 TFLOP/s), and an
@@ -63,11 +64,11 @@ def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, 
             and k // (chunks * 2) >= 256:
         chunks *= 2
     if chunks == 1:
-        return ops.gemm_nt(A, Bt, c_lower=c_lower)
+        return ops.gemm_nt(A, Bt, c_lower=c_lower, alpha=alpha)
     kc = k // chunks
     A3 = torch.as_strided(A, (chunks, m, kc), (kc, A.stride(0), 1), A.storage_offset())
     B3 = torch.as_strided(Bt, (chunks, n, kc), (kc, Bt.stride(0), 1), Bt.storage_offset())
-    return ops.gemm_nt(A3, B3, c_lower=c_lower).sum(0)
+    return ops.gemm_nt(A3, B3, c_lower=c_lower, alpha=alpha).sum(0)
 
 
 def _phi_(T: torch.Tensor) -> torch.Tensor:
@@ -85,7 +86,7 @@ def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor) 
     T1 = ops.gemm_nt(LT, ops.transpose(Lbar), b_tri=1)          # L^T L_bar
     Y = ops.gemm_nt(_phi_(T1), LinvT, b_tri=1)                  # Phi L^-1        (lower)
     S = ops.gemm_nt(LinvT, ops.transpose(Y, mode=1), b_tri=1)   # L^-T (Phi L^-1)
-    return 0.5 * (S + S.t())
+    return S.add_(ops.transpose(S)).mul_(0.5)
 
 
 def se_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, variance: float, lengthscales,
@@ -97,16 +98,20 @@ def se_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, 
     n1, D = A.shape
     ls = torch.as_tensor(np.broadcast_to(np.asarray(lengthscales, dtype=np.float64), (D,)).copy(), device=A.device)
     G = ops.kernel_matrix_hadamard(A, Bm, Kbar, variance=variance, lengthscales=lengthscales)   # Kbar .* K
-    V = torch.cat([torch.ones((Bm.shape[0], 1), dtype=torch.float64, device=A.device), Bm, Bm * Bm], dim=1)
-    R = splitk_gemm_nt(G, V.t().contiguous())        # [n1, 1 + 2D] = G [1, B, B^2]
+    Vt = torch.empty((1 + 2 * D, Bm.shape[0]), dtype=torch.float64, device=A.device)             # [1, B, B^2]^T
+    Vt[0] = 1.0
+    Vt[1:1 + D] = Bm.t()
+    torch.mul(Vt[1:1 + D], Vt[1:1 + D], out=Vt[1 + D:])
+    R = splitk_gemm_nt(G, Vt)                        # [n1, 1 + 2D] = G [1, B, B^2]
     rs, GB, GB2 = R[:, 0:1], R[:, 1:1 + D], R[:, 1 + D:]
     dvar = rs.sum() / variance
-    if symmetric:
-        Abar = 2.0 * (GB - A * rs) / (ls * ls)
-        dls = (2.0 * (A * A * rs).sum(0) - 2.0 * (A * GB).sum(0)) / ls ** 3
-    else:
-        Abar = (GB - A * rs) / (ls * ls)
-        dls = (GB2 - 2.0 * A * GB + A * A * rs).sum(0) / ls ** 3
+    T = torch.addcmul(GB, A, rs, value=-1.0)         # G B - A rowsum(G)
+    if symmetric:   # both arguments: A_bar = 2 T / ls^2,  d/dls = (2 sum A^2 rs - 2 sum A GB) / ls^3 = -sum(A A_bar) / ls
+        Abar = T * (2.0 / (ls * ls))
+        dls = -(A * Abar).sum(0) / ls
+    else:           # d/dls = sum(GB2 - 2 A GB + A^2 rs) / ls^3 = sum(GB2 - A (GB + T)) / ls^3
+        Abar = T / (ls * ls)
+        dls = (GB2 - A * (GB + T)).sum(0) / ls ** 3
     return dvar, dls, Abar
 
 
@@ -159,9 +164,10 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
 
     def branch_q():
         g_mu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                # At^T r - q_mu
-        g = torch.stack([torch.tril(splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True)) for p in range(P)])
-        g *= 2.0 * c                                                                    # 2c tril(At^T W_p)
-        g.sub_(Lq, alpha=kl_weight)
+        g = torch.stack([torch.tril(splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c))
+                         for p in range(P)]) if P > 1 else \
+            torch.tril(splitk_gemm_nt(A, ops.transpose(W[0]), c_lower=True, alpha=2.0 * c)).unsqueeze(0)
+        g.sub_(Lq, alpha=kl_weight)                                                     # 2c tril(At^T W_p) - Lq_p
         g.diagonal(dim1=1, dim2=2).add_(kl_weight / Lq.diagonal(dim1=1, dim2=2))
         return g_mu, g
 
@@ -171,7 +177,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
         side.wait_stream(main)
         with torch.cuda.stream(side):
             g_qmu, g_qs = branch_q()
-    Lbar = -torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True))                       # -tril(Kfu_bar^T At)
+    Lbar = torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0))            # -tril(Kfu_bar^T At)
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
     dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
     dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
