@@ -183,7 +183,7 @@ def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
     kb_alg = n * n * 8 + n * d * 8  # algorithmic bytes: the full N x N fp64 write + the N x D read
     # the trailing update on its own (north_star: ">= 60 % of fp64 MFMA peak on the N=16384 Cholesky trailing update"):
     # HIP events around every GEMM launch of one more factorisation; the outer rest-updates  A22 -= P P^T  (lower tiles,
-    # K = 768) are the launches with >= 2e10 algorithmic flop (look-ahead strips and panel-internal GEMMs are smaller)
+    # K = 640) are the launches with >= 2e10 algorithmic flop (look-ahead strips and panel-internal GEMMs are smaller)
     lib.gpk_profile_gemm_enable(1)
     ops.gpr_lml(X, Y, **kw)
     ms_t, n_t, fl_t = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
@@ -203,7 +203,7 @@ def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
         traffic = float(pj["gemm_nt_fast<0,false> trailing update"]["hbm_bytes_per_launch"])
     except Exception:
         kb_traffic = None
-    trailing = {"bound": "mfma", "kernel": "gemm_nt_fast<0,false>, lower tiles, K = 768 (outer trailing updates)",
+    trailing = {"bound": "mfma", "kernel": "gemm_nt_fast<0,false>, lower tiles, K = 640 (outer trailing updates)",
                 "achieved": tu_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tu_tf / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
                 "launches": int(n_t.value), "algorithmic_gflop": fl_t.value / 1e9,
