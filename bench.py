@@ -287,12 +287,17 @@ def main():  # noqa: C901
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
     from gpflow_amd import _lib, ops
     lib = _lib.load()
+    if world > 1:
+        # The library's internal streams are created by its first factorisation with n > 128, in an order chosen so
+        # that chain and bulk streams land on different microengine pipes.  RCCL creates streams
+        # of its own when the communicator comes up: let the library place its streams FIRST, as in the 1-GPU run.
+        warm = torch.eye(256, dtype=torch.float64, device=device)
+        ops.potrf_(warm, 256)
+        torch.cuda.synchronize()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     n_data, m_ind, d_in, global_rows, strong, seed = WORKLOADS[args.workload]
     if strong and global_rows % world:
         raise SystemExit("c4-strong needs a GPU count that divides 8192")

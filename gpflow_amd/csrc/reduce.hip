@@ -165,6 +165,44 @@ __global__ void sum_parts_kernel(const double* part, int nt, int rows, long stri
   ssq[(long)p * rows + b] = s;
 }
 
+// ---- out = alpha * sum_p part[p]  (optionally lower-triangular: zeros above the diagonal, diagonal scaled) --------
+// The partial products of a split-K GEMM summed in a fixed order (p = 0, 1, ...): deterministic, one pass, 16-byte
+// accesses; with lower != 0 entries above the diagonal are never read (a lower-only GEMM does not write those tiles).
+__global__ __launch_bounds__(256) void combine_parts_kernel(const double* __restrict__ part, int np, long stridePart, int m,
+                                                           int n, long ldp, double alpha, int lower, double diag_scale,
+                                                           double* __restrict__ out, long ldo) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= n) return;
+  const bool two = c + 1 < n;
+  const bool vec_ok = two && ((ldp & 1) == 0) && ((stridePart & 1) == 0) && ((reinterpret_cast<uintptr_t>(part) & 15) == 0);
+  for (int r = blockIdx.y; r < m; r += gridDim.y) {
+    const bool k0 = !lower || c <= r, k1 = two && (!lower || c + 1 <= r);
+    double s0 = 0.0, s1 = 0.0;
+    if (k0 || k1) {
+      const double* q = part + (long)r * ldp + c;
+      if (vec_ok && k0 && k1) {
+        for (int p = 0; p < np; ++p, q += stridePart) {
+          const d2 v = *reinterpret_cast<const d2*>(q);
+          s0 += v.x; s1 += v.y;
+        }
+      } else {
+        for (int p = 0; p < np; ++p, q += stridePart) {
+          if (k0) s0 += q[0];
+          if (k1) s1 += q[1];
+        }
+      }
+      s0 *= alpha; s1 *= alpha;
+      if (lower) {
+        if (c == r) s0 *= diag_scale;
+        if (c + 1 == r) s1 *= diag_scale;
+      }
+    }
+    double* o = out + (long)r * ldo + c;
+    o[0] = k0 ? s0 : 0.0;
+    if (two) o[1] = k1 ? s1 : 0.0;
+  }
+}
+
 // ---- Gaussian variational expectations, stage 1 -----------------------------------------------------
 struct VarexpArgs {
   const double* Y; long ldy; const double* fmean; int rows, P;
@@ -342,6 +380,17 @@ int gpk_launch_sum_parts(hipStream_t s, const double* part, int nt, int rows, lo
   if (rows == 0 || P == 0) return 0;
   dim3 grid((unsigned)gpk_cdiv(rows, 256), (unsigned)P);
   hipLaunchKernelGGL(sum_parts_kernel, grid, dim3(256), 0, s, part, nt, rows, stridePart, ssq);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gpk_combine_parts(void* stream, const double* parts, int nparts, long stride_part, int m, int n, long ldp,
+                                 double alpha, int lower, double diag_scale, double* out, long ldo) {
+  if (!parts || !out || nparts <= 0 || m < 0 || n < 0 || ldp < n || ldo < n) return GPK_E_ARG;
+  if (m == 0 || n == 0) return 0;
+  dim3 grid((unsigned)gpk_cdiv(gpk_cdiv(n, 2), 256), (unsigned)(m < 65535 ? m : 65535));
+  hipLaunchKernelGGL(combine_parts_kernel, grid, dim3(256), 0, (hipStream_t)stream, parts, nparts, stride_part, m, n, ldp,
+                     alpha, lower, diag_scale, out, ldo);
   GPK_LAUNCH_CHECK();
   return 0;
 }

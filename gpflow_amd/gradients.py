@@ -47,12 +47,13 @@ def _side_stream(dev: torch.device):
 
 
 def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, target_wgs: int = 1100,
-                   alpha: float = 1.0) -> torch.Tensor:
-    """A Bt^T for a LONG inner dimension and few output tiles (At^T r, At^T W, G [1, x, x^2]): the K range is cut into
-    chunks that run as the batch dimension of one launch (strided views, no copies) and the partial products are summed
-    -- without it a [2048, 2048] lower-only output is 136 workgroups each walking K = 8192 (33 TFLOP/s), and an
-    [M, 17] output is 16 workgroups.  target_wgs ~ two full rounds of the 512 resident workgroups (A/B on the training
-    step: 272 workgroups 8.08 ms, 544 7.9, 1088 7.65, 2176 7.78)."""
+                   alpha: float = 1.0, diag_scale: float = 1.0) -> torch.Tensor:
+    """alpha A Bt^T for a LONG inner dimension and few output tiles (At^T r, At^T W, G [1, x, x^2]): the K range is cut
+    into chunks that run as the batch dimension of one launch (strided views, no copies) and the partial products are
+    summed by ops.combine_parts in a fixed order -- without the split a [2048, 2048] lower-only output is 136 workgroups
+    each walking K = 8192 (33 TFLOP/s), and an [M, 17] output is 16 workgroups.  target_wgs ~ two full rounds of the 512
+    resident workgroups (A/B on the training step: 272 workgroups 8.08 ms, 544 7.9, 1088 7.65, 2176 7.78).
+    c_lower=True returns tril(.) (exact zeros above the diagonal) with the diagonal multiplied by diag_scale."""
     m, k = A.shape
     n = Bt.shape[0]
     tm, tn = -(-m // 128), -(-n // 128)
@@ -64,18 +65,27 @@ def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, 
             and k // (chunks * 2) >= 256:
         chunks *= 2
     if chunks == 1:
-        return ops.gemm_nt(A, Bt, c_lower=c_lower, alpha=alpha)
+        R = ops.gemm_nt(A, Bt, c_lower=c_lower, alpha=alpha)
+        return ops.combine_parts(R, lower=True, diag_scale=diag_scale) if c_lower else R
     kc = k // chunks
     A3 = torch.as_strided(A, (chunks, m, kc), (kc, A.stride(0), 1), A.storage_offset())
     B3 = torch.as_strided(Bt, (chunks, n, kc), (kc, Bt.stride(0), 1), Bt.storage_offset())
-    return ops.gemm_nt(A3, B3, c_lower=c_lower, alpha=alpha).sum(0)
+    return ops.combine_parts(ops.gemm_nt(A3, B3, c_lower=c_lower), alpha=alpha, lower=c_lower, diag_scale=diag_scale)
+
+
+def _tril(x: torch.Tensor) -> torch.Tensor:
+    """band_part(x, -1, 0) of [M, M] or [P, M, M] as a fresh tensor (one 16-byte-access pass per matrix)."""
+    if x.dim() == 2:
+        return ops.combine_parts(x, lower=True)
+    out = torch.empty_like(x)
+    for p in range(x.shape[0]):
+        ops.combine_parts(x[p], lower=True, out=out[p])
+    return out
 
 
 def _phi_(T: torch.Tensor) -> torch.Tensor:
-    """Phi(T): lower triangle with the diagonal halved (in place on a fresh tensor)."""
-    P = torch.tril(T)
-    P.diagonal().mul_(0.5)
-    return P
+    """Phi(T): lower triangle with the diagonal halved (a fresh tensor)."""
+    return ops.combine_parts(T, lower=True, diag_scale=0.5)
 
 
 def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor) -> torch.Tensor:
@@ -141,7 +151,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     ops.kernel_matrix(Xb, Z, out=T[M:M + B], **kw)                                      # Kfu
     invd, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)                  # (the last M rows: I -> Lm^-T)
     L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
-    Lq = torch.tril(q_sqrt)                                                             # band_part(q_sqrt, -1, 0)
+    Lq = _tril(q_sqrt)                                                                     # band_part(q_sqrt, -1, 0)
     LqT = ops.transpose(q_sqrt, mode=1)                                                 # [P, M, M] = tril(q_sqrt)^T
     s0, fmean, _ = ops.row_stats(At, V=q_mu)                                            # rowsum(At^2), At q_mu
     W = ops.gemm_nt(At, LqT, b_tri=1)                                                   # [P, B, M]: W_p = At Lq_p
@@ -164,9 +174,9 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
 
     def branch_q():
         g_mu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                # At^T r - q_mu
-        g = torch.stack([torch.tril(splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c))
+        g = torch.stack([splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c)
                          for p in range(P)]) if P > 1 else \
-            torch.tril(splitk_gemm_nt(A, ops.transpose(W[0]), c_lower=True, alpha=2.0 * c)).unsqueeze(0)
+            splitk_gemm_nt(A, ops.transpose(W[0]), c_lower=True, alpha=2.0 * c).unsqueeze(0)
         g.sub_(Lq, alpha=kl_weight)                                                     # 2c tril(At^T W_p) - Lq_p
         g.diagonal(dim1=1, dim2=2).add_(kl_weight / Lq.diagonal(dim1=1, dim2=2))
         return g_mu, g
@@ -177,7 +187,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
         side.wait_stream(main)
         with torch.cuda.stream(side):
             g_qmu, g_qs = branch_q()
-    Lbar = torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0))            # -tril(Kfu_bar^T At)
+    Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)            # -tril(Kfu_bar^T At)
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
     dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
     dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
@@ -260,7 +270,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     L, At, LinvT = T[:M], T[M:M + N], T[M + N:]
     err = (Y - mean_const).contiguous()
     A = ops.transpose(At)                                                               # [M, N]
-    Slow = torch.tril(splitk_gemm_nt(A, A, c_lower=True))
+    Slow = splitk_gemm_nt(A, A, c_lower=True)
     S = Slow + torch.tril(Slow, -1).t()
     a = splitk_gemm_nt(A, err.t().contiguous())                                         # [M, P]
     e2, q = ops.sumsq(err)[0], ops.sumsq(At)[0]
@@ -284,7 +294,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     ops.gemm_nt(At, Ssym, alpha=1.0, beta=1.0, C=Atb)                                   # + At (2 S_bar + 2 q_bar I)
     Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)
     Kuf_bar = ops.transpose(Kfu_bar)
-    Lbar = -torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True))
+    Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
     dv1, dl1, Zb1 = se_kernel_adjoint(Z, X, Kuf_bar, symmetric=False, **kw)
     dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
@@ -330,7 +340,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
     L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
     Linv = ops.transpose(LinvT)                                                         # lower
-    Lq = torch.tril(q_sqrt)
+    Lq = _tril(q_sqrt)        
     LqT = ops.transpose(q_sqrt, mode=1)
     A2t = ops.gemm_nt(At, LinvT, b_tri=1)                                               # At Linv   (util.py:139)
     s0 = ops.row_stats(At)[0]
@@ -361,19 +371,19 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     # q(u) gradients: data part through A2t, KL part through Kuu^-1
     Kinv_qmu_t = ops.gemm_nt(alphat, LinvT, b_tri=1)                                    # (Linv^T alpha)^T  [P, M]
     g_qmu = splitk_gemm_nt(A2, r.t().contiguous()) - k * Kinv_qmu_t.t()
-    g_qs = torch.stack([torch.tril(splitk_gemm_nt(A2, ops.transpose(W[p]), c_lower=True)) for p in range(P)]) * (2.0 * c)
+    g_qs = torch.stack([splitk_gemm_nt(A2, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c) for p in range(P)])
     for p in range(P):
         KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p], mode=1), b_tri=1)              # Linv^T V_p = Kuu^-1 Lq_p (V_p lower)
         g_qs[p] -= k * torch.tril(KinvLq)
     g_qs.diagonal(dim1=1, dim2=2).add_(k / Lq.diagonal(dim1=1, dim2=2))
     # Linv_bar (lower) and its pull-back to Lm
-    Linv_bar = torch.tril(splitk_gemm_nt(A, ops.transpose(A2tb), c_lower=True))         # tril(At^T A2t_bar)
+    Linv_bar = splitk_gemm_nt(A, ops.transpose(A2tb), c_lower=True)         # tril(At^T A2t_bar)
     Linv_bar -= k * torch.tril(ops.gemm_nt(alphat.t().contiguous(), q_mu))              # alpha q_mu^T
     for p in range(P):
         Linv_bar -= k * torch.tril(ops.gemm_nt(V[p], Lq[p], b_tri=2))                   # V_p Lq_p^T
     X1 = ops.gemm_nt(LinvT, ops.transpose(Linv_bar, mode=1), b_tri=1)                   # Linv^T Linv_bar (Linv_bar lower)
     X2 = ops.gemm_nt(X1, Linv, b_tri=2)                                                 # (.) Linv^T
-    Lbar = -torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True)) - torch.tril(X2)
+    Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0) - torch.tril(X2)
     Lbar.diagonal().sub_(k * P / L.diagonal())
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
     dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)

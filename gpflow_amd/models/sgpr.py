@@ -224,7 +224,7 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         err = (self.data[1] - c).contiguous()
         T = torch.empty((M + M + P, M), dtype=torch.float64, device=Z.device)
         kuu = ops.kernel_matrix(Z, None, diag_add=config.default_jitter(), **kw)
-        T[:M] = kuu + torch.tril(gradients.splitk_gemm_nt(Kuf, Kuf, c_lower=True)) / s2   # sig (lower triangle is read)
+        T[:M] = kuu + gradients.splitk_gemm_nt(Kuf, Kuf, c_lower=True) / s2   # sig (lower triangle is read)
         T[M:2 * M] = kuu                                                                # rows -> kuu sig_sqrt^-T
         T[2 * M:] = gradients.splitk_gemm_nt(Kuf, err.t().contiguous()).t() / s2         # (scaled_kuf scaled_err)^T
         _, info = ops.potrf_(T, M, zero_upper=True)

@@ -405,6 +405,28 @@ def sum_log_diag(L: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def combine_parts(parts: torch.Tensor, *, alpha: float = 1.0, lower: bool = False, diag_scale: float = 1.0,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """alpha * sum_p parts[p] for parts [np, m, n] (or [m, n]: one part), summed in the order p = 0, 1, ...; with
+    lower=True the result is lower-triangular (zeros above the diagonal, which is never read -- a lower-only GEMM leaves
+    those tiles unwritten) and its diagonal is multiplied by diag_scale (0.5: the Phi of the Cholesky adjoint)."""
+    lib = _lib.load()
+    _chk(parts, "parts")
+    p3 = parts if parts.dim() == 3 else parts.unsqueeze(0)
+    if p3.dim() != 3:
+        raise ValueError("parts must be [np, m, n] or [m, n]")
+    npart, m, n = p3.shape
+    ldp = _rowmajor(p3[0], "parts")
+    stride = int(p3.stride(0)) if npart > 1 else 0
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float64, device=parts.device)
+    _chk(out, "out", 2)
+    rc = lib.gpk_combine_parts(_stream(), p3.data_ptr(), npart, stride, m, n, ldp, float(alpha), int(lower),
+                               float(diag_scale), out.data_ptr(), _rowmajor(out, "out"))
+    _lib.check(rc, "gpk_combine_parts")
+    return out
+
+
 def sumsq(A: torch.Tensor, *, upper_only: bool = False) -> torch.Tensor:
     lib = _lib.load()
     _chk(A, "A", 2)

@@ -18,11 +18,12 @@
  *
  * Internal state and threading (the complete list; nothing else in the library is mutable)
  *   - gpk_potrf with n > 128 (and the two fused drivers, which call it) uses per-device state created lazily on the
- *     first such call: five internal HIP streams (panel / bulk / bulk-small / bulk-late / extra-rows), a pool of
- *     timing-disabled events that grows to 2 * panels + 8, a 4 KiB device table of the compute units reserved for the
- *     latency chain (filled once from a census kernel: THIS FIRST CALL synchronises its panel stream once and
- *     allocates ~4.2 KiB of device memory) and 64 bytes of self-resetting ticket counters.  Work is forked from and
- *     joined to the caller's stream with events only.
+ *     first such call: six internal HIP streams (panel, high priority / extra rows / one placeholder that fixes the
+ *     stream-to-hardware-queue layout / bulk-small / bulk and bulk-late, both CU-masked) and a pool of timing-disabled
+ *     events that grows to 3 * panels + 8.  No device memory is allocated and nothing synchronises: work is forked
+ *     from and joined to the caller's stream with events only.  (The streams are created in an order that keeps the
+ *     panel and bulk streams on different microengine pipes -- INTEGRATION.md section 4: create this state, i.e. make
+ *     one such call, before other libraries of the process create their streams.)
  *   - One recursive mutex per device serialises the ENQUEUE section of these calls, so they may be issued from any
  *     number of host threads and on any caller streams; factorisations of one device share the internal streams and
  *     therefore execute one after the other on the GPU.
@@ -184,6 +185,14 @@ int gpk_sum_log_diag(void* stream, const double* L, int n, long ldl, int batch, 
 /* out[0] = sum of squares of A [rows,cols] (upper_only: c >= r) -- mahalanobis / trace terms */
 int gpk_sumsq(void* stream, const double* A, int rows, int cols, long lda, int upper_only,
               double* out, void* ws, size_t ws_bytes);
+
+/* out [m,n] = alpha * sum_p parts[p]  (parts [nparts, m, n], row stride ldp, part stride stride_part), summed in the
+ * order p = 0, 1, ... (deterministic).  lower != 0: entries above the diagonal are written as zeros and never read,
+ * the diagonal is multiplied by diag_scale -- i.e. tril(.) (tf.linalg.band_part(., -1, 0), conditionals/util.py:151)
+ * or, with diag_scale = 0.5, the Phi(.) of the Cholesky adjoint.  The reduction step of the split-K products of the
+ * reverse pass (gradients.py), where TF autodiff's matmul gradients need none. */
+int gpk_combine_parts(void* stream, const double* parts, int nparts, long stride_part, int m, int n, long ldp,
+                      double alpha, int lower, double diag_scale, double* out, long ldo);
 
 /* ---- fused drivers -----------------------------------------------------------------------------------
  * GPR.log_marginal_likelihood (gpr.py:91-107), stationary kernel, Gaussian noise, constant mean:

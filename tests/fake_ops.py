@@ -249,6 +249,21 @@ def gauss_kl_white(q_mu, q_sqrt):
     return torch.tensor([kl], dtype=torch.float64)
 
 
+def combine_parts(parts, *, alpha=1.0, lower=False, diag_scale=1.0, out=None):
+    p3 = _np(parts if parts.dim() == 3 else parts.unsqueeze(0))
+    if lower:   # entries above the diagonal may be NaN (unwritten tiles of a lower-only GEMM): never read
+        p3 = np.where(np.tril(np.ones(p3.shape[1:], dtype=bool))[None], p3, 0.0)
+    r = alpha * p3.sum(0)
+    if lower:
+        r = np.tril(r)
+        r[np.diag_indices(min(r.shape))] *= diag_scale
+    t = torch.from_numpy(r)
+    if out is not None:
+        out.copy_(t)
+        return out
+    return t
+
+
 def sumsq(A, *, upper_only=False):
     a = _np(A)
     if upper_only:

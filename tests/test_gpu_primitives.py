@@ -300,3 +300,86 @@ def test_gemm_nt_fast_path(gpu, m, n, k, b_tri, c_lower):
         np.testing.assert_allclose(np.tril(out), np.tril(ref), rtol=0, atol=2e-11)
     else:
         np.testing.assert_allclose(out, ref, rtol=0, atol=2e-11)
+
+
+@pytest.mark.parametrize("np_,m,n,lower", [(1, 300, 300, True), (8, 2048, 2048, True), (5, 130, 17, False), (3, 257, 511, False),
+                                          (4, 515, 515, True)])
+def test_combine_parts(gpu, np_, m, n, lower):
+    """gpk_combine_parts: alpha * sum of the split-K partial products in a fixed order; lower: tril with exact zeros and
+    a scaled diagonal, entries above the diagonal never read (NaN there on purpose).  Bit-exact against the same
+    left-to-right sum in NumPy."""
+    import torch
+    from gpflow_amd import ops
+    rng = np.random.default_rng(9)
+    parts = rng.normal(size=(np_, m, n))
+    ref = np.zeros((m, n))
+    for p in range(np_):
+        ref = ref + parts[p]
+    ref = -1.5 * ref
+    src = parts.copy()
+    if lower:
+        src[:, np.triu(np.ones((m, n), dtype=bool), 1)] = np.nan
+        ref = np.tril(ref)
+        ref[np.diag_indices(min(m, n))] *= 0.5
+    out = ops.combine_parts(_t(src), alpha=-1.5, lower=lower, diag_scale=0.5 if lower else 1.0).cpu().numpy()
+    assert np.array_equal(out, ref)
+    # strided view (a column block of a wider matrix) and a caller-provided output
+    if not lower and n > 20:
+        wide = _t(np.concatenate([parts, parts], axis=2))
+        o = torch.empty((m, n - 3), dtype=torch.float64, device=wide.device)
+        ops.combine_parts(wide[:, :, 3:n], out=o)
+        r2 = np.zeros((m, n - 3))
+        for p in range(np_):
+            r2 = r2 + parts[p][:, 3:]
+        assert np.array_equal(o.cpu().numpy(), r2)
+
+
+def test_two_host_threads_one_device(gpu):
+    """include/gpk.h, "Internal state and threading": factorisations with n > 128 share per-device streams and events,
+    calls from several host threads are serialised by a per-device mutex while they ENQUEUE (the work itself overlaps on
+    the device as far as its streams allow).  Two threads, each on its own stream, 12 factorisations each, against the
+    results of the same calls made one after the other: bit for bit."""
+    import threading
+    import torch
+    from gpflow_amd import ops
+    rng = np.random.default_rng(77)
+    probs = []
+    for n, extra in ((700, 300), (1300, 40)):
+        _, K = _spd(rng, n, noise=0.2)
+        probs.append((n, _t(np.vstack([K, rng.normal(size=(extra, n))]))))
+    expected = []
+    for n, T0 in probs:
+        T = T0.clone()
+        _, info = ops.potrf_(T, n, zero_upper=True)
+        ops.check_info(info)
+        expected.append(T.cpu().numpy())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in probs]
+    out, errs = [[] for _ in probs], []
+
+    def work(i):
+        try:
+            n, T0 = probs[i]
+            with torch.cuda.stream(streams[i]):
+                for _ in range(12):
+                    T = T0.clone()
+                    _, info = ops.potrf_(T, n, zero_upper=True)
+                    out[i].append((T, info))
+                streams[i].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    for s_ in streams:
+        s_.wait_stream(torch.cuda.current_stream())
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(probs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(len(probs)):
+        assert len(out[i]) == 12
+        for T, info in out[i]:
+            assert int(info.cpu()[0]) == 0
+            assert np.array_equal(T.cpu().numpy(), expected[i])
