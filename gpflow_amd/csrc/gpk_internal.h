@@ -127,6 +127,28 @@ int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
                     long strideInv, int* info, int col0, int batch, int already_factored);
 
+// ---- chain panel (leaf.hip, A/B build): ONE launch per 128-column panel of an SVGP-sized factorisation ------------
+// workgroup 0 = the leaf of panel p; 8 helpers per row block solve the rows of blocks p+1 and p+2 against the new
+// inverse and apply panel p to the three tiles the NEXT TWO leaves depend on -- (p+1,p+1), (p+2,p+1), (p+2,p+2) -- with
+// in-kernel flags instead of launch boundaries; everything else of panel p (the other rows' solve, strips, rest-update)
+// is bulk work on other streams, released by hipStreamWaitValue32 on flagK.
+struct LeafKArgs {
+  double* A; long lda;       // the whole trapezoid (row-major)
+  int nblk;                  // number of 128-column blocks of the square part (n = 128 nblk)
+  int p;                     // panel
+  double* invd;              // [nblk][128][128] block inverses (block p written here)
+  int* info;
+  unsigned* flagL;           // device word: leaf of this launch done (agent scope)
+  unsigned long long* cnt;   // [2] device counters: helpers past the solve / helpers finished (zeroed by workgroup 0)
+  unsigned* flagK;           // signal memory: the critical tiles of this launch are done (system scope)
+  const unsigned* flagB;     // signal memory (hipStreamWriteValue32): strips of the previous panel done
+  unsigned epoch;            // value raised on flagL / flagK
+  unsigned need_b;           // flagB must have reached this value (0: nothing to wait for)
+  int nh;                    // helpers: 8 (block p+1) + 8 (block p+2) + 8 (tile (p+2,p+2)), fewer at the end
+  int nsolve;                // of which solve a sliver (the first 8 or 16)
+};
+int gpk_launch_leafk(hipStream_t s, const LeafKArgs& a);
+
 // ---- rbf.hip ---------------------------------------------------------------------------------
 // (entry point gpk_kernel_matrix is defined there)
 

@@ -95,6 +95,11 @@ struct Aux {
   unsigned* flow_state = nullptr;
   unsigned* flow_flags = nullptr;
   unsigned epoch = 0;
+  // chain-panel schedule (A/B build): bulk streams masked away from the CUs the chain launches need, flag words
+  hipStream_t Mb = nullptr, Mr = nullptr, Mx = nullptr, Mpad = nullptr;
+  unsigned* ck_flagL = nullptr; unsigned long long* ck_cnt = nullptr;  // device memory
+  unsigned* ck_flagK = nullptr; unsigned* ck_flagB = nullptr;          // signal memory (stream value waits / writes)
+  unsigned ck_epoch = 0;
   struct Plan { int n = 0, rows = 0, P = 0, proj = 0; FlowTask* dev = nullptr; int off[9] = {0}; std::vector<FlowGroup> groups; };
   Plan plans[4];
   int nplans = 0;
@@ -194,6 +199,34 @@ int aux_get(int dev, int need, Aux** out) {
     if (kGpkExp) {  // the software CU reservation is an A/B-build experiment (gpk_internal.h)
       rc = build_reservation(a, GPK_TUNE(SOFT_RESERVED_CUS, 32));
       if (rc) return rc;
+    }
+    if (kGpkExp && GPK_TUNE(LEAFK, 0)) {
+      // chain-panel schedule: three bulk streams that leave LEAFK_RESERVED CUs to the chain launches (25 workgroups
+      // of 147 KB LDS each).  Masked streams get hardware queues of their own, in creation order over the four
+      // pipes: B -> pipe 3, Bl -> pipe 0, so one placeholder (pipe 1 = the chain's), then pipes 2, 3, 0.
+      int res = GPK_TUNE(LEAFK_RESERVED, 32);
+      if (res < 0 || res >= ncu) res = 0;
+      rc = masked_stream(&a.Mpad, ncu, res > 0 ? res : 1, ncu);
+      if (rc) return rc;
+      if (GPK_TUNE(LEAFK_MB_PRIO, 0)) {  // (variant: the chain-side bulk stream unmasked at high priority)
+        GPK_HIP(hipStreamCreateWithPriority(&a.Mb, hipStreamNonBlocking, hi));
+      } else {
+        rc = masked_stream(&a.Mb, ncu, res, ncu);
+        if (rc) return rc;
+      }
+      rc = masked_stream(&a.Mr, ncu, res, ncu);
+      if (rc) return rc;
+      rc = masked_stream(&a.Mx, ncu, res, ncu);
+      if (rc) return rc;
+      GPK_HIP(hipMalloc((void**)&a.ck_flagL, 64));
+      GPK_HIP(hipMemset(a.ck_flagL, 0, 64));
+      GPK_HIP(hipMalloc((void**)&a.ck_cnt, 64));
+      GPK_HIP(hipMemset(a.ck_cnt, 0, 64));
+      GPK_HIP(hipExtMallocWithFlags((void**)&a.ck_flagK, 8, hipMallocSignalMemory));
+      GPK_HIP(hipExtMallocWithFlags((void**)&a.ck_flagB, 8, hipMallocSignalMemory));
+      GPK_HIP(hipMemset(a.ck_flagK, 0, 8));
+      GPK_HIP(hipMemset(a.ck_flagB, 0, 8));
+      GPK_HIP(hipDeviceSynchronize());
     }
     a.ready = true;
   }
@@ -440,6 +473,145 @@ struct ExtraOut {
 };
 inline size_t ginv_ws_doubles(int n) { return ((size_t)gpk_cdiv(n, NBO) + 2) * 2 * NBO * NBO; }  // one slot per group with an inverse
 
+// ---- chain-panel schedule (A/B build; gpk_internal.h: LeafKArgs) ---------------------------------------------------
+// P : one leafk launch per panel (leaf + solve of row blocks p+1, p+2 + the tiles (p+1,p+1), (p+2,p+1), (p+2,p+2)).
+// Mb: [value-wait flagK(p)] solve of the rows from block p+3 on; [evR(p-1)] strip = those rows x column blocks
+//     p+1..p+3 (everything panel p owes to the tiles the next chain launch touches); [write flagB(p)].
+// Mr: [evS(p)] rest-update: columns from block p+4 on, lower tiles.
+// X : the extra rows, group by group, behind evS of the group's last panel (as in the stream schedule).
+// No packet is ever put on P between two chain launches.
+int potrf_leafk(Aux* aux, hipStream_t S, double* A, int n, int extra, long lda, double* invd, int zero_upper, int* info,
+                const ExtraOut* xo, const std::function<int(hipStream_t)>* x_prologue, int tri) {
+  const int nblk = n / NB;
+  const long strideInv = (long)nblk * NB * NB;
+  const bool ride = extra > 0 && extra <= 256;
+  const int R = ride ? n + extra : n;
+  const bool useX = extra > 0 && !ride;
+  double* E = A + (long)n * lda;
+  const bool oop = xo && xo->Eout && useX;
+  double* Eo = oop ? xo->Eout : E;
+  const long ldeo = oop ? xo->ldeout : lda;
+  const bool use_ginv = oop && xo->gws && GPK_TUNE(GROUP_INVERSE, 0);
+  hipStream_t P = aux->P, Mb = aux->Mb, Mr = aux->Mr, X = aux->Mx;
+  hipEvent_t* evS = aux->ev;
+  hipEvent_t* evR = aux->ev + nblk;
+  hipEvent_t* evG = aux->ev + 2 * nblk;
+  hipEvent_t evFork = aux->ev[3 * nblk], evJoinP = aux->ev[3 * nblk + 1], evJoinB = aux->ev[3 * nblk + 2],
+             evJoinX = aux->ev[3 * nblk + 3], evJoinR = aux->ev[3 * nblk + 4];
+  int rc;
+  if (x_prologue && !useX) {
+    rc = (*x_prologue)(S);
+    if (rc) return rc;
+  }
+  if (aux->ck_epoch > 0x7fff0000u) {  // (epochs are compared with >=: start over long before they wrap)
+    GPK_HIP(hipDeviceSynchronize());
+    GPK_HIP(hipMemset(aux->ck_flagL, 0, 64));
+    GPK_HIP(hipMemset(aux->ck_flagK, 0, 8));
+    GPK_HIP(hipMemset(aux->ck_flagB, 0, 8));
+    GPK_HIP(hipDeviceSynchronize());
+    aux->ck_epoch = 0;
+  }
+  const unsigned base = aux->ck_epoch;
+  aux->ck_epoch += (unsigned)nblk + 1u;
+  GPK_HIP(hipEventRecord(evFork, S));
+  GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
+  GPK_HIP(hipStreamWaitEvent(Mb, evFork, 0));
+  GPK_HIP(hipStreamWaitEvent(Mr, evFork, 0));
+  if (useX) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
+  Bulk bulk;  // (uncapped: the bulk streams cannot reach the chain's CUs)
+  bulk.cap = GPK_TUNE(LEAFK_EXTRA_MAX_WGS, 0);
+  int last_rest = -1, xg0 = 0;
+  const int xgroup = std::max(NB, (GPK_TUNE(XGROUP, NBO) / NB) * NB);
+  for (int p = 0; p < nblk; ++p) {
+    const int c0 = p * NB, c1 = c0 + NB;
+    const bool b1 = p + 1 < nblk, b2 = p + 2 < nblk;
+    LeafKArgs a{};
+    a.A = A; a.lda = lda; a.nblk = nblk; a.p = p; a.invd = invd; a.info = info;
+    a.flagL = aux->ck_flagL; a.cnt = aux->ck_cnt; a.flagK = aux->ck_flagK; a.flagB = aux->ck_flagB;
+    a.epoch = base + (unsigned)p + 1u;
+    a.need_b = p > 0 ? base + (unsigned)p : 0u;
+    a.nh = b1 ? (b2 ? 24 : 8) : 0;
+    a.nsolve = b1 ? (b2 ? 16 : 8) : 0;
+    rc = gpk_launch_leafk(P, a);
+    if (rc) return rc;
+    // ---- Mb: the other rows of panel p, then what panel p owes to the next chain launch's tiles -----------------
+    GPK_HIP(hipStreamWaitValue32(Mb, aux->ck_flagK, a.epoch, hipStreamWaitValueGte, 0xffffffffu));
+    const int rs = std::min((p + 3) * NB, n);  // first row of the bulk side (blocks p+1, p+2 belong to the chain launch)
+    const double* invp = invd + (long)p * NB * NB;
+    if (R > rs) {
+      double* panel = A + (long)rs * lda + c0;
+      GemmArgs g = gemm_base(R - rs, NB, NB, 1.0, panel, lda, invp, NB, 0.0, panel, lda, 1, 0, 0, 0);
+      g.b_tri = 2;
+      rc = gpk_launch_gemm(Mb, g);
+      if (rc) return rc;
+    }
+    GPK_HIP(hipEventRecord(evS[p], Mb));
+    const int cE = std::min((p + 4) * NB, n);
+    if (R > rs && cE > c1) {
+      if (last_rest >= 0) GPK_HIP(hipStreamWaitEvent(Mb, evR[last_rest], 0));  // (column block p+3 also got rest-update p-1)
+      GemmArgs u = gemm_base(R - rs, cE - c1, NB, -1.0, A + (long)rs * lda + c0, lda, A + (long)c1 * lda + c0, lda, 1.0,
+                             A + (long)rs * lda + c1, lda, 1, 0, 0, 0);
+      rc = gpk_launch_gemm(Mb, u);
+      if (rc) return rc;
+    }
+    GPK_HIP(hipStreamWriteValue32(Mb, aux->ck_flagB, a.epoch, 0));
+    // ---- Mr: rest of the trailing update, columns from block p+4 on ------------------------------------------------
+    const int c4 = (p + 4) * NB;
+    if (c4 < n) {
+      GPK_HIP(hipStreamWaitEvent(Mr, evS[p], 0));
+      const double* P4 = A + (long)c4 * lda + c0;
+      GemmArgs u = gemm_base(R - c4, n - c4, NB, -1.0, P4, lda, P4, lda, 1.0, A + (long)c4 * lda + c4, lda, 1, 0, 0, 0);
+      u.c_lower = 1;
+      rc = gpk_launch_gemm(Mr, u);
+      if (rc) return rc;
+      GPK_HIP(hipEventRecord(evR[p], Mr));
+      last_rest = p;
+    }
+    if (p == 0 && x_prologue && useX) {
+      rc = (*x_prologue)(X);
+      if (rc) return rc;
+    }
+    // ---- X: the extra rows against the finished columns (same grouping as the stream schedule) -----------------------
+    const bool tail_zone = n >= 8 * NB;
+    const bool tail_group = tail_zone && (c1 == n - 2 * NB || c1 == n - NB);
+    const bool full_group = (c1 - xg0) >= xgroup && !(tail_zone && c1 > n - 2 * NB && c1 < n);
+    if (useX && (c1 == n || full_group || tail_group)) {
+      const int g0 = xg0;
+      xg0 = c1;
+      const double* ginv = nullptr;
+      if (use_ginv && c1 - g0 == NBO && (g0 % NBO) == 0) {
+        double* wT = xo->gws + (size_t)(g0 / NBO) * 2 * NBO * NBO;
+        double* gi = wT + (size_t)NBO * NBO;
+        GPK_HIP(hipStreamWaitEvent(Mr, evS[p], 0));
+        rc = group_inverse(Mr, A, lda, invd, strideInv, g0, c1, wT, gi);
+        if (rc) return rc;
+        GPK_HIP(hipEventRecord(evG[p], Mr));
+        GPK_HIP(hipStreamWaitEvent(X, evG[p], 0));
+        ginv = gi;
+      }
+      GPK_HIP(hipStreamWaitEvent(X, evS[p], 0));
+      for (int h0 = g0; h0 < c1; h0 += NBO) {
+        const int h1 = std::min(h0 + NBO, c1);
+        const int xrows = tri ? extra - tri + h1 : extra;
+        rc = solve_group_fwd(X, bulk, E, lda, Eo, ldeo, xrows, A, lda, invd, strideInv, n, h0, h1, 1, 0, 0, 0, ginv);
+        if (rc) return rc;
+      }
+    }
+  }
+  GPK_HIP(hipEventRecord(evJoinP, P));
+  GPK_HIP(hipStreamWaitEvent(S, evJoinP, 0));
+  GPK_HIP(hipEventRecord(evJoinB, Mb));
+  GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
+  GPK_HIP(hipEventRecord(evJoinR, Mr));
+  GPK_HIP(hipStreamWaitEvent(S, evJoinR, 0));
+  if (useX) {
+    GPK_HIP(hipEventRecord(evJoinX, X));
+    GPK_HIP(hipStreamWaitEvent(S, evJoinX, 0));
+  }
+  if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, 1, 0);
+  return 0;
+}
+
 // x_prologue: work of the CALLER that belongs on the bulk stream before the first extra-row group (the SVGP driver's Kfu
 // build, transposes, KL).  It is enqueued after the first panel's chain kernels: every host call issued before the first
 // leaf delays the whole step, and nothing on the bulk stream is needed for ~4 panels.
@@ -498,6 +670,9 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   rc = aux_get(dev, 3 * npanels + 8, &aux);
   if (rc) return rc;
   const bool large = n >= 4096;
+  if (kGpkExp && GPK_TUNE(LEAFK, 0) && aux->Mb && !large && batch == 1 && (n % NB) == 0 && n >= 3 * NB && !proj) {
+    return potrf_leafk(aux, S, A, n, extra, lda, invd, zero_upper, info, xo, x_prologue, tri);
+  }
   hipStream_t P = aux->P, B = large ? aux->B : aux->Bs;
   // ONE bulk stream beside the chain: for large factorisations the extra rows share the (hardware-masked) stream of the
   // trailing updates; for small ones they have stream X, whose GEMMs are ticketed under the software reservation.
