@@ -832,6 +832,7 @@ int launch_small(hipStream_t s, const GemmArgs& a) {
   unsigned gy = (unsigned)gpk_cdiv(a.m, SM_BM);
   const unsigned gxs = (unsigned)gpk_cdiv(a.n, SM_BN);
   if (a.max_wgs > 0 && gy * gxs > (unsigned)a.max_wgs) gy = ((unsigned)a.max_wgs + gxs - 1) / gxs;  // row blocks walked in-kernel
+  else if (a.small_loop && a.max_wgs <= 0 && gy * gxs > 512u) gy = (512u + gxs - 1) / gxs;
   dim3 grid(gxs, gy, (unsigned)(a.batch > 0 ? a.batch : 1));
   g_last_kind = 1;
   hipLaunchKernelGGL(gemm_nt_small, grid, dim3(SM_THREADS), lds, s, a, ldk);
@@ -847,6 +848,7 @@ bool small_ok(const GemmArgs& a) {
   if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
   if (a.beta != 0.0 && a.alpha == 0.0) return false;
   const long max_wgs = GPK_TUNE(SMALL_MAX_WGS, 512);
+  if (a.small_loop && a.batch <= 1) return true;
   return (long)gpk_cdiv(a.m, SM_BM) * gpk_cdiv(a.n, SM_BN) * (a.batch > 0 ? a.batch : 1) <= max_wgs && a.batch < 65536;
 }
 

@@ -80,6 +80,8 @@ struct GemmArgs {
   int stagger_first;  // fast path only: number of CUs the launch stream may use (first workgroup of the 2nd resident set), 0 = 256
   int stagger_ticks;  // fast path only: start delay (100 MHz ticks) of the second resident workgroup set, 0 = none
   int no_small;     // never take the one-shot LDS-DMA latency kernel (150 KB of LDS per workgroup: needs a CU free of GEMM workgroups)
+  int small_loop;   // K <= 128 launches with MORE than 512 row slivers may still take the one-shot latency kernel: its workgroups
+                    // then walk the row blocks with their B tile staged once (the in-group updates of the extra rows)
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
   // Ticketed launch (fast path, batch 1): workgroups draw tiles from per-XCD counters instead of owning a fixed tile
   // list, and a workgroup that finds itself on a compute unit listed in `resv` takes none and exits -- the SOFTWARE

@@ -319,6 +319,14 @@ int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, double
         GemmArgs u = gemm_base(rows, c1 - j1, nb, -1.0, Eo + j0, ldeo, L + (long)j1 * ldl + j0, ldl, 1.0,
                                E + j1, lde, batch, strideEo, strideL, strideE);
         bulk.apply(u);
+        // K = 128 updates inside a group: the one-shot latency kernel with its workgroups walking the row blocks (B tile
+        // staged once) instead of the tiled kernel, which runs K = 128 at 16-24 TFLOP/s (33-45 us per launch at 8192 rows).
+        // Same-box A/B: SVGP step 2.251 -> 2.222 ms, GPR predict 56.5 -> 56.0 ms, cached posterior 20.9 -> 20.7 ms
+        // (512 workgroups; 256: 2.238, 768: 2.246).
+        if (GPK_TUNE(XSMALL, 1) && batch <= 1 && !u.ctr) {
+          u.small_loop = 1;
+          u.max_wgs = GPK_TUNE(XSMALL_WGS, 512);
+        }
         rc = gpk_launch_gemm(s, u);
         if (rc) return rc;
       }
