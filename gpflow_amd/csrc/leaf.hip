@@ -478,8 +478,24 @@ template <bool FACTORED>
 __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, long lda, long strideA, int nb,
                                                    double* __restrict__ invbase, long strideInv,
                                                    int* __restrict__ info, int col0,
-                                                   long long* __restrict__ dbg) {
+                                                   long long* __restrict__ dbg, int fake_ticks) {
   extern __shared__ __attribute__((aligned(16))) double S[];
+#ifdef GPK_EXPERIMENTAL
+  if (fake_ticks > 0) {
+    // TIMING EXPERIMENT ONLY (GPK_LEAF_FAKE_US): stands in for a leaf of the given duration -- writes L = I and its
+    // inverse and spins; results are meaningless, the launch structure of the factorisation is unchanged.
+    const long long t0 = wall_clock64();
+    double* A = Abase + (long)blockIdx.x * strideA;
+    double* inv = invbase + (long)blockIdx.x * strideInv;
+    for (int e = threadIdx.x; e < NB * NB; e += NT) {
+      const int i = e / NB, j = e % NB;
+      if (i < nb && j <= i && j < nb) A[(long)i * lda + j] = (i == j) ? 1.0 : 0.0;
+      inv[e] = (i == j) ? 1.0 : 0.0;
+    }
+    while (wall_clock64() - t0 < fake_ticks) {}
+    return;
+  }
+#endif
   leaf_body<FACTORED>(S, Abase + (long)blockIdx.x * strideA, lda, nb, invbase + (long)blockIdx.x * strideInv,
                       info ? info + blockIdx.x : nullptr, col0, dbg);
 }
@@ -650,12 +666,13 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
   GPK_HIP(attr1);
   GPK_HIP(attr0);
   dim3 grid((unsigned)(batch > 0 ? batch : 1));
+  const int fake = kGpkExp ? GPK_TUNE(LEAF_FAKE_US, 0) * 100 : 0;
   if (already_factored)
     hipLaunchKernelGGL((leaf_kernel<true>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd,
-                       strideInv, info, col0, nullptr);
+                       strideInv, info, col0, nullptr, 0);
   else
     hipLaunchKernelGGL((leaf_kernel<false>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd,
-                       strideInv, info, col0, nullptr);
+                       strideInv, info, col0, nullptr, fake);
   GPK_LAUNCH_CHECK();
   return 0;
 }
