@@ -34,6 +34,30 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert built_lib.gpk_svgp_elbo_workspace_bytes(2048, 8192, 8, 1, 0) > (2048 + 8192) * 2048 * 8
 
 
+def test_header_is_plain_c_and_a_c_client_links(built_lib, tmp_path):
+    """The drop-in boundary is a C ABI: include/gpk.h must compile as C99 (and C++), and a C client that references
+    every declared entry point must link against libgpk.so (no C++ types or mangled names leak through)."""
+    import shutil
+    import subprocess
+    from gpflow_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "gpk.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    names = sorted(_lib.EXPORTED_SYMBOLS)
+    src = tmp_path / "client.c"
+    src.write_text('#include "gpk.h"\n#include <stdio.h>\nint main(void) {\n  const void* f[] = {' +
+                   ", ".join(f"(const void*){n}" for n in names) +
+                   '};\n  printf("%s %d\\n", gpk_version(), (int)(sizeof f / sizeof f[0]));\n  return f[0] == 0;\n}\n')
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(_lib.lib_path())
+    subprocess.run(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
+                    "-l:" + os.path.basename(_lib.lib_path()), "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("gpk") and out.split()[-1] == str(len(names))
+
+
 def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
     from gpflow_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
