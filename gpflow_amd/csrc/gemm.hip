@@ -127,6 +127,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
       ke = l < p.k ? l : p.k;
     }
   }
+  if (p.a_tri == 1) {         // rows m0.. of an upper-triangular A are zero left of column m0
+    const int f = m0 & ~(BK - 1);
+    kb = kb > f ? kb : f;
+  } else if (p.a_tri == 2) {  // rows ..m0+BM-1 of a lower-triangular A are zero right of column m0+BM-1
+    int l = (m0 + BM + BK - 1) & ~(BK - 1);
+    l = l < p.k ? l : p.k;
+    ke = ke < l ? ke : l;
+  }
   const bool vec_ok = ((p.lda & 1) == 0) && ((p.ldb & 1) == 0) &&
                       ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
@@ -318,6 +326,14 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
       const int l = n0 + BN + p.b_tri_off;
       ke = l < p.k ? l : p.k;
     }
+  }
+  if (p.a_tri == 1) {         // (see gemm_nt_kernel)
+    const int f = m0 & ~(BK - 1);
+    kb = kb > f ? kb : f;
+  } else if (p.a_tri == 2) {
+    int l = (m0 + BM + BK - 1) & ~(BK - 1);
+    l = l < p.k ? l : p.k;
+    ke = ke < l ? ke : l;
   }
   const int nk = ke > kb ? (ke - kb) / BK : 0;
 
@@ -1239,7 +1255,9 @@ extern "C" int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, cons
   g.B = B; g.ldb = ldb; g.strideB = strideB;
   g.C = C; g.ldc = ldc; g.strideC = strideC;
   g.m = m; g.n = n; g.k = k; g.alpha = alpha; g.beta = beta;
-  g.c_lower = c_lower; g.b_tri = b_tri; g.b_tri_off = 0; g.b_tri_rows = n;
+  g.c_lower = c_lower; g.b_tri = b_tri & 3; g.b_tri_off = 0; g.b_tri_rows = n;
+  g.a_tri = (m <= k) ? ((b_tri >> 4) & 3) : 0;  // (a hint: ignoring it is always correct)
+  if ((b_tri & ~0x33) || g.b_tri == 3 || g.a_tri == 3) return GPK_E_ARG;
   g.epi = 0; g.batch = batch > 0 ? batch : 1;
   return gpk_launch_gemm((hipStream_t)stream, g);
 }

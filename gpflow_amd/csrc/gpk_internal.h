@@ -68,6 +68,7 @@ struct GemmArgs {
   double alpha, beta;
   int c_lower;      // skip tiles strictly above the diagonal (row r / col c of C: skip if c0 > r_last)
   int b_tri;        // 0 dense, 1 B[j,kk]==0 for kk<j, 2 B[j,kk]==0 for kk>j (+ b_tri_off on kk)
+  int a_tri;        // structure of A, a hint that only shortens the K range of a tile: 1 A[i,kk]==0 for kk<i (upper), 2 for kk>i (lower)
   int b_tri_off;    // the triangular structure is B[j,kk] vs kk - b_tri_off
   int b_tri_rows;   // structure applies to rows j < b_tri_rows of B only (rows beyond are dense)
   // epilogue 1 ("project"): columns < sq_cols are squared and row-summed into part[(tile_n*2+wn), row];

@@ -93,9 +93,10 @@ def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor) 
     LT = L^T, LinvT = L^-T (both upper, zero below the diagonal) and L_bar lower.  Three triangular-K GEMMs; the
     explicit inverse comes for free from the factorisation (identity rows appended to the trapezoid)."""
     # every B operand below is the transpose of a lower-triangular matrix: B[j, kk] = 0 for kk < j  -> b_tri = 1
-    T1 = ops.gemm_nt(LT, ops.transpose(Lbar), b_tri=1)          # L^T L_bar
-    Y = ops.gemm_nt(_phi_(T1), LinvT, b_tri=1)                  # Phi L^-1        (lower)
-    S = ops.gemm_nt(LinvT, ops.transpose(Y, mode=1), b_tri=1)   # L^-T (Phi L^-1)
+    # (a_tri: A is triangular as well -- upper L^T / L^-T, lower Phi -- so a tile's K range is the intersection of both)
+    T1 = ops.gemm_nt(LT, ops.transpose(Lbar), b_tri=1, a_tri=1)          # L^T L_bar
+    Y = ops.gemm_nt(_phi_(T1), LinvT, b_tri=1, a_tri=2)                  # Phi L^-1        (lower)
+    S = ops.gemm_nt(LinvT, ops.transpose(Y, mode=1), b_tri=1, a_tri=1)   # L^-T (Phi L^-1)
     return S.add_(ops.transpose(S)).mul_(0.5)
 
 
@@ -233,7 +234,7 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
     lml = -0.5 * a2 - 0.5 * N * P * LOG2PI - P * torch.log(torch.diagonal(L)).sum()
     # beta^T = alpha^T L^-1  [P, N];  K^-1 = L^-T (L^-T)^T, lower tiles only
     betat = ops.gemm_nt(alphat, LinvT, b_tri=1)
-    Kbar = ops.gemm_nt(LinvT, LinvT, b_tri=1, c_lower=True)
+    Kbar = ops.gemm_nt(LinvT, LinvT, b_tri=1, c_lower=True, a_tri=1)               # (both factors upper: N^3/3 multiply-adds)
     beta = betat.t().contiguous()                                                       # [N, P]
     ops.gemm_nt(beta, beta, alpha=0.5, beta=-0.5 * P, C=Kbar, c_lower=True)             # 0.5 beta beta^T - 0.5 P K^-1
     low = torch.tril(Kbar)
@@ -283,7 +284,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     F = (-0.5 * N * P * LOG2PI - P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * (N * variance - q) / s2)
          - 0.5 * (e2 / s2 - ops.sumsq(ct)[0]))
     # ---- backward
-    Binv = ops.gemm_nt(LBinvT, LBinvT, b_tri=1)                                         # B^-1 = LB^-T LB^-1
+    Binv = ops.gemm_nt(LBinvT, LBinvT, b_tri=1, a_tri=1)                                         # B^-1 = LB^-T LB^-1
     wt = ops.gemm_nt(ct.contiguous(), LBinvT, b_tri=1)                                  # w^T = c^T LB^-1  [P, M]
     w = wt.t().contiguous()                                                             # [M, P]
     Bbar = -0.5 * P * Binv
@@ -350,7 +351,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
                                     mean_const=mean_const)
     alphat = ops.gemm_nt(q_mu.t().contiguous(), Linv, b_tri=2)                          # (Linv q_mu)^T  [P, M]
-    V = ops.gemm_nt(Linv, LqT, b_tri=1)                                                 # [P, M, M]: V_p = Linv Lq_p
+    V = ops.gemm_nt(Linv, LqT, b_tri=1, a_tri=2)                                                 # [P, M, M]: V_p = Linv Lq_p
     if V.dim() == 2:
         V = V.unsqueeze(0)
     kl = 0.5 * (ops.sumsq(alphat)[0] - M * P - torch.log(Lq.diagonal(dim1=1, dim2=2) ** 2).sum()
@@ -373,7 +374,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     g_qmu = splitk_gemm_nt(A2, r.t().contiguous()) - k * Kinv_qmu_t.t()
     g_qs = torch.stack([splitk_gemm_nt(A2, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c) for p in range(P)])
     for p in range(P):
-        KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p], mode=1), b_tri=1)              # Linv^T V_p = Kuu^-1 Lq_p (V_p lower)
+        KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p], mode=1), b_tri=1, a_tri=1)              # Linv^T V_p = Kuu^-1 Lq_p (V_p lower)
         g_qs[p] -= k * torch.tril(KinvLq)
     g_qs.diagonal(dim1=1, dim2=2).add_(k / Lq.diagonal(dim1=1, dim2=2))
     # Linv_bar (lower) and its pull-back to Lm
@@ -381,7 +382,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     Linv_bar -= k * torch.tril(ops.gemm_nt(alphat.t().contiguous(), q_mu))              # alpha q_mu^T
     for p in range(P):
         Linv_bar -= k * torch.tril(ops.gemm_nt(V[p], Lq[p], b_tri=2))                   # V_p Lq_p^T
-    X1 = ops.gemm_nt(LinvT, ops.transpose(Linv_bar, mode=1), b_tri=1)                   # Linv^T Linv_bar (Linv_bar lower)
+    X1 = ops.gemm_nt(LinvT, ops.transpose(Linv_bar, mode=1), b_tri=1, a_tri=1)                   # Linv^T Linv_bar (Linv_bar lower)
     X2 = ops.gemm_nt(X1, Linv, b_tri=2)                                                 # (.) Linv^T
     Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0) - torch.tril(X2)
     Lbar.diagonal().sub_(k * P / L.diagonal())

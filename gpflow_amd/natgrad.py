@@ -47,18 +47,18 @@ def natgrad_update(q_mu: torch.Tensor, q_sqrt: torch.Tensor, g_mu: torch.Tensor,
         L = torch.tril(q_sqrt[p]).contiguous()
         mu_t = q_mu[:, p].reshape(1, M).contiguous()
         gmu_t = g_mu[:, p].reshape(1, M).contiguous()
-        S = ops.gemm_nt(L, L, b_tri=2)                                   # L L^T (L[j, kk] = 0 for kk > j)
+        S = ops.gemm_nt(L, L, b_tri=2, a_tri=2)                                   # L L^T (L[j, kk] = 0 for kk > j)
         # Lc = chol(S): equals L when L's diagonal is positive.  The reference pushes g_L through
         # expectation_to_meanvarsqrt (natgrad.py:484-487, :327-329), i.e. through THIS factor, whatever the signs of
         # q_sqrt's diagonal -- mirrored here (a q_sqrt with negative diagonal entries gets the same step as there).
         Lc, LcinvT, _ = _factor_with_inverse(S)
-        Sinv = ops.gemm_nt(LcinvT, LcinvT, b_tri=1)                       # S^-1 = Lc^-T Lc^-1
+        Sinv = ops.gemm_nt(LcinvT, LcinvT, b_tri=1, a_tri=1)                       # S^-1 = Lc^-T Lc^-1
         G = gradients.cholesky_adjoint(ops.transpose(Lc, mode=1), LcinvT, torch.tril(g_sqrt[p]).contiguous())
         Gmu_t = ops.gemm_nt(mu_t, G)                                      # (G mu)^T  (G symmetric)
         th1_t = ops.gemm_nt(mu_t, Sinv) - gamma * (gmu_t - 2.0 * Gmu_t)   # theta1'^T
         Pm = Sinv + (2.0 * gamma) * G                                     # -2 theta2'
         _, CinvT, w_t = _factor_with_inverse(Pm, th1_t)                   # C = chol(Pm); w^T = theta1'^T C^-T
-        Snew = ops.gemm_nt(CinvT, CinvT, b_tri=1)                         # S' = C^-T C^-1
+        Snew = ops.gemm_nt(CinvT, CinvT, b_tri=1, a_tri=1)                         # S' = C^-T C^-1
         new_mu[:, p] = ops.gemm_nt(w_t.contiguous(), CinvT, b_tri=1).reshape(-1)   # mu' = C^-T (C^-1 theta1')
         Tn = Snew.clone()
         _, info = ops.potrf_(Tn, M, zero_upper=True)                      # L' = chol(S')

@@ -126,8 +126,12 @@ int gpk_transpose_factor(void* stream, const double* L, long ldl, const double* 
 
 /* ---- GEMM  C = alpha * A * B^T + beta * C  (A [m,k], B [n,k], C [m,n]; fp64 MFMA) ----------------
  * tf.linalg.matmul call sites (conditionals/util.py:129,144,157,162; posteriors.py:734,803-818).
- * b_tri: 0 dense; 1 B is upper in [n,k] (B[j,kk] == 0 for kk < j, must be stored as zeros);
- *        2 B is lower (B[j,kk] == 0 for kk > j).  c_lower: only tiles touching the lower triangle. */
+ * b_tri, bits 0-1: 0 dense; 1 B is upper in [n,k] (B[j,kk] == 0 for kk < j, must be stored as zeros);
+ *        2 B is lower (B[j,kk] == 0 for kk > j).  Bits 4-5 (optional hint about A, m <= k): 16 = A is upper
+ *        (A[i,kk] == 0 for kk < i), 32 = A is lower (A[i,kk] == 0 for kk > i), stored as zeros as well; a tile's K range
+ *        is then the intersection of both structures -- the triangular x triangular products of the reverse pass
+ *        (K^-1 = L^-T L^-1, the Cholesky adjoint) at half the multiply-adds.  c_lower: only tiles touching the lower
+ *        triangle. */
 int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, const double* A, long lda,
                 const double* B, long ldb, double beta, double* C, long ldc, int b_tri,
                 int c_lower, int batch, long strideA, long strideB, long strideC);

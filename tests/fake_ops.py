@@ -168,7 +168,10 @@ def trsm_(B, L, invd, *, trans=0):
     return B
 
 
-def gemm_nt(A, B, *, alpha=1.0, beta=0.0, C=None, b_tri=0, c_lower=False):
+def gemm_nt(A, B, *, alpha=1.0, beta=0.0, C=None, b_tri=0, c_lower=False, a_tri=0):
+    if a_tri:   # the hint must be TRUE: the device kernel skips the K range it declares zero
+        A2 = _np(A if A.dim() == 2 else A[0])
+        assert np.all((np.tril(A2, -1) if a_tri == 1 else np.triu(A2, 1)) == 0), "a_tri set on a matrix without that structure"
     batched = A.dim() == 3 or B.dim() == 3
     A3 = A if A.dim() == 3 else A.unsqueeze(0)
     B3 = B if B.dim() == 3 else B.unsqueeze(0)

@@ -334,6 +334,24 @@ def test_combine_parts(gpu, np_, m, n, lower):
         assert np.array_equal(o.cpu().numpy(), r2)
 
 
+@pytest.mark.parametrize("n", [300, 1024, 2048 + 40])
+@pytest.mark.parametrize("a_tri,b_tri,c_lower", [(1, 1, True), (1, 1, False), (2, 1, False), (2, 2, False), (1, 2, False), (2, 0, False)])
+def test_gemm_nt_triangular_a_hint(gpu, n, a_tri, b_tri, c_lower):
+    """gpk_gemm_nt with the A-structure hint (b_tri bits 4-5): same result as the dense product of the same operands --
+    the hint only shortens K ranges -- on the tiled kernel (aligned sizes), the generic one (ragged) and with c_lower."""
+    from gpflow_amd import ops
+    rng = np.random.default_rng(12)
+    A = rng.normal(size=(n, n)); B = rng.normal(size=(n, n))
+    A = np.triu(A) if a_tri == 1 else np.tril(A)
+    if b_tri:
+        B = np.triu(B) if b_tri == 1 else np.tril(B)
+    out = ops.gemm_nt(_t(A), _t(B), alpha=0.75, b_tri=b_tri, c_lower=c_lower, a_tri=a_tri).cpu().numpy()
+    ref = 0.75 * (A @ B.T)
+    if c_lower:
+        out, ref = np.tril(out), np.tril(ref)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10 * max(1.0, np.abs(ref).max()))
+
+
 def test_two_host_threads_one_device(gpu):
     """include/gpk.h, "Internal state and threading": factorisations with n > 128 share per-device streams and events,
     calls from several host threads are serialised by a per-device mutex while they ENQUEUE (the work itself overlaps on
