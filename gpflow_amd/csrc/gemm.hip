@@ -24,7 +24,7 @@ constexpr int BK = 16;
 constexpr int LDSS = BK + 2;
 // kernel the launcher picked last (bench profiling facility only; see gpk_profile_gemm_collect_kind):
 // 1 gemm_nt_small, 2 + 2 EPI + PAIR gemm_nt_fast<EPI, PAIR>, 6 gemm_nt_kernel
-int g_last_kind = 0;
+thread_local int g_last_kind = 0;  // (per host thread: the GEMM entry points are reentrant)
 constexpr int GROUP_N = 8;
 
 template <int BM, int BN, int WGM, int WGN>
@@ -392,11 +392,6 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   if (load_c) {
     const double* __restrict__ C = p.C + (long)bz * p.strideC;
     const double sc = p.beta / p.alpha;
-#ifdef GPK_EXPERIMENTAL
-    const bool bypass = p.c_l1_bypass != 0;  // (workgroup-uniform)
-#else
-    constexpr bool bypass = false;
-#endif
     const char* cb = reinterpret_cast<const char*>(C + (long)m0 * p.ldc + n0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -406,9 +401,7 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const double* cp = reinterpret_cast<const double*>(rowp + c_coff[j]);
-          // (experimental dataflow kernel: device-scope atomic load = `global_load ... sc1`, never served by the CU's L1)
-          const double cv = bypass ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *cp;
-          acc[i][j][r] = sc * cv;
+          acc[i][j][r] = sc * *cp;
         }
       }
   } else {
@@ -495,11 +488,6 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   if constexpr (EPI == 0) {
     double* __restrict__ C = p.C + (long)bz * p.strideC;
     const double alpha = p.alpha;
-#ifdef GPK_EXPERIMENTAL
-    const bool through = p.c_l1_bypass != 0;  // (workgroup-uniform)
-#else
-    constexpr bool through = false;
-#endif
     char* cb = reinterpret_cast<char*>(C + (long)m0 * p.ldc + n0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -511,9 +499,7 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
           for (int j = 0; j < 4; ++j) {
             if (c_c0 + j * 16 <= c_cmax) {
               double* cp = reinterpret_cast<double*>(rowp + c_coff[j]);
-              // (experimental dataflow kernel: device-scope store = `global_store ... sc1`, written through)
-              if (through) __hip_atomic_store(cp, alpha * acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              else *cp = alpha * acc[i][j][r];
+              *cp = alpha * acc[i][j][r];
             }
           }
         }
@@ -547,75 +533,6 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   }
 }
 
-#ifdef GPK_EXPERIMENTAL
-// ---- ticketed tiles + software CU reservation ---------------------------------------------------------------------
-// A bulk GEMM that runs BESIDE the latency chain of a factorisation must not sit on every CU: the chain's kernels need
-// whole CUs (the leaf: 133 KB of LDS; the one-shot solve / strip kernels: 150 KB) and a resident 128x128x16 workgroup
-// holds 256 VGPRs per lane, so two of them leave a CU no room for anything.  CU-masked HIP queues solve that in
-// hardware but were measured to dispatch short kernels slowly; here it is done in software: the launch is a set of
-// persistent workgroups that DRAW tiles (atomic tickets) and a workgroup that finds itself on a reserved CU
-// (HW_REG_HW_ID / HW_REG_XCC_ID looked up in a table built from a census of the chip) draws none and exits, leaving
-// that CU to the chain for good.  Tickets are per XCD (own range first = the XCD-contiguous L2 order of tile_order,
-// then stealing), so load balance no longer depends on which workgroups survived.
-// Guarantee: if NO workgroup survives (every non-reserved CU was busy with other kernels while the grid was placed),
-// the last workgroup to leave processes the whole tile list itself -- slow, never wrong.  Counters reset themselves:
-// ctr[0..7] tickets per XCD, ctr[8] workgroups that left, ctr[9] workgroups that took part.
-__device__ __forceinline__ unsigned cu_key() {
-  const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);    // HW_REG_HW_ID[15:8]: SE_ID, SH_ID, CU_ID
-  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
-  return (xcc << 8) | hw;
-}
-
-template <int EPI>
-__device__ __forceinline__ void ticketed_tiles(const GemmArgs& p, int gx, int gy, int total, int compact, double* smem) {
-  __shared__ int s_lin, s_flag;
-  const int tid = threadIdx.x;
-  const unsigned key = cu_key();
-  const bool survivor = !(p.resv != nullptr && p.resv[key & (GPK_CU_KEYS - 1)] != 0);
-  const int x = (int)(key >> 8) & 7;
-  const int q = total >> 3, r = total & 7;
-  unsigned* ctr = p.ctr;
-  auto run = [&]() {
-    int k0 = 0;  // (thread 0) XCD offsets below k0 are known to be exhausted
-    for (;;) {
-      if (tid == 0) {
-        int lin = -1;
-        for (int k = k0; k < 8; ++k) {
-          const int xx = (x + k) & 7;
-          const int cnt = q + (xx < r ? 1 : 0);
-          const int local = (int)__hip_atomic_fetch_add(&ctr[xx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (local < cnt) { lin = local * 8 + xx; k0 = k; break; }
-          k0 = k + 1;
-        }
-        s_lin = lin;
-      }
-      __syncthreads();
-      const int lin = s_lin;
-      if (lin < 0) break;
-      int tile_m, tile_n;
-      tile_order(lin, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
-      fast_tile<EPI>(p, tile_m, tile_n, smem);
-      __syncthreads();  // both LDS buffers (and s_lin) are about to be rewritten
-    }
-  };
-  if (survivor) {
-    if (tid == 0) __hip_atomic_fetch_add(&ctr[9], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    run();
-  }
-  if (tid == 0) {
-    const unsigned left = __hip_atomic_fetch_add(&ctr[8], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    int flag = 0;
-    if (left == gridDim.x - 1)  // every other workgroup has left
-      flag = (__hip_atomic_load(&ctr[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 2;
-    s_flag = flag;
-  }
-  __syncthreads();
-  const int flag = s_flag;
-  if (flag == 2) run();  // nobody took part: this last workgroup does the whole launch, wherever it sits
-  if (flag != 0 && tid < 10) __hip_atomic_store(&ctr[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-#endif  // GPK_EXPERIMENTAL
 
 // pair = 0: one tile per workgroup, XCD-contiguous / column-grouped order.
 // pair = 1 (triangular-K operand, b_tri = 1): the K range of column tile j shrinks with j, so a workgroup
@@ -633,12 +550,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
       const long long t0 = wall_clock64();
       while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
     }
-#ifdef GPK_EXPERIMENTAL
-    if (p.ctr != nullptr) {
-      ticketed_tiles<EPI>(p, gx, gy, total, compact, smem);
-      return;
-    }
-#endif
     // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
       int tile_m, tile_n;
@@ -687,7 +598,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   // is lower-only or capped.
   {
     const bool pair_ok = (EPI == 1) ? (a.b_tri == 1)
-                                    : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0 && a.ctr == nullptr);
+                                    : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0);
     if (pair_ok && gx >= 4 && a.b_tri_rows >= a.n) {
       total = ((gx + 1) / 2) * gy;
       g_last_kind = 2 + 2 * EPI + 1;
@@ -701,21 +612,6 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   if (a.max_wgs > 0 && (unsigned)a.max_wgs < nwg) nwg = (unsigned)a.max_wgs;
   GemmArgs b = a;
   g_last_kind = 2 + 2 * EPI;
-#ifdef GPK_EXPERIMENTAL
-  if (a.ctr != nullptr && nb == 1) {
-    // ticketed: one resident set (2 workgroups per CU by LDS and VGPRs) unless capped; reserved-CU workgroups exit
-    // (a quarter more workgroups than tiles when there are few tiles: the ones that land on reserved CUs leave at once,
-    //  and the survivors should still be able to take one tile each)
-    const unsigned cap = a.max_wgs > 0 ? (unsigned)a.max_wgs : 512u;
-    const unsigned want = (unsigned)total + (unsigned)total / 4u + 16u;
-    nwg = want < cap ? want : cap;
-    b.stagger_ticks = 0;
-    hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, 1, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total, compact);
-    GPK_LAUNCH_CHECK();
-    return 0;
-  }
-#endif
-  b.ctr = nullptr;
   {
     // half a tile in 100 MHz ticks: a 128x128x16 slab costs ~1.7 us per workgroup when two share a CU
     // (A/B, 16384^2 x 512, beta = 1: 60.7 -> 63.0 TFLOP/s; lower-only 55.8 -> 58.8; percent of a half tile, 0 = off)
@@ -1031,7 +927,7 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
   const long tiles = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
   if (!a.no_small && small_ok(a)) return launch_small(s, a);  // K <= 128, <= 512 workgroups: the latency path
   if (a.epi == 1 && a.beta != 0.0 && a.C && !fast_ok(a)) return GPK_E_UNSUPPORTED;  // only the fast tile preloads C for epi 1
-  if (a.epi == 0 && a.k >= 1024 && a.m > 64 && a.n > 64 && !a.ctr) {
+  if (a.epi == 0 && a.k >= 1024 && a.m > 64 && a.n > 64) {
     // under-filled long-K launches (the M^3 triangular products of the reverse pass: 256 tiles of 128 x 128 = ONE
     // workgroup per CU, so the launch lasts as long as its longest tile, 283 us at M = 2048) go to 64 x 128 tiles:
     // twice the workgroups, half the longest tile.  Training step 7.15 -> 6.90 ms (same box, 300; 600: 7.00).
@@ -1049,201 +945,6 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
   return launch_cfg<128, 128, 2, 2>(s, a);
 }
 
-#ifdef GPK_EXPERIMENTAL
-// =====================================================================================================================
-// Tile-dataflow bulk kernel.  The bulk work of an SVGP step (flow_tasks.h) used to be ~30 dependent GEMM launches on one
-// stream: 64 to 768 tiles each on 448 workgroup slots, i.e. every launch boundary left most of the chip idle for the
-// last partial round, and a launch could only start when the chain had delivered what its FIRST tile needed.  Here it is
-// one launch of persistent workgroups (2 per CU, none on the reserved CUs) that draw tiles from the per-XCD ticket lists
-// and spin (s_sleep) on the two things a tile can be waiting for: the chain flag of its column group and the progress
-// counter of its 128-row block.  Dependencies of a ticket are earlier tickets of the same list or chain flags, the chain
-// runs on compute units this kernel never occupies, so it cannot deadlock; if no workgroup survives the reservation check
-// the last one to leave processes every list itself.
-namespace {
-__device__ __forceinline__ GemmArgs flow_gemm(const FlowArgs& f, const FlowTask& t) {
-  GemmArgs g{};
-  const int gi = t.group;
-  const int g0 = f.g0[gi], g1 = f.g1[gi], w = g1 - g0;
-  g.m = f.rows; g.alpha = 1.0; g.beta = 0.0; g.batch = 1;
-  g.c_l1_bypass = (f.coh == 5) ? 0 : 1;
-  switch (t.type) {
-    case FLOW_SOLVE:
-      g.A = f.E + g0; g.lda = f.lde;
-      g.B = f.ginv[gi] ? f.gws + (size_t)gi * 2 * 512 * 512 + (size_t)512 * 512
-                       : f.invd + (size_t)(g0 / GPK_NB) * GPK_NB * GPK_NB;
-      g.ldb = f.ginv[gi] ? w : GPK_NB;
-      g.C = f.Eo + g0; g.ldc = f.ldeo;
-      g.n = w; g.k = w; g.b_tri = 2; g.b_tri_rows = w;
-      break;
-    case FLOW_UPDATE:
-      g.A = f.Eo + g0; g.lda = f.ldeo;
-      g.B = f.L + (long)g1 * f.ldl + g0; g.ldb = f.ldl;
-      g.C = f.E + g1; g.ldc = f.lde;
-      g.n = f.n - g1; g.k = w; g.alpha = -1.0; g.beta = 1.0; g.b_tri_rows = g.n;
-      break;
-    case FLOW_PROJ_RECT:
-      g.A = f.Eo + g0; g.lda = f.ldeo;
-      g.B = f.LqT + (long)t.bz * f.strideQ + g0; g.ldb = f.ldq;
-      g.C = f.Cacc + (long)t.bz * f.strideC; g.ldc = f.ldc;
-      g.n = g0; g.k = w; g.beta = 1.0; g.b_tri_rows = g.n;
-      if (t.last) {
-        g.epi = 1; g.sq_cols = g0;
-        g.part = f.part + (long)t.bz * f.stridePart; g.part_ld = f.part_ld;
-        g.C2 = g.part;
-      }
-      break;
-    default:  // FLOW_PROJ_TRI
-      g.A = f.Eo + g0; g.lda = f.ldeo;
-      g.B = f.LqT + (long)t.bz * f.strideQ + (long)g0 * f.ldq + g0; g.ldb = f.ldq;
-      g.C = f.Cacc + (long)t.bz * f.strideC + g0; g.ldc = f.ldc;
-      g.n = w; g.k = w; g.b_tri = 1; g.b_tri_rows = w;
-      if (t.last) {
-        g.C = nullptr;
-        g.epi = 1; g.sq_cols = w;
-        g.part = f.part + (long)t.bz * f.stridePart + (long)(g0 / GPK_NB) * 2 * f.part_ld; g.part_ld = f.part_ld;
-        g.C2 = g.part;
-      }
-      break;
-  }
-  return g;
-}
-
-// Coherence.  MI355X has one L2 per XCD and they are NOT coherent with each other for ordinary device memory: a
-// device-scope release / acquire is `buffer_wbl2 sc1` / `buffer_inv sc1`, i.e. write back / invalidate the XCD's whole
-// L2 -- done per tile that throws away every shared operand (the first version ran at 21 TFLOP/s: 7 TB/s of operand
-// re-fetches).  The schedule is built so that this is never needed in the normal case:
-//   * a row block's tiles live in ONE list and a workgroup only draws from the list of the XCD it runs on (no stealing),
-//     so producer and consumer of E / S / C tiles share an L2; the producer waits for its stores (vmcnt(0): the vector L1
-//     is write-through).  The consumer's L1 needs no invalidation either: the only tiles that are rewritten after having
-//     been read are the read-modify-write accumulators (E[rb, c] of the updates, C[rb, i] of the projection), and those
-//     are only ever READ through the accumulator preload, which uses L1-bypassing device-scope (sc1) loads (GemmArgs.c_l1_bypass) -- so no
-//     CU ever holds a stale line of them; every other operand enters an L1 only after its final value was written;
-//   * everything that comes from the chain (factor columns, block / group inverses) was written by kernels that finished
-//     before the group's flag was raised and is first touched by this kernel after the flag has been seen (sc1 load).
-// Only the fallback -- the last workgroup mopping up lists whose XCD had no surviving workgroup -- crosses XCDs and uses
-// the device-scope fences.
-__global__ __launch_bounds__(256, 2) void flow_kernel(FlowArgs f) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ int s_task, s_flag;
-  const int tid = threadIdx.x;
-  const unsigned key = cu_key();
-  const bool survivor = !(f.resv != nullptr && f.resv[key & (GPK_CU_KEYS - 1)] != 0);
-  const int x = (int)(key >> 8) & 7;
-  unsigned* ctr = f.ctr;
-  auto run = [&](const bool all_lists) {
-    int k0 = 0;  // (thread 0) lists below this offset are exhausted
-    for (;;) {
-      if (tid == 0) {
-        int t = -1;
-        for (int k = k0; k < (all_lists ? 8 : 1); ++k) {
-          const int xx = (x + k) & 7;
-          const int cnt = f.off[xx + 1] - f.off[xx];
-          const int local = (int)__hip_atomic_fetch_add(&ctr[xx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (local < cnt) { t = f.off[xx] + local; k0 = k; break; }
-          k0 = k + 1;
-        }
-        if (t >= 0) {
-          // Waits are BOUNDED (2 s of the 100 MHz wall clock): if the chain never delivers -- a bug, not a data condition --
-          // the tile proceeds on whatever is there and the factorisation status is set to an impossible column, so the
-          // caller sees a failed factorisation instead of a hung GPU.
-          const FlowTask tk = f.tasks[t];
-          const long long t0 = wall_clock64();
-          bool late = false;
-          if (tk.flag >= 0)
-            while (__hip_atomic_load(&f.flags[tk.flag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.epoch) {
-              __builtin_amdgcn_s_sleep(32);
-              if (wall_clock64() - t0 > 200000000LL) { late = true; break; }
-            }
-          while ((int)__hip_atomic_load(&f.prog[tk.rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tk.need) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 200000000LL) { late = true; break; }
-          }
-          if (late && f.info) __hip_atomic_fetch_max(f.info, 0x40000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // protocol 5: ONE lane drops this CU's L1 (buffer_inv sc1 does exactly that on gfx950 and leaves the L2 alone),
-          // everything is then read with ordinary loads from the XCD's L2, which producer and consumer share
-          if (f.coh == 5 && !all_lists) asm volatile("buffer_inv sc1" ::: "memory");
-        }
-        s_task = t;
-      }
-      __syncthreads();
-      const int t = s_task;
-      if (t < 0) break;
-      const FlowTask tk = f.tasks[t];
-      if (all_lists || f.coh == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      else if (f.coh == 3 || (f.coh == 2 && tk.type == FLOW_SOLVE)) asm volatile("buffer_inv sc1" ::: "memory");
-      const GemmArgs g = flow_gemm(f, tk);
-      if (g.epi) fast_tile<1>(g, tk.rb, tk.tn, smem);
-      else fast_tile<0>(g, tk.rb, tk.tn, smem);
-      if (all_lists || f.coh == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's (device-scope) stores are complete
-      __syncthreads();  // (also: both LDS buffers and s_task are about to be rewritten)
-      if (tid == 0) __hip_atomic_fetch_add(&f.prog[tk.rb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  if (survivor) {
-    if (tid == 0) __hip_atomic_fetch_add(&ctr[9], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    run(false);
-  }
-  if (tid == 0) {
-    const unsigned left = __hip_atomic_fetch_add(&ctr[8], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_flag = (left == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  // the last workgroup to leave: every other one has finished its own XCD's list; lists of XCDs that had no surviving
-  // workgroup (or the whole launch, if nobody survived the reservation check) are still (partly) untouched
-  if (s_flag) run(true);
-}
-
-__global__ void set_flag_kernel(unsigned* flag, unsigned value) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-}  // namespace
-
-int gpk_launch_flow(hipStream_t s, const FlowArgs& f) {
-  constexpr size_t LDS_BYTES = 2 * (size_t)256 * LDSS * sizeof(double);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-  GPK_HIP(attr);
-  const int total = f.off[8];
-  if (total <= 0) return 0;
-  const unsigned nwg = total < 512 ? (unsigned)total : 512u;
-  hipLaunchKernelGGL(flow_kernel, dim3(nwg), dim3(256), LDS_BYTES, s, f);
-  GPK_LAUNCH_CHECK();
-  return 0;
-}
-
-int gpk_launch_set_flag(hipStream_t s, unsigned* flag, unsigned value) {
-  hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(64), 0, s, flag, value);
-  GPK_LAUNCH_CHECK();
-  return 0;
-}
-
-namespace {
-__global__ __launch_bounds__(256) void cu_census_kernel(unsigned* keys) {
-  extern __shared__ double pad[];  // 80 KB per workgroup: exactly two fit a CU, so 512 resident workgroups cover the chip
-  if (threadIdx.x == 0) {
-    keys[blockIdx.x] = cu_key();
-    pad[0] = 0.0;
-  }
-  const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(8);  // 20 us: keep the workgroup resident while the grid is placed
-}
-}  // namespace
-
-int gpk_cu_census(hipStream_t s, unsigned* keys_dev, int n) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(cu_census_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  GPK_HIP(attr);
-  hipLaunchKernelGGL(cu_census_kernel, dim3((unsigned)n), dim3(256), 80 * 1024, s, keys_dev);
-  GPK_LAUNCH_CHECK();
-  return 0;
-}
-
-#else   // product build: no experimental kernels
-int gpk_launch_flow(hipStream_t, const FlowArgs&) { return GPK_E_UNSUPPORTED; }
-int gpk_launch_set_flag(hipStream_t, unsigned*, unsigned) { return GPK_E_UNSUPPORTED; }
-int gpk_cu_census(hipStream_t, unsigned*, int) { return GPK_E_UNSUPPORTED; }
-#endif  // GPK_EXPERIMENTAL
 
 extern "C" int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, const double* A,
                            long lda, const double* B, long ldb, double beta, double* C, long ldc,

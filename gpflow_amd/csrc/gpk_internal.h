@@ -29,10 +29,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GPK_TRACE(...) do { } while (0)
 #endif
 
-// Experimental device code (ticketed GEMM tiles under a software CU reservation, the tile-dataflow bulk kernel, the CU
-// census) exists only in the A/B build: each of these was built, is parity-tested through the A/B library and measured
-// SLOWER than the default scheme on MI355X (DESIGN.md section 6 has the numbers and the reasons).  The product library
-// contains none of those kernels; the host code that would drive them is constant-folded away (kGpkExp).
+// kGpkExp: host branches that only exist in the A/B build are constant-folded away in the product library.
 #ifdef GPK_EXPERIMENTAL
 constexpr bool kGpkExp = true;
 #else
@@ -84,44 +81,9 @@ struct GemmArgs {
   int small_loop;   // K <= 128 launches with MORE than 512 row slivers may still take the one-shot latency kernel: its workgroups
                     // then walk the row blocks with their B tile staged once (the in-group updates of the extra rows)
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
-  // Ticketed launch (fast path, batch 1): workgroups draw tiles from per-XCD counters instead of owning a fixed tile
-  // list, and a workgroup that finds itself on a compute unit listed in `resv` takes none and exits -- the SOFTWARE
-  // CU reservation that keeps the latency chain of a factorisation (leaf / panel solve / strip) dispatchable while a
-  // bulk GEMM owns the rest of the chip.  ctr: 16 zeroed device words owned by the launch stream (self-resetting).
-  unsigned* ctr;
-  const unsigned char* resv;   // [GPK_CU_KEYS] 1 = reserved, or NULL
-  int c_l1_bypass;  // fast tile: preload C with L1-bypassing (device-scope, sc1) loads -- C may have been rewritten by another CU of this XCD
-                    // since this CU last saw it (dataflow kernel: read-modify-write tiles change hands between tasks)
 };
-#define GPK_CU_KEYS 4096   // key = XCC_ID << 8 | HW_ID[15:8] (SE_ID, SH_ID, CU_ID)
-// census of the physical compute units (gemm.hip): fills keys[0..n) with the key of the CU each of n workgroups ran on
-int gpk_cu_census(hipStream_t s, unsigned* keys_dev, int n);
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
 
-// ---- tile-dataflow bulk kernel (gemm.hip; task lists: flow_tasks.h) ---------------------------------------------------
-#include "flow_tasks.h"
-struct FlowArgs {
-  double* E; long lde;                 // minibatch rows, consumed: [rows, n]
-  double* Eo; long ldeo;               // solved rows A^T = E L^-T: [rows, n]
-  const double* L; long ldl;           // the factor being built (columns of group g are final once flag g is raised)
-  const double* invd;                  // leaf block inverses [n / 128][128][128]
-  const double* gws;                   // explicit group inverses: group i lives at gws + i * 2 * 512 * 512 + 512 * 512, leading dimension = its width
-  const double* LqT; long ldq; long strideQ;    // [P][n, ldq] tril(q_sqrt)^T, or NULL (no projection tasks in the list)
-  double* Cacc; long ldc; long strideC;          // [P][rows, ldc] running A^T Lq
-  double* part; long part_ld; long stridePart;  // [P][2 * n / 128, rows] partial row sums of squares
-  int rows, n, P, ng;
-  int g0[GPK_FLOW_MAX_GROUPS], g1[GPK_FLOW_MAX_GROUPS], ginv[GPK_FLOW_MAX_GROUPS];
-  const FlowTask* tasks; int off[9];   // per-XCD ticket lists: tasks[off[x] .. off[x + 1])
-  unsigned* ctr;                       // [16] tickets per XCD, workgroups that left / took part (zeroed before the launch)
-  unsigned* prog;                      // [rows / 128] finished tasks per row block (zeroed before the launch)
-  const unsigned* flags;               // [ng] chain flags: == epoch once the group's columns (and inverse) exist
-  unsigned epoch;
-  const unsigned char* resv;           // software CU reservation table or NULL
-  int* info;                           // factorisation status word: set to 0x40000000 if a bounded wait expires
-  int coh;                             // coherence protocol between tasks (see flow_kernel)
-};
-int gpk_launch_flow(hipStream_t s, const FlowArgs& f);
-int gpk_launch_set_flag(hipStream_t s, unsigned* flag, unsigned value);
 int gpk_gemm_tiles_n(int n);   // number of column tiles the launcher will use for n columns
 int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg)
 
@@ -129,28 +91,6 @@ int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline
 // A: pointer to the diagonal block (row-major, lda); nb <= NB valid rows/cols.
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
                     long strideInv, int* info, int col0, int batch, int already_factored);
-
-// ---- chain panel (leaf.hip, A/B build): ONE launch per 128-column panel of an SVGP-sized factorisation ------------
-// workgroup 0 = the leaf of panel p; 8 helpers per row block solve the rows of blocks p+1 and p+2 against the new
-// inverse and apply panel p to the three tiles the NEXT TWO leaves depend on -- (p+1,p+1), (p+2,p+1), (p+2,p+2) -- with
-// in-kernel flags instead of launch boundaries; everything else of panel p (the other rows' solve, strips, rest-update)
-// is bulk work on other streams, released by hipStreamWaitValue32 on flagK.
-struct LeafKArgs {
-  double* A; long lda;       // the whole trapezoid (row-major)
-  int nblk;                  // number of 128-column blocks of the square part (n = 128 nblk)
-  int p;                     // panel
-  double* invd;              // [nblk][128][128] block inverses (block p written here)
-  int* info;
-  unsigned* flagL;           // device word: leaf of this launch done (agent scope)
-  unsigned long long* cnt;   // [2] device counters: helpers past the solve / helpers finished (zeroed by workgroup 0)
-  unsigned* flagK;           // signal memory: the critical tiles of this launch are done (system scope)
-  const unsigned* flagB;     // signal memory (hipStreamWriteValue32): strips of the previous panel done
-  unsigned epoch;            // value raised on flagL / flagK
-  unsigned need_b;           // flagB must have reached this value (0: nothing to wait for)
-  int nh;                    // helpers: 8 (block p+1) + 8 (block p+2) + 8 (tile (p+2,p+2)), fewer at the end
-  int nsolve;                // of which solve a sliver (the first 8 or 16)
-};
-int gpk_launch_leafk(hipStream_t s, const LeafKArgs& a);
 
 // ---- rbf.hip ---------------------------------------------------------------------------------
 // (entry point gpk_kernel_matrix is defined there)

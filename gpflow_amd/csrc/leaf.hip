@@ -279,7 +279,7 @@ __device__ __forceinline__ d4 inv_level3_X(const double* __restrict__ S, int a, 
 
 // The leaf as a device function (one workgroup of NT threads, LDS block S of LEAF_LDS bytes): used by the
 // stand-alone kernel below.
-template <bool FACTORED, bool THROUGH = false>
+template <bool FACTORED>
 __device__ __forceinline__ void leaf_body(double* __restrict__ S, double* __restrict__ A, long lda, int nb,
                                           double* __restrict__ inv, int* __restrict__ info, int col0,
                                           long long* __restrict__ dbg) {
@@ -455,12 +455,7 @@ __device__ __forceinline__ void leaf_body(double* __restrict__ S, double* __rest
       d2 xv;
       xv.x = xval(jp);
       xv.y = xval(jp + 1);
-      if (THROUGH) {  // (chain-panel kernel: read by other workgroups of the SAME launch -> device-scope, written through)
-        __hip_atomic_store(&inv[i * NB + jp], xv.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&inv[i * NB + jp + 1], xv.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        *reinterpret_cast<d2*>(&inv[i * NB + jp]) = xv;
-      }
+      *reinterpret_cast<d2*>(&inv[i * NB + jp]) = xv;
     }
   }
   if (dbg && tid == 0) {
@@ -500,160 +495,7 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
                       info ? info + blockIdx.x : nullptr, col0, dbg);
 }
 
-
-#ifdef GPK_EXPERIMENTAL
-// =====================================================================================================================
-// Chain panel: leaf + the critical tiles of the look-ahead in one launch (gpk_internal.h: LeafKArgs).
-//   Measured with tools/leafk_probe (MI355X): a helper sees the leaf's flag 0.7 us after it is raised, all slivers are
-//   solved 5.5 us and the tile updates done 10.5 us after the leaf; 16 such launches back to back take 50 us each with a
-//   35-us leaf (the stream version: leaf 35 + solve 8 + two packets 12 + strip 8 = 63 when nothing stalls).
-// Coherence: whatever one workgroup of the launch writes for another -- the inverse block, the solved slivers
-// -- is stored device-scope (written through) and loaded with L1-bypassing loads after the flag / counter has been seen;
-// tiles that only the NEXT launch (or a bulk kernel released by flagK) reads again are stored through as well when a bulk
-// kernel may read them before this launch ends (the solved slivers), plainly otherwise.
-constexpr int KLD = NB + 2;
-constexpr long long CHAIN_SPIN_TICKS = 300000;  // 3 ms of the 100 MHz clock: every wait is bounded
-
-template <typename T>
-__device__ __forceinline__ bool chain_wait_ge(const T* f, T v, bool system_scope) {
-  const long long t0 = wall_clock64();
-  for (;;) {
-    const T cur = system_scope ? __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                               : __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur >= v) return true;
-    __builtin_amdgcn_s_sleep(1);
-    if (wall_clock64() - t0 > CHAIN_SPIN_TICKS) return false;
-  }
-}
-
-// nrows rows of 128 doubles (row stride ld) -> LDS rows of KLD doubles; one LDS-DMA instruction per row per wave
-template <bool BYPASS>
-__device__ __forceinline__ void chain_stage(const double* src, long ld, double* dst, int nrows) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int q = wave; q < nrows; q += NW) {
-    const double* s = src + (long)q * ld + 2 * lane;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                     (__attribute__((address_space(3))) void*)(dst + q * KLD), 16, 0, BYPASS ? 16 : 0);
-  }
-}
-
-// this wave's 16 x 16 piece of  As [16 x 128] * Bs[128 x 128]^T : lane (r = lane & 15, g = lane >> 4), entry e <->
-// row g + 4 e, column 16 wave + r
-__device__ __forceinline__ d4 chain_sliver(const double* As, const double* Bs) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const double* ap = As + r * KLD + g;
-  const double* bp = Bs + (wave * 16 + r) * KLD + g;
-  d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int kk = 0; kk < NB / 4; kk += 2) {
-    a0 = mfma4(ap[kk * 4], bp[kk * 4], a0);
-    a1 = mfma4(ap[kk * 4 + 4], bp[kk * 4 + 4], a1);
-  }
-  return a0 + a1;
-}
-
-__global__ __launch_bounds__(NT) void leafk_kernel(LeafKArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double S[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p = a.p;
-  const long c0 = (long)p * NB;
-  double* invp = a.invd + (long)p * NB * NB;
-  if (blockIdx.x == 0) {
-    // (the helpers touch the two counters only after they have seen flagL, which is released below)
-    if (tid == 0) {
-      __hip_atomic_store(&a.cnt[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&a.cnt[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    leaf_body<false, true>(S, a.A + c0 * a.lda + c0, a.lda, NB, invp, a.info, (int)c0, nullptr);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_store(a.flagL, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.nh == 0) __hip_atomic_store(a.flagK, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
-  __shared__ int ok;
-  const int h = (int)blockIdx.x - 1;
-  const int grp = h >> 3, sl = h & 7;          // grp 0: row block p+1, 1: row block p+2, 2: tile (p+2, p+2) only
-  const int rb = p + 1 + (grp == 0 ? 0 : 1);   // row block this helper works on
-  const long r0 = (long)rb * NB + sl * 16;     // its 16 rows
-  double* As = S;
-  double* Bs = S + 16 * KLD;
-  const int r = lane & 15, g = lane >> 4;
-  bool fine = true;
-  if (tid == 0) {
-    bool w = true;
-    if (a.need_b) w = chain_wait_ge(a.flagB, a.need_b, true);
-    w = chain_wait_ge(a.flagL, a.epoch, false) && w;
-    ok = w ? 1 : 0;
-  }
-  __syncthreads();
-  fine = fine && ok;
-  d4 own = {0.0, 0.0, 0.0, 0.0};
-  double* Srow = a.A + r0 * a.lda + c0;        // this helper's rows of column block p
-  if (grp < 2) {
-    // ---- solve: S = raw * inv^T, in place, written through ------------------------------------------------------
-    chain_stage<true>(invp, NB, Bs, NB);
-    chain_stage<false>(Srow, a.lda, As, 16);
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();
-    own = chain_sliver(As, Bs);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      __hip_atomic_store(Srow + (long)(g + 4 * e) * a.lda + wave * 16 + r, own[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();   // (every wave has read As / Bs and its stores have been issued and acknowledged)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) As[(g + 4 * e) * KLD + wave * 16 + r] = own[e];   // S_own stays in LDS as the next A operand
-  }
-  // ---- all slivers of this launch solved ---------------------------------------------------------------------------
-  if (tid == 0) {
-    if (grp < 2) __hip_atomic_fetch_add(&a.cnt[0], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    ok = chain_wait_ge(&a.cnt[0], (unsigned long long)a.nsolve, false) ? 1 : 0;
-  }
-  __syncthreads();
-  fine = fine && ok;
-  const long c1 = c0 + NB, c2 = c1 + NB;
-  if (grp == 2) chain_stage<true>(Srow, a.lda, As, 16);   // (no solve of its own: S rows of block p+2 from memory)
-  // first B operand: S1 (rows of block p+1) for groups 0 and 1, S2 (rows of block p+2) for group 2
-  chain_stage<true>(a.A + (grp == 2 ? c2 : c1) * a.lda + c0, a.lda, Bs, NB);
-  double* Cp = a.A + r0 * a.lda + (grp == 2 ? c2 : c1);  // (p+1,p+1) | (p+2,p+1) | (p+2,p+2), this helper's rows
-  double cv[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) cv[e] = Cp[(long)(g + 4 * e) * a.lda + wave * 16 + r];
-  __builtin_amdgcn_s_waitcnt(0x0070);
-  __syncthreads();
-  const d4 upd = chain_sliver(As, Bs);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) Cp[(long)(g + 4 * e) * a.lda + wave * 16 + r] = cv[e] - upd[e];
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (tid == 0) {
-    if (!fine && a.info) atomicOr(a.info, 0x40000000);
-    const unsigned long long mine = __hip_atomic_fetch_add(&a.cnt[1], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
-    if (mine == (unsigned long long)a.nh) __hip_atomic_store(a.flagK, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-#endif  // GPK_EXPERIMENTAL
-
 }  // namespace
-
-#ifdef GPK_EXPERIMENTAL
-int gpk_launch_leafk(hipStream_t s, const LeafKArgs& a) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(leafk_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
-  GPK_HIP(attr);
-  static_assert(LEAF_LDS >= (size_t)(16 + NB) * KLD * sizeof(double), "helper operands must fit the leaf's LDS block");
-  hipLaunchKernelGGL(leafk_kernel, dim3((unsigned)(1 + a.nh)), dim3(NT), LEAF_LDS, s, a);
-  GPK_LAUNCH_CHECK();
-  return 0;
-}
-#else
-int gpk_launch_leafk(hipStream_t, const LeafKArgs&) { return GPK_E_UNSUPPORTED; }
-#endif
 
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
                     long strideInv, int* info, int col0, int batch, int already_factored) {

@@ -18,7 +18,7 @@
  *
  * Internal state and threading (the complete list; nothing else in the library is mutable)
  *   - gpk_potrf with n > 128 (and the two fused drivers, which call it) uses per-device state created lazily on the
- *     first such call: six internal HIP streams (panel, high priority / extra rows / one placeholder that fixes the
+ *     first such call: six internal HIP streams (panel, high priority / side / one placeholder that fixes the
  *     stream-to-hardware-queue layout / bulk-small / bulk and bulk-late, both CU-masked) and a pool of timing-disabled
  *     events that grows to 3 * panels + 8.  No device memory is allocated and nothing synchronises: work is forked
  *     from and joined to the caller's stream with events only.  (The streams are created in an order that keeps the
@@ -39,6 +39,10 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+/* libgpk.so is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
 #endif
 
 #define GPK_NB 128 /* Cholesky inner block: diag-block inverses are GPK_NB x GPK_NB */
@@ -242,6 +246,9 @@ int gpk_profile_gemm_window(double min_flops, double* window_ms, double* flops_a
 int gpk_bench_mfma_f64(void* stream, int blocks, int iters, double* sink);
 int gpk_bench_stream_store(void* stream, double* out, long n_doubles);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

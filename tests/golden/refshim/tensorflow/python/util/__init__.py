@@ -1,0 +1,1 @@
+"""stand-in sub-package (see ../README.md)"""

@@ -240,20 +240,3 @@ def test_adam_state_matches_tf_keras_rule():
         lr_t = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
         np.testing.assert_allclose(p_new, p - lr_t * m / (np.sqrt(v) + 1e-7), rtol=1e-14)
         p = p_new
-
-
-def test_flow_schedule_simulation(tmp_path):
-    """The task lists of the tile-dataflow bulk kernel (gpflow_amd/csrc/flow_tasks.h, host-only header) under a CPU
-    simulation of the device scheduler (tests/flow_sim.cpp): random workgroup interleavings with stealing, 1 / 7 / 448
-    workers, chain flags raised at random moments -- no deadlock, every tile starts after its true producers, no two
-    tasks write one tile at the same time, every projection tile receives all its contributions."""
-    import shutil
-    import subprocess
-    gxx = shutil.which("g++")
-    if gxx is None:
-        pytest.skip("no g++")
-    exe = str(tmp_path / "flow_sim")
-    subprocess.run([gxx, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "gpflow_amd", "csrc"),
-                    os.path.join(ROOT, "tests", "flow_sim.cpp"), "-o", exe], check=True)
-    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
-    assert "flow schedule ok" in out, out

@@ -4,7 +4,7 @@
 # The first line is always the product library with no tunables.  Every run is under a 75 s timeout.
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 run() {
-  for rep in 1 2; do
+  for rep in $(seq 1 ${AB_REPS:-2}); do
     env $1 timeout 75 python $root/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-gpr --no-train --no-extras 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

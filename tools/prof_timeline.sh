@@ -6,5 +6,5 @@ cd /tmp && export TMPDIR=/tmp
 env "$@" timeout 200 rocprofv3 --kernel-trace -d $root/gpurun_out/${tag}_tl -o tl -- python $root/tools/prof_run.py svgp > $root/gpurun_out/${tag}_tl.log 2>&1
 cd $root
 db=$(find gpurun_out/${tag}_tl -name "*.db" | head -1)
-python tools/timeline.py $db rbf_kernel 4 140 > gpurun_out/${tag}_timeline.txt 2>&1
+python tools/timeline.py $db rbf_kernel 4 220 > gpurun_out/${tag}_timeline.txt 2>&1
 rm -rf gpurun_out/${tag}_tl
