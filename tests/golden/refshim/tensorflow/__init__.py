@@ -169,6 +169,19 @@ class Tensor(np.lib.mixins.NDArrayOperatorsMixin):
             return tuple(_wrap(x) for x in r)
         return _wrap(r)
 
+    # `x += y` on a tf.Tensor rebinds the name (tensors are immutable)
+    def __iadd__(self, o):
+        return self + o
+
+    def __isub__(self, o):
+        return self - o
+
+    def __imul__(self, o):
+        return self * o
+
+    def __itruediv__(self, o):
+        return self / o
+
     def __matmul__(self, other):
         return _wrap(np.matmul(self._value(), _np(other)))
 
