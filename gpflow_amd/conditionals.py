@@ -107,14 +107,36 @@ def conditional_tail(At: torch.Tensor, fac: Factor, Knn: torch.Tensor, f: torch.
     return fmean, (fvar0[None, :] + ssq).t().contiguous()
 
 
-def _restore(fmean, fvar, lead, full_cov):
-    """Undo the row flattening of leading batch dims (util.py:108-124)."""
+def tail_over_batches(At: torch.Tensor, lead: Tuple[int, ...], knn_of, tail, full_cov: bool):
+    """Leading batch dims of Xnew / Kmn (util.py:108-131) were flattened into the rows of At [prod(lead), M],
+    lead = batch... + (T,).  Marginal variances: one call on all rows, reshaped to [batch..., T, R].  full_cov: the
+    reference broadcasts A^T A over the batch dims and returns [batch..., R, T, T]; here the tail runs once per batch
+    element on its T rows (a contiguous row block of At).  knn_of(b) -> Knn of batch element b (None: all rows,
+    marginal); tail(At_rows, Knn) -> (fmean [rows, R], fvar)."""
     if len(lead) == 1:
-        return fmean, fvar
-    if full_cov:
-        raise NotImplementedError("full_cov with leading batch dimensions in Kmn")
-    R = fmean.shape[-1]
-    return fmean.reshape(*lead, R), fvar.reshape(*lead, R)
+        return tail(At, knn_of(None))
+    if not full_cov:
+        fmean, fvar = tail(At, knn_of(None))
+        return fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
+    T = lead[-1]
+    nb = At.shape[0] // T
+    mus, vs = [], []
+    for b in range(nb):
+        mu, var = tail(At[b * T:(b + 1) * T], knn_of(b))
+        mus.append(mu)
+        vs.append(var)
+    fmean = torch.stack(mus).reshape(*lead, -1)
+    fvar = torch.stack(vs)  # [nb, R, T, T]
+    return fmean, fvar.reshape(*lead[:-1], *fvar.shape[1:])
+
+
+def _knn_blocks(Knn: torch.Tensor, lead, full_cov: bool):
+    """Knn as handed to base_conditional: [batch..., N] or [batch..., N, N] -> accessor per batch element."""
+    if full_cov and len(lead) > 1:
+        blocks = Knn.reshape(-1, lead[-1], lead[-1])
+        return lambda b: blocks[b]
+    flat = Knn if full_cov else Knn.reshape(-1)
+    return lambda b: flat
 
 
 def base_conditional(Kmn, Kmm, Knn, f, *, full_cov: bool = False, q_sqrt=None, white: bool = False):
@@ -124,9 +146,9 @@ def base_conditional(Kmn, Kmm, Knn, f, *, full_cov: bool = False, q_sqrt=None, w
     q_sqrt = ops.to_device(q_sqrt) if q_sqrt is not None else None
     rows, lead = _as_rows(Kmn)
     fac, At = factor_with_rows(Kmm, rows)
-    fmean, fvar = conditional_tail(At, fac, Knn.reshape(-1) if not full_cov else Knn, f,
-                                   full_cov=full_cov, q_sqrt=q_sqrt, white=white)
-    return _restore(fmean, fvar, lead, full_cov)
+    return tail_over_batches(At, lead, _knn_blocks(Knn, lead, full_cov),
+                             lambda A, K: conditional_tail(A, fac, K, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white),
+                             full_cov)
 
 
 def base_conditional_with_lm(Kmn, Lm, Knn, f, *, full_cov: bool = False, q_sqrt=None,
@@ -138,9 +160,9 @@ def base_conditional_with_lm(Kmn, Lm, Knn, f, *, full_cov: bool = False, q_sqrt=
     rows, lead = _as_rows(Kmn)
     At = rows.contiguous().clone() if rows.data_ptr() == Kmn.data_ptr() else rows.contiguous()
     ops.trsm_(At, fac.L, fac.invd, trans=0)  # A = Lm^-1 Kmn (util.py:125)
-    fmean, fvar = conditional_tail(At, fac, Knn.reshape(-1) if not full_cov else Knn, f,
-                                   full_cov=full_cov, q_sqrt=q_sqrt, white=white)
-    return _restore(fmean, fvar, lead, full_cov)
+    return tail_over_batches(At, lead, _knn_blocks(Knn, lead, full_cov),
+                             lambda A, K: conditional_tail(A, fac, K, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white),
+                             full_cov)
 
 
 def expand_independent_outputs(fvar: torch.Tensor, full_cov: bool, full_output_cov: bool) -> torch.Tensor:

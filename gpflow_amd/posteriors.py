@@ -11,7 +11,7 @@ import torch
 from . import config, covariances, ops
 from .base import Module
 from .conditionals import (Factor, base_conditional, conditional_tail, expand_independent_outputs,
-                           factor_with_rows, separate_independent_conditional_implementation)
+                           factor_with_rows, separate_independent_conditional_implementation, tail_over_batches)
 from .inducing_variables import (InducingPoints, InducingVariables,
                                  SeparateIndependentInducingVariables,
                                  SharedIndependentInducingVariables)
@@ -52,6 +52,21 @@ def _flatten_rows(Xnew: torch.Tensor):
     broadcasting, conditionals/util.py:108-124; here they become rows)."""
     lead = tuple(Xnew.shape[:-1])
     return Xnew.reshape(-1, Xnew.shape[-1]).contiguous(), lead
+
+
+def _knn_of(kernel_call, Xf: torch.Tensor, lead, full_cov: bool):
+    """Knn accessor for tail_over_batches: marginal variances of all rows at once, or the [T, T] block of one batch
+    element of Xnew [batch..., T, D] (the reference's kernel broadcasts over the batch dims, util.py:108-131)."""
+    if full_cov and len(lead) > 1:
+        T = lead[-1]
+        return lambda b: kernel_call(Xf[b * T:(b + 1) * T], True)
+    cache = {}
+
+    def all_rows(b):
+        if "k" not in cache:
+            cache["k"] = kernel_call(Xf, full_cov)
+        return cache["k"]
+    return all_rows
 
 
 class AbstractPosterior(Module, ABC):
@@ -160,25 +175,20 @@ class GPRPosterior(AbstractPosterior):
         own = self._factor is not None and self._factor.L is Lm
         fac = self._factor if own else Factor(Lm, ops.trtri_blocks(Lm))
         Xf, lead = _flatten_rows(Xnew)
-        if full_cov and len(lead) > 1:
-            raise NotImplementedError("full_cov with leading batch dimensions")
         Xs, Xd = self.kernel.slice(Xf, self.X_data)
         At = self.kernel.K_into(Xs, Xd, None)  # Kmn^T [T, N]
         ops.trsm_(At, fac.L, fac.invd, trans=0)
-        Knn = self.kernel(Xf, full_cov=full_cov)
-        fmean, fvar = conditional_tail(At, fac, Knn, err, full_cov=full_cov, q_sqrt=None, white=False,
-                                       Linv_f=self._alpha if own else None)
-        if len(lead) > 1:
-            fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
-        return fmean, fvar
+        alpha = self._alpha if own else None
+        return tail_over_batches(
+            At, lead, _knn_of(lambda x, fc: self.kernel(x, full_cov=fc), Xf, lead, full_cov),
+            lambda A, K: conditional_tail(A, fac, K, err, full_cov=full_cov, q_sqrt=None, white=False, Linv_f=alpha),
+            full_cov)
 
     def _conditional_fused(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):
         """posteriors.py:435-443: Cholesky redone on every call, as in the reference -- here fused
         with the solve of Kmn (extra rows of one trapezoidal factorisation)."""
         assert_params_false(self._conditional_fused, full_output_cov=full_output_cov)
         Xf, lead = _flatten_rows(Xnew)
-        if full_cov and len(lead) > 1:
-            raise NotImplementedError("full_cov with leading batch dimensions")
         Xs, Xd = self.kernel.slice(Xf, self.X_data)
         n, t = Xd.shape[0], Xs.shape[0]
         err = self._err()
@@ -191,12 +201,11 @@ class GPRPosterior(AbstractPosterior):
         invd, info = ops.potrf_(T, n, zero_upper=True)
         ops.check_info(info)
         fac = Factor(T[:n], invd)
-        Knn = self.kernel(Xf, full_cov=full_cov)
-        fmean, fvar = conditional_tail(T[n:n + t], fac, Knn, err, full_cov=full_cov, q_sqrt=None,
-                                       white=False, Linv_f=ops.transpose(T[n + t:]))
-        if len(lead) > 1:
-            fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
-        return fmean, fvar
+        alpha = ops.transpose(T[n + t:])
+        return tail_over_batches(
+            T[n:n + t], lead, _knn_of(lambda x, fc: self.kernel(x, full_cov=fc), Xf, lead, full_cov),
+            lambda A, K: conditional_tail(A, fac, K, err, full_cov=full_cov, q_sqrt=None, white=False, Linv_f=alpha),
+            full_cov)
 
 
 class BasePosterior(AbstractPosterior):
@@ -231,13 +240,32 @@ class BasePosterior(AbstractPosterior):
         return self._dev(self._q_sqrt_src)
 
     def _precompute(self):
-        """alpha [M,L], Qinv [L,M,M] (posteriors.py:694-746) for [M,M] Kuu (single kernel)."""
+        """posteriors.py:694-746.  One kernel shared by the latents (Kuu [M,M]): alpha [M,L], Qinv [L,M,M].  Separate
+        kernels (Kuu [L,M,M]): the L factorisations are ONE batched launch sequence, then per latent
+        alpha_l = solve with q_mu[:, l] -> alpha [L,M,1], Qinv [L,M,M] (the reference's layout, :698-701)."""
         Kuu = covariances.Kuu(self.X_data, self.kernel, jitter=config.default_jitter())
-        if Kuu.dim() != 2:
-            raise NotImplementedError("cached posterior for separate kernels: use fused_predict_f")
         q_mu, q_sqrt = self.q_mu, self.q_sqrt
         M, Lnum = q_mu.shape
-        fac, _ = factor_with_rows(Kuu, None)
+        if Kuu.dim() == 2:
+            fac, _ = factor_with_rows(Kuu, None)
+            return self._alpha_qinv(fac, q_mu, q_sqrt)
+        T = Kuu.contiguous().clone()  # [L, M, M]: batched factorisation (conditionals/util.py:618 is a tf.map_fn loop)
+        invd, info = ops.potrf_(T, M, zero_upper=True)
+        ops.check_info(info)
+        invd = invd.reshape(Lnum, -1)
+        alphas, Qinvs = [], []
+        for l in range(Lnum):
+            qs = None
+            if q_sqrt is not None:
+                qs = q_sqrt[:, l:l + 1].contiguous() if q_sqrt.dim() == 2 else q_sqrt[l:l + 1]
+            a, Q = self._alpha_qinv(Factor(T[l], invd[l]), q_mu[:, l:l + 1].contiguous(), qs)
+            alphas.append(a)
+            Qinvs.append(Q[0])
+        return torch.stack(alphas), torch.stack(Qinvs)  # [L, M, 1], [L, M, M]
+
+    def _alpha_qinv(self, fac: Factor, q_mu: torch.Tensor, q_sqrt: Optional[torch.Tensor]):
+        """alpha [M,R] and Qinv [R,M,M] of R latents that share the factor `fac` of Kuu (posteriors.py:703-744)."""
+        M, Lnum = q_mu.shape
         LT, invdT = fac.transposed()
         alphaT = ops.transpose(q_mu)  # [L, M] rows
         if not self.whiten:
@@ -286,27 +314,40 @@ class IndependentPosterior(BasePosterior):
         return self.kernel(Xnew, full_cov=full_cov)
 
     def _conditional_with_precompute(self, cache, Xnew, full_cov: bool = False, full_output_cov: bool = False):
-        """posteriors.py:794-822 in the row-major form: mean = Kfu alpha, cov = Kff - rowdot(Kfu Qinv, Kfu)."""
+        """posteriors.py:794-822 in the row-major form: mean = Kfu alpha, cov = Kff - rowdot(Kfu Qinv, Kfu).  One kernel:
+        Kfu [N,M], alpha [M,L]; separate kernels: Kfu [L,N,M], alpha [L,M,1] (:813-815).  Xnew may carry leading batch
+        dims; with full_cov the [T,T] blocks are formed per batch element."""
         alpha, Qinv = cache
         Xf, lead = _flatten_rows(Xnew)
-        if full_cov and len(lead) > 1:
-            raise NotImplementedError("full_cov with leading batch dimensions")
         Kfu = covariances.Kfu(self.X_data, self.kernel, Xf)
-        if Kfu.dim() != 2:
-            raise NotImplementedError("cached posterior for separate kernels: use fused_predict_f")
-        Kff = self._get_Kff(Xf, full_cov)
-        _, mean, _ = ops.row_stats(Kfu, V=alpha.contiguous(), want_sumsq=False)
+        separate = Kfu.dim() == 3
         Lnum = Qinv.shape[0]
-        covs = []
-        for l in range(Lnum):
-            W = ops.gemm_nt(Kfu, Qinv[l])  # Kfu Qinv (Qinv symmetric)
-            if full_cov:
-                covs.append(Kff - ops.gemm_nt(W, Kfu))
-            else:
-                covs.append(Kff - ops.row_dot(W, Kfu))
-        cov = torch.stack(covs, dim=0) if full_cov else torch.stack(covs, dim=-1)
+        if separate:
+            mean = torch.stack([ops.row_stats(Kfu[l], V=alpha[l].contiguous(), want_sumsq=False)[1][:, 0] for l in range(Lnum)],
+                               dim=-1)
+        else:
+            _, mean, _ = ops.row_stats(Kfu, V=alpha.contiguous(), want_sumsq=False)
+        Ws = [ops.gemm_nt(Kfu[l] if separate else Kfu, Qinv[l]) for l in range(Lnum)]  # Kfu Qinv (Qinv symmetric)
+        if not full_cov:
+            Kff = self._get_Kff(Xf, False)  # [N] or [L, N]
+            cov = torch.stack([(Kff[l] if separate else Kff) - ops.row_dot(Ws[l], Kfu[l] if separate else Kfu)
+                               for l in range(Lnum)], dim=-1)
+            if len(lead) > 1:
+                mean, cov = mean.reshape(*lead, -1), cov.reshape(*lead, -1)
+            return self._post_process_mean_and_cov(mean, cov, full_cov, full_output_cov)
+        T = lead[-1]
+        nb = Xf.shape[0] // T
+        blocks = []
+        for b in range(nb):
+            r = slice(b * T, (b + 1) * T)
+            Kff = self._get_Kff(Xf[r], True)  # [T, T] or [L, T, T]
+            blocks.append(torch.stack([(Kff[l] if separate else Kff)
+                                       - ops.gemm_nt(Ws[l][r], (Kfu[l] if separate else Kfu)[r]) for l in range(Lnum)], dim=0))
+        cov = torch.stack(blocks)  # [nb, L, T, T]
         if len(lead) > 1:
-            mean, cov = mean.reshape(*lead, -1), cov.reshape(*lead, -1)
+            mean, cov = mean.reshape(*lead, -1), cov.reshape(*lead[:-1], Lnum, T, T)
+        else:
+            cov = cov[0]
         return self._post_process_mean_and_cov(mean, cov, full_cov, full_output_cov)
 
     # shared machinery of the fused paths ---------------------------------------------------------
@@ -314,8 +355,6 @@ class IndependentPosterior(BasePosterior):
         """Kuu (+jitter), Kuf and base_conditional for ONE kernel shared by all latents
         (posteriors.py:828-841 / 849-861), as one trapezoidal factorisation built in place."""
         Xf, lead = _flatten_rows(Xnew)
-        if full_cov and len(lead) > 1:
-            raise NotImplementedError("full_cov with leading batch dimensions")
         Xs, Zs = kernel.slice(Xf, Z)
         M, N = Zs.shape[0], Xs.shape[0]
         T = torch.empty((M + N, M), dtype=torch.float64, device=Zs.device)
@@ -323,12 +362,10 @@ class IndependentPosterior(BasePosterior):
         kernel.K_into(Xs, Zs, T[M:])
         invd, info = ops.potrf_(T, M, zero_upper=True)
         ops.check_info(info)
-        Knn = kernel(Xf, full_cov=full_cov)
-        fmean, fvar = conditional_tail(T[M:], Factor(T[:M], invd), Knn, self.q_mu, full_cov=full_cov,
-                                       q_sqrt=self.q_sqrt, white=self.whiten)
-        if len(lead) > 1:
-            fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
-        return fmean, fvar
+        fac, q_mu, q_sqrt = Factor(T[:M], invd), self.q_mu, self.q_sqrt
+        return tail_over_batches(
+            T[M:], lead, _knn_of(lambda x, fc: kernel(x, full_cov=fc), Xf, lead, full_cov),
+            lambda A, K: conditional_tail(A, fac, K, q_mu, full_cov=full_cov, q_sqrt=q_sqrt, white=self.whiten), full_cov)
 
 
 class IndependentPosteriorSingleOutput(IndependentPosterior):
@@ -349,17 +386,29 @@ class IndependentPosteriorMultiOutput(IndependentPosterior):
                                                     full_cov)
         else:
             Xf, lead = _flatten_rows(Xnew)
-            if len(lead) > 1:
-                raise NotImplementedError("leading batch dimensions with separate kernels")
             Kmms = covariances.Kuu(self.X_data, self.kernel, jitter=config.default_jitter())  # [P,M,M]
-            Kmns = covariances.Kuf(self.X_data, self.kernel, Xf)  # [P,M,N]
             if isinstance(self.kernel, SeparateIndependent):
                 kernel_list = self.kernel.kernels
             else:
                 kernel_list = [self.kernel.kernel] * len(self.X_data.inducing_variable_list)
-            Knns = torch.stack([k.K(Xf) if full_cov else k.K_diag(Xf) for k in kernel_list], dim=0)
-            fmean, fvar = separate_independent_conditional_implementation(
-                Kmns, Kmms, Knns, self.q_mu, q_sqrt=self.q_sqrt, full_cov=full_cov, white=self.whiten)
+
+            def one(Xr):
+                Kmns = covariances.Kuf(self.X_data, self.kernel, Xr)  # [P,M,N]
+                Knns = torch.stack([k.K(Xr) if full_cov else k.K_diag(Xr) for k in kernel_list], dim=0)
+                return separate_independent_conditional_implementation(
+                    Kmns, Kmms, Knns, self.q_mu, q_sqrt=self.q_sqrt, full_cov=full_cov, white=self.whiten)
+
+            if len(lead) == 1:
+                fmean, fvar = one(Xf)
+            elif not full_cov:
+                fmean, fvar = one(Xf)
+                fmean, fvar = fmean.reshape(*lead, -1), fvar.reshape(*lead, -1)
+            else:  # [batch..., P, T, T]: one block per batch element
+                T = lead[-1]
+                res = [one(Xf[b * T:(b + 1) * T].contiguous()) for b in range(Xf.shape[0] // T)]
+                fmean = torch.stack([r[0] for r in res]).reshape(*lead, -1)
+                fvar = torch.stack([r[1] for r in res])
+                fvar = fvar.reshape(*lead[:-1], *fvar.shape[1:])
         return self._post_process_mean_and_cov(fmean, fvar, full_cov, full_output_cov)
 
 

@@ -1,0 +1,169 @@
+"""GPU parity of the gpflow_amd surface against values computed by the REFERENCE'S OWN SOURCE
+(tests/golden/ref_golden.npz, written by tests/golden/make_golden_ref.py: the unmodified GPflow package run over NumPy
+stand-ins for TensorFlow).  Every call goes Python host -> ctypes -> libgpk.so.  The same bodies run in the CPU tier
+against the emulated primitives (tests/test_host_emulated.py), which checks the host layer's routing and shapes.
+
+Tolerances: 1e-9 absolute on O(1) quantities (two correct fp64 algorithms: the reference solves triangular systems by
+substitution, the device multiplies by explicit inverses of 128-blocks), 1e-9 relative on ELBO / LML scalars; the cached
+posteriors go through Kuu^-1-like products and get 1e-7.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_golden.npz"))
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+def close(a, b, atol=1e-9):
+    a, b = _np(a), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.max(np.abs(b)))) if b.size else 1.0
+    assert float(np.max(np.abs(a - b))) <= atol * scale, float(np.max(np.abs(a - b))) / scale
+
+
+@pytest.fixture(scope="module")
+def gp(gpu):
+    import gpflow_amd
+    return gpflow_amd
+
+
+def test_ref_kernels(gp):
+    X, X2, ls, var = G["k_X"], G["k_X2"], G["k_ls"], float(G["k_var"])
+    for name in ("SquaredExponential", "Matern12", "Matern32", "Matern52"):
+        k = getattr(gp.kernels, name)(variance=var, lengthscales=ls)
+        close(k(X), G[f"k_{name}_sym"], 1e-12); close(k(X, X2), G[f"k_{name}_cross"], 1e-12)
+        close(k(X, full_cov=False), G[f"k_{name}_diag"], 1e-14)
+    k_ad = gp.kernels.SquaredExponential(variance=0.8, lengthscales=[0.5, 1.5], active_dims=[1, 3])
+    k_sl = gp.kernels.SquaredExponential(variance=0.8, lengthscales=0.6, active_dims=slice(0, 2))
+    close(k_ad(X), G["k_active_dims_sym"], 1e-12)
+    close((k_ad + k_sl)(X, X2), G["k_sum_cross"], 1e-12)
+    close((k_ad * gp.kernels.Matern32(variance=1.1, lengthscales=0.9))(X), G["k_prod_sym"], 1e-12)
+    close((k_ad + k_sl)(X, full_cov=False), G["k_sum_diag"], 1e-14)
+
+
+def test_ref_gpr(gp):
+    m = gp.models.GPR((G["gpr_X"], G["gpr_Y"]), gp.kernels.SquaredExponential(variance=1.0, lengthscales=2.0), noise_variance=1.0)
+    Xn = G["gpr_Xnew"]
+    np.testing.assert_allclose(float(m.log_marginal_likelihood()), float(G["gpr_lml"]), rtol=1e-10)
+    mu, var = m.predict_f(Xn)
+    close(mu, G["gpr_mu"]); close(var, G["gpr_var"])
+    close(m.predict_f(Xn, full_cov=True)[1], G["gpr_var_fullcov"])
+    ymu, yvar = m.predict_y(Xn)
+    close(ymu, G["gpr_ymu"]); close(yvar, G["gpr_yvar"])
+    close(m.predict_log_density((Xn, np.cos(Xn))), G["gpr_logdens"])
+    pmu, pvar = m.posterior().predict_f(Xn)
+    close(pmu, G["gpr_cached_mu"]); close(pvar, G["gpr_cached_var"])
+    # two output columns, constant mean, ARD, Xnew with leading batch dims -- incl. full_cov over the batch dims
+    m2 = gp.models.GPR((G["gpr2_X"], G["gpr2_Y"]), gp.kernels.SquaredExponential(variance=1.3, lengthscales=G["gpr2_ls"]),
+                       mean_function=gp.mean_functions.Constant(np.array([0.3])), noise_variance=0.07)
+    np.testing.assert_allclose(float(m2.log_marginal_likelihood()), float(G["gpr2_lml"]), rtol=1e-10)
+    Xb = G["gpr2_Xnew"]
+    mu, var = m2.predict_f(Xb)
+    close(mu, G["gpr2_mu"]); close(var, G["gpr2_var"])
+    mu_fc, var_fc = m2.predict_f(Xb, full_cov=True)
+    close(mu_fc, G["gpr2_mu"]); close(var_fc, G["gpr2_var_fullcov"])
+    pmu, pvar = m2.posterior().predict_f(Xb, full_cov=True)
+    close(pmu, G["gpr2_mu"]); close(pvar, G["gpr2_var_fullcov"])
+    # BASELINE config C1
+    m1 = gp.models.GPR((G["c1_X"], G["c1_Y"]), gp.kernels.SquaredExponential(), noise_variance=0.1)
+    np.testing.assert_allclose(float(m1.log_marginal_likelihood()), float(G["c1_lml"]), rtol=1e-10)
+    mu, var = m1.predict_f(G["c1_Xnew"])
+    close(mu, G["c1_mu"]); close(var, G["c1_var"])
+
+
+def test_ref_gauss_kl(gp):
+    kl = gp.kullback_leiblers.gauss_kl
+    mu, sq, K, Kb = G["kl_mu"], G["kl_sqrt"], G["kl_K"], G["kl_Kb"]
+    for val, key in ((kl(mu, sq), "kl_white"), (kl(mu, sq, K), "kl_K_val"), (kl(mu, sq, Kb), "kl_Kb_val"),
+                     (kl(mu, G["kl_sqrt_diag"]), "kl_diag_white"), (kl(mu, G["kl_sqrt_diag"], K), "kl_diag_K"),
+                     (kl(mu, G["kl_sqrt_upper"], K), "kl_upper_ignored"),
+                     (kl(mu, sq, K_cholesky=np.linalg.cholesky(K)), "kl_Kchol")):
+        np.testing.assert_allclose(float(val), float(G[key]), rtol=1e-8)  # (K has a 1e-6 jitter: kappa ~ 1e7)
+
+
+def test_ref_conditionals(gp):
+    Z, Xn, f, qs, qd = G["cond_Z"], G["cond_X"], G["cond_f"], G["cond_qs"], G["cond_qd"]
+    kern = gp.kernels.SquaredExponential(variance=1.4, lengthscales=[0.8, 1.2])
+    iv = gp.inducing_variables.InducingPoints(Z)
+    for white in (False, True):
+        for fc in (False, True):
+            for tag, q in (("full", qs), ("diag", qd), ("none", None)):
+                mu, var = gp.conditionals.conditional(Xn, iv, kern, f, full_cov=fc, q_sqrt=q, white=white)
+                close(mu, G[f"cond_w{int(white)}_fc{int(fc)}_{tag}_mu"], 1e-8); close(var, G[f"cond_w{int(white)}_fc{int(fc)}_{tag}_var"], 1e-8)
+    Xb = G["cond_Xb"]  # [2, 3, N, D]: leading batch dims, with and without full_cov (util.py:108-131)
+    for white, key in ((True, "cond_batch"), (False, "cond_batch_unw")):
+        for fc in (False, True):
+            mu, var = gp.conditionals.conditional(Xb, iv, kern, f, full_cov=fc, q_sqrt=qs, white=white)
+            close(mu, G[f"{key}_fc{int(fc)}_mu"], 1e-8); close(var, G[f"{key}_fc{int(fc)}_var"], 1e-8)
+    mu, var = gp.conditionals.base_conditional(G["bc_Kmn"], G["bc_Kmm"], G["bc_Knn"], f, q_sqrt=qs, white=False)
+    close(mu, G["bc_mu"], 1e-8); close(var, G["bc_var"], 1e-8)
+
+
+def test_ref_svgp(gp):
+    X, Y, Z, q_mu, q_sqrt, Xs = (G[k] for k in ("svgp_X", "svgp_Y", "svgp_Z", "svgp_q_mu", "svgp_q_sqrt", "svgp_Xnew"))
+    for w in (0, 1):
+        s = gp.models.SVGP(gp.kernels.SquaredExponential(variance=1.0, lengthscales=1.0), gp.likelihoods.Gaussian(variance=1.0),
+                           Z.copy(), q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(), whiten=bool(w), num_latent_gps=2)
+        np.testing.assert_allclose(float(s.elbo((X, Y))), float(G[f"svgp_elbo_w{w}"]), rtol=1e-9)
+        np.testing.assert_allclose(float(s.prior_kl()), float(G[f"svgp_kl_w{w}"]), rtol=1e-9)
+        mu, var = s.predict_f(Xs)
+        close(mu, G[f"svgp_mu_w{w}"]); close(var, G[f"svgp_var_w{w}"])
+        close(s.predict_f(Xs, full_cov=True)[1], G[f"svgp_var_fullcov_w{w}"])
+        pmu, pvar = s.posterior().predict_f(Xs)
+        close(pmu, G[f"svgp_cached_mu_w{w}"], 1e-7); close(pvar, G[f"svgp_cached_var_w{w}"], 1e-7)
+        sd = gp.models.SVGP(gp.kernels.SquaredExponential(variance=1.0, lengthscales=1.0), gp.likelihoods.Gaussian(variance=1.0),
+                            Z.copy(), q_mu=q_mu.copy(), q_sqrt=G["svgp_q_sqrt_diag"].copy(), q_diag=True, whiten=bool(w),
+                            num_latent_gps=2, num_data=100)
+        np.testing.assert_allclose(float(sd.elbo((X, Y))), float(G[f"svgp_elbo_diag_w{w}"]), rtol=1e-9)
+        sm = gp.models.SVGP(gp.kernels.SquaredExponential(variance=1.0, lengthscales=G["mid_ls"]), gp.likelihoods.Gaussian(variance=0.1),
+                            G["mid_Z"].copy(), q_mu=G["mid_q_mu"].copy(), q_sqrt=G["mid_q_sqrt"].copy(), whiten=bool(w),
+                            num_data=100000, mean_function=gp.mean_functions.Constant(np.array([0.2])))
+        np.testing.assert_allclose(float(sm.elbo((G["mid_X"], G["mid_Y"]))), float(G[f"mid_elbo_w{w}"]), rtol=1e-9)
+
+
+def test_ref_multi_output(gp):
+    X, Y, Z, Xs, q_mu, q_sqrt = (G[k] for k in ("mo_X", "mo_Y", "mo_Z", "mo_Xnew", "mo_q_mu", "mo_q_sqrt"))
+    L = q_mu.shape[1]
+    mo = gp.kernels.SharedIndependent(gp.kernels.SquaredExponential(variance=1.2, lengthscales=[0.9, 1.1]), output_dim=L)
+    ivs = gp.inducing_variables.SharedIndependentInducingVariables(gp.inducing_variables.InducingPoints(Z.copy()))
+    for w in (0, 1):
+        s = gp.models.SVGP(mo, gp.likelihoods.Gaussian(variance=0.2), ivs, q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(), whiten=bool(w),
+                           num_latent_gps=L)
+        np.testing.assert_allclose(float(s.elbo((X, Y))), float(G[f"mo_shared_elbo_w{w}"]), rtol=1e-9)
+        mu, var = s.predict_f(Xs)
+        close(mu, G[f"mo_shared_mu_w{w}"]); close(var, G[f"mo_shared_var_w{w}"])
+        pmu, pvar = s.posterior().predict_f(Xs)
+        close(pmu, G[f"mo_shared_cached_mu_w{w}"], 1e-7); close(pvar, G[f"mo_shared_cached_var_w{w}"], 1e-7)
+    lss, vars_, Zs = G["mo_sep_ls"], G["mo_sep_var"], G["mo_sep_Z"]
+    ksep = gp.kernels.SeparateIndependent([gp.kernels.SquaredExponential(variance=float(vars_[i]), lengthscales=lss[i]) for i in range(L)])
+    ivsep = gp.inducing_variables.SeparateIndependentInducingVariables([gp.inducing_variables.InducingPoints(z.copy()) for z in Zs])
+    for w in (0, 1):
+        s = gp.models.SVGP(ksep, gp.likelihoods.Gaussian(variance=0.2), ivsep, q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(), whiten=bool(w),
+                           num_latent_gps=L)
+        np.testing.assert_allclose(float(s.elbo((X, Y))), float(G[f"mo_sep_elbo_w{w}"]), rtol=1e-9)
+        post = s.posterior()  # separate-kernel cache: alpha [L,M,1], Qinv [L,M,M] (posteriors.py:694-746)
+        for fc in (0, 1):
+            mu, var = s.predict_f(Xs, full_cov=bool(fc))
+            close(mu, G[f"mo_sep_mu_w{w}_fc{fc}"]); close(var, G[f"mo_sep_var_w{w}_fc{fc}"])
+            pmu, pvar = post.predict_f(Xs, full_cov=bool(fc))
+            close(pmu, G[f"mo_sep_cached_mu_w{w}_fc{fc}"], 1e-7); close(pvar, G[f"mo_sep_cached_var_w{w}_fc{fc}"], 1e-7)
+        close(s.predict_f(Xs, full_output_cov=True)[1], G[f"mo_sep_var_w{w}_foc"])
+        close(post.predict_f(Xs, full_output_cov=True)[1], G[f"mo_sep_var_w{w}_foc"], 1e-7)
+
+
+def test_ref_sgpr(gp):
+    sg = gp.models.SGPR((G["sgpr_X"], G["sgpr_Y"]), gp.kernels.SquaredExponential(variance=1.1, lengthscales=[0.8, 1.2]),
+                        G["sgpr_Z"].copy(), noise_variance=0.05)
+    np.testing.assert_allclose(float(sg.elbo()), float(G["sgpr_elbo"]), rtol=1e-9)
+    np.testing.assert_allclose(float(sg.upper_bound()), float(G["sgpr_upper"]), rtol=1e-9)
+    mu, var = sg.predict_f(G["sgpr_Xnew"])
+    close(mu, G["sgpr_mu"], 1e-8); close(var, G["sgpr_var"], 1e-8)
+    qmu, qcov = sg.compute_qu()
+    close(qmu, G["sgpr_qu_mu"], 1e-7); close(qcov, G["sgpr_qu_cov"], 1e-7)

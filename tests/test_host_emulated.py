@@ -36,9 +36,10 @@ _names = [n for n in dir(T) if n.startswith("test_")]
 for _n in _names:
     globals()[_n] = getattr(T, _n)
 import test_gpu_gradients as TG  # noqa: E402
+import test_gpu_reference_golden as TR  # noqa: E402  (values computed by the reference's own source)
 import test_gpu_sgpr as TS  # noqa: E402
 
-for _mod, _pre in ((TG, "grad"), (TS, "sgpr")):
+for _mod, _pre in ((TG, "grad"), (TS, "sgpr"), (TR, "refgolden")):
     for _n in [n for n in dir(_mod) if n.startswith("test_")]:
         globals()[f"test_{_pre}_{_n[5:]}"] = getattr(_mod, _n)
 del _n, _mod, _pre
