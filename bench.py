@@ -56,6 +56,16 @@ WORKLOADS = {
 P_LAT = 1
 
 
+def host_threads() -> int:
+    """Threads the CPU baseline actually runs on: the BLAS pool behind NumPy / SciPy (one definition for every
+    `cpu_baseline.cores`)."""
+    try:
+        import threadpoolctl
+        return int(max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [os.cpu_count() or 1]))
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
 def svgp_step_flops(m: int, b: int, p: int) -> float:
     """Algorithmic flops of one whitened step: M^3/3 + M^2 B (1 + P)."""
     return m ** 3 / 3.0 + float(m) * m * b * (1 + p)
@@ -65,14 +75,16 @@ def make_inputs(n_data, m_ind, d_in, seed, device):
     """X ~ N(0,1), Y = sin(sum x) + 0.1 eps, Z = first M rows + 0.01 noise, q_mu ~ 0.1 N(0,1),
     q_sqrt = tril(0.05 N(0,1)) + 0.5 I, ARD lengthscales sqrt(D)(0.8 + 0.05 d), noise 0.1.  The rows are i.i.d., so
     minibatch s of rank r is simply a contiguous slice (a fixed permutation of i.i.d. rows changes nothing).
-    Generated on the device (identical on every rank: same seed)."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    X = torch.randn((n_data, d_in), generator=g, dtype=torch.float64, device=device)
-    Y = torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn((n_data, P_LAT), generator=g, dtype=torch.float64, device=device)
-    Z = (X[:m_ind] + 0.01 * torch.randn((m_ind, d_in), generator=g, dtype=torch.float64, device=device)).contiguous()
-    q_mu = (0.1 * torch.randn((m_ind, P_LAT), generator=g, dtype=torch.float64, device=device)).contiguous()
-    q_sqrt = (torch.tril(0.05 * torch.randn((P_LAT, m_ind, m_ind), generator=g, dtype=torch.float64, device=device))
-              + 0.5 * torch.eye(m_ind, dtype=torch.float64, device=device)).contiguous()
+    Generated on the host from NumPy seeds (bit-reproducible anywhere; identical on every rank), then moved to HBM before
+    the timed region."""
+    rng = np.random.default_rng(seed)
+    Xh = rng.standard_normal((n_data, d_in))
+    Yh = np.sin(Xh.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((n_data, P_LAT))
+    Zh = Xh[:m_ind] + 0.01 * rng.standard_normal((m_ind, d_in))
+    q_mu_h = 0.1 * rng.standard_normal((m_ind, P_LAT))
+    q_sqrt_h = np.tril(0.05 * rng.standard_normal((P_LAT, m_ind, m_ind))) + 0.5 * np.eye(m_ind)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    X, Y, Z, q_mu, q_sqrt = to(Xh), to(Yh), to(Zh), to(q_mu_h), to(q_sqrt_h)
     ls = np.sqrt(d_in) * (0.8 + 0.05 * np.arange(d_in))
     return X, Y, Z, q_mu, q_sqrt, ls
 
@@ -90,11 +102,7 @@ def cpu_baseline_and_parity(Xb, Yb, Z, q_mu, q_sqrt, ls, n_data, gpu_elbo, budge
         orc.svgp_elbo(Xb, Yb, Z, q_mu, q_sqrt, **kw)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    try:
-        import threadpoolctl
-        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    threads = host_threads()
     m, b, d = Z.shape[0], Xb.shape[0], Xb.shape[1]
     base = {"value": 1.0 / med, "unit": "steps/s", "cores": int(threads), "kind": "port",
             "sample": f"{len(times)} ELBO steps on the arrays of the last timed GPU step (M={m}, B={b}, D={d}, P=1, whitened), "
@@ -133,12 +141,108 @@ def train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, n_data, b_rows, steps: int = 20):
         elbo, info = one(3 + s)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    flops = 3.0 * svgp_step_flops(m_ind, b_rows, P_LAT)  # forward + ~2x for the reverse pass (same GEMM shapes)
+    # counted, not guessed: HIP events + algorithmic flops of every GEMM launch of one more evaluation
+    from gpflow_amd import _lib
+    lib = _lib.load()
+    lib.gpk_profile_gemm_enable(1)
+    one(3 + steps)
+    ms_g, n_g, fl_g = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+    lib.gpk_profile_gemm_collect_min(ctypes.c_double(0.0), 0, ctypes.byref(ms_g), ctypes.byref(n_g), ctypes.byref(fl_g))
+    lib.gpk_profile_gemm_enable(0)
+    flops = fl_g.value
     return {"workload": "SVGP training step (ELBO + gradients w.r.t. Z, q_mu, q_sqrt, kernel and noise parameters + Adam), "
                         f"M={m_ind}, {b_rows} rows", "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "last_elbo": elbo,
-            "info": info, "approx_tflops": flops / dt / 1e12,
+            "info": info, "gemm_gflop_per_step_counted": flops / 1e9, "gemm_launches_per_step": int(n_g.value),
+            "tflops": flops / dt / 1e12, "frac_of_fp64_peak": flops / dt / 1e12 / FP64_PEAK_TFLOPS,
             "note": "hyper-parameters held fixed in this leg (their gradients are computed and read back); "
                     "SVGPTrainer updates them on the host"}
+
+
+def other_workloads_leg(device, with_oracle: bool, steps: int = 20):
+    """Every other BASELINE config in the same driver-run line: C3 (M=1024), the C4 rank shard (D=16; 8192 rows
+    = weak scaling, 1024 rows = one of 8 ranks of the strong-scaled step), C5 through the model surface with a shared and
+    with separate kernels.  Inputs from NumPy seeds (a pool of 8 minibatches); ms/step = wall-clock of `steps` evaluations
+    incl. the scalar landing on the host; parity of the LAST step against the oracle on the same arrays."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import ops
+    from oracle import gp_oracle as orc
+    out = {}
+
+    def pool(seed, b, d, p, m):
+        rng = np.random.default_rng(seed)
+        Xh = rng.normal(size=(8 * b, d))
+        Yh = np.sin(Xh.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(8 * b, p))
+        Z = Xh[:m] + 0.01 * rng.normal(size=(m, d))
+        q_mu = 0.1 * rng.normal(size=(m, p))
+        q_sqrt = np.stack([np.tril(0.05 * rng.normal(size=(m, m))) + 0.5 * np.eye(m) for _ in range(p)])
+        return Xh, Yh, Z, q_mu, q_sqrt, np.sqrt(d) * (0.8 + 0.05 * np.arange(d))
+
+    def run(name, note, step, flops, oracle_fn):
+        for s in range(3):
+            step(s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            v = step(3 + s)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        rec = {"workload": note, "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "algorithmic_gflop_per_step": flops / 1e9,
+               "step_tflops": flops / dt / 1e12, "step_frac_of_fp64_peak": flops / dt / 1e12 / FP64_PEAK_TFLOPS, "last_elbo": v}
+        if with_oracle:
+            t1 = time.perf_counter()
+            ref = float(oracle_fn((3 + steps - 1) % 8))
+            rec.update(oracle_elbo=ref, parity_rel_err=abs(v - ref) / abs(ref), oracle_seconds=time.perf_counter() - t1)
+        out[name] = rec
+
+    # C3 and the C4 shards through the fused C-ABI driver, exactly like the headline step
+    for name, note, (n_data, m, d, b, seed) in (
+            ("c3", "BASELINE config C3: SVGP N=1e6 M=1024 D=8, 8192 rows", (1_000_000, 1024, 8, 8192, 14)),
+            ("c4_shard_8192", "BASELINE config C4 per-rank problem, weak scaling: N=1e7 M=2048 D=16, 8192 rows", (10_000_000, 2048, 16, 8192, 16)),
+            ("c4_shard_1024", "BASELINE config C4 per-rank problem, one of 8 ranks of a strong-scaled 8192-row step: 1024 rows",
+             (10_000_000, 2048, 16, 1024, 17))):
+        Xh, Yh, Zh, qmh, qsh, ls = pool(seed, b, d, 1, m)
+        Xd, Yd, Z, q_mu, q_sqrt = (ops.to_device(a) for a in (Xh, Yh, Zh, qmh, qsh))
+        ws = ops.svgp_elbo_workspace(m, b, d, 1, False)
+        o = torch.empty(2, dtype=torch.float64, device=device)
+        inf = torch.zeros(1, dtype=torch.int32, device=device)
+        scale = float(n_data) / b
+
+        def step(s, Xd=Xd, Yd=Yd, Z=Z, q_mu=q_mu, q_sqrt=q_sqrt, ls=ls, ws=ws, o=o, inf=inf, b=b, scale=scale):
+            lo = (s % 8) * b
+            ops.svgp_elbo_shard(Z, Xd[lo:lo + b], Yd[lo:lo + b], q_mu, q_sqrt, variance=1.0, lengthscales=ls, noise_variance=0.1,
+                                jitter=1e-6, ws=ws, out=o, info=inf)
+            h = o.cpu()
+            return float(h[0]) * scale - float(h[1])
+
+        def orc_fn(i, Xh=Xh, Yh=Yh, Zh=Zh, qmh=qmh, qsh=qsh, ls=ls, b=b, n_data=n_data):
+            return orc.svgp_elbo(Xh[i * b:(i + 1) * b], Yh[i * b:(i + 1) * b], Zh, qmh, qsh, variance=1.0, lengthscales=ls,
+                                 noise_variance=0.1, whiten=True, num_data=n_data)
+        run(name, note, step, svgp_step_flops(m, b, 1), orc_fn)
+        del Xd, Yd, ws
+    # C5: multi-output SVGP, 4 latent GPs, M = 1024, through gpflow_amd.models.SVGP
+    m, b, d, p = 1024, 8192, 8, 4
+    Xh, Yh, Zh, qmh, qsh, ls = pool(18, b, d, p, m)
+    Xd, Yd = ops.to_device(Xh), ops.to_device(Yh)
+    shared_iv = gpflow.inducing_variables.SharedIndependentInducingVariables(gpflow.inducing_variables.InducingPoints(Zh))
+    ms = gpflow.models.SVGP(gpflow.kernels.SharedIndependent(gpflow.kernels.SquaredExponential(variance=1.0, lengthscales=ls), output_dim=p),
+                            gpflow.likelihoods.Gaussian(0.1), shared_iv, q_mu=qmh, q_sqrt=qsh, num_latent_gps=p, num_data=1_000_000)
+    run("c5_shared", "BASELINE config C5, SharedIndependent kernel + shared inducing points (one Cholesky, P-batched projection), "
+        "4 latent GPs, M=1024, 8192 rows, through gpflow_amd.models.SVGP.elbo",
+        lambda s: float(ms.elbo((Xd[(s % 8) * b:(s % 8 + 1) * b], Yd[(s % 8) * b:(s % 8 + 1) * b]))),
+        m ** 3 / 3.0 + float(m) * m * b * (1 + p),
+        lambda i: orc.svgp_elbo(Xh[i * b:(i + 1) * b], Yh[i * b:(i + 1) * b], Zh, qmh, qsh, variance=1.0, lengthscales=ls,
+                                noise_variance=0.1, whiten=True, num_data=1_000_000))
+    sep_var, sep_ls = [1.0, 0.8, 1.2, 0.9], [2.4, 2.8, 3.2, 3.6]
+    ksep = gpflow.kernels.SeparateIndependent([gpflow.kernels.SquaredExponential(variance=v, lengthscales=l) for v, l in zip(sep_var, sep_ls)])
+    shared_iv2 = gpflow.inducing_variables.SharedIndependentInducingVariables(gpflow.inducing_variables.InducingPoints(Zh))
+    mp = gpflow.models.SVGP(ksep, gpflow.likelihoods.Gaussian(0.1), shared_iv2, q_mu=qmh, q_sqrt=qsh, num_latent_gps=p, num_data=1_000_000)
+    run("c5_separate", "BASELINE config C5, SeparateIndependent kernels (batched [4,M,M] Cholesky + batched solves), 4 latent GPs, "
+        "M=1024, 8192 rows, whitened, through gpflow_amd.models.SVGP.elbo",
+        lambda s: float(mp.elbo((Xd[(s % 8) * b:(s % 8 + 1) * b], Yd[(s % 8) * b:(s % 8 + 1) * b]))),
+        p * (m ** 3 / 3.0 + 2.0 * float(m) * m * b),
+        lambda i: orc.svgp_elbo_separate(Xh[i * b:(i + 1) * b], Yh[i * b:(i + 1) * b], [Zh] * p, qmh, qsh, variances=sep_var,
+                                         lengthscales_list=sep_ls, noise_variance=0.1, whiten=True, num_data=1_000_000))
+    return out
 
 
 def _event_time(fn, reps: int, warm: int = 1):
@@ -261,7 +365,7 @@ def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
         t_cpu = time.perf_counter() - t0
         res["parity_rel_err"] = abs(res["lml"] - ref) / abs(ref)
         res["oracle_lml"] = float(ref)
-        res["cpu_baseline"] = {"value": flops / t_cpu / 1e9, "unit": "GF/s", "cores": os.cpu_count() or 1, "kind": "port",
+        res["cpu_baseline"] = {"value": flops / t_cpu / 1e9, "unit": "GF/s", "cores": host_threads(), "kind": "port",
                                "sample": f"one oracle GPR.log_marginal_likelihood at N={n} on the same arrays "
                                          f"({t_cpu:.1f} s: K build + LAPACK dpotrf + solve, NumPy/SciPy OpenBLAS)"}
     return res
@@ -277,6 +381,10 @@ def main():  # noqa: C901
     ap.add_argument("--no-gpr", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and Python-mirror legs")
+    ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE configs (C3, C4 shards, C5)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="N=1 only: bring up a world-size-1 nccl (RCCL) process group and put the 8-byte all-reduce of the "
+                         "multi-GPU path behind every step -- what RCCL's own streams cost beside the library's")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -289,14 +397,19 @@ def main():  # noqa: C901
     import torch.distributed as dist
     from gpflow_amd import _lib, ops
     lib = _lib.load()
-    if world > 1:
-        # The library's internal streams are created by its first factorisation with n > 128, in an order chosen so
-        # that chain and bulk streams land on different microengine pipes.  RCCL creates streams
-        # of its own when the communicator comes up: let the library place its streams FIRST, as in the 1-GPU run.
-        warm = torch.eye(256, dtype=torch.float64, device=device)
-        ops.potrf_(warm, 256)
-        torch.cuda.synchronize()
+    selftest = args.rccl_selftest and world == 1
+    # The library's internal streams are created by its first factorisation with n > 128, in an order chosen so that
+    # chain and bulk streams land on different microengine pipes.  Let the library place its
+    # streams FIRST: before RCCL brings up its own (multi-GPU runs) and before the host-to-device copies of the synthetic
+    # inputs make the runtime open its copy queues.
+    warm = torch.eye(256, dtype=torch.float64, device=device)
+    ops.potrf_(warm, 256)
+    torch.cuda.synchronize()
+    del warm
+    if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if selftest:
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     n_data, m_ind, d_in, global_rows, strong, seed = WORKLOADS[args.workload]
     if strong and global_rows % world:
@@ -322,7 +435,7 @@ def main():  # noqa: C901
         lo = shard_lo(s, rank)
         ops.svgp_elbo_shard(Z, X[lo:lo + b_rows], Y[lo:lo + b_rows], q_mu, q_sqrt, variance=1.0, lengthscales=ls,
                             noise_variance=0.1, jitter=1e-6, ws=ws, out=out, info=info)
-        if world > 1:
+        if world > 1 or selftest:
             # RCCL over xGMI: one 8-byte all-reduce per step, enqueued behind the shard (no host sync in between)
             dist.all_reduce(out[0:1], op=dist.ReduceOp.SUM)
         h_out.copy_(out, non_blocking=True)
@@ -453,6 +566,9 @@ def main():  # noqa: C901
         "library": lib.gpk_version().decode(),
         "roofline": roof,
     }
+    if selftest:
+        res["rccl_selftest"] = ("world-size-1 nccl process group: every step above carries the 8-byte all-reduce (RCCL "
+                                "initialised AFTER the library placed its streams); compare ms_per_step with a run without the flag")
     if not args.no_cpu_baseline:
         # parity of the LAST TIMED step against the oracle on the same arrays (all shards of that global minibatch; the
         # data are replicated on every rank), and the oracle's own wall-clock as the CPU baseline
@@ -505,12 +621,16 @@ def main():  # noqa: C901
         res["python_mirror_last_elbo"] = v
     if world == 1 and not args.no_train:
         res["train_step"] = train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, n_data, b_rows)
+    if world == 1 and not args.no_other:
+        X = Y = None
+        torch.cuda.empty_cache()
+        res["other_workloads"] = other_workloads_leg(device, with_oracle=not args.no_cpu_baseline)
     if world == 1 and not args.no_gpr:
-        del X, Y
+        X = Y = None
         torch.cuda.empty_cache()
         res["gpr_cholesky"] = gpr_leg(ops, lib, device, with_oracle=not args.no_cpu_baseline)
     print(json.dumps(res))
-    if world > 1:
+    if world > 1 or selftest:
         dist.destroy_process_group()
 
 

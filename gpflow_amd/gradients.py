@@ -184,16 +184,22 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
 
     side = _side_stream(dev) if (OVERLAP_BRANCHES and Z.is_cuda) else None
     if side is not None:
+        # The side branch reads A, W, r, Lq, q_mu (allocated on the main stream) and allocates its split-K partials from
+        # the side stream's pool (~270 MB per latent at M = 2048).  The join below sits in a `finally`: if anything on the
+        # main branch raises, the function still waits for the side stream before its locals go back to the allocator.
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             g_qmu, g_qs = branch_q()
-    Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)            # -tril(Kfu_bar^T At)
-    Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
-    dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
-    dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+    try:
+        Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)            # -tril(Kfu_bar^T At)
+        Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
+        dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
+        dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+    finally:
+        if side is not None:
+            main.wait_stream(side)
     if side is not None:
-        main.wait_stream(side)
         g_qmu.record_stream(main)
         g_qs.record_stream(main)
     else:

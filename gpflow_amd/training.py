@@ -125,14 +125,18 @@ class SVGPTrainer:
             raise GpkError("Cholesky decomposition of Kuu was not successful" +
                            (f" (non-positive pivot at column {self.last_info - 1})" if world == 1 else
                             " on at least one rank") + "; the step was NOT applied")
-        self.opt.t += 1
         adam_names = ("Z", "q_mu", "q_sqrt")
+        nat = None
         if self.natgrad_gamma is not None:
+            # into temporaries first: natgrad_update has a status check of its own ("precision (step too long?)"); if it
+            # raises, neither q(u), nor the Adam step counter, nor any moment has been touched
             from . import natgrad
             adam_names = ("Z",)
-            mu, sq = natgrad.natgrad_update(self.dev["q_mu"], self.dev["q_sqrt"], -g["q_mu"], -g["q_sqrt"], self.natgrad_gamma)
-            self.dev["q_mu"].copy_(mu)
-            self.dev["q_sqrt"].copy_(sq)
+            nat = natgrad.natgrad_update(self.dev["q_mu"], self.dev["q_sqrt"], -g["q_mu"], -g["q_sqrt"], self.natgrad_gamma)
+        self.opt.t += 1
+        if nat is not None:
+            self.dev["q_mu"].copy_(nat[0])
+            self.dev["q_sqrt"].copy_(nat[1])
         for name in adam_names:                                  # minimise -F
             if self.dev_params[name].trainable:
                 self.opt.update_device(name, self.dev[name], -g[name])

@@ -180,3 +180,25 @@ def test_svgp_c5_separate_independent_at_size(gpu, whiten):
     ref = orc.svgp_elbo_separate(X, Y, [Z] * 4, q_mu, q_sqrt, variances=variances, lengthscales_list=lss,
                                  noise_variance=0.1, whiten=whiten, num_data=1_000_000)
     assert abs(elbo - ref) <= 1e-8 * abs(ref), (elbo, ref)
+
+
+def test_training_step_full_size_vs_autograd_oracle(gpu):
+    """The TIMED training step of bench.py (config Cm: M = 2048, B = 8192, D = 8, whitened -- split-K x 8, 64 x 128 half
+    tiles, paired triangular-K tiles, the two-stream reverse pass all engage only at this shape): ELBO value and every
+    gradient against the torch-CPU autograd oracle, 1e-8 of each gradient's largest entry
+    (gpflow/optimizers/scipy.py:322-331 is what the reference differentiates)."""
+    from gpflow_amd import gradients, ops
+    from oracle import gp_oracle_grad as orcg
+    M, B, D, N = 2048, 8192, 8, 1_000_000
+    X, Y, Z, q_mu, q_sqrt, ls = _svgp_inputs(M, B, D, 23)
+    Z = X[:M] + 0.01 * np.random.default_rng(24).normal(size=(M, D))  # (bench.py's inducing points: data rows + noise)
+    kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1)
+    t = ops.to_device
+    F, g, info = gradients.svgp_elbo_and_grad(t(Z), t(X), t(Y), t(q_mu), t(q_sqrt), jitter=1e-6, scale=float(N) / B, **kw)
+    ops.check_info(info)
+    v, go = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=N, **kw)
+    assert abs(float(F.cpu()[0]) - v) <= 1e-8 * abs(v), (float(F.cpu()[0]), v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt"):
+        got, ref = g[name].cpu().numpy(), np.asarray(go[name])
+        tol = 1e-8 * max(1.0, np.abs(ref).max())
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=tol, err_msg=name)

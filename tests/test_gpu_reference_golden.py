@@ -38,13 +38,19 @@ def test_ref_kernels(gp):
     X, X2, ls, var = G["k_X"], G["k_X2"], G["k_ls"], float(G["k_var"])
     for name in ("SquaredExponential", "Matern12", "Matern32", "Matern52"):
         k = getattr(gp.kernels, name)(variance=var, lengthscales=ls)
-        close(k(X), G[f"k_{name}_sym"], 1e-12); close(k(X, X2), G[f"k_{name}_cross"], 1e-12)
+        # Matern K(X, X): r = sqrt(max(r2, 1e-36)) with r2 from the expansion formula, which is 0 +- a few ulp of |x|^2 on
+        # the diagonal -- r, and with it exp(-r), carries sqrt(ulp) ~ 1e-8 of rounding noise THERE in the reference itself
+        # (kernels/stationaries.py:111-116); any other summation order lands elsewhere inside that noise.
+        sym_tol = 1e-12 if name == "SquaredExponential" else 3e-7
+        close(k(X), G[f"k_{name}_sym"], sym_tol); close(k(X, X2), G[f"k_{name}_cross"], 1e-12)
+        off = ~np.eye(len(X), dtype=bool)
+        assert np.max(np.abs(_np(k(X)) - G[f"k_{name}_sym"])[off]) <= 1e-12 * var
         close(k(X, full_cov=False), G[f"k_{name}_diag"], 1e-14)
     k_ad = gp.kernels.SquaredExponential(variance=0.8, lengthscales=[0.5, 1.5], active_dims=[1, 3])
     k_sl = gp.kernels.SquaredExponential(variance=0.8, lengthscales=0.6, active_dims=slice(0, 2))
     close(k_ad(X), G["k_active_dims_sym"], 1e-12)
     close((k_ad + k_sl)(X, X2), G["k_sum_cross"], 1e-12)
-    close((k_ad * gp.kernels.Matern32(variance=1.1, lengthscales=0.9))(X), G["k_prod_sym"], 1e-12)
+    close((k_ad * gp.kernels.Matern32(variance=1.1, lengthscales=0.9))(X), G["k_prod_sym"], 3e-7)  # (Matern diagonal, see above)
     close((k_ad + k_sl)(X, full_cov=False), G["k_sum_diag"], 1e-14)
 
 

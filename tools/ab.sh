@@ -5,7 +5,7 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 run() {
   for rep in $(seq 1 ${AB_REPS:-2}); do
-    env $1 timeout 75 python $root/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-gpr --no-train --no-extras 2>/dev/null | python -c "
+    env $1 timeout 75 python $root/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-gpr --no-train --no-extras --no-other 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 r=d['roofline']
