@@ -752,6 +752,124 @@ int launch_small(hipStream_t s, const GemmArgs& a) {
   return 0;
 }
 
+// =====================================================================================================
+// Fused in-group solve of right-hand-side ROWS against a column group of the factor (nb <= 4 leaf blocks):
+//     for j = 0 .. nb-1:   S_j = E_j X_j^T                       (X_j = L_jj^-1, the leaf's block inverse)
+//                          E_j' -= S_j L_j'j^T   for j' > j       (the rest of the group)
+// i.e. exactly the 2 nb - 1 launches of the latency kernel above that the right-looking row solve issues per group
+// (4 solves + 3 updates at nb = 4), with the SAME arithmetic per element (two alternating accumulators over K = 128,
+// the update accumulated onto -C and negated) -- so the results are bit-identical -- but as ONE launch: a workgroup owns
+// 16 rows, keeps their nb x (16 x 128) panel in accumulator registers for the whole group (8 waves x one 16 x 16 tile
+// per block), and only the 10 operand tiles X_j / L_j'j stream through LDS.  The extra-row stream of an SVGP step spent
+// ~150 us per group in those seven dependent launches (mostly launch ramp and drain on a 256-CU chip); this is one.
+struct GroupSolveArgs {
+  const double* E; long lde;     // rows to solve, columns of the group start at E (in/out unless Eo differs)
+  double* Eo; long ldeo;         // solved rows out (may alias E)
+  const double* L; long ldl;     // L[c0, c0]: top-left element of the group's diagonal block
+  const double* X;               // block inverses of the group, consecutive [nb][128][128]
+  int rows, nb;
+};
+
+__global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
+  constexpr int LDK = 130, NBK = 128;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  double* As = smem;               // [16][LDK]
+  double* Bs = smem + 16 * LDK;    // [128][LDK]
+  const int m0 = blockIdx.x * 16;
+  int rowi[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int rr = m0 + g + 4 * e;
+    rowi[e] = rr < p.rows ? rr : p.rows - 1;
+  }
+  const int colw = wave * 16 + r;  // this lane's column inside a 128-block
+  d4 c[4];
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) {
+    if (jb < p.nb) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[jb][e] = p.E[(long)rowi[e] * p.lde + jb * NBK + colw];
+    }
+  }
+  const double* ap = As + r * LDK + g;
+  const double* bp = Bs + (wave * 16 + r) * LDK + g;
+  auto stage_b = [&](const double* src, long ld) {  // 128 rows of 128 doubles, one LDS-DMA instruction each
+    for (int q = wave; q < NBK; q += 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)q * ld + 2 * lane),
+                                       (__attribute__((address_space(3))) void*)(Bs + q * LDK), 16, 0, 0);
+  };
+  auto put_a = [&](const d4& v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) As[(g + 4 * e) * LDK + colw] = v[e];
+  };
+  auto product = [&](d4& acc0, d4& acc1) {
+#pragma unroll 4
+    for (int kk = 0; kk < 32; kk += 2) {
+      const double a0 = ap[kk * 4], b0 = bp[kk * 4];
+      const double a1 = ap[kk * 4 + 4], b1 = bp[kk * 4 + 4];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j >= p.nb) break;
+    // ---- S_j = E_j X_j^T ------------------------------------------------------------------------------------------
+    if (j > 0) __syncthreads();  // previous readers of As / Bs are done
+    put_a(c[j]);
+    stage_b(p.X + (long)j * NBK * NBK, NBK);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): this wave's LDS-DMA rows have landed
+    __syncthreads();
+    d4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
+    product(s0, s1);
+    d4 sj;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sj[e] = 1.0 * (s0[e] + s1[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rr = m0 + g + 4 * e;
+      if (rr < p.rows) p.Eo[(long)rr * p.ldeo + j * NBK + colw] = sj[e];
+    }
+    if (j + 1 >= p.nb) break;
+    __syncthreads();  // everyone has read E_j / X_j
+    put_a(sj);
+    // ---- E_j' -= S_j L_j'j^T ----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int jp = 1; jp < 4; ++jp) {
+      if (jp <= j || jp >= p.nb) continue;
+      if (jp > j + 1) __syncthreads();  // the previous operand tile is no longer read
+      stage_b(p.L + (long)jp * NBK * p.ldl + (long)j * NBK, p.ldl);
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      __syncthreads();
+      d4 u0, u1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u0[e] = -1.0 * c[jp][e];  // (beta / alpha) C with alpha = -1, beta = 1
+      product(u0, u1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[jp][e] = -1.0 * (u0[e] + u1[e]);
+    }
+  }
+}
+
+int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
+                       const double* X, int nb) {
+  if (rows <= 0) return 0;
+  if (!E || !Eo || !Lgg || !X || nb < 1 || nb > 4) return GPK_E_ARG;
+  if ((ldl & 1) || (reinterpret_cast<uintptr_t>(Lgg) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return GPK_E_UNSUPPORTED;
+  constexpr size_t LDS = (size_t)(16 + 128) * 130 * sizeof(double);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(group_solve_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+  GPK_HIP(attr);
+  GroupSolveArgs a{};
+  a.E = E; a.lde = lde; a.Eo = Eo; a.ldeo = ldeo; a.L = Lgg; a.ldl = ldl; a.X = X; a.rows = rows; a.nb = nb;
+  hipLaunchKernelGGL(group_solve_kernel, dim3((unsigned)gpk_cdiv(rows, 16)), dim3(512), LDS, s, a);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
 // small-K latency path: K <= 128 in whole 16-slabs, 16-byte aligned rows, modest row count
 bool small_ok(const GemmArgs& a) {
   if (GPK_TUNE(GEMM_NO_SMALL, 0) || a.epi != 0) return false;
@@ -796,6 +914,11 @@ int launch_cfg(hipStream_t s, const GemmArgs& a) {
 }  // namespace
 
 int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
+
+int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
+                           const double* X, int nb) {
+  return launch_group_solve(s, E, lde, Eo, ldeo, rows, Lgg, ldl, X, nb);
+}
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events around every GEMM launch, on the
 // stream the kernel is launched on.  Off by default; adds two event records per launch when on. -------

@@ -84,6 +84,10 @@ struct GemmArgs {
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
 
+// fused in-group solve of `rows` right-hand-side rows against nb <= 4 leaf blocks of the factor (gemm.hip); E / Eo point at
+// the group's first column, Lgg at L[c0, c0], X at the group's first block inverse
+int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
+                           const double* X, int nb);
 int gpk_gemm_tiles_n(int n);   // number of column tiles the launcher will use for n columns
 int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg)
 

@@ -202,7 +202,14 @@ int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, double
                     long ldl, const double* invd, long strideInv, int n, int c0, int c1, int batch, long strideE,
                     long strideEo, long strideL) {
   int rc;
-  {
+  const int nbk = (c1 - c0) / NB;
+  if (batch <= 1 && nbk >= 2 && nbk <= 4 && nbk * NB == c1 - c0 && (c0 % NB) == 0 && rows >= GPK_TUNE(GROUP_FUSED_MIN_ROWS, 1024) &&
+      !(ldl & 1) && GPK_TUNE(GROUP_FUSED, 1)) {
+    // the whole in-group phase (nbk solves + nbk - 1 updates of the latency kernel) as ONE launch with the same arithmetic
+    rc = gpk_launch_group_solve(s, E + c0, lde, Eo + c0, ldeo, rows, L + (long)c0 * ldl + c0, ldl, invd + (long)(c0 / NB) * NB * NB,
+                                nbk);
+    if (rc) return rc;
+  } else {
     for (int j0 = c0; j0 < c1; j0 += NB) {
       const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
       const int nb = j1 - j0;
