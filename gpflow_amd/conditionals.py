@@ -186,6 +186,13 @@ def separate_independent_conditional_implementation(Kmns, Kmms, Knns, f, *, full
     T = torch.empty((P, M + N, M), dtype=torch.float64, device=Kmms.device)
     T[:, :M].copy_(Kmms)
     T[:, M:].copy_(Kmns.transpose(1, 2))
+    return separate_independent_trapezoid_tail(T, M, Knns, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white)
+
+
+def separate_independent_trapezoid_tail(T: torch.Tensor, M: int, Knns, f, *, full_cov: bool, q_sqrt, white: bool):
+    """The same from the batched trapezoid T [P, M + N, M] = [Kmm_p ; Kfu_p] (consumed): callers that can BUILD the
+    covariances straight into T (the posteriors) skip the [P,M,M] / [P,M,N] intermediates and their copies."""
+    P = T.shape[0]
     invd, info = ops.potrf_(T, M, zero_upper=True)
     ops.check_info(info)
     invd = invd.reshape(P, -1)

@@ -11,7 +11,7 @@ import torch
 from . import config, covariances, ops
 from .base import Module
 from .conditionals import (Factor, base_conditional, conditional_tail, expand_independent_outputs,
-                           factor_with_rows, separate_independent_conditional_implementation, tail_over_batches)
+                           factor_with_rows, separate_independent_trapezoid_tail, tail_over_batches)
 from .inducing_variables import (InducingPoints, InducingVariables,
                                  SeparateIndependentInducingVariables,
                                  SharedIndependentInducingVariables)
@@ -386,17 +386,22 @@ class IndependentPosteriorMultiOutput(IndependentPosterior):
                                                     full_cov)
         else:
             Xf, lead = _flatten_rows(Xnew)
-            Kmms = covariances.Kuu(self.X_data, self.kernel, jitter=config.default_jitter())  # [P,M,M]
-            if isinstance(self.kernel, SeparateIndependent):
-                kernel_list = self.kernel.kernels
-            else:
-                kernel_list = [self.kernel.kernel] * len(self.X_data.inducing_variable_list)
+            pairs = covariances._pairs(self.X_data, self.kernel)  # (Z_p, kernel_p) per latent
+            kernel_list = [k for _, k in pairs]
+            q_mu, q_sqrt = self.q_mu, self.q_sqrt
 
             def one(Xr):
-                Kmns = covariances.Kuf(self.X_data, self.kernel, Xr)  # [P,M,N]
-                Knns = torch.stack([k.K(Xr) if full_cov else k.K_diag(Xr) for k in kernel_list], dim=0)
-                return separate_independent_conditional_implementation(
-                    Kmns, Kmms, Knns, self.q_mu, q_sqrt=self.q_sqrt, full_cov=full_cov, white=self.whiten)
+                # Kuu_p + jitter I and Kfu_p built STRAIGHT into the batched trapezoid [P, M + N, M] (posteriors.py:862-887
+                # stacks [P,M,M] and [P,M,N] tensors first): one batched factorisation + solve, no intermediate copies
+                M, N = pairs[0][0].shape[0], Xr.shape[0]
+                T = torch.empty((len(pairs), M + N, M), dtype=torch.float64, device=Xr.device)
+                for p, (z, k) in enumerate(pairs):
+                    Xs, Zs = k.slice(Xr, z)
+                    k.K_into(Zs, None, T[p, :M], diag_add=config.default_jitter(), lower_only=True)
+                    k.K_into(Xs, Zs, T[p, M:])
+                Knns = torch.stack([k(Xr, full_cov=full_cov) for k in kernel_list], dim=0)
+                return separate_independent_trapezoid_tail(T, M, Knns, q_mu, full_cov=full_cov, q_sqrt=q_sqrt,
+                                                           white=self.whiten)
 
             if len(lead) == 1:
                 fmean, fvar = one(Xf)
