@@ -139,8 +139,9 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     M, D = Z.shape
     B = Xb.shape[0]
     P = q_mu.shape[1]
-    if q_sqrt.dim() != 3 or tuple(q_sqrt.shape) != (P, M, M):
-        raise ValueError("svgp_elbo_and_grad needs the full q_sqrt [P, M, M]")
+    q_diag = q_sqrt.dim() == 2
+    if tuple(q_sqrt.shape) not in ((P, M, M), (M, P)):
+        raise ValueError("svgp_elbo_and_grad needs q_sqrt [P, M, M] or, for q_diag, [M, P]")
     dev = Z.device
     kw = dict(variance=variance, lengthscales=lengthscales)
 
@@ -152,11 +153,15 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     ops.kernel_matrix(Xb, Z, out=T[M:M + B], **kw)                                      # Kfu
     invd, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)                  # (the last M rows: I -> Lm^-T)
     L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
-    Lq = _tril(q_sqrt)                                                                     # band_part(q_sqrt, -1, 0)
-    LqT = ops.transpose(q_sqrt, mode=1)                                                 # [P, M, M] = tril(q_sqrt)^T
-    s0, fmean, _ = ops.row_stats(At, V=q_mu)                                            # rowsum(At^2), At q_mu
-    W = ops.gemm_nt(At, LqT, b_tri=1)                                                   # [P, B, M]: W_p = At Lq_p
-    ssq = torch.stack([ops.row_stats(W[p])[0] for p in range(P)])                       # [P, B]
+    if q_diag:   # q_sqrt [M, P] holds standard deviations (svgp.py:90-148, conditionals/util.py:149,164)
+        s0, fmean, ssq = ops.row_stats(At, V=q_mu, W=q_sqrt.contiguous())                # rowsum(At^2), At q_mu, sum_k At^2 q^2
+        Lq = LqT = W = None
+    else:
+        Lq = _tril(q_sqrt)                                                                 # band_part(q_sqrt, -1, 0)
+        LqT = ops.transpose(q_sqrt, mode=1)                                             # [P, M, M] = tril(q_sqrt)^T
+        s0, fmean, _ = ops.row_stats(At, V=q_mu)                                        # rowsum(At^2), At q_mu
+        W = ops.gemm_nt(At, LqT, b_tri=1)                                               # [P, B, M]: W_p = At Lq_p
+        ssq = torch.stack([ops.row_stats(W[p])[0] for p in range(P)])                   # [P, B]
     ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
                                     mean_const=mean_const)
     kl = ops.gauss_kl_white(q_mu, q_sqrt)
@@ -166,15 +171,21 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     c = -0.5 * scale / noise_variance                                                   # dF/dfvar (every b, p)
     r = (scale / noise_variance) * (Yb - fmean - mean_const)                            # dF/dfmean [B, P]
     Atb = ops.gemm_nt(r, q_mu)                                                          # r q_mu^T  [B, M]
-    for p in range(P):                                                                  # + 2c W_p Lq_p^T (Lq_p lower: b_tri 2)
-        ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=Atb, b_tri=2)
-    Atb.add_(At, alpha=-2.0 * c * P)                                                    # - 2 c P At
+    if q_diag:                                                                          # + 2c At (sum_p q_p^2 - P) per column
+        Atb.addcmul_(At, (2.0 * c) * ((q_sqrt * q_sqrt).sum(1) - P)[None, :])
+    else:
+        for p in range(P):                                                              # + 2c W_p Lq_p^T (Lq_p lower: b_tri 2)
+            ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=Atb, b_tri=2)
+        Atb.add_(At, alpha=-2.0 * c * P)                                                # - 2 c P At
     A = ops.transpose(At)                                                               # [M, B]
     Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)                                          # At_bar Lm^-1  [B, M]
     Kuf_bar = ops.transpose(Kfu_bar)                                                    # [M, B]
 
     def branch_q():
         g_mu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                # At^T r - q_mu
+        if q_diag:   # d/dq = 2c colsum(At^2) q - (q - 1/q)   (KL of a diagonal q: kullback_leiblers.py:131-133,146-148)
+            colsq = ops.row_stats(A)[0]
+            return g_mu, (2.0 * c) * colsq[:, None] * q_sqrt - kl_weight * (q_sqrt - 1.0 / q_sqrt)
         g = torch.stack([splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c)
                          for p in range(P)]) if P > 1 else \
             splitk_gemm_nt(A, ops.transpose(W[0]), c_lower=True, alpha=2.0 * c).unsqueeze(0)

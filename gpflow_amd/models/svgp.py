@@ -112,47 +112,121 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             scale = 1.0
         return terms[0] * scale - terms[1]
 
-    def gradient_config(self):
+    def gradient_config(self, allow_active_dims: bool = False, allow_q_diag: bool = False):
         """(SquaredExponential kernel, InducingPoints, mean constant) if the hand-written reverse pass covers this model:
         whitened or not, Gaussian likelihood with a variance parameter, full q_sqrt, constant mean, and ONE SquaredExponential
-        kernel (no active_dims) over InducingPoints -- either directly or as SharedIndependent +
-        SharedIndependentInducingVariables (BASELINE config C5: P latents share Kuu / Kuf).  Raises NotImplementedError."""
+        kernel (`active_dims`, and `q_diag` for a whitened model, only where the caller handles them itself: `elbo_and_grad`) over InducingPoints -- either directly or as SharedIndependent +
+        SharedIndependentInducingVariables (BASELINE config C5: P latents share Kuu / Kuf).  SeparateIndependent kernels
+        are differentiated latent by latent (`_separate_gradient_config`).  Raises NotImplementedError."""
         from ..kernels.stationaries import SquaredExponential
         k, iv, lik = self.kernel, self.inducing_variable, self.likelihood
         if isinstance(k, SharedIndependent) and isinstance(iv, SharedIndependentInducingVariables):
             k, iv = k.kernel, iv.inducing_variable
         c = self.mean_function.constant_value()
         if not (isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
-                and isinstance(iv, InducingPoints) and c is not None and self.q_sqrt.numpy().ndim == 3
-                and k.has_default_active_dims):
-            raise NotImplementedError("gradients: SVGP with a SquaredExponential kernel (no active_dims; optionally shared by "
-                                      "independent latents), Gaussian likelihood, InducingPoints, full q_sqrt, constant mean")
+                and isinstance(iv, InducingPoints) and c is not None
+                and (self.q_sqrt.numpy().ndim == 3 or (allow_q_diag and self.whiten and self.q_sqrt.numpy().ndim == 2))
+                and (allow_active_dims or k.has_default_active_dims)):
+            raise NotImplementedError("gradients: SVGP with a SquaredExponential kernel (optionally shared by independent "
+                                      "latents, or one per latent), Gaussian likelihood, InducingPoints, full q_sqrt, constant mean")
         return k, iv, float(c)
+
+    def _separate_gradient_config(self):
+        """[(SquaredExponential kernel_p, InducingPoints_p)] per latent for SeparateIndependent kernels (over shared or
+        separate inducing points), else None."""
+        from ..covariances import _pairs  # noqa: F401  (same pairing rule as Kuu / Kuf)
+        from ..kernels import SeparateIndependent
+        from ..kernels.stationaries import SquaredExponential
+        from ..inducing_variables import SeparateIndependentInducingVariables
+        k, iv, lik = self.kernel, self.inducing_variable, self.likelihood
+        if not isinstance(k, SeparateIndependent):
+            return None
+        if isinstance(iv, SeparateIndependentInducingVariables):
+            ivs = list(iv.inducing_variable_list)
+        elif isinstance(iv, SharedIndependentInducingVariables):
+            ivs = [iv.inducing_variable] * len(k.kernels)
+        else:
+            return None
+        c = self.mean_function.constant_value()
+        if not (all(isinstance(kk, SquaredExponential) for kk in k.kernels) and all(isinstance(v, InducingPoints) for v in ivs)
+                and isinstance(lik, Gaussian) and lik.variance is not None and c is not None and self.q_sqrt.numpy().ndim == 3
+                and len(ivs) == len(k.kernels)):
+            raise NotImplementedError("gradients: SeparateIndependent needs SquaredExponential members over InducingPoints, a "
+                                      "Gaussian likelihood, full q_sqrt and a constant mean")
+        return list(zip(k.kernels, ivs)), float(c)
+
+    @staticmethod
+    def _sliced(k, Z, X):
+        """Inputs restricted to the kernel's active_dims + the scatter of a gradient w.r.t. the sliced Z back to Z's shape
+        (gpflow/kernels/base.py:90-109: the kernel only ever sees these columns, so dF/dZ is zero elsewhere)."""
+        if k.has_default_active_dims:
+            return Z, X, (lambda gz: gz)
+        Xs, Zs = k.slice(X, Z)
+        dims = k._active_dims
+        cols = torch.arange(Z.shape[1], device=Z.device)[dims] if isinstance(dims, slice) else torch.as_tensor(dims, device=Z.device)
+
+        def scatter(gz):
+            full = torch.zeros_like(Z)
+            full.index_copy_(1, cols, gz)
+            return full
+        return Zs, Xs, scatter
 
     def elbo_and_grad(self, data):
         """(ELBO on `data` as a float, {Parameter: dELBO/d(unconstrained value) as NumPy}) for the trainable parameters
-        -- the pair `optimizers/scipy.py:322-331` gets from TF autodiff over `training_loss_closure(data)`.  Whitened,
-        SquaredExponential kernel, Gaussian likelihood, InducingPoints, full q_sqrt (gradients.svgp_elbo_and_grad).
-        For minibatch training keep the variables on the device instead: training.SVGPTrainer."""
+        -- the pair `optimizers/scipy.py:322-331` gets from TF autodiff over `training_loss_closure(data)`.  Whitened or
+        not, SquaredExponential kernel (with `active_dims`; shared by the latents or one per latent), Gaussian likelihood,
+        InducingPoints, full q_sqrt (gradients.svgp_elbo_and_grad).  For minibatch training keep the variables on the
+        device instead: training.SVGPTrainer."""
         from .. import gradients
         from ..base import FillTriangular
         from ..mean_functions import Constant
-        k, iv, c = self.gradient_config()
         lik, mf = self.likelihood, self.mean_function
+        # scope checks first: a model outside the reverse pass is refused before anything touches the device
+        sep = self._separate_gradient_config()
+        single = self.gradient_config(allow_active_dims=True, allow_q_diag=True) if sep is None else None
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
-        _, var, ls = k.hyper()
         fn = gradients.svgp_elbo_and_grad if self.whiten else gradients.svgp_elbo_and_grad_unwhitened
-        F, g, info = fn(iv.Z.device_value(), X, Y, self.q_mu.device_value(),
-                                                  self.q_sqrt.device_value(), variance=var, lengthscales=ls,
-                                                  noise_variance=lik.noise_variance(), jitter=config.default_jitter(),
-                                                  scale=scale, mean_const=float(c))
-        ops.check_info(info)
-        host = {n: t.cpu().numpy() for n, t in g.items()}
-        pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (lik.variance, host["noise_variance"]),
-                 (iv.Z, host["Z"]), (self.q_mu, host["q_mu"]), (self.q_sqrt, host["q_sqrt"])]
+        common = dict(noise_variance=lik.noise_variance(), jitter=config.default_jitter(), scale=scale)
+        pairs = []
+        if sep is None:
+            k, iv, c = single
+            Zs, Xs, scatter = self._sliced(k, iv.Z.device_value(), X)
+            _, var, ls = k.hyper()
+            F, g, info = fn(Zs, Xs, Y, self.q_mu.device_value(), self.q_sqrt.device_value(), variance=var, lengthscales=ls,
+                            mean_const=float(c), **common)
+            ops.check_info(info)
+            Fv = float(F.cpu()[0])
+            host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
+            pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (iv.Z, host["Z"])]
+            g_noise, g_mean, g_qmu, g_qs = host["noise_variance"], host["mean_const"], host["q_mu"], host["q_sqrt"]
+        else:
+            # SeparateIndependent (conditionals/util.py:566-629): L independent single-output problems that share the
+            # likelihood, the mean constant and the rows of the minibatch; ELBO and the shared gradients are their sums
+            members, c = sep
+            q_mu, q_sqrt = self.q_mu.device_value(), self.q_sqrt.device_value()
+            Fv, g_noise, g_mean = 0.0, 0.0, 0.0
+            g_qmu = np.zeros(tuple(q_mu.shape))
+            g_qs = np.zeros(tuple(q_sqrt.shape))
+            zgrads = {}
+            for p_, (k, iv) in enumerate(members):
+                Zs, Xs, scatter = self._sliced(k, iv.Z.device_value(), X)
+                _, var, ls = k.hyper()
+                F, g, info = fn(Zs, Xs, Y[:, p_:p_ + 1].contiguous(), q_mu[:, p_:p_ + 1].contiguous(), q_sqrt[p_:p_ + 1].contiguous(),
+                                variance=var, lengthscales=ls, mean_const=float(c), **common)
+                ops.check_info(info)
+                Fv += float(F.cpu()[0])
+                host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
+                pairs += [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"])]
+                zgrads[id(iv.Z)] = (iv.Z, zgrads.get(id(iv.Z), (None, 0.0))[1] + host["Z"])  # shared Z: contributions add up
+                g_noise = g_noise + host["noise_variance"]
+                g_mean = g_mean + host["mean_const"]
+                g_qmu[:, p_:p_ + 1] = host["q_mu"]
+                g_qs[p_:p_ + 1] = host["q_sqrt"]
+            pairs += list(zgrads.values())
+        pairs += [(lik.variance, g_noise), (self.q_mu, g_qmu), (self.q_sqrt, g_qs)]
         if isinstance(mf, Constant):
-            pairs.append((mf.c, host["mean_const"]))
+            pairs.append((mf.c, g_mean))
         out = {}
         for par, gc in pairs:
             if not par.trainable:
@@ -161,10 +235,11 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                 raise NotImplementedError("parameter priors are not differentiated here")
             u = par.unconstrained_variable
             if isinstance(par.transform, FillTriangular):   # linear embedding: the vector entries are the lower-triangular ones
-                out[par] = par.transform.inverse(np.asarray(gc, dtype=np.float64)).reshape(u.shape)
+                gu = par.transform.inverse(np.asarray(gc, dtype=np.float64)).reshape(u.shape)
             else:
-                out[par] = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
-        return float(F.cpu()[0]), out
+                gu = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+            out[par] = out[par] + gu if par in out else gu
+        return Fv, out
 
     def posterior(self, precompute_cache=posteriors.PrecomputeCacheType.TENSOR):
         """svgp.py:210-240"""

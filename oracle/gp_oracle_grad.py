@@ -40,6 +40,15 @@ def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_varianc
     if not whiten:
         A = torch.linalg.solve_triangular(Lm.T, A, upper=True)                              # :137-139
     fmean = A.T @ q_mu + mean                                                               # :144
+    if q_sqrt.dim() == 2:   # q_diag: q_sqrt [M, P] standard deviations (:147-149, 164; kullback_leiblers.py:131-148)
+        if not whiten:
+            raise NotImplementedError("q_diag is only restated for the whitened case here")
+        LTA = A[None, :, :] * q_sqrt.T[:, :, None]                                          # [P, M, B]
+        fvar = (fvar[None, :] + (LTA * LTA).sum(1)).T
+        ve = -0.5 * LOG2PI - 0.5 * torch.log(noise_variance) - 0.5 * ((Y - fmean) ** 2 + fvar) / noise_variance
+        kl = 0.5 * ((q_mu * q_mu).sum() - M * q_mu.shape[1] - torch.log(q_sqrt ** 2).sum() + (q_sqrt ** 2).sum())
+        scale = 1.0 if num_data is None else float(num_data) / B
+        return ve.sum() * scale - kl
     Lq = torch.tril(q_sqrt)                                                                 # :151
     LTA = Lq.transpose(1, 2) @ A                                                            # :157  [P, M, B]
     fvar = fvar[None, :] + (LTA * LTA).sum(1)                                               # :164  [P, B]

@@ -250,3 +250,100 @@ def test_shared_independent_svgp_gradients_and_trainer(gpu):
     tr = training.SVGPTrainer(m, learning_rate=2e-2)
     vals = [float(tr.step((X, Y)).cpu()[0]) for _ in range(15)]
     assert abs(vals[0] - rv) <= 1e-9 * abs(rv) and vals[-1] > vals[0]
+
+
+def test_active_dims_and_separate_independent_model_gradients(gpu):
+    """SVGP.elbo_and_grad beyond the plain kernel: (i) `active_dims` (the kernel sees a column subset; dF/dZ is zero
+    elsewhere, kernels/base.py:90-109), (ii) SeparateIndependent kernels over shared and over separate inducing points
+    (one single-output problem per latent, conditionals/util.py:566-629) -- against the autograd oracle on the
+    equivalent sliced / per-latent problems, and against the model's own fused forward."""
+    import gpflow_amd as gpflow
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(50, 240, 4, 1, 31)
+    dims = [3, 1]
+    ls = np.array([0.9, 1.4])
+    k = gpflow.kernels.SquaredExponential(variance=1.3, lengthscales=ls, active_dims=dims)
+    m = gpflow.models.SVGP(k, gpflow.likelihoods.Gaussian(0.2), Z.copy(), q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(), num_data=2000)
+    v, g = m.elbo_and_grad((X, Y))
+    rv, rg = orcg.svgp_elbo_value_and_grads(X[:, dims], Y, Z[:, dims], q_mu, q_sqrt, num_data=2000, variance=1.3, lengthscales=ls,
+                                            noise_variance=0.2)
+    assert abs(v - rv) <= 1e-9 * abs(rv) and abs(v - float(m.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+    gz = np.asarray(g[m.inducing_variable.Z])
+    np.testing.assert_allclose(gz[:, dims], rg["Z"], rtol=0, atol=1e-8 * np.abs(rg["Z"]).max())
+    assert np.all(gz[:, [0, 2]] == 0.0)
+    np.testing.assert_allclose(g[m.q_mu], rg["q_mu"], rtol=0, atol=1e-8 * np.abs(rg["q_mu"]).max())
+    # (ii) three latents, one kernel each; shared Z, then separate Z
+    P = 3
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(40, 200, 2, P, 33)
+    vs, lss = [1.0, 0.7, 1.4], [np.array([0.8, 1.1]), np.array([1.3, 0.9]), np.array([1.0, 1.6])]
+    for separate_z in (False, True):
+        Zs = [Z + 0.1 * p for p in range(P)] if separate_z else [Z] * P
+        kern = gpflow.kernels.SeparateIndependent([gpflow.kernels.SquaredExponential(variance=vs[p], lengthscales=lss[p]) for p in range(P)])
+        if separate_z:
+            iv = gpflow.inducing_variables.SeparateIndependentInducingVariables([gpflow.inducing_variables.InducingPoints(z.copy()) for z in Zs])
+        else:
+            iv = gpflow.inducing_variables.SharedIndependentInducingVariables(gpflow.inducing_variables.InducingPoints(Z.copy()))
+        m = gpflow.models.SVGP(kern, gpflow.likelihoods.Gaussian(0.2), iv, q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(), num_latent_gps=P,
+                               num_data=2000)
+        v, g = m.elbo_and_grad((X, Y))
+        rv, gq, gnoise, gzs = 0.0, [], 0.0, []
+        for p in range(P):
+            r, rg = orcg.svgp_elbo_value_and_grads(X, Y[:, p:p + 1], Zs[p], q_mu[:, p:p + 1], q_sqrt[p:p + 1], num_data=2000,
+                                                   variance=vs[p], lengthscales=lss[p], noise_variance=0.2)
+            rv += r; gq.append(rg["q_mu"]); gnoise += rg["noise_variance"]; gzs.append(rg["Z"])
+        assert abs(v - rv) <= 1e-9 * abs(rv), (v, rv)
+        assert abs(v - float(m.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+        np.testing.assert_allclose(g[m.q_mu], np.concatenate(gq, 1), rtol=0, atol=1e-8 * max(np.abs(q).max() for q in gq))
+        u = m.likelihood.variance.unconstrained_variable
+        np.testing.assert_allclose(np.asarray(g[m.likelihood.variance]).ravel(),
+                                   (np.ravel(gnoise) * m.likelihood.variance.transform.forward_grad(u)).ravel(), rtol=1e-8)
+        if separate_z:
+            for p in range(P):
+                zp = iv.inducing_variable_list[p].Z
+                np.testing.assert_allclose(g[zp], gzs[p], rtol=0, atol=1e-8 * np.abs(gzs[p]).max())
+        else:
+            np.testing.assert_allclose(g[iv.inducing_variable.Z], sum(gzs), rtol=0, atol=1e-8 * np.abs(sum(gzs)).max())
+
+
+@pytest.mark.parametrize("M,B,D,P", [(70, 300, 3, 2), (200, 640, 4, 1)])
+def test_q_diag_svgp_elbo_and_grad_vs_autograd_oracle(gpu, M, B, D, P):
+    """q_diag = True (q_sqrt [M, P] of standard deviations, svgp.py:90-148): value and every gradient of the whitened
+    reverse pass against the autograd oracle; the oracle's q_diag forward is itself pinned to the NumPy oracle."""
+    from gpflow_amd import gradients, ops
+    from oracle import gp_oracle as orc
+    X, Y, Z, q_mu, _, kw = _problem(M, B, D, P, 41)
+    q = 0.3 + np.abs(np.random.default_rng(42).normal(size=(M, P)))
+    t = ops.to_device
+    F, g, info = gradients.svgp_elbo_and_grad(t(Z), t(X), t(Y), t(q_mu), t(q), jitter=1e-6, scale=1000.0 / B, mean_const=0.1, **kw)
+    ops.check_info(info)
+    v, go = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q, num_data=1000, mean=0.1, **kw)
+    ref = orc.svgp_elbo(X, Y, Z, q_mu, q, num_data=1000, mean=0.1, whiten=True, **kw)
+    assert abs(v - ref) <= 1e-10 * abs(ref)
+    assert abs(float(F.cpu()[0]) - v) <= 1e-9 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt", "mean_const"):
+        got, refg = g[name].cpu().numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(refg.shape), refg, rtol=0, atol=1e-8 * max(1.0, np.abs(refg).max()), err_msg=name)
+
+
+def test_q_diag_model_gradients(gpu):
+    """SVGP(q_diag=True).elbo_and_grad in the unconstrained space (softplus on the standard deviations) against finite
+    differences of the model's own fused ELBO."""
+    import gpflow_amd as gpflow
+    X, Y, Z, q_mu, _, kw = _problem(40, 200, 2, 2, 43)
+    q = 0.3 + np.abs(np.random.default_rng(44).normal(size=(40, 2)))
+    m = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=kw["variance"], lengthscales=kw["lengthscales"]),
+                           gpflow.likelihoods.Gaussian(kw["noise_variance"]), Z.copy(), q_mu=q_mu.copy(), q_sqrt=q.copy(), q_diag=True,
+                           num_latent_gps=2, num_data=2000)
+    v, g = m.elbo_and_grad((X, Y))
+    assert abs(v - float(m.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+    h = 1e-5
+    for par, idx in [(m.q_sqrt, (7, 1)), (m.q_sqrt, (31, 0)), (m.q_mu, (3, 1)), (m.kernel.lengthscales, (0,)), (m.inducing_variable.Z, (5, 1))]:
+        u0 = np.array(par.unconstrained_variable, dtype=np.float64, copy=True)
+        vals = []
+        for d in (h, -h):
+            u = u0.copy(); u[idx] += d
+            par.assign_unconstrained(u)
+            vals.append(float(m.elbo((X, Y)).cpu()))
+        par.assign_unconstrained(u0)
+        fd = (vals[0] - vals[1]) / (2 * h)
+        got = float(np.asarray(g[par])[idx])
+        assert abs(got - fd) <= 1e-5 * max(1.0, abs(fd)), (par.name, idx, got, fd)

@@ -222,9 +222,13 @@ def test_gradient_entry_points_refuse_unsupported_models_before_touching_the_dev
         with pytest.raises(NotImplementedError):
             training.SVGPTrainer(m)
         with pytest.raises(NotImplementedError):
-            m.elbo_and_grad(data)
-        with pytest.raises(NotImplementedError):
             gpflow.optimizers.NaturalGradient(1.0).minimize(m, data)
+    # (round 3: SVGP.elbo_and_grad itself covers q_diag and active_dims -- tests/test_gpu_gradients.py; Matern stays out)
+    with pytest.raises(NotImplementedError):
+        matern.elbo_and_grad(data)
+    unwhitened_qdiag = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), lik, Z, q_diag=True, whiten=False)
+    with pytest.raises(NotImplementedError):
+        unwhitened_qdiag.elbo_and_grad(data)
     with pytest.raises(NotImplementedError):
         gpflow.optimizers.Scipy().minimize(object())
 
