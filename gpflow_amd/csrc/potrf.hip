@@ -122,6 +122,36 @@ int aux_create(Aux& a, int dev) {
   return masked_stream(&a.Bl, ncu, late_res, ncu);
 }
 
+// Cost of one cross-stream hand-off (kernel on a -> event -> kernel on b -> event -> ...), microseconds: ~5 when the two
+// hardware queues sit on different microengine pipes, ~50 when they share one.
+int handoff_us(hipStream_t a, hipStream_t b, double* us) {
+  const int n = 24;
+  hipEvent_t e0, e1, ea, eb;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  GPK_HIP(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+  GPK_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+  int rc = 0;
+  for (int rep = 0; rep < 2 && !rc; ++rep) {  // (first repetition warms the queues up)
+    GPK_HIP(hipEventRecord(e0, a));
+    for (int i = 0; i < n && !rc; ++i) {
+      rc = gpk_launch_noop(a);
+      if (!rc) rc = (int)hipEventRecord(ea, a);
+      if (!rc) rc = (int)hipStreamWaitEvent(b, ea, 0);
+      if (!rc) rc = gpk_launch_noop(b);
+      if (!rc) rc = (int)hipEventRecord(eb, b);
+      if (!rc) rc = (int)hipStreamWaitEvent(a, eb, 0);
+    }
+    if (!rc) rc = (int)hipEventRecord(e1, a);
+    if (!rc) rc = (int)hipEventSynchronize(e1);
+  }
+  float ms = 0.f;
+  if (!rc) rc = (int)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+  *us = (double)ms * 1e3 / (2.0 * n);
+  return rc;
+}
+
 // (caller holds a.mu)
 int aux_get(int dev, int need, Aux** out) {
   Aux& a = g_aux[dev];
@@ -135,6 +165,12 @@ int aux_get(int dev, int need, Aux** out) {
       }
       a.init_rc = rc;
       return rc;
+    }
+    if (kGpkExp && GPK_TUNE(STREAM_SELFTEST, 0)) {
+      double pq = 0, pb = 0, xb = 0, pm = 0;
+      (void)handoff_us(a.P, a.X, &pq); (void)handoff_us(a.P, a.Bs, &pb); (void)handoff_us(a.X, a.Bs, &xb);
+      (void)handoff_us(a.P, a.B, &pm);
+      fprintf(stderr, "[gpk] stream hand-off us: P<->X %.1f  P<->Bs %.1f  X<->Bs %.1f  P<->B(masked) %.1f\n", pq, pb, xb, pm);
     }
     a.ready = true;
   }
