@@ -152,6 +152,33 @@ int handoff_us(hipStream_t a, hipStream_t b, double* us) {
   return rc;
 }
 
+// Per-kernel cost (microseconds) of n empty kernels on EACH of the given streams while all of them are being fed at the
+// same time -- two active hardware queues on one microengine pipe show up here ("pipes").
+int concurrent_us(hipStream_t* st, int ns, double* us) {
+  const int n = 48;
+  hipEvent_t e0[4], e1[4];
+  for (int i = 0; i < ns; ++i) {
+    GPK_HIP(hipEventCreate(&e0[i]));
+    GPK_HIP(hipEventCreate(&e1[i]));
+  }
+  int rc = 0;
+  for (int rep = 0; rep < 2 && !rc; ++rep) {
+    for (int i = 0; i < ns && !rc; ++i) rc = (int)hipEventRecord(e0[i], st[i]);
+    for (int k = 0; k < n && !rc; ++k)
+      for (int i = 0; i < ns && !rc; ++i) rc = gpk_launch_noop(st[i]);
+    for (int i = 0; i < ns && !rc; ++i) rc = (int)hipEventRecord(e1[i], st[i]);
+    for (int i = 0; i < ns && !rc; ++i) rc = (int)hipEventSynchronize(e1[i]);
+  }
+  for (int i = 0; i < ns; ++i) {
+    float ms = 0.f;
+    if (!rc) rc = (int)hipEventElapsedTime(&ms, e0[i], e1[i]);
+    us[i] = (double)ms * 1e3 / n;
+    (void)hipEventDestroy(e0[i]);
+    (void)hipEventDestroy(e1[i]);
+  }
+  return rc;
+}
+
 // (caller holds a.mu)
 int aux_get(int dev, int need, Aux** out) {
   Aux& a = g_aux[dev];
@@ -170,7 +197,11 @@ int aux_get(int dev, int need, Aux** out) {
       double pq = 0, pb = 0, xb = 0, pm = 0;
       (void)handoff_us(a.P, a.X, &pq); (void)handoff_us(a.P, a.Bs, &pb); (void)handoff_us(a.X, a.Bs, &xb);
       (void)handoff_us(a.P, a.B, &pm);
-      fprintf(stderr, "[gpk] stream hand-off us: P<->X %.1f  P<->Bs %.1f  X<->Bs %.1f  P<->B(masked) %.1f\n", pq, pb, xb, pm);
+      hipStream_t trio[3] = {a.P, a.X, a.Bs};
+      double cu[3] = {0, 0, 0};
+      (void)concurrent_us(trio, 3, cu);
+      fprintf(stderr, "[gpk] stream hand-off us: P<->X %.1f  P<->Bs %.1f  X<->Bs %.1f  P<->B(masked) %.1f | concurrent noop us/kernel: P %.1f X %.1f Bs %.1f\n",
+              pq, pb, xb, pm, cu[0], cu[1], cu[2]);
     }
     a.ready = true;
   }
