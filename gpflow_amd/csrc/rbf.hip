@@ -46,12 +46,32 @@ __device__ __forceinline__ double kern_eval(double r2, double variance) {
   return variance * (1.0 + sqrt5 * r + 5.0 / 3.0 * (r * r)) * exp(-sqrt5 * r);
 }
 
+// -2 dk/dr2 at the SCALED squared distance: the factor every lengthscale / input gradient of a stationary kernel starts
+// from (for the SquaredExponential it is k itself).  r = sqrt(max(r2, 1e-36)) has derivative 0 where the clamp is
+// active (stationaries.py:103-116 under TF autodiff: tf.maximum passes nothing to the clamped argument).
+template <int family>
+__device__ __forceinline__ double kern_dr2(double r2, double variance) {
+  if (family == GPK_KERN_SE) return variance * exp(-0.5 * r2);
+  if (!(r2 > 1e-36)) return 0.0;
+  const double r = sqrt(r2);
+  if (family == GPK_KERN_MATERN12) return variance * exp(-r) / r;
+  if (family == GPK_KERN_MATERN32) {
+    const double sqrt3 = 1.7320508075688772;
+    return 3.0 * variance * exp(-sqrt3 * r);
+  }
+  const double sqrt5 = 2.23606797749979;
+  return (5.0 / 3.0) * variance * (1.0 + sqrt5 * r) * exp(-sqrt5 * r);
+}
+
 // MIRROR (symmetric full build): only tiles on or below the diagonal are computed; each is also written
 // transposed to its mirror position (K(X,X) from the expansion formula is bitwise symmetric: products and the
 // two-term sums commute), which halves the fp64 exp/FMA work of what is otherwise a store-bound kernel.
 // COMB = 0: plain build.  COMB = 1 / 2: out = G .* k / G + k, the other factor / term G read from memory (may alias
 // the output: every element is read and written by the same thread) -- kernel products and sums (kernels/base.py:216-
 // 329) and the elementwise factor of the kernel backward, without materialising the second matrix.
+// COMB = 3: out = G .* (-2 dk/dr2); with comb_diag (X2 is X1) the diagonal is written as exact zeros: r2_ii = 0 for
+// every parameter value, so it carries no gradient (autodiff of the expansion formula gets rounding noise there,
+// amplified by 1/r for Matern12).
 template <int FAMILY, int COMB = 0>
 __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -115,12 +135,12 @@ __global__ __launch_bounds__(256) void rbf_kernel(RbfArgs p) {
     for (int j = 0; j < 4; ++j) {
       const int gc = c0 + tx * 4 + j;
       const double r2 = (-2.0 * dot[i][j]) + (ni + nr2[tx * 4 + j]);
-      double k = kern_eval<FAMILY>(r2, p.variance);
+      double k = (COMB == 3) ? kern_dr2<FAMILY>(r2, p.variance) : kern_eval<FAMILY>(r2, p.variance);
       if (p.sym && gr == gc) k += p.diag_add;
       if constexpr (COMB != 0) {
         const double g = (gr < p.n1 && gc < p.n2) ? p.G[(long)gr * p.ldg + gc] : 0.0;
-        k = (COMB == 1) ? k * g : k + g;
-        if (p.comb_diag && gr == gc) k += p.diag_add;
+        k = (COMB == 2) ? k + g : k * g;
+        if (p.comb_diag && gr == gc) k = (COMB == 3) ? 0.0 : k + p.diag_add;
       }
       v[i][j] = k;
     }
@@ -252,7 +272,7 @@ extern "C" int gpk_kernel_matrix_combine(void* stream, int family, int op, const
                                          long ldo) {
   if (!X1 || !G || !out || !ls_host || n1 < 0 || n2 < 0 || d <= 0 || d > GPK_MAX_D) return GPK_E_ARG;
   if (family < GPK_KERN_SE || family > GPK_KERN_MATERN52) return GPK_E_UNSUPPORTED;
-  if (op != 1 && op != 2) return GPK_E_ARG;
+  if (op < 1 || op > 3) return GPK_E_ARG;
   RbfArgs a{};
   a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1;
   a.sym = 0;
@@ -265,6 +285,7 @@ extern "C" int gpk_kernel_matrix_combine(void* stream, int family, int op, const
   if (a.n1 == 0 || a.n2 == 0) return 0;
   const size_t lds = ((size_t)2 * d * T + 2 * T) * sizeof(double);
   dim3 grid((unsigned)gpk_cdiv(a.n2, T), (unsigned)gpk_cdiv(a.n1, T));
+  if (op == 3) return launch_combine<3>((hipStream_t)stream, family, a, grid, lds);
   return op == 1 ? launch_combine<1>((hipStream_t)stream, family, a, grid, lds)
                  : launch_combine<2>((hipStream_t)stream, family, a, grid, lds);
 }

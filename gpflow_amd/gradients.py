@@ -100,22 +100,35 @@ def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor) 
     return S.add_(ops.transpose(S)).mul_(0.5)
 
 
-def se_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, variance: float, lengthscales,
-                      symmetric: bool):
-    """Adjoint of K = variance * exp(-0.5 r2(A / ls, Bm / ls)) [n1, n2] given Kbar [n1, n2].
+def stationary_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, variance: float, lengthscales,
+                              symmetric: bool, family: str = "SquaredExponential"):
+    """Adjoint of K = variance * f(r(A / ls, Bm / ls)) [n1, n2] given Kbar [n1, n2], f one of the stationary families of
+    `ops.KERNEL_FAMILIES` (stationaries.py:209-210 SquaredExponential, :254-313 Matern12 / 32 / 52).
 
     Returns (d/dvariance, d/dlengthscales [D], A_bar [n1, D]); with symmetric=True (Bm is A, Kbar symmetric) A_bar
-    collects both arguments.  B_bar of the non-symmetric case is not needed on this path (B = the minibatch)."""
+    collects both arguments.  B_bar of the non-symmetric case is not needed on this path (B = the minibatch).
+
+    With r2 the scaled squared distance, dF/dtheta = sum_ij Kbar_ij dK_ij/dr2 dr2_ij/dtheta.  G = Kbar .* (-2 dK/dr2) is
+    one elementwise pass that recomputes r2 from the inputs (`gpk_kernel_matrix_combine` op 3); for the
+    SquaredExponential -2 dK/dr2 = K, so G also carries d/dvariance = sum(Kbar .* K) / variance; the Matern families
+    take that sum from a second pass (op 1)."""
     n1, D = A.shape
     ls = torch.as_tensor(np.broadcast_to(np.asarray(lengthscales, dtype=np.float64), (D,)).copy(), device=A.device)
-    G = ops.kernel_matrix_hadamard(A, Bm, Kbar, variance=variance, lengthscales=lengthscales)   # Kbar .* K
+    if family == "SquaredExponential":
+        G = ops.kernel_matrix_hadamard(A, Bm, Kbar, variance=variance, lengthscales=lengthscales)   # Kbar .* K
+        sum_kbar_k = None
+    else:
+        G = ops.kernel_matrix_hadamard(A, Bm, Kbar, variance=variance, lengthscales=lengthscales, family=family)
+        sum_kbar_k = G.sum()
+        ops.kernel_matrix_combine(A, None if symmetric else Bm, Kbar, op="dr2", variance=variance,
+                                  lengthscales=lengthscales, family=family, out=G)
     Vt = torch.empty((1 + 2 * D, Bm.shape[0]), dtype=torch.float64, device=A.device)             # [1, B, B^2]^T
     Vt[0] = 1.0
     Vt[1:1 + D] = Bm.t()
     torch.mul(Vt[1:1 + D], Vt[1:1 + D], out=Vt[1 + D:])
     R = splitk_gemm_nt(G, Vt)                        # [n1, 1 + 2D] = G [1, B, B^2]
     rs, GB, GB2 = R[:, 0:1], R[:, 1:1 + D], R[:, 1 + D:]
-    dvar = rs.sum() / variance
+    dvar = (rs.sum() if sum_kbar_k is None else sum_kbar_k) / variance
     T = torch.addcmul(GB, A, rs, value=-1.0)         # G B - A rowsum(G)
     if symmetric:   # both arguments: A_bar = 2 T / ls^2,  d/dls = (2 sum A^2 rs - 2 sum A GB) / ls^3 = -sum(A A_bar) / ls
         Abar = T * (2.0 / (ls * ls))
@@ -126,9 +139,12 @@ def se_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, 
     return dvar, dls, Abar
 
 
+se_kernel_adjoint = stationary_kernel_adjoint   # (the name of rounds 1-2)
+
+
 def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor, q_sqrt: torch.Tensor,
                        *, variance: float, lengthscales, noise_variance: float, jitter: float, scale: float = 1.0,
-                       mean_const: float = 0.0, kl_weight: float = 1.0
+                       mean_const: float = 0.0, kl_weight: float = 1.0, family: str = "SquaredExponential"
                        ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """F = scale * sum_b var_exp_b - kl_weight * KL for the whitened SVGP with a SquaredExponential kernel, a Gaussian likelihood
     and a full q_sqrt [P, M, M], and dF/d{variance, lengthscales, noise_variance, Z, q_mu, q_sqrt, mean_const}.
@@ -143,7 +159,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     if tuple(q_sqrt.shape) not in ((P, M, M), (M, P)):
         raise ValueError("svgp_elbo_and_grad needs q_sqrt [P, M, M] or, for q_diag, [M, P]")
     dev = Z.device
-    kw = dict(variance=variance, lengthscales=lengthscales)
+    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
 
     # ---------------------------------------------------------------- forward (intermediates kept)
     # trapezoid = [Kuu + jitter I ; Kfu ; I]: the factorisation returns Lm, At = Kfu Lm^-T and, from the identity
@@ -205,8 +221,8 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     try:
         Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)            # -tril(Kfu_bar^T At)
         Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
-        dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
-        dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+        dv1, dl1, Zb1 = stationary_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
+        dv2, dl2, Zb2 = stationary_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
     finally:
         if side is not None:
             main.wait_stream(side)
@@ -229,7 +245,8 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
 
 
 def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
-                     mean_const: float = 0.0) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+                     mean_const: float = 0.0, family: str = "SquaredExponential"
+                     ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """GPR.log_marginal_likelihood (gpr.py:91-107) and its gradient w.r.t. {variance, lengthscales, noise_variance,
     mean_const} for a SquaredExponential kernel -- what `optimizers/scipy.py:322-331` asks TF autodiff for.
 
@@ -241,7 +258,7 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
     N, D = X.shape
     P = Y.shape[1]
     dev = X.device
-    kw = dict(variance=variance, lengthscales=lengthscales)
+    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
     T = torch.empty((N + P + N, N), dtype=torch.float64, device=dev)
     ops.kernel_matrix(X, None, diag_add=noise_variance, lower_only=False, out=T[:N], **kw)
     T[N:N + P] = (Y - mean_const).t()
@@ -256,7 +273,7 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
     ops.gemm_nt(beta, beta, alpha=0.5, beta=-0.5 * P, C=Kbar, c_lower=True)             # 0.5 beta beta^T - 0.5 P K^-1
     low = torch.tril(Kbar)
     Kbar = low + torch.tril(low, -1).t()                                                # symmetric, full
-    dvar, dls, _ = se_kernel_adjoint(X, X, Kbar, symmetric=True, **kw)
+    dvar, dls, _ = stationary_kernel_adjoint(X, X, Kbar, symmetric=True, **kw)
     if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
         dls = dls.sum().reshape(1)
     grads = {"variance": dvar.reshape(1), "lengthscales": dls, "noise_variance": torch.diagonal(Kbar).sum().reshape(1),
@@ -265,7 +282,8 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
 
 
 def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales,
-                       noise_variance: float, jitter: float, mean_const: float = 0.0
+                       noise_variance: float, jitter: float, mean_const: float = 0.0,
+                       family: str = "SquaredExponential"
                        ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """SGPR.elbo (sgpr.py:181-290) and its gradient w.r.t. {variance, lengthscales, noise_variance, Z, mean_const}
     (single process; SquaredExponential).  With At = Kfu Lm^-T, S = At^T At, a = At^T err, q = |At|^2, e2 = |err|^2,
@@ -279,7 +297,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     N, P = Y.shape
     dev = Z.device
     s2 = float(noise_variance)
-    kw = dict(variance=variance, lengthscales=lengthscales)
+    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
     eye = torch.eye(M, dtype=torch.float64, device=dev)
     T = torch.empty((M + N + M, M), dtype=torch.float64, device=dev)
     ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
@@ -314,8 +332,8 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     Kuf_bar = ops.transpose(Kfu_bar)
     Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
-    dv1, dl1, Zb1 = se_kernel_adjoint(Z, X, Kuf_bar, symmetric=False, **kw)
-    dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+    dv1, dl1, Zb1 = stationary_kernel_adjoint(Z, X, Kuf_bar, symmetric=False, **kw)
+    dv2, dl2, Zb2 = stationary_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
     g_var = dv1 + dv2 - 0.5 * P * N / s2
     g_ls = dl1 + dl2
     if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
@@ -331,8 +349,9 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
 
 def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor,
                                   q_sqrt: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
-                                  jitter: float, scale: float = 1.0, mean_const: float = 0.0, kl_weight: float = 1.0
-                                  ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+                                  jitter: float, scale: float = 1.0, mean_const: float = 0.0, kl_weight: float = 1.0,
+                                  family: str = "SquaredExponential"
+                       ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """The `whiten=False` SVGP: q(u) = N(q_mu, Lq Lq^T) on u itself (conditionals/util.py:137-139, kullback_leiblers.py:
     98-165 with K = Kuu).  With Linv = Lm^-1 (from the identity rows of the trapezoid):
 
@@ -341,16 +360,20 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
         backward  A2t_bar = r q_mu^T + 2c sum_p W_p Lq_p^T,   At_bar = -2cP At + A2t_bar Linv^T,
                   Linv_bar = tril(At^T A2t_bar) - k (alpha q_mu^T + sum_p V_p Lq_p^T)      (alpha = Linv q_mu, V_p = Linv Lq_p)
                   Lm_bar   = -tril(Kfu_bar^T At) - tril(Linv^T Linv_bar Linv^T) - k P diag(1 / Lm)
-    and then the same Cholesky / kernel adjoints as the whitened path.  Reached through `SVGP.elbo_and_grad` /
+    and then the same Cholesky / kernel adjoints as the whitened path.  q_diag (q_sqrt [M, P] of standard deviations;
+    conditionals/util.py:147-149, kullback_leiblers.py:131-133, 146-152) is the same algebra with Lq_p = diag(q_p): W_p =
+    A2t diag(q_p) is never formed (row statistics with weights), sum_p V_p Lq_p^T = Linv diag(sum_p q_p^2), and the trace
+    term is sum_m (Kuu^-1)_mm sum_p q_mp^2 with diag(Kuu^-1) = column sums of Linv^2.  Reached through `SVGP.elbo_and_grad` /
     `SVGPTrainer` when `whiten=False`; parity vs the autograd oracle on the emulated primitives
     (tests/test_gradients_cpu.py) and on the GPU (tests/test_gpu_gradients.py)."""
     M, D = Z.shape
     B = Xb.shape[0]
     P = q_mu.shape[1]
-    if q_sqrt.dim() != 3 or tuple(q_sqrt.shape) != (P, M, M):
-        raise ValueError("needs the full q_sqrt [P, M, M]")
+    q_diag = q_sqrt.dim() == 2
+    if tuple(q_sqrt.shape) not in ((P, M, M), (M, P)):
+        raise ValueError("svgp_elbo_and_grad_unwhitened needs q_sqrt [P, M, M] or, for q_diag, [M, P]")
     dev = Z.device
-    kw = dict(variance=variance, lengthscales=lengthscales)
+    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
     k = float(kl_weight)
     T = torch.empty((M + B + M, M), dtype=torch.float64, device=dev)
     ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
@@ -358,27 +381,37 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
     L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
     Linv = ops.transpose(LinvT)                                                         # lower
-    Lq = _tril(q_sqrt)        
-    LqT = ops.transpose(q_sqrt, mode=1)
     A2t = ops.gemm_nt(At, LinvT, b_tri=1)                                               # At Linv   (util.py:139)
     s0 = ops.row_stats(At)[0]
-    _, fmean, _ = ops.row_stats(A2t, V=q_mu, want_sumsq=False)
-    W = ops.gemm_nt(A2t, LqT, b_tri=1)                                                  # [P, B, M]
-    ssq = torch.stack([ops.row_stats(W[p])[0] for p in range(P)])
+    alphat = ops.gemm_nt(q_mu.t().contiguous(), Linv, b_tri=2)                          # (Linv q_mu)^T  [P, M]
+    if q_diag:
+        qd = q_sqrt.contiguous()
+        s = (qd * qd).sum(1)                                                            # sum_p q_mp^2  [M]
+        _, fmean, ssq = ops.row_stats(A2t, V=q_mu, W=qd)                                # A2t q_mu, sum_m A2t^2 q_mp^2
+        kinv_diag = ops.row_stats(LinvT)[0]                                             # diag(Kuu^-1) = rowsum((Lm^-T)^2)
+        kl = 0.5 * (ops.sumsq(alphat)[0] - M * P - torch.log(qd * qd).sum() + (kinv_diag * s).sum()) \
+            + P * ops.sum_log_diag(L)[0]
+    else:
+        Lq = _tril(q_sqrt)
+        LqT = ops.transpose(q_sqrt, mode=1)
+        _, fmean, _ = ops.row_stats(A2t, V=q_mu, want_sumsq=False)
+        W = ops.gemm_nt(A2t, LqT, b_tri=1)                                              # [P, B, M]
+        ssq = torch.stack([ops.row_stats(W[p])[0] for p in range(P)])
+        V = ops.gemm_nt(Linv, LqT, b_tri=1, a_tri=2)                                    # [P, M, M]: V_p = Linv Lq_p
+        if V.dim() == 2:
+            V = V.unsqueeze(0)
+        kl = 0.5 * (ops.sumsq(alphat)[0] - M * P - torch.log(Lq.diagonal(dim1=1, dim2=2) ** 2).sum()
+                    + sum(ops.sumsq(V[p])[0] for p in range(P))) + P * ops.sum_log_diag(L)[0]
     ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
                                     mean_const=mean_const)
-    alphat = ops.gemm_nt(q_mu.t().contiguous(), Linv, b_tri=2)                          # (Linv q_mu)^T  [P, M]
-    V = ops.gemm_nt(Linv, LqT, b_tri=1, a_tri=2)                                                 # [P, M, M]: V_p = Linv Lq_p
-    if V.dim() == 2:
-        V = V.unsqueeze(0)
-    kl = 0.5 * (ops.sumsq(alphat)[0] - M * P - torch.log(Lq.diagonal(dim1=1, dim2=2) ** 2).sum()
-                + sum(ops.sumsq(V[p])[0] for p in range(P))) + P * ops.sum_log_diag(L)[0]
     F = scale * ve - k * kl
     # ---- backward
     c = -0.5 * scale / noise_variance
     r = (scale / noise_variance) * (Yb - fmean - mean_const)
     A2tb = ops.gemm_nt(r, q_mu)
-    for p in range(P):
+    if q_diag:
+        A2tb.addcmul_(A2t, (2.0 * c) * s[None, :])
+    for p in range(0 if q_diag else P):
         ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=A2tb, b_tri=2)
     Atb = ops.gemm_nt(A2tb, Linv, b_tri=2)                                              # A2t_bar Linv^T
     Atb.add_(At, alpha=-2.0 * c * P)
@@ -389,23 +422,28 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     # q(u) gradients: data part through A2t, KL part through Kuu^-1
     Kinv_qmu_t = ops.gemm_nt(alphat, LinvT, b_tri=1)                                    # (Linv^T alpha)^T  [P, M]
     g_qmu = splitk_gemm_nt(A2, r.t().contiguous()) - k * Kinv_qmu_t.t()
-    g_qs = torch.stack([splitk_gemm_nt(A2, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c) for p in range(P)])
-    for p in range(P):
-        KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p], mode=1), b_tri=1, a_tri=1)              # Linv^T V_p = Kuu^-1 Lq_p (V_p lower)
-        g_qs[p] -= k * torch.tril(KinvLq)
-    g_qs.diagonal(dim1=1, dim2=2).add_(k / Lq.diagonal(dim1=1, dim2=2))
+    if q_diag:   # d/dq_mp = 2c colsum(A2t^2)_m q_mp - k ((Kuu^-1)_mm q_mp - 1 / q_mp)
+        g_qs = (2.0 * c) * ops.row_stats(A2)[0][:, None] * qd - k * (kinv_diag[:, None] * qd - 1.0 / qd)
+    else:
+        g_qs = torch.stack([splitk_gemm_nt(A2, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c) for p in range(P)])
+        for p in range(P):
+            KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p], mode=1), b_tri=1, a_tri=1)  # Linv^T V_p = Kuu^-1 Lq_p (V_p lower)
+            g_qs[p] -= k * torch.tril(KinvLq)
+        g_qs.diagonal(dim1=1, dim2=2).add_(k / Lq.diagonal(dim1=1, dim2=2))
     # Linv_bar (lower) and its pull-back to Lm
     Linv_bar = splitk_gemm_nt(A, ops.transpose(A2tb), c_lower=True)         # tril(At^T A2t_bar)
     Linv_bar -= k * torch.tril(ops.gemm_nt(alphat.t().contiguous(), q_mu))              # alpha q_mu^T
-    for p in range(P):
+    if q_diag:
+        Linv_bar -= k * torch.tril(Linv) * s[None, :]                                   # Linv diag(sum_p q_p^2)
+    for p in range(0 if q_diag else P):
         Linv_bar -= k * torch.tril(ops.gemm_nt(V[p], Lq[p], b_tri=2))                   # V_p Lq_p^T
     X1 = ops.gemm_nt(LinvT, ops.transpose(Linv_bar, mode=1), b_tri=1, a_tri=1)                   # Linv^T Linv_bar (Linv_bar lower)
     X2 = ops.gemm_nt(X1, Linv, b_tri=2)                                                 # (.) Linv^T
     Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0) - torch.tril(X2)
     Lbar.diagonal().sub_(k * P / L.diagonal())
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
-    dv1, dl1, Zb1 = se_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
-    dv2, dl2, Zb2 = se_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+    dv1, dl1, Zb1 = stationary_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
+    dv2, dl2, Zb2 = stationary_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
     g_var = dv1 + dv2 + c * B * P
     g_ls = dl1 + dl2
     if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:

@@ -59,22 +59,22 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
 
     def log_marginal_likelihood_and_grad(self):
         """(LML as a float, {Parameter: dLML/d(unconstrained value) as NumPy}) for the trainable parameters -- what
-        `optimizers/scipy.py:322-331` obtains from TF autodiff.  SquaredExponential kernel, constant / zero mean,
-        constant noise variance (gradients.gpr_lml_and_grad); anything else raises NotImplementedError."""
+        `optimizers/scipy.py:322-331` obtains from TF autodiff.  SquaredExponential or Matern12 / 32 / 52 kernel (with `active_dims`), constant / zero
+        mean, constant noise variance (gradients.gpr_lml_and_grad); anything else raises NotImplementedError."""
         import numpy as np
         from .. import gradients
-        from ..kernels.stationaries import SquaredExponential
+        from ..kernels.stationaries import IsotropicStationary
         from ..mean_functions import Constant
         k, lik, mf = self.kernel, self.likelihood, self.mean_function
         c = mf.constant_value()
-        if not isinstance(k, SquaredExponential) or c is None or lik.variance is None \
-                or not k.has_default_active_dims:
-            raise NotImplementedError("gradients: SquaredExponential kernel (no active_dims), constant mean, Gaussian "
+        if not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES) or c is None or lik.variance is None:
+            raise NotImplementedError("gradients: SquaredExponential / Matern kernel, constant mean, Gaussian "
                                       "likelihood with a variance parameter")
         X, Y = self.data
-        _, var, ls = k.hyper()
-        lml, g, info = gradients.gpr_lml_and_grad(X, Y, variance=var, lengthscales=ls,
-                                                  noise_variance=lik.noise_variance(), mean_const=c)
+        X, _ = k.slice(X, None)    # active_dims (kernels/base.py:90-109); nothing is differentiated w.r.t. X
+        family, var, ls = k.hyper()
+        lml, g, info = gradients.gpr_lml_and_grad(X.contiguous(), Y, variance=var, lengthscales=ls,
+                                                  noise_variance=lik.noise_variance(), mean_const=c, family=family)
         ops.check_info(info)
         host = {n: t.cpu().numpy() for n, t in g.items()}
         pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (lik.variance, host["noise_variance"])]

@@ -161,18 +161,21 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
     def objective_and_grad(self):
         """(ELBO as a float, {Parameter: dELBO/d(unconstrained value)}) for the trainable parameters among kernel variance,
         lengthscales, noise variance, Z and a Constant mean -- the gradient `optimizers/scipy.py:322-331` takes from TF
-        (gradients.sgpr_elbo_and_grad; single process, SquaredExponential kernel)."""
-        from ..kernels.stationaries import SquaredExponential
+        (gradients.sgpr_elbo_and_grad; single process; SquaredExponential or Matern12 / 32 / 52 kernel, `active_dims`
+        allowed: dELBO/dZ is zero in the columns the kernel does not see)."""
+        from ..kernels.stationaries import IsotropicStationary
         from ..mean_functions import Constant
+        from .svgp import SVGP
         if self.sharded:
             raise NotImplementedError("gradients of a row-sharded SGPR")
-        kw, X, Z, c, s2 = self._config()
-        if not isinstance(self.kernel, SquaredExponential) or not self.kernel.has_default_active_dims:
-            raise NotImplementedError("gradients: SquaredExponential kernel without active_dims")
-        F, g, info = gradients.sgpr_elbo_and_grad(Z, X, self.data[1], variance=kw["variance"], lengthscales=kw["lengthscales"],
-                                                  noise_variance=s2, jitter=config.default_jitter(), mean_const=c)
+        kw, _, _, c, s2 = self._config()
+        if not (isinstance(self.kernel, IsotropicStationary) and kw["family"] in ops.KERNEL_FAMILIES):
+            raise NotImplementedError("gradients: SquaredExponential / Matern kernel")
+        Z, X, scatter = SVGP._sliced(self.kernel, self.inducing_variable.Z.device_value(), self.data[0])
+        F, g, info = gradients.sgpr_elbo_and_grad(Z, X, self.data[1], noise_variance=s2, jitter=config.default_jitter(),
+                                                  mean_const=c, **kw)
         ops.check_info(info)
-        host = {n: t.cpu().numpy() for n, t in g.items()}
+        host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
         pairs = [(self.kernel.variance, host["variance"]), (self.kernel.lengthscales, host["lengthscales"]),
                  (self.likelihood.variance, host["noise_variance"]), (self.inducing_variable.Z, host["Z"])]
         if isinstance(self.mean_function, Constant):

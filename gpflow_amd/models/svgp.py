@@ -113,30 +113,31 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         return terms[0] * scale - terms[1]
 
     def gradient_config(self, allow_active_dims: bool = False, allow_q_diag: bool = False):
-        """(SquaredExponential kernel, InducingPoints, mean constant) if the hand-written reverse pass covers this model:
-        whitened or not, Gaussian likelihood with a variance parameter, full q_sqrt, constant mean, and ONE SquaredExponential
-        kernel (`active_dims`, and `q_diag` for a whitened model, only where the caller handles them itself: `elbo_and_grad`) over InducingPoints -- either directly or as SharedIndependent +
+        """(kernel, InducingPoints, mean constant) if the hand-written reverse pass covers this model: whitened or not,
+        Gaussian likelihood with a variance parameter, full q_sqrt, constant mean, and ONE isotropic stationary kernel
+        (SquaredExponential / Matern12 / 32 / 52; `active_dims` and `q_diag` only where the caller
+        handles them itself: `elbo_and_grad`) over InducingPoints -- either directly or as SharedIndependent +
         SharedIndependentInducingVariables (BASELINE config C5: P latents share Kuu / Kuf).  SeparateIndependent kernels
         are differentiated latent by latent (`_separate_gradient_config`).  Raises NotImplementedError."""
-        from ..kernels.stationaries import SquaredExponential
+        from ..kernels.stationaries import IsotropicStationary
         k, iv, lik = self.kernel, self.inducing_variable, self.likelihood
         if isinstance(k, SharedIndependent) and isinstance(iv, SharedIndependentInducingVariables):
             k, iv = k.kernel, iv.inducing_variable
         c = self.mean_function.constant_value()
-        if not (isinstance(k, SquaredExponential) and isinstance(lik, Gaussian) and lik.variance is not None
+        if not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES and isinstance(lik, Gaussian) and lik.variance is not None
                 and isinstance(iv, InducingPoints) and c is not None
-                and (self.q_sqrt.numpy().ndim == 3 or (allow_q_diag and self.whiten and self.q_sqrt.numpy().ndim == 2))
+                and (self.q_sqrt.numpy().ndim == 3 or (allow_q_diag and self.q_sqrt.numpy().ndim == 2))
                 and (allow_active_dims or k.has_default_active_dims)):
-            raise NotImplementedError("gradients: SVGP with a SquaredExponential kernel (optionally shared by independent "
+            raise NotImplementedError("gradients: SVGP with a SquaredExponential / Matern kernel (optionally shared by independent "
                                       "latents, or one per latent), Gaussian likelihood, InducingPoints, full q_sqrt, constant mean")
         return k, iv, float(c)
 
     def _separate_gradient_config(self):
-        """[(SquaredExponential kernel_p, InducingPoints_p)] per latent for SeparateIndependent kernels (over shared or
+        """[(isotropic stationary kernel_p, InducingPoints_p)] per latent for SeparateIndependent kernels (over shared or
         separate inducing points), else None."""
         from ..covariances import _pairs  # noqa: F401  (same pairing rule as Kuu / Kuf)
         from ..kernels import SeparateIndependent
-        from ..kernels.stationaries import SquaredExponential
+        from ..kernels.stationaries import IsotropicStationary
         from ..inducing_variables import SeparateIndependentInducingVariables
         k, iv, lik = self.kernel, self.inducing_variable, self.likelihood
         if not isinstance(k, SeparateIndependent):
@@ -148,10 +149,10 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         else:
             return None
         c = self.mean_function.constant_value()
-        if not (all(isinstance(kk, SquaredExponential) for kk in k.kernels) and all(isinstance(v, InducingPoints) for v in ivs)
+        if not (all(isinstance(kk, IsotropicStationary) and kk.family in ops.KERNEL_FAMILIES for kk in k.kernels) and all(isinstance(v, InducingPoints) for v in ivs)
                 and isinstance(lik, Gaussian) and lik.variance is not None and c is not None and self.q_sqrt.numpy().ndim == 3
                 and len(ivs) == len(k.kernels)):
-            raise NotImplementedError("gradients: SeparateIndependent needs SquaredExponential members over InducingPoints, a "
+            raise NotImplementedError("gradients: SeparateIndependent needs SquaredExponential / Matern members over InducingPoints, a "
                                       "Gaussian likelihood, full q_sqrt and a constant mean")
         return list(zip(k.kernels, ivs)), float(c)
 
@@ -174,7 +175,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
     def elbo_and_grad(self, data):
         """(ELBO on `data` as a float, {Parameter: dELBO/d(unconstrained value) as NumPy}) for the trainable parameters
         -- the pair `optimizers/scipy.py:322-331` gets from TF autodiff over `training_loss_closure(data)`.  Whitened or
-        not, SquaredExponential kernel (with `active_dims`; shared by the latents or one per latent), Gaussian likelihood,
+        not, SquaredExponential or Matern12 / 32 / 52 kernel (with `active_dims`; shared by the latents or one per latent), Gaussian likelihood,
         InducingPoints, full q_sqrt (gradients.svgp_elbo_and_grad).  For minibatch training keep the variables on the
         device instead: training.SVGPTrainer."""
         from .. import gradients
@@ -192,9 +193,9 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         if sep is None:
             k, iv, c = single
             Zs, Xs, scatter = self._sliced(k, iv.Z.device_value(), X)
-            _, var, ls = k.hyper()
+            family, var, ls = k.hyper()
             F, g, info = fn(Zs, Xs, Y, self.q_mu.device_value(), self.q_sqrt.device_value(), variance=var, lengthscales=ls,
-                            mean_const=float(c), **common)
+                            mean_const=float(c), family=family, **common)
             ops.check_info(info)
             Fv = float(F.cpu()[0])
             host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
@@ -211,9 +212,9 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             zgrads = {}
             for p_, (k, iv) in enumerate(members):
                 Zs, Xs, scatter = self._sliced(k, iv.Z.device_value(), X)
-                _, var, ls = k.hyper()
+                family, var, ls = k.hyper()
                 F, g, info = fn(Zs, Xs, Y[:, p_:p_ + 1].contiguous(), q_mu[:, p_:p_ + 1].contiguous(), q_sqrt[p_:p_ + 1].contiguous(),
-                                variance=var, lengthscales=ls, mean_const=float(c), **common)
+                                variance=var, lengthscales=ls, mean_const=float(c), family=family, **common)
                 ops.check_info(info)
                 Fv += float(F.cpu()[0])
                 host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}

@@ -131,8 +131,10 @@ def kernel_matrix_hadamard(X1: torch.Tensor, X2: torch.Tensor, G: torch.Tensor, 
 def kernel_matrix_combine(X1: torch.Tensor, X2: Optional[torch.Tensor], G: torch.Tensor, *, op: str, variance: float,
                           lengthscales, family: str = "SquaredExponential", diag_add: float = 0.0,
                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = G .* K(X1, X2) (op "mul") or G + K(X1, X2) (op "add"), K recomputed on the fly; `out` may be G itself.
-    X2 None: K(X1, X1) and `diag_add` goes onto the diagonal of the combined result."""
+    """out = G .* K(X1, X2) (op "mul"), G + K(X1, X2) (op "add") or G .* (-2 dK/dr2)(X1, X2) (op "dr2": the factor of the
+    lengthscale / input gradients of a stationary kernel; r2 = scaled squared distance), K recomputed on the fly; `out`
+    may be G itself.  X2 None: K(X1, X1); `diag_add` goes onto the diagonal of the combined result ("mul" / "add"), and
+    "dr2" writes exact zeros on the diagonal."""
     lib = _lib.load()
     _chk(X1, "X1", 2)
     _chk(G, "G", 2)
@@ -150,7 +152,7 @@ def kernel_matrix_combine(X1: torch.Tensor, X2: Optional[torch.Tensor], G: torch
         out = torch.empty((n1, n2), dtype=torch.float64, device=X1.device)
     _chk(out, "out", 2)
     ls, ard = _ls_host(lengthscales, d)
-    rc = lib.gpk_kernel_matrix_combine(_stream(), KERNEL_FAMILIES[family], {"mul": 1, "add": 2}[op], X1.data_ptr(), n1,
+    rc = lib.gpk_kernel_matrix_combine(_stream(), KERNEL_FAMILIES[family], {"mul": 1, "add": 2, "dr2": 3}[op], X1.data_ptr(), n1,
                                        _rowmajor(X1, "X1"), X2.data_ptr() if X2 is not None else None, n2,
                                        _rowmajor(X2, "X2") if X2 is not None else 0, d, ls, ard, float(variance),
                                        float(diag_add), G.data_ptr(), _rowmajor(G, "G"), out.data_ptr(),

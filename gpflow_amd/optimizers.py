@@ -54,7 +54,7 @@ class NaturalGradient:
 
         NaturalGradient(gamma=1.0).minimize(model, data)      # one step; updates model.q_mu / model.q_sqrt
 
-    (SVGP, whitened or not, SquaredExponential kernel, Gaussian likelihood, full q_sqrt -- the scope of the reverse pass)."""
+    (SVGP, whitened or not, SquaredExponential / Matern kernel, Gaussian likelihood, full q_sqrt -- the scope of the reverse pass)."""
 
     def __init__(self, gamma: float = 1.0):
         self.gamma = float(gamma)
@@ -65,12 +65,12 @@ class NaturalGradient:
         lik = model.likelihood
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if model.num_data is None else float(model.num_data) / float(X.shape[0])
-        _, var, ls = k.hyper()
+        family, var, ls = k.hyper()
         q_mu, q_sqrt = model.q_mu.device_value(), model.q_sqrt.device_value()
         fn = gradients.svgp_elbo_and_grad if model.whiten else gradients.svgp_elbo_and_grad_unwhitened
         _, g, info = fn(iv.Z.device_value(), X, Y, q_mu, q_sqrt, variance=var, lengthscales=ls,
                                                   noise_variance=lik.noise_variance(), jitter=config.default_jitter(),
-                                                  scale=scale, mean_const=float(c))
+                                                  scale=scale, mean_const=float(c), family=family)
         ops.check_info(info)
         mu, sq = natgrad.natgrad_update(q_mu, q_sqrt, -g["q_mu"], -g["q_sqrt"], self.gamma)   # loss = -ELBO
         model.q_mu.assign(mu.cpu().numpy())

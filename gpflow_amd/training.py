@@ -68,6 +68,7 @@ class SVGPTrainer:
         self.model, self.group = model, group
         self.natgrad_gamma = None if natgrad_gamma is None else float(natgrad_gamma)
         self.mean_const = float(c)
+        self.family = k.family
         self.opt = _Adam(learning_rate, beta_1, beta_2, epsilon)
         # host side: unconstrained scalars (their constrained values are host arguments of the C-ABI)
         self.host = {"variance": k.variance, "lengthscales": k.lengthscales, "noise_variance": lik.variance}
@@ -107,7 +108,7 @@ class SVGPTrainer:
         F, g, info = fn(
             self.dev["Z"], Xb, Yb, self.dev["q_mu"], self.dev["q_sqrt"], variance=var, lengthscales=ls,
             noise_variance=noise, jitter=config.default_jitter(), scale=scale, mean_const=self.mean_const,
-            kl_weight=1.0 / world)
+            kl_weight=1.0 / world, family=self.family)
         g = dict(g)
         g["_status"] = info.to(torch.float64).reshape(-1)[:1]   # rides in the packed all-reduce: > 0 iff ANY rank failed
         F, g = distributed.all_reduce_grads(F, g, self.group)

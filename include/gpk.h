@@ -72,10 +72,14 @@ int gpk_kernel_matrix(void* stream, int family, const double* X1, int n1, long l
                       const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
                       double variance, double diag_add, int lower_only, double* K, long ldk);
 
-/* out = G .* k(X1, X2) (op 1) or G + k(X1, X2) (op 2), k recomputed from the inputs (one read of G, one write; G may
+/* out = G .* k(X1, X2) (op 1), G + k(X1, X2) (op 2) or G .* (-2 dk/dr2)(X1, X2) (op 3), k recomputed from the inputs (one read of G, one write; G may
  * alias out).  Replaces the tf.multiply / tf.add_n reductions of Product / Sum kernels (kernels/base.py:216-220,
  * 283-329): the second factor / term is folded into the first matrix in place instead of being materialised.
- * X2 == NULL: K(X1, X1), and diag_add goes onto the diagonal of the COMBINED result (noise / jitter). */
+ * X2 == NULL: K(X1, X1), and diag_add goes onto the diagonal of the COMBINED result (noise / jitter).
+ * op 3 is the reverse pass of the Matern family (stationaries.py:254-313: r = sqrt(max(r2, 1e-36)), K_r): with
+ * r2 the SCALED squared distance, every lengthscale / input gradient contracts Kbar .* dk/dr2 with d r2 / d theta;
+ * -2 dk/dr2 equals k for the SquaredExponential, so the same contraction code serves all four families.  X2 == NULL
+ * writes exact zeros on the diagonal (r2_ii = 0 identically: no gradient flows through it). */
 int gpk_kernel_matrix_combine(void* stream, int family, int op, const double* X1, int n1, long ldx1,
                               const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
                               double variance, double diag_add, const double* G, long ldg, double* out, long ldo);

@@ -3,9 +3,10 @@ formulas as oracle/gp_oracle.py, differentiated by torch autograd -- the stand-i
 the reference uses (`optimizers/scipy.py:322-331`, `models/training_mixins.py:59-78`).
 
 TEST INFRASTRUCTURE ONLY (same rules as gp_oracle.py: imported by tests/ only, never by gpflow_amd/).
-Pinned by tests/test_oracle.py: the VALUE equals gp_oracle.svgp_elbo (the NumPy restatement, itself pinned by the
-reference's in-test restatements) to 1e-12, and every gradient agrees with central finite differences of
-gp_oracle.svgp_elbo.  "Absolute values vs TensorFlow" remain unpinned, as for the forward oracle.
+Pinned by tests/test_oracle.py: the VALUE equals gp_oracle.svgp_elbo to 1e-12 (the NumPy restatement, itself pinned
+to the reference's own source through tests/golden/ref_golden.npz: tests/test_reference_golden.py), and every gradient
+agrees with central finite differences of gp_oracle.svgp_elbo.  The reference's gradients themselves (TensorFlow
+autodiff) cannot be produced here; the pin is value-of-the-reference + derivative-of-that-value.
 """
 from __future__ import annotations
 
@@ -22,18 +23,31 @@ def _sqdist(X, X2):
     return -2.0 * X @ X2.T + Xs[:, None] + X2s[None, :]
 
 
-def _rbf(X, X2, variance, ls):
-    """stationaries.py:77-79, 103-116, 209-210"""
-    return variance * torch.exp(-0.5 * _sqdist(X / ls, X2 / ls))
+def _rbf(X, X2, variance, ls, family="SquaredExponential"):
+    """stationaries.py:77-79, 103-116; K_r2 of SquaredExponential :209-210, K_r of Matern12 :254-255, Matern32 :281-283,
+    Matern52 :311-313 (r = sqrt(max(r2, 1e-36)), :113-114)"""
+    r2 = _sqdist(X / ls, X2 / ls)
+    if family == "SquaredExponential":
+        return variance * torch.exp(-0.5 * r2)
+    r = torch.sqrt(torch.clamp(r2, min=1e-36))
+    if family == "Matern12":
+        return variance * torch.exp(-r)
+    if family == "Matern32":
+        s3 = float(np.sqrt(3.0))
+        return variance * (1.0 + s3 * r) * torch.exp(-s3 * r)
+    if family == "Matern52":
+        s5 = float(np.sqrt(5.0))
+        return variance * (1.0 + s5 * r + 5.0 / 3.0 * r * r) * torch.exp(-s5 * r)
+    raise KeyError(family)
 
 
 def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_variance, *, num_data=None, jitter=1e-6,
-                    mean=0.0, whiten=True):
+                    mean=0.0, whiten=True, family="SquaredExponential"):
     """SVGP.elbo (svgp.py:166-181) on torch fp64 tensors; q_sqrt [P, M, M]; whiten as in the reference."""
     M = Z.shape[0]
     B = X.shape[0]
-    Kmm = _rbf(Z, Z, variance, lengthscales) + jitter * torch.eye(M, dtype=torch.float64)   # covariances/kuus.py:29-34
-    Kmn = _rbf(Z, X, variance, lengthscales)                                                # kufs.py:31-34
+    Kmm = _rbf(Z, Z, variance, lengthscales, family) + jitter * torch.eye(M, dtype=torch.float64)   # covariances/kuus.py:29-34
+    Kmn = _rbf(Z, X, variance, lengthscales, family)                                         # kufs.py:31-34
     Lm = torch.linalg.cholesky(Kmm)                                                         # conditionals/util.py:67
     A = torch.linalg.solve_triangular(Lm, Kmn, upper=False)                                 # :125
     fvar = variance - (A * A).sum(0)                                                        # :133 (Knn = K_diag)
@@ -41,12 +55,18 @@ def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_varianc
         A = torch.linalg.solve_triangular(Lm.T, A, upper=True)                              # :137-139
     fmean = A.T @ q_mu + mean                                                               # :144
     if q_sqrt.dim() == 2:   # q_diag: q_sqrt [M, P] standard deviations (:147-149, 164; kullback_leiblers.py:131-148)
-        if not whiten:
-            raise NotImplementedError("q_diag is only restated for the whitened case here")
         LTA = A[None, :, :] * q_sqrt.T[:, :, None]                                          # [P, M, B]
         fvar = (fvar[None, :] + (LTA * LTA).sum(1)).T
         ve = -0.5 * LOG2PI - 0.5 * torch.log(noise_variance) - 0.5 * ((Y - fmean) ** 2 + fvar) / noise_variance
-        kl = 0.5 * ((q_mu * q_mu).sum() - M * q_mu.shape[1] - torch.log(q_sqrt ** 2).sum() + (q_sqrt ** 2).sum())
+        if whiten:
+            kl = 0.5 * ((q_mu * q_mu).sum() - M * q_mu.shape[1] - torch.log(q_sqrt ** 2).sum() + (q_sqrt ** 2).sum())
+        else:   # kullback_leiblers.py:107-165 with K = Kuu and a diagonal q: trace = sum diag(K^-1)[:, None] * q_sqrt^2 (:146-148)
+            alpha = torch.linalg.solve_triangular(Lm, q_mu, upper=False)
+            Lm_inv = torch.linalg.solve_triangular(Lm, torch.eye(M, dtype=torch.float64), upper=False)
+            K_inv = torch.linalg.solve_triangular(Lm.T, Lm_inv, upper=True)
+            kl = 0.5 * ((alpha * alpha).sum() - M * q_mu.shape[1] - torch.log(q_sqrt ** 2).sum()
+                        + (torch.diagonal(K_inv)[:, None] * q_sqrt ** 2).sum()
+                        + q_mu.shape[1] * torch.log(torch.diagonal(Lm) ** 2).sum())
         scale = 1.0 if num_data is None else float(num_data) / B
         return ve.sum() * scale - kl
     Lq = torch.tril(q_sqrt)                                                                 # :151
@@ -68,32 +88,33 @@ def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_varianc
 
 
 def svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, *, variance, lengthscales, noise_variance, num_data=None,
-                              jitter=1e-6, mean=0.0, whiten=True):
+                              jitter=1e-6, mean=0.0, whiten=True, family="SquaredExponential"):
     """NumPy in, (value, dict of NumPy gradients w.r.t. the constrained quantities) out."""
     t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
     Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
     var, ls, nv, mc = t(variance, True), t(np.atleast_1d(lengthscales), True), t(noise_variance, True), t(mean, True)
-    F = svgp_elbo_torch(t(X), t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=mc, whiten=whiten)
+    F = svgp_elbo_torch(t(X), t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=mc, whiten=whiten,
+                        family=family)
     F.backward()
     g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "Z": Zt.grad, "q_mu": qm.grad,
          "q_sqrt": qs.grad, "mean_const": mc.grad}
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}
 
 
-def gpr_lml_torch(X, Y, variance, lengthscales, noise_variance, mean=0.0):
+def gpr_lml_torch(X, Y, variance, lengthscales, noise_variance, mean=0.0, family="SquaredExponential"):
     """GPR.log_marginal_likelihood (gpr.py:91-107; logdensities.py:139-156) on torch fp64 tensors."""
     N = X.shape[0]
-    K = _rbf(X, X, variance, lengthscales) + noise_variance * torch.eye(N, dtype=torch.float64)   # gpr.py:100-101
+    K = _rbf(X, X, variance, lengthscales, family) + noise_variance * torch.eye(N, dtype=torch.float64)   # gpr.py:100-101
     L = torch.linalg.cholesky(K)                                                                 # :102
     alpha = torch.linalg.solve_triangular(L, Y - mean, upper=False)                              # logdensities.py:150
     P = Y.shape[1]
     return -0.5 * (alpha * alpha).sum() - 0.5 * N * P * LOG2PI - P * torch.log(torch.diagonal(L)).sum()
 
 
-def gpr_lml_value_and_grads(X, Y, *, variance, lengthscales, noise_variance, mean=0.0):
+def gpr_lml_value_and_grads(X, Y, *, variance, lengthscales, noise_variance, mean=0.0, family="SquaredExponential"):
     t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
     var, ls, nv, mc = t(variance, True), t(np.atleast_1d(lengthscales), True), t(noise_variance, True), t(mean, True)
-    F = gpr_lml_torch(t(X), t(Y), var, ls, nv, mc)
+    F = gpr_lml_torch(t(X), t(Y), var, ls, nv, mc, family)
     F.backward()
     g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "mean_const": mc.grad}
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}
@@ -126,13 +147,14 @@ def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma):
 
 
 # ----------------------------------------------------------------------------- SGPR gradients (SURVEY 8f rows 1 + 3)
-def sgpr_elbo_torch(X, Y, Z, variance, lengthscales, noise_variance, *, jitter=1e-6, mean=0.0):
+def sgpr_elbo_torch(X, Y, Z, variance, lengthscales, noise_variance, *, jitter=1e-6, mean=0.0,
+                    family="SquaredExponential"):
     """SGPR.elbo (gpflow/models/sgpr.py:181-290) on torch fp64 tensors, constant noise variance."""
     N, P = Y.shape
     M = Z.shape[0]
     sigma = torch.sqrt(noise_variance)
-    kuf = _rbf(Z, X, variance, lengthscales)
-    kuu = _rbf(Z, Z, variance, lengthscales) + jitter * torch.eye(M, dtype=torch.float64)
+    kuf = _rbf(Z, X, variance, lengthscales, family)
+    kuu = _rbf(Z, Z, variance, lengthscales, family) + jitter * torch.eye(M, dtype=torch.float64)
     L = torch.linalg.cholesky(kuu)
     A = torch.linalg.solve_triangular(L, kuf / sigma, upper=False)
     AAT = A @ A.T
@@ -145,11 +167,12 @@ def sgpr_elbo_torch(X, Y, Z, variance, lengthscales, noise_variance, *, jitter=1
     return -0.5 * N * P * LOG2PI + logdet + quad
 
 
-def sgpr_elbo_value_and_grads(X, Y, Z, *, variance, lengthscales, noise_variance, jitter=1e-6, mean=0.0):
+def sgpr_elbo_value_and_grads(X, Y, Z, *, variance, lengthscales, noise_variance, jitter=1e-6, mean=0.0,
+                              family="SquaredExponential"):
     t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
     Zt = t(Z, True)
     var, ls, nv, mc = t(variance, True), t(np.atleast_1d(lengthscales), True), t(noise_variance, True), t(mean, True)
-    F = sgpr_elbo_torch(t(X), t(Y), Zt, var, ls, nv, jitter=jitter, mean=mc)
+    F = sgpr_elbo_torch(t(X), t(Y), Zt, var, ls, nv, jitter=jitter, mean=mc, family=family)
     F.backward()
     g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "Z": Zt.grad, "mean_const": mc.grad}
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}

@@ -21,7 +21,10 @@ NB = 128
 
 
 def _np(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
+
+
+KERNEL_FAMILIES = {"SquaredExponential": 0, "Matern12": 1, "Matern32": 2, "Matern52": 3}
 
 
 def device():
@@ -68,9 +71,28 @@ def kernel_matrix(X1, X2, *, variance, lengthscales, family="SquaredExponential"
     return out
 
 
+def _dr2(X1, X2, variance, lengthscales, family):
+    """-2 dk/dr2 at the scaled squared distance (zero where the 1e-36 clamp is active)."""
+    a, b = _np(X1) / _ls(lengthscales, X1.shape[1]), _np(X2) / _ls(lengthscales, X1.shape[1])
+    r2 = -2.0 * a @ b.T + (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :]
+    if family == "SquaredExponential":
+        return variance * np.exp(-0.5 * r2)
+    ok = r2 > 1e-36
+    r = np.sqrt(np.where(ok, r2, 1.0))
+    if family == "Matern12":
+        f = variance * np.exp(-r) / r
+    elif family == "Matern32":
+        f = 3.0 * variance * np.exp(-np.sqrt(3.0) * r)
+    elif family == "Matern52":
+        f = (5.0 / 3.0) * variance * (1.0 + np.sqrt(5.0) * r) * np.exp(-np.sqrt(5.0) * r)
+    else:
+        raise KeyError(family)
+    return np.where(ok, f, 0.0)
+
+
 def kernel_matrix_hadamard(X1, X2, G, *, variance, lengthscales, family="SquaredExponential", out=None):
-    assert family == "SquaredExponential" and tuple(G.shape) == (X1.shape[0], X2.shape[0])
-    R = torch.from_numpy(_k(X1, X2, variance, lengthscales) * _np(G))
+    assert tuple(G.shape) == (X1.shape[0], X2.shape[0])
+    R = torch.from_numpy(_k(X1, X2, variance, lengthscales, family) * _np(G))
     if out is None:
         return R
     out.copy_(R)
@@ -78,10 +100,15 @@ def kernel_matrix_hadamard(X1, X2, G, *, variance, lengthscales, family="Squared
 
 
 def kernel_matrix_combine(X1, X2, G, *, op, variance, lengthscales, family="SquaredExponential", diag_add=0.0, out=None):
-    K = _k(X1, X1 if X2 is None else X2, variance, lengthscales, family)
-    R = K * _np(G) if op == "mul" else K + _np(G)
-    if X2 is None:
-        R = R + diag_add * np.eye(R.shape[0])
+    if op == "dr2":
+        R = _dr2(X1, X1 if X2 is None else X2, variance, lengthscales, family) * _np(G)
+        if X2 is None:
+            np.fill_diagonal(R, 0.0)
+    else:
+        K = _k(X1, X1 if X2 is None else X2, variance, lengthscales, family)
+        R = K * _np(G) if op == "mul" else K + _np(G)
+        if X2 is None:
+            R = R + diag_add * np.eye(R.shape[0])
     Rt = torch.from_numpy(R)
     if out is None:
         return Rt

@@ -347,3 +347,157 @@ def test_q_diag_model_gradients(gpu):
         fd = (vals[0] - vals[1]) / (2 * h)
         got = float(np.asarray(g[par])[idx])
         assert abs(got - fd) <= 1e-5 * max(1.0, abs(fd)), (par.name, idx, got, fd)
+
+
+# ----------------------------------------------------------------------------- Matern families (stationaries.py:254-313)
+MATERN_VALUE_TOL = {"Matern12": 1e-7, "Matern32": 1e-9, "Matern52": 1e-9}
+# (Matern12 VALUE: K_ii = variance * exp(-sqrt(max(r2_ii, 1e-36))) with r2_ii the rounding noise of the expansion formula, i.e.
+#  1 - O(1e-8) or exactly 1 depending on the sign of that noise -- a different FMA order moves every diagonal entry by ~1e-8.)
+MATERN_TOL = {"Matern12": 2e-6, "Matern32": 1e-8, "Matern52": 1e-8}
+# (Matern12: d exp(-r)/dr2 = -exp(-r)/(2r) is unbounded at r -> 0; the autograd oracle differentiates the expansion formula,
+#  whose diagonal r2_ii is rounding noise -- amplified by 1/r to ~1e-8 relative there.  The product writes the diagonal's
+#  factor as exact zeros: r2_ii = 0 identically, no gradient flows through it.)
+
+
+@pytest.mark.parametrize("family", ["SquaredExponential", "Matern12", "Matern32", "Matern52"])
+def test_kernel_matrix_dr2_factor(gpu, family):
+    """gpk_kernel_matrix_combine op 3: G .* (-2 dk/dr2) against the NumPy formulas; exact zeros on the diagonal of the
+    symmetric form and where the 1e-36 clamp is active (duplicate rows)."""
+    import fake_ops
+    from gpflow_amd import ops
+    rng = np.random.default_rng(5)
+    for n1, n2, d in [(70, 130, 3), (256, 512, 8), (1, 5, 1)]:
+        A, Bm, G = rng.normal(size=(n1, d)), rng.normal(size=(n2, d)), rng.normal(size=(n1, n2))
+        if n2 > 3:
+            Bm[2] = A[0]                      # an exactly coincident pair: r2 = rounding noise, possibly clamped
+        ls = 0.7 + 0.1 * np.arange(d)
+        got = ops.kernel_matrix_combine(ops.to_device(A), ops.to_device(Bm), ops.to_device(G), op="dr2", variance=1.7,
+                                        lengthscales=ls, family=family).cpu().numpy()
+        ref = fake_ops._dr2(A, Bm, 1.7, ls, family) * G
+        mask = np.ones_like(ref, dtype=bool)
+        if n2 > 3:
+            mask[0, 2] = False                # (noise-level r2: either side of the clamp; not comparable)
+        np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-11, atol=1e-13)
+        S = rng.normal(size=(n1, n1))
+        got = ops.kernel_matrix_combine(ops.to_device(A), None, ops.to_device(S), op="dr2", variance=1.7, lengthscales=ls,
+                                        family=family).cpu().numpy()
+        ref = fake_ops._dr2(A, A, 1.7, ls, family) * S
+        np.fill_diagonal(ref, 0.0)
+        assert np.all(np.diag(got) == 0.0)
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("family", ["Matern12", "Matern32", "Matern52"])
+@pytest.mark.parametrize("whiten", [True, False])
+def test_matern_svgp_elbo_and_grad_vs_autograd_oracle(gpu, family, whiten):
+    from gpflow_amd import gradients, ops
+    M, B, D, P = 200, 520, 4, 2
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(M, B, D, P, 52, True)
+    t = ops.to_device
+    fn = gradients.svgp_elbo_and_grad if whiten else gradients.svgp_elbo_and_grad_unwhitened
+    F, g, info = fn(t(Z), t(X), t(Y), t(q_mu), t(q_sqrt), jitter=1e-6, scale=1000.0 / B, mean_const=0.1, family=family, **kw)
+    ops.check_info(info)
+    v, go = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=1000, mean=0.1, whiten=whiten, family=family, **kw)
+    assert abs(float(F.cpu()[0]) - v) <= MATERN_VALUE_TOL[family] * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt", "mean_const"):
+        got, ref = g[name].cpu().numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=MATERN_TOL[family] * max(1.0, np.abs(ref).max()),
+                                   err_msg=f"{family} {name}")
+
+
+@pytest.mark.parametrize("family", ["Matern12", "Matern32", "Matern52"])
+def test_matern_gpr_and_sgpr_gradients_vs_autograd_oracle(gpu, family):
+    from gpflow_amd import gradients, ops
+    rng = np.random.default_rng(53)
+    N, M, D, P = 700, 130, 3, 2
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P)); Z = rng.normal(size=(M, D))
+    kw = dict(variance=1.4, lengthscales=np.sqrt(D) * (0.8 + 0.05 * np.arange(D)), noise_variance=0.15)
+    t = ops.to_device
+    F, g, info = gradients.gpr_lml_and_grad(t(X), t(Y), mean_const=0.2, family=family, **kw)
+    ops.check_info(info)
+    v, go = orcg.gpr_lml_value_and_grads(X, Y, mean=0.2, family=family, **kw)
+    assert abs(float(F.cpu()[0]) - v) <= MATERN_VALUE_TOL[family] * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "mean_const"):
+        got, ref = g[name].cpu().numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=MATERN_TOL[family] * max(1.0, np.abs(ref).max()),
+                                   err_msg=f"gpr {family} {name}")
+    F, g, info = gradients.sgpr_elbo_and_grad(t(Z), t(X), t(Y), jitter=1e-6, mean_const=0.2, family=family, **kw)
+    ops.check_info(info)
+    v, go = orcg.sgpr_elbo_value_and_grads(X, Y, Z, mean=0.2, family=family, **kw)
+    assert abs(float(F.cpu()[0]) - v) <= MATERN_VALUE_TOL[family] * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "mean_const"):
+        got, ref = g[name].cpu().numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=MATERN_TOL[family] * max(1.0, np.abs(ref).max()),
+                                   err_msg=f"sgpr {family} {name}")
+
+
+def test_matern_models_train_through_the_public_surface(gpu):
+    """Matern kernels through the model entry points: GPR(Matern32, active_dims).log_marginal_likelihood_and_grad and
+    SGPR(Matern52, active_dims).objective_and_grad against the autograd oracle on the sliced inputs (chain rule to the
+    unconstrained variables included), the Scipy optimizer on a Matern52 GPR, the SVGP trainer on a Matern32 SVGP."""
+    import gpflow_amd as gpflow
+    rng = np.random.default_rng(54)
+    N, D = 300, 4
+    X = rng.normal(size=(N, D)); Y = np.sin(X[:, [1]] + X[:, [3]]) + 0.1 * rng.normal(size=(N, 1))
+    dims, ls = [3, 1], np.array([0.9, 1.4])
+    k = gpflow.kernels.Matern32(variance=1.3, lengthscales=ls, active_dims=dims)
+    m = gpflow.models.GPR((X, Y), k, noise_variance=0.2)
+    v, g = m.log_marginal_likelihood_and_grad()
+    rv, rg = orcg.gpr_lml_value_and_grads(X[:, dims], Y, variance=1.3, lengthscales=ls, noise_variance=0.2, family="Matern32")
+    assert abs(v - rv) <= 1e-9 * abs(rv) and abs(v - float(m.log_marginal_likelihood().cpu())) <= 1e-9 * abs(v)
+    u = k.lengthscales.unconstrained_variable
+    np.testing.assert_allclose(np.asarray(g[k.lengthscales]).ravel(), (rg["lengthscales"] * k.lengthscales.transform.forward_grad(u)).ravel(),
+                               rtol=1e-7)
+    # SGPR, Matern52, active_dims: Z gradient lands in the active columns only
+    Z = rng.normal(size=(40, D))
+    k2 = gpflow.kernels.Matern52(variance=1.1, lengthscales=ls, active_dims=dims)
+    s = gpflow.models.SGPR((X, Y), k2, Z.copy(), noise_variance=0.2)
+    v, g = s.objective_and_grad()
+    rv, rg = orcg.sgpr_elbo_value_and_grads(X[:, dims], Y, Z[:, dims], variance=1.1, lengthscales=ls, noise_variance=0.2, family="Matern52")
+    assert abs(v - rv) <= 1e-9 * abs(rv)
+    gz = np.asarray(g[s.inducing_variable.Z])
+    np.testing.assert_allclose(gz[:, dims], rg["Z"], rtol=0, atol=1e-8 * np.abs(rg["Z"]).max())
+    assert np.all(gz[:, [0, 2]] == 0.0)
+    with pytest.raises(NotImplementedError):      # kernel sums / products are outside the reverse pass
+        gpflow.models.GPR((X, Y), k + gpflow.kernels.SquaredExponential()).log_marginal_likelihood_and_grad()
+    # Scipy on a Matern52 GPR improves the LML
+    m2 = gpflow.models.GPR((X, Y), gpflow.kernels.Matern52(lengthscales=np.ones(D)), noise_variance=1.0)
+    before = float(m2.log_marginal_likelihood().cpu())
+    gpflow.optimizers.Scipy().minimize(m2, options=dict(maxiter=15))
+    assert float(m2.log_marginal_likelihood().cpu()) > before + 10.0
+    # the device-resident trainer on a Matern32 SVGP
+    sv = gpflow.models.SVGP(gpflow.kernels.Matern32(lengthscales=np.ones(D)), gpflow.likelihoods.Gaussian(0.5), Z.copy(), num_data=N)
+    tr = gpflow.training.SVGPTrainer(sv, learning_rate=0.05)
+    first = float(tr.step((X, Y)).cpu()[0])
+    for _ in range(30):
+        last = tr.step((X, Y))
+    assert float(last.cpu()[0]) > first
+    tr.sync_to_model()
+    assert abs(float(sv.elbo((X, Y)).cpu()) - float(tr.step((X, Y)).cpu()[0])) <= 1e-8 * abs(first)
+
+
+@pytest.mark.parametrize("M,B,D,P,family", [(70, 300, 3, 2, "SquaredExponential"), (200, 640, 4, 1, "Matern52")])
+def test_unwhitened_q_diag_svgp_elbo_and_grad_vs_autograd_oracle(gpu, M, B, D, P, family):
+    """whiten=False with q_diag=True: value and every gradient against the autograd oracle (whose forward is pinned to the
+    NumPy oracle for this combination in tests/test_gradients_cpu.py), then through SVGP.elbo_and_grad against the model's
+    own fused forward."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import gradients, ops
+    X, Y, Z, q_mu, _, kw = _problem(M, B, D, P, 61)
+    q = 0.3 + np.abs(np.random.default_rng(62).normal(size=(M, P)))
+    t = ops.to_device
+    F, g, info = gradients.svgp_elbo_and_grad_unwhitened(t(Z), t(X), t(Y), t(q_mu), t(q), jitter=1e-6, scale=1000.0 / B,
+                                                         mean_const=0.1, family=family, **kw)
+    ops.check_info(info)
+    v, go = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q, num_data=1000, mean=0.1, whiten=False, family=family, **kw)
+    assert abs(float(F.cpu()[0]) - v) <= 1e-9 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt", "mean_const"):
+        got, refg = g[name].cpu().numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(refg.shape), refg, rtol=0, atol=1e-8 * max(1.0, np.abs(refg).max()), err_msg=name)
+    kern = getattr(gpflow.kernels, family)(variance=kw["variance"], lengthscales=kw["lengthscales"])
+    m = gpflow.models.SVGP(kern, gpflow.likelihoods.Gaussian(kw["noise_variance"]), Z.copy(), q_mu=q_mu.copy(), q_sqrt=q.copy(),
+                           q_diag=True, whiten=False, num_latent_gps=P, num_data=1000 * 1, mean_function=gpflow.mean_functions.Constant(0.1))
+    mv, mg = m.elbo_and_grad((X, Y))
+    scale_fix = (1000.0 / B)   # (the model scales by num_data / B itself)
+    assert abs(mv - float(m.elbo((X, Y)).cpu())) <= 1e-9 * abs(mv) and abs(mv - v) <= 1e-9 * abs(v), (mv, v, scale_fix)
+    np.testing.assert_allclose(mg[m.q_mu], go["q_mu"], rtol=0, atol=1e-8 * np.abs(go["q_mu"]).max())

@@ -141,12 +141,11 @@ def test_active_dims_through_models(gp, dims):
                                          whiten=whiten)
         np.testing.assert_allclose(_np(mu), mu_r, atol=1e-9)
         np.testing.assert_allclose(_np(var), var_r, atol=1e-9)
-    # gradients: SVGP.elbo_and_grad slices the inputs itself (round 3) and agrees with its own forward; the GPR entry point
-    # still refuses active_dims with NotImplementedError (not an unrelated ValueError)
+    # gradients: both entry points slice the inputs themselves (round 3) and agree with their own forward
     v, g = s.elbo_and_grad((X, Y))
     np.testing.assert_allclose(v, float(s.elbo((X, Y))), rtol=1e-9)
-    with pytest.raises(NotImplementedError):
-        m.log_marginal_likelihood_and_grad()
+    v, g = m.log_marginal_likelihood_and_grad()
+    np.testing.assert_allclose(v, float(m.log_marginal_likelihood()), rtol=1e-9)
 
 
 def test_kernel_sum_and_product(gp):

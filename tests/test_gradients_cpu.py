@@ -321,3 +321,112 @@ def test_unwhitened_adjoint_on_emulated_primitives(monkeypatch, M, B, D, P, ard)
         got, ref_g = g[name].numpy(), np.asarray(go[name])
         tol = 1e-7 * max(1.0, np.abs(ref_g).max())
         np.testing.assert_allclose(got.reshape(ref_g.shape), ref_g, rtol=0, atol=tol, err_msg=name)
+
+
+# ----------------------------------------------------------------------------- Matern families (stationaries.py:254-313)
+MATERN_TOL = {"Matern12": 2e-6, "Matern32": 1e-8, "Matern52": 1e-8}
+# (Matern12: d exp(-r)/dr2 = -exp(-r)/(2r) is unbounded at r -> 0.  The autograd oracle differentiates the expansion
+#  formula, whose diagonal r2_ii is rounding noise of either sign: where it comes out positive the oracle picks up
+#  noise * 1/r ~ 1e-8 relative; the product writes the diagonal's factor as exact zeros (r2_ii = 0 identically).)
+
+
+@pytest.mark.parametrize("family", ["Matern12", "Matern32", "Matern52"])
+def test_matern_autograd_oracle_value_and_finite_differences(family):
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(12, 30, 2, 2, 21)
+    v, g = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=200, family=family, **kw)
+    ref = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt, whiten=True, num_data=200, kernel=family, **kw)
+    assert abs(v - ref) <= 1e-12 * abs(ref)
+
+    def f(**over):
+        a = dict(Z=Z, **kw)
+        a.update(over)
+        return orc.svgp_elbo(X, Y, a["Z"], q_mu, q_sqrt, variance=a["variance"], lengthscales=a["lengthscales"],
+                             noise_variance=a["noise_variance"], whiten=True, num_data=200, kernel=family)
+
+    # Matern12 as the reference writes it is not smooth at rounding level: K_ii = variance * exp(-sqrt(max(r2_ii, 1e-36)))
+    # with r2_ii = rounding noise of the expansion formula, i.e. the VALUE jitters by ~1e-8 per diagonal entry whenever an
+    # input moves.  Finite differences need a step far above that (and get a correspondingly loose tolerance).
+    h, tol = (1e-3, 2e-3) if family == "Matern12" else (1e-6, 5e-6)
+    for name, idx in [("variance", None), ("lengthscales", (0,)), ("lengthscales", (1,)), ("Z", (3, 1)), ("Z", (0, 0))]:
+        base = np.array(dict(Z=Z, **kw)[name], dtype=np.float64)
+        def at(delta):
+            w = base.copy()
+            if idx is None:
+                w = w + delta
+            else:
+                w[idx] += delta
+            return f(**{name: w if w.ndim else float(w)})
+        fd = (at(h) - at(-h)) / (2 * h)
+        got = float(np.asarray(g[name]).reshape(-1)[0]) if idx is None else float(g[name][idx])
+        assert abs(got - fd) <= tol * max(1.0, abs(fd)), (family, name, idx, got, fd)
+
+
+@pytest.mark.parametrize("family", ["Matern12", "Matern32", "Matern52"])
+@pytest.mark.parametrize("whiten", [True, False])
+def test_matern_svgp_adjoint_on_emulated_primitives(monkeypatch, family, whiten):
+    import torch
+    from gpflow_amd import gradients
+    import fake_ops
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    M, B, D, P = 90, 260, 3, 2
+    X, Y, Z, q_mu, q_sqrt, kw = _problem(M, B, D, P, 22, True)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    fn = gradients.svgp_elbo_and_grad if whiten else gradients.svgp_elbo_and_grad_unwhitened
+    F, g, info = fn(t(Z), t(X), t(Y), t(q_mu), t(q_sqrt), jitter=1e-6, scale=1000.0 / B, mean_const=0.1, family=family, **kw)
+    v, go = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, num_data=1000, mean=0.1, whiten=whiten, family=family, **kw)
+    assert int(info) == 0 and abs(float(F[0]) - v) <= 1e-10 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt", "mean_const"):
+        got, ref = g[name].numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=MATERN_TOL[family] * max(1.0, np.abs(ref).max()),
+                                   err_msg=f"{family} {name}")
+
+
+@pytest.mark.parametrize("family", ["Matern12", "Matern32", "Matern52"])
+def test_matern_gpr_and_sgpr_adjoints_on_emulated_primitives(monkeypatch, family):
+    import torch
+    from gpflow_amd import gradients
+    import fake_ops
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    rng = np.random.default_rng(23)
+    N, M, D, P = 220, 60, 3, 2
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P)); Z = rng.normal(size=(M, D))
+    kw = dict(variance=1.4, lengthscales=np.sqrt(D) * (0.8 + 0.05 * np.arange(D)), noise_variance=0.15)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    F, g, info = gradients.gpr_lml_and_grad(t(X), t(Y), mean_const=0.2, family=family, **kw)
+    v, go = orcg.gpr_lml_value_and_grads(X, Y, mean=0.2, family=family, **kw)
+    assert abs(v - float(np.sum(orc.gpr_log_marginal_likelihood(X, Y, mean=0.2, kernel=family, **kw)))) <= 1e-11 * abs(v)
+    assert abs(float(F[0]) - v) <= 1e-10 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "mean_const"):
+        got, ref = g[name].numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=MATERN_TOL[family] * max(1.0, np.abs(ref).max()),
+                                   err_msg=f"gpr {family} {name}")
+    F, g, info = gradients.sgpr_elbo_and_grad(t(Z), t(X), t(Y), jitter=1e-6, mean_const=0.2, family=family, **kw)
+    v, go = orcg.sgpr_elbo_value_and_grads(X, Y, Z, mean=0.2, family=family, **kw)
+    assert abs(float(F[0]) - v) <= 1e-10 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "mean_const"):
+        got, ref = g[name].numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=MATERN_TOL[family] * max(1.0, np.abs(ref).max()),
+                                   err_msg=f"sgpr {family} {name}")
+
+
+@pytest.mark.parametrize("family", ["SquaredExponential", "Matern52"])
+def test_unwhitened_q_diag_adjoint_on_emulated_primitives(monkeypatch, family):
+    """whiten=False with q_diag=True (q_sqrt [M, P] standard deviations): the autograd oracle's forward equals the NumPy
+    oracle (gauss_kl with K and a diagonal q: kullback_leiblers.py:131-152), and the hand-written adjoint equals autograd."""
+    import torch
+    from gpflow_amd import gradients
+    import fake_ops
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    M, B, D, P = 80, 230, 3, 2
+    X, Y, Z, q_mu, _, kw = _problem(M, B, D, P, 24, True)
+    q = 0.3 + np.abs(np.random.default_rng(25).normal(size=(M, P)))
+    v, go = orcg.svgp_elbo_value_and_grads(X, Y, Z, q_mu, q, num_data=1000, mean=0.1, whiten=False, family=family, **kw)
+    ref = orc.svgp_elbo(X, Y, Z, q_mu, q, num_data=1000, mean=0.1, whiten=False, kernel=family, **kw)
+    assert abs(v - ref) <= 1e-9 * abs(ref)     # (Kuu^-1 at jitter 1e-6: two LAPACK routes through cond ~1e6)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    F, g, info = gradients.svgp_elbo_and_grad_unwhitened(t(Z), t(X), t(Y), t(q_mu), t(q), jitter=1e-6, scale=1000.0 / B,
+                                                         mean_const=0.1, family=family, **kw)
+    assert int(info) == 0 and abs(float(F[0]) - v) <= 1e-9 * abs(v)
+    for name in ("variance", "lengthscales", "noise_variance", "Z", "q_mu", "q_sqrt", "mean_const"):
+        got, refg = g[name].numpy(), np.asarray(go[name])
+        np.testing.assert_allclose(got.reshape(refg.shape), refg, rtol=0, atol=1e-8 * max(1.0, np.abs(refg).max()), err_msg=name)

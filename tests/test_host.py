@@ -208,27 +208,25 @@ def test_bijector_forward_grad_matches_finite_differences():
 
 
 def test_gradient_entry_points_refuse_unsupported_models_before_touching_the_device():
-    """The reverse pass covers the SVGP (whitened or not) / GPR / SGPR with a SquaredExponential kernel and a Gaussian
-    likelihood; everything else must say so (NotImplementedError), not silently compute something else."""
+    """The reverse pass covers the SVGP (whitened or not) / GPR / SGPR with ONE SquaredExponential or Matern kernel and a
+    Gaussian likelihood; everything else must say so (NotImplementedError), not silently compute something else."""
     import gpflow_amd as gpflow
     from gpflow_amd import training
     Z = np.random.default_rng(0).normal(size=(5, 2))
     lik = gpflow.likelihoods.Gaussian(0.1)
-    matern = gpflow.models.SVGP(gpflow.kernels.Matern32(), lik, Z)
+    summed = gpflow.models.SVGP(gpflow.kernels.Matern32() + gpflow.kernels.SquaredExponential(), lik, Z)
     qdiag = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), lik, Z, q_diag=True)
     sliced = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(active_dims=[0]), lik, Z)
     data = (np.zeros((4, 2)), np.zeros((4, 1)))
-    for m in (matern, qdiag, sliced):
+    for m in (summed, qdiag, sliced):
         with pytest.raises(NotImplementedError):
             training.SVGPTrainer(m)
         with pytest.raises(NotImplementedError):
             gpflow.optimizers.NaturalGradient(1.0).minimize(m, data)
-    # (round 3: SVGP.elbo_and_grad itself covers q_diag and active_dims -- tests/test_gpu_gradients.py; Matern stays out)
+    # (round 3: SVGP.elbo_and_grad itself covers q_diag, active_dims and the Matern families -- tests/test_gpu_gradients.py;
+    #  kernel sums / products stay out)
     with pytest.raises(NotImplementedError):
-        matern.elbo_and_grad(data)
-    unwhitened_qdiag = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), lik, Z, q_diag=True, whiten=False)
-    with pytest.raises(NotImplementedError):
-        unwhitened_qdiag.elbo_and_grad(data)
+        summed.elbo_and_grad(data)
     with pytest.raises(NotImplementedError):
         gpflow.optimizers.Scipy().minimize(object())
 
