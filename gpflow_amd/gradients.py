@@ -23,7 +23,7 @@ lengthscales, noise variance, Z, q_mu, q_sqrt); `SVGP.elbo_and_grad` chains them
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -283,33 +283,56 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
 
 def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales,
                        noise_variance: float, jitter: float, mean_const: float = 0.0,
-                       family: str = "SquaredExponential"
+                       family: str = "SquaredExponential", group=None, sharded: bool = False,
+                       num_data: Optional[int] = None
                        ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
-    """SGPR.elbo (sgpr.py:181-290) and its gradient w.r.t. {variance, lengthscales, noise_variance, Z, mean_const}
-    (single process; SquaredExponential).  With At = Kfu Lm^-T, S = At^T At, a = At^T err, q = |At|^2, e2 = |err|^2,
-    B = I + S / s2, w = B^-1 a / s2:
+    """SGPR.elbo (sgpr.py:181-290) and its gradient w.r.t. {variance, lengthscales, noise_variance, Z, mean_const}.
+    With At = Kfu Lm^-T, S = At^T At, a = At^T err, q = |At|^2, e2 = |err|^2, B = I + S / s2, w = B^-1 a / s2:
 
         F     = -N P log(2 pi)/2 - P (logdet B / 2 + N log(s2)/2 + (N var - q) / (2 s2)) - e2 / (2 s2) + a^T w / (2 s2)
         B_bar = -(P B^-1 + w w^T) / 2,   S_bar = B_bar / s2,   a_bar = w / s2,   q_bar = P / (2 s2)
         At_bar = At (2 S_bar + 2 q_bar I) + err a_bar^T        -> then exactly the SVGP chain: Kfu_bar, Lm_bar, Kuu_bar, kernel
-    """
+
+    `sharded=True` (NEW: the reference is single process): (X, Y) is THIS rank's row shard (possibly empty), `num_data`
+    the global row count.  The forward statistics (S, a, e2, q) are summed over `group` as in models/sgpr.py; everything
+    of size M x M after that is replicated.  The reverse pass is linear in what the shards contribute -- At_bar, Kfu_bar,
+    -tril(Kfu_bar^T At) and the Kuf part of the kernel adjoint are per-shard -- so ONE more all-reduce of the packed
+    (Lm_bar part [M, M], d/dvariance, d/dlengthscales, Z_bar, d/dmean) gives every rank the complete gradient: two
+    collectives of M^2 + O(M) doubles per evaluation, none proportional to the data."""
     M, D = Z.shape
-    N, P = Y.shape
+    n, P = Y.shape
     dev = Z.device
     s2 = float(noise_variance)
+    N = int(num_data) if num_data is not None else n
+    if not sharded and N != n:
+        raise ValueError("num_data differs from the number of rows of a model that is not sharded")
     kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+
+    def all_reduce(t):
+        if sharded:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+
     eye = torch.eye(M, dtype=torch.float64, device=dev)
-    T = torch.empty((M + N + M, M), dtype=torch.float64, device=dev)
+    T = torch.empty((M + n + M, M), dtype=torch.float64, device=dev)
     ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
-    ops.kernel_matrix(X, Z, out=T[M:M + N], **kw)
+    if n:
+        ops.kernel_matrix(X, Z, out=T[M:M + n], **kw)
     _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
-    L, At, LinvT = T[:M], T[M:M + N], T[M + N:]
+    L, At, LinvT = T[:M], T[M:M + n], T[M + n:]
     err = (Y - mean_const).contiguous()
-    A = ops.transpose(At)                                                               # [M, N]
-    Slow = splitk_gemm_nt(A, A, c_lower=True)
+    stats = torch.zeros(M * M + M * P + 2, dtype=torch.float64, device=dev)
+    if n:
+        A = ops.transpose(At)                                                           # [M, n]
+        stats[:M * M] = torch.tril(splitk_gemm_nt(A, A, c_lower=True)).reshape(-1)
+        stats[M * M:M * M + M * P] = splitk_gemm_nt(A, err.t().contiguous()).reshape(-1)
+        stats[-2], stats[-1] = ops.sumsq(err)[0], ops.sumsq(At)[0]
+    all_reduce(stats)                                                                   # ---- exchange 1: S, a, e2, q
+    Slow = stats[:M * M].reshape(M, M)
     S = Slow + torch.tril(Slow, -1).t()
-    a = splitk_gemm_nt(A, err.t().contiguous())                                         # [M, P]
-    e2, q = ops.sumsq(err)[0], ops.sumsq(At)[0]
+    a = stats[M * M:M * M + M * P].reshape(M, P)
+    e2, q = stats[-2], stats[-1]
     T2 = torch.empty((2 * M + P, M), dtype=torch.float64, device=dev)
     T2[:M] = S / s2 + eye
     T2[M:M + P] = a.t() / s2
@@ -318,33 +341,46 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     half_logdet_b = ops.sum_log_diag(LB)[0]
     F = (-0.5 * N * P * LOG2PI - P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * (N * variance - q) / s2)
          - 0.5 * (e2 / s2 - ops.sumsq(ct)[0]))
-    # ---- backward
-    Binv = ops.gemm_nt(LBinvT, LBinvT, b_tri=1, a_tri=1)                                         # B^-1 = LB^-T LB^-1
+    # ---- backward: the M x M tail (replicated)
+    Binv = ops.gemm_nt(LBinvT, LBinvT, b_tri=1, a_tri=1)                                # B^-1 = LB^-T LB^-1
     wt = ops.gemm_nt(ct.contiguous(), LBinvT, b_tri=1)                                  # w^T = c^T LB^-1  [P, M]
     w = wt.t().contiguous()                                                             # [M, P]
     Bbar = -0.5 * P * Binv
     ops.gemm_nt(w, w, alpha=-0.5, beta=1.0, C=Bbar)                                     # - w w^T / 2
     Ssym = (2.0 / s2) * Bbar + (P / s2) * eye                                           # 2 S_bar + 2 q_bar I
     abar = w / s2
-    Atb = ops.gemm_nt(err, abar)                                                        # err a_bar^T  [N, M]
-    ops.gemm_nt(At, Ssym, alpha=1.0, beta=1.0, C=Atb)                                   # + At (2 S_bar + 2 q_bar I)
-    Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)
-    Kuf_bar = ops.transpose(Kfu_bar)
-    Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)
+    # ---- this shard's rows
+    nls = D if np.size(lengthscales) > 1 else 1
+    part = torch.zeros(M * M + 1 + D + M * D + 1, dtype=torch.float64, device=dev)      # [Lm_bar part, dvar, dls, Z_bar, dmean]
+    if n:
+        Atb = ops.gemm_nt(err, abar)                                                    # err a_bar^T  [n, M]
+        ops.gemm_nt(At, Ssym, alpha=1.0, beta=1.0, C=Atb)                               # + At (2 S_bar + 2 q_bar I)
+        Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)
+        Kuf_bar = ops.transpose(Kfu_bar)
+        part[:M * M] = torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)).reshape(-1)
+        dv1, dl1, Zb1 = stationary_kernel_adjoint(Z, X, Kuf_bar, symmetric=False, **kw)
+        o = M * M
+        part[o] = dv1
+        part[o + 1:o + 1 + D] = dl1
+        part[o + 1 + D:o + 1 + D + M * D] = Zb1.reshape(-1)
+        part[-1] = (err / s2 - ops.gemm_nt(At, abar.t().contiguous())).sum()
+    all_reduce(part)                                                                    # ---- exchange 2: the shards' sums
+    o = M * M
+    Lbar = part[:o].reshape(M, M)
+    dv1, dl1, Zb1, g_mean = part[o], part[o + 1:o + 1 + D], part[o + 1 + D:o + 1 + D + M * D].reshape(M, D), part[-1]
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
-    dv1, dl1, Zb1 = stationary_kernel_adjoint(Z, X, Kuf_bar, symmetric=False, **kw)
     dv2, dl2, Zb2 = stationary_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
     g_var = dv1 + dv2 - 0.5 * P * N / s2
     g_ls = dl1 + dl2
-    if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
+    if nls == 1:
         g_ls = g_ls.sum().reshape(1)
     wa, ww = (w * a).sum(), (w * w).sum()
     g_noise = (-P * (-0.5 * (M - torch.diagonal(Binv).sum()) / s2 + 0.5 * N / s2 - 0.5 * (N * variance - q) / s2 ** 2)
                + 0.5 * e2 / s2 ** 2 - 0.5 * wa / s2 ** 2 - 0.5 * ww / s2)
-    g_mean = (err / s2 - ops.gemm_nt(At, abar.t().contiguous())).sum()
+    status = torch.maximum(info, info2)
     grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1), "Z": Zb1 + Zb2,
              "mean_const": g_mean.reshape(1)}
-    return F.reshape(1), grads, torch.maximum(info, info2)
+    return F.reshape(1), grads, status
 
 
 def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor,

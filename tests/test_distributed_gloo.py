@@ -166,6 +166,67 @@ def test_sgpr_row_sharded_world2_gloo():
     assert abs(e0 - ref0) <= 1e-10 * abs(ref0)
 
 
+def _sgpr_grad_worker(rank, world, port, q):
+    """Gradients of the row-sharded SGPR through the MODEL surface (SGPR(sharded=True).objective_and_grad): every rank holds
+    the complete ELBO and gradient after two all-reduces; rank 1 of the second case holds an EMPTY shard."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fake_ops
+        import gpflow_amd as gpflow
+        from gpflow_amd import ops
+        from gpflow_amd.distributed import shard_bounds
+        from oracle import gp_oracle_grad as orcg
+        for name in dir(fake_ops):
+            if not name.startswith("_") and callable(getattr(fake_ops, name)) and hasattr(ops, name) \
+                    and name not in ("torch", "np", "sla"):
+                setattr(ops, name, getattr(fake_ops, name))
+        rng = np.random.default_rng(41)
+        N, M, D, P = 257, 36, 3, 2
+        X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P)); Z = rng.normal(size=(M, D))
+        ls = np.array([0.8, 1.1, 1.4])
+        out = []
+        for family, bounds in (("SquaredExponential", shard_bounds(N, world, rank)), ("Matern52", (0, N) if rank == 0 else (N, N))):
+            lo, hi = bounds
+            kern = getattr(gpflow.kernels, family)(variance=1.2, lengthscales=ls)
+            m = gpflow.models.SGPR((X[lo:hi], Y[lo:hi]), kern, Z.copy(), noise_variance=0.3, sharded=True,
+                                   mean_function=gpflow.mean_functions.Constant(0.2))
+            v, g = m.objective_and_grad()
+            rv, rg = orcg.sgpr_elbo_value_and_grads(X, Y, Z, variance=1.2, lengthscales=ls, noise_variance=0.3, mean=0.2, family=family)
+            errs = {"value": abs(v - rv) / abs(rv), "elbo": abs(v - float(m.elbo())) / abs(rv),
+                    "Z": float(np.abs(np.asarray(g[m.inducing_variable.Z]) - rg["Z"]).max() / np.abs(rg["Z"]).max()),
+                    "mean": float(abs(np.ravel(g[m.mean_function.c])[0] - rg["mean_const"]) / max(1.0, abs(float(rg["mean_const"]))))}
+            for par, name in ((kern.variance, "variance"), (kern.lengthscales, "lengthscales"), (m.likelihood.variance, "noise_variance")):
+                u = par.unconstrained_variable
+                ref = np.ravel(rg[name]) * np.ravel(par.transform.forward_grad(u))
+                errs[name] = float(np.abs(np.ravel(g[par]) - ref).max() / max(1.0, np.abs(ref).max()))
+            out.append((family, v, errs))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sgpr_row_sharded_gradients_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sgpr_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, out0), (_, out1) = results
+    for (fam, v0, e0), (_, v1, e1) in zip(out0, out1):
+        assert v0 == v1, fam                                   # both ranks hold the same ELBO
+        for errs in (e0, e1):
+            for name, e in errs.items():
+                assert e <= 1e-8, (fam, name, e)
+
+
 def _product_worker(rank, world, port, q, backend):
     """`distributed.svgp_elbo_data_parallel` on the PRODUCT host code (SVGP model surface -> elbo_terms -> fused shard):
     gloo + emulated primitives on CPU, nccl (= RCCL) + the HIP library when GPUs are visible."""
