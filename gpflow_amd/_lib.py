@@ -49,6 +49,7 @@ _SIGS = {
     "gpk_row_sumsq": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_double, c_double, _dp]),
     "gpk_project_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gpk_project": (c_int, [c_void_p, _dp, c_int, c_int, c_long, _dp, c_long, c_int, _dp, _dp, c_size_t]),
+    "gpk_project_batched": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_long, _dp, c_long, c_int, _dp, _dp, c_size_t]),
     "gpk_reduce_workspace_bytes": (c_size_t, [c_int]),
     "gpk_gaussian_varexp_sum": (c_int, [c_void_p, _dp, c_long, _dp, c_int, c_int, _dp, c_int, _dp,
                                         C.POINTER(c_double), c_int, c_double, c_double, _dp, _dp, _dp,

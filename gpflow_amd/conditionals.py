@@ -68,18 +68,22 @@ def conditional_tail(At: torch.Tensor, fac: Factor, Knn: torch.Tensor, f: torch.
     f = f.contiguous()
     if not white and q_sqrt is None and Linv_f is not None:
         white, f = True, Linv_f.contiguous()
+    diag_w = q_sqrt.contiguous() if (q_sqrt is not None and q_sqrt.dim() == 2 and not full_cov) else None
+    one_pass = white and not full_cov      # A is not replaced: sum_k A^2, A^T f and the diagonal-q term share ONE read of A
     if full_cov:
         fvar0 = Knn - ops.gemm_nt(At, At)  # Knn - A^T A           (util.py:129)
-        s0 = None
+    elif one_pass:
+        s0, fmean, wsq = ops.row_stats(At, V=f, W=diag_w)
+        fvar0 = Knn - s0
     else:
         s0, _, _ = ops.row_stats(At)  # sum_k A^2              (util.py:133)
         fvar0 = Knn - s0
     if not white:
         LT, invdT = fac.transposed()
         ops.trsm_(At, LT, invdT, trans=1)  # A <- Lm^-T A           (util.py:139)
-    diag_w = q_sqrt.contiguous() if (q_sqrt is not None and q_sqrt.dim() == 2 and not full_cov) else None
-    # A^T f (util.py:144) and, for a diagonal q_sqrt, sum_k (A q_sqrt)^2 (util.py:149,164) in one pass
-    _, fmean, wsq = ops.row_stats(At, V=f, W=diag_w, want_sumsq=False)
+    if not one_pass:
+        # A^T f (util.py:144) and, for a diagonal q_sqrt, sum_k (A q_sqrt)^2 (util.py:149,164) in one pass
+        _, fmean, wsq = ops.row_stats(At, V=f, W=diag_w, want_sumsq=False)
     if q_sqrt is None:
         if full_cov:
             fvar = fvar0[None].expand(R, N, N).contiguous()
@@ -196,6 +200,25 @@ def separate_independent_trapezoid_tail(T: torch.Tensor, M: int, Knns, f, *, ful
     invd, info = ops.potrf_(T, M, zero_upper=True)
     ops.check_info(info)
     invd = invd.reshape(P, -1)
+    if not full_cov and q_sqrt is not None and q_sqrt.dim() == 3:
+        # marginal variances with full q_sqrt (the SVGP ELBO / predict_f of BASELINE config C5 with separate kernels): the
+        # P projections onto q_sqrt_p are ONE launch over the batched trapezoid (gpk_project_batched)
+        s0s, mus = [], []
+        for p in range(P):
+            At = T[p, M:]
+            fp = f[:, p:p + 1].contiguous()
+            if white:
+                s0, mu, _ = ops.row_stats(At, V=fp)
+            else:
+                s0, _, _ = ops.row_stats(At)
+                LT, invdT = Factor(T[p, :M], invd[p]).transposed()
+                ops.trsm_(At, LT, invdT, trans=1)
+                _, mu, _ = ops.row_stats(At, V=fp, want_sumsq=False)
+            s0s.append(s0)
+            mus.append(mu[:, 0])
+        ssq = ops.project(T[:, M:], ops.transpose(q_sqrt.contiguous(), mode=1))           # [P, rows]
+        fvar = torch.stack([Knns[p] - s0s[p] for p in range(P)]) + ssq
+        return torch.stack(mus, dim=-1), fvar.t().contiguous()
     mus, vs = [], []
     for p in range(P):
         fac = Factor(T[p, :M], invd[p])

@@ -588,15 +588,14 @@ extern "C" size_t gpk_project_workspace_bytes(int rows, int m, int P) {
   return (size_t)P * 2 * gpk_gemm_tiles_n(m) * rows * sizeof(double);
 }
 
-extern "C" int gpk_project(void* stream, const double* At, int rows, int m, long ldat,
-                           const double* LqT, long ldl, int P, double* ssq, void* ws,
-                           size_t ws_bytes) {
-  if (!At || !LqT || !ssq || rows < 0 || m <= 0 || P <= 0) return GPK_E_ARG;
+extern "C" int gpk_project_batched(void* stream, const double* At, int rows, int m, long ldat, long strideAt,
+                                   const double* LqT, long ldl, int P, double* ssq, void* ws, size_t ws_bytes) {
+  if (!At || !LqT || !ssq || rows < 0 || m <= 0 || P <= 0 || strideAt < 0) return GPK_E_ARG;
   if (!ws || ws_bytes < gpk_project_workspace_bytes(rows, m, P)) return GPK_E_WORKSPACE;
   if (rows == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int nt = 2 * gpk_gemm_tiles_n(m);
-  GemmArgs g = gemm_base(rows, m, m, 1.0, At, ldat, LqT, ldl, 0.0, nullptr, 0, P, 0, (long)m * ldl, 0);
+  GemmArgs g = gemm_base(rows, m, m, 1.0, At, ldat, LqT, ldl, 0.0, nullptr, 0, P, strideAt, (long)m * ldl, 0);
   g.b_tri = 1;  // LqT[j,k] = Lq[k,j] vanishes for k < j
   g.epi = 1; g.sq_cols = m; g.c2_cols = 0;
   g.part = (double*)ws; g.part_ld = rows; g.stridePart = (long)nt * rows;
@@ -604,6 +603,12 @@ extern "C" int gpk_project(void* stream, const double* At, int rows, int m, long
   int rc = gpk_launch_gemm(s, g);
   if (rc) return rc;
   return gpk_launch_sum_parts(s, (const double*)ws, nt, rows, (long)nt * rows, P, ssq);
+}
+
+extern "C" int gpk_project(void* stream, const double* At, int rows, int m, long ldat,
+                           const double* LqT, long ldl, int P, double* ssq, void* ws,
+                           size_t ws_bytes) {
+  return gpk_project_batched(stream, At, rows, m, ldat, 0, LqT, ldl, P, ssq, ws, ws_bytes);
 }
 
 // ---- fused driver: GPR.log_marginal_likelihood ----------------------------------------------------------

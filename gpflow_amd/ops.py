@@ -336,20 +336,28 @@ def row_dot(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
 
 
 def project(At: torch.Tensor, LqT: torch.Tensor) -> torch.Tensor:
-    """ssq [P, rows] = sum_j (At Lq_p)[b, j]^2 with LqT [P, m, m] = tril(q_sqrt_p)^T."""
+    """ssq [P, rows] = sum_j (At_p Lq_p)[b, j]^2 with LqT [P, m, m] = tril(q_sqrt_p)^T.  At [rows, m]: one matrix shared by
+    the P latents; At [P, rows, m] (any batch stride, unit column stride): one per latent (SeparateIndependent)."""
     lib = _lib.load()
-    _chk(At, "At", 2)
     _chk(LqT, "LqT", 3)
-    rows, m = At.shape
     P = LqT.shape[0]
+    if At.dim() == 3:
+        if At.dtype != torch.float64 or At.shape[0] != P or At.stride(2) != 1:
+            raise ValueError("batched At must be float64 [P, rows, m] with unit column stride")
+        rows, m = At.shape[1], At.shape[2]
+        ldat, stride_at = At.stride(1), At.stride(0)
+    else:
+        _chk(At, "At", 2)
+        rows, m = At.shape
+        ldat, stride_at = _rowmajor(At, "At"), 0
     if LqT.shape[1] != m or LqT.shape[2] != m or not LqT.is_contiguous():
         raise ValueError("LqT must be contiguous [P, m, m]")
     ssq = torch.empty((P, rows), dtype=torch.float64, device=At.device)
     nbytes = int(lib.gpk_project_workspace_bytes(rows, m, P))
     ws = _ws(nbytes)
-    rc = lib.gpk_project(_stream(), At.data_ptr(), rows, m, _rowmajor(At, "At"), LqT.data_ptr(), m, P,
-                         ssq.data_ptr(), ws.data_ptr(), ws.numel() * 8)
-    _lib.check(rc, "gpk_project")
+    rc = lib.gpk_project_batched(_stream(), At.data_ptr(), rows, m, ldat, stride_at, LqT.data_ptr(), m, P,
+                                 ssq.data_ptr(), ws.data_ptr(), ws.numel() * 8)
+    _lib.check(rc, "gpk_project_batched")
     return ssq
 
 

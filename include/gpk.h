@@ -170,6 +170,10 @@ int gpk_row_dot(void* stream, const double* A, long lda, const double* B, long l
 size_t gpk_project_workspace_bytes(int rows, int m, int P);
 int gpk_project(void* stream, const double* At, int rows, int m, long ldat, const double* LqT,
                 long ldl, int P, double* ssq, void* ws, size_t ws_bytes);
+/* The same with one At PER latent, At_p = At + p * strideAt (strideAt = 0: gpk_project): the SeparateIndependent
+ * conditional (util.py:566-629), whose tf.map_fn over the P problems becomes ONE launch over the batched trapezoid. */
+int gpk_project_batched(void* stream, const double* At, int rows, int m, long ldat, long strideAt,
+                        const double* LqT, long ldl, int P, double* ssq, void* ws, size_t ws_bytes);
 
 /* ---- scalar tails (deterministic two-stage reductions) ---------------------------------------------
  * Gaussian variational expectations summed over rows and outputs

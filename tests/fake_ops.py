@@ -313,7 +313,8 @@ def row_dot(A, B):
 def project(At, LqT):
     """ssq [P, rows] = sum_j (At Lq_p)[b, j]^2 with LqT[p] = tril(q_sqrt_p)^T (already triangular-clean)."""
     a = _np(At)
-    return torch.from_numpy(np.stack([((a @ _np(LqT[p]).T) ** 2).sum(1) for p in range(LqT.shape[0])]))
+    return torch.from_numpy(np.stack([(((a[p] if a.ndim == 3 else a) @ _np(LqT[p]).T) ** 2).sum(1)
+                                      for p in range(LqT.shape[0])]))
 
 
 def gpr_lml(X, Y, *, variance, lengthscales, noise_variance, mean_const=0.0, family="SquaredExponential", ws=None):

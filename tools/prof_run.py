@@ -1,4 +1,5 @@
-"""Workload for rocprofv3 --kernel-trace --stats: a few SVGP steps (Cm) and one N=16384 GPR LML."""
+"""Workload for rocprofv3 --kernel-trace --stats: a few SVGP steps (Cm), one N=16384 GPR LML, or (c5sep) a few ELBO
+evaluations of BASELINE config C5 with SeparateIndependent kernels through the model surface."""
 import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 import sys
@@ -35,3 +36,18 @@ if which in ("gpr", "both"):
         out, info = ops.gpr_lml(X, Y, variance=1.0, lengthscales=ls, noise_variance=0.1)
     torch.cuda.synchronize()
     print("gpr", out.cpu().numpy(), info.cpu().numpy())
+if which == "c5sep":
+    import gpflow_amd as gpflow
+    m, b, d, p = 1024, 8192, 8, 4
+    Zh = rng.normal(size=(m, d))
+    X = ops.to_device(rng.normal(size=(b, d)))
+    Y = ops.to_device(rng.normal(size=(b, p)))
+    qm = 0.1 * rng.normal(size=(m, p))
+    qs = np.stack([np.tril(0.05 * rng.normal(size=(m, m))) + 0.5 * np.eye(m) for _ in range(p)])
+    ksep = gpflow.kernels.SeparateIndependent([gpflow.kernels.SquaredExponential(variance=v, lengthscales=l)
+                                               for v, l in zip([1.0, 0.8, 1.2, 0.9], [2.4, 2.8, 3.2, 3.6])])
+    iv = gpflow.inducing_variables.SharedIndependentInducingVariables(gpflow.inducing_variables.InducingPoints(Zh))
+    mp = gpflow.models.SVGP(ksep, gpflow.likelihoods.Gaussian(0.1), iv, q_mu=qm, q_sqrt=qs, num_latent_gps=p, num_data=1_000_000)
+    for _ in range(4):
+        v = float(mp.elbo((X, Y)))
+    print("c5sep", v)
