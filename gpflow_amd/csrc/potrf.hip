@@ -209,9 +209,13 @@ int aux_get(int dev, int need, Aux** out) {
     hipEvent_t* n = (hipEvent_t*)realloc(a.ev, sizeof(hipEvent_t) * need);
     if (!n) return GPK_E_ARG;
     a.ev = n;
-    // (hipEventDisableSystemFence measured SLOWER here: 283 vs 308 steps/s on the SVGP step)
+    // The events only order streams of ONE device against each other (never inspected from the host), so they carry no
+    // system-scope fence: the producing kernels' own release at the end of their dispatch makes the data visible to the
+    // device.  Round 3, same box: chain of n = 2048 alone 0.98 -> 0.925 ms, SVGP step 2.085 -> 2.063 ms, GPR N = 16384
+    // 32.75 -> 32.45 ms, the 1024-row rank shard 1.447 -> 1.388 ms, all bit-identical (profiles/r03_ab_svgp_schedules.log).
+    // (Round 1 had measured this flag slower on a different schedule: 283 vs 308 steps/s.)
     for (int i = a.nev; i < need; ++i) {
-      GPK_HIP(hipEventCreateWithFlags(&a.ev[i], hipEventDisableTiming));
+      GPK_HIP(hipEventCreateWithFlags(&a.ev[i], hipEventDisableTiming | (GPK_TUNE(EV_NOFENCE, 1) ? hipEventDisableSystemFence : 0)));
       a.nev = i + 1;
     }
   }
