@@ -461,7 +461,7 @@ __device__ __forceinline__ void leaf_body(double* __restrict__ S, double* __rest
   if (dbg && tid == 0) {
     const long long t_end = wall_clock64();
     dbg[0] = t_loaded - t_begin; dbg[1] = t_factored - t_loaded; dbg[2] = t_inverted - t_factored;
-    dbg[3] = t_end - t_inverted; dbg[4] = t_end - t_begin;
+    dbg[3] = t_end - t_inverted; dbg[4] = t_end - t_begin; dbg[5] = t_begin;
   }
   if (!FACTORED && info) {
     // bad_col is wave-0 state; lane 0 of wave 0 reports (first failing pivot of the matrix wins)
@@ -497,6 +497,29 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
 
 }  // namespace
 
+#ifdef GPK_EXPERIMENTAL
+namespace {
+constexpr int DBG_CAP = 4096;
+long long* g_dbg = nullptr;
+int g_dbg_n = 0;
+int g_dbg_col[DBG_CAP];
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int gpk_exp_leaf_dbg_dump(int first) {
+  if (!g_dbg || g_dbg_n <= first) return 0;
+  static long long host[8 * DBG_CAP];
+  if (hipMemcpy(host, g_dbg, sizeof(long long) * 8 * g_dbg_n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  printf("# leaf phases in us (100 MHz wall clock): col0 load factor invert store total | begin since the first leaf, gap since the previous leaf's end\n");
+  for (int i = first; i < g_dbg_n; ++i)
+    printf("leaf %5d  %6.1f %6.1f %6.1f %6.1f  %6.1f | %9.1f %7.1f\n", g_dbg_col[i], host[8 * i] / 100.0, host[8 * i + 1] / 100.0,
+           host[8 * i + 2] / 100.0, host[8 * i + 3] / 100.0, host[8 * i + 4] / 100.0, (host[8 * i + 5] - host[8 * first + 5]) / 100.0,
+           i > first ? (host[8 * i + 5] - host[8 * (i - 1) + 5] - host[8 * (i - 1) + 4]) / 100.0 : 0.0);
+  fflush(stdout);
+  const int n = g_dbg_n;
+  g_dbg_n = 0;
+  return n;
+}
+#endif
+
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
                     long strideInv, int* info, int col0, int batch, int already_factored) {
   if (nb <= 0 || nb > NB) return GPK_E_ARG;
@@ -509,6 +532,17 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
   GPK_HIP(attr0);
   dim3 grid((unsigned)(batch > 0 ? batch : 1));
   const int fake = kGpkExp ? GPK_TUNE(LEAF_FAKE_US, 0) * 100 : 0;
+#ifdef GPK_EXPERIMENTAL
+  // phase timers of every leaf launch (GPK_LEAF_DBG=1; printed by gpk_exp_leaf_dbg_dump): load / factor / invert / store
+  if (!already_factored && GPK_TUNE(LEAF_DBG, 0) && g_dbg_n < DBG_CAP) {
+    if (!g_dbg) GPK_HIP(hipMalloc(&g_dbg, sizeof(long long) * 8 * DBG_CAP));
+    g_dbg_col[g_dbg_n] = col0;
+    hipLaunchKernelGGL((leaf_kernel<false>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd, strideInv, info, col0,
+                       g_dbg + 8 * (g_dbg_n++), fake);
+    GPK_LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   if (already_factored)
     hipLaunchKernelGGL((leaf_kernel<true>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd,
                        strideInv, info, col0, nullptr, 0);

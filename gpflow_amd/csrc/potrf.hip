@@ -194,14 +194,14 @@ int aux_get(int dev, int need, Aux** out) {
       return rc;
     }
     if (kGpkExp && GPK_TUNE(STREAM_SELFTEST, 0)) {
-      double pq = 0, pb = 0, xb = 0, pm = 0;
+      double pq = 0, pb = 0, xb = 0, pm = 0, pl = 0;
       (void)handoff_us(a.P, a.X, &pq); (void)handoff_us(a.P, a.Bs, &pb); (void)handoff_us(a.X, a.Bs, &xb);
-      (void)handoff_us(a.P, a.B, &pm);
+      (void)handoff_us(a.P, a.B, &pm); (void)handoff_us(a.P, a.Bl, &pl);
       hipStream_t trio[3] = {a.P, a.X, a.Bs};
       double cu[3] = {0, 0, 0};
       (void)concurrent_us(trio, 3, cu);
-      fprintf(stderr, "[gpk] stream hand-off us: P<->X %.1f  P<->Bs %.1f  X<->Bs %.1f  P<->B(masked) %.1f | concurrent noop us/kernel: P %.1f X %.1f Bs %.1f\n",
-              pq, pb, xb, pm, cu[0], cu[1], cu[2]);
+      fprintf(stderr, "[gpk] stream hand-off us: P<->X %.1f  P<->Bs %.1f  X<->Bs %.1f  P<->B(masked) %.1f  P<->Bl(masked) %.1f | concurrent noop us/kernel: P %.1f X %.1f Bs %.1f\n",
+              pq, pb, xb, pm, pl, cu[0], cu[1], cu[2]);
     }
     a.ready = true;
   }
@@ -368,7 +368,20 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // where the whole factorisation is a latency chain
   const int nbo_large = (GPK_TUNE(NBO, 640) / NB) * NB;
   const int nbo = (n >= 4096) ? (nbo_large >= NB ? nbo_large : NBO) : NB;
-  const int npanels = gpk_cdiv(n, nbo);
+  // Panel boundaries.  The END of a large factorisation is a latency chain again (trailing matrix too small to hide the
+  // panel): there a wide panel costs 5 leaves + 4 in-panel updates + one K = 640 look-ahead strip of < 256 tiles, i.e. ONE
+  // under-filled tile time of ~170 us -- 450 - 480 us per 640 columns (in-kernel time stamps, tools/leaf_phase_probe.py) --
+  // while single-leaf panels cost 56 - 63 us each once their K = 128 rest-updates keep up.  So the last `narrow_tail`
+  // columns are factored with the SVGP-size scheme (nbo = NB).  A/B at N = 16384, same box (profiles/r03_ab_gpr_nbo.log):
+  // off 32.7 ms, 2048 -> 32.65, 3072 -> 32.4, 4096 -> 31.9, 5120 -> 32.2, 6144 -> 32.5, 8192 -> 33.2.
+  const int narrow_tail = (nbo > NB) ? (GPK_TUNE(NARROW_TAIL, 4096) / NB) * NB : 0;
+  std::vector<int> cuts;
+  for (int c = 0; c < n;) {
+    cuts.push_back(c);
+    c += (nbo > NB && n - c > narrow_tail) ? nbo : NB;
+  }
+  cuts.push_back(n);
+  const int npanels = (int)cuts.size() - 1;
   // Few extra rows (GPR: the P columns of Y) simply ride along through the panel solves and trailing
   // updates of the square part; many extra rows (SVGP: the minibatch; GPR: the test rows of predict_f) are solved
   // right-looking, group by group, as bulk work overlapped with the factorisation.
@@ -428,9 +441,9 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   const int late_rows = GPK_TUNE(LATE_ROWS, 3072);  // A/B at N = 16384: 3072 -> 32.9 ms, 6144 -> 33.8, off -> 33.1
   const int xgroup = std::max(NB, (GPK_TUNE(XGROUP, NBO) / NB) * NB);
   for (int p = 0; p < npanels; ++p) {
-    const int c0 = p * nbo;
-    const int c1 = (c0 + nbo < n) ? c0 + nbo : n;
-    const int c2 = (c1 + nbo < n) ? c1 + nbo : n;
+    const int c0 = cuts[p], c1 = cuts[p + 1];
+    const int c2 = (p + 2 <= npanels) ? cuts[p + 2] : n;
+    const bool narrow = large && (c1 - c0 <= NB) && nbo > NB;  // single-leaf panel in the chain-bound end of a large factorisation
     // ---- P: the critical path.  Panel p, then the strip = columns of panel p+1 (look-ahead) -----------
     rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
@@ -449,10 +462,17 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // While the trailing matrix is large the factorisation is bound by these GEMMs and they start as soon as
     // panel p is solved.  Near the end it is bound by the latency chain of P instead: there the strip goes
     // first (alone on the chip) and the rest-update overlaps the NEXT panel's chain rather than the strip.
-    const bool strip_first = large && (n - c1 <= late_rows) && (c1 < n);
+    const bool strip_first = large && !narrow && (n - c1 <= late_rows) && (c1 < n);
     if (c2 < n) {
       hipStream_t Bp = B;
-      if (strip_first) {
+      if (narrow) {
+        // the unmasked stream of the SVGP-size scheme.  (The half-masked Bl would keep CUs free for the leaf, but while both
+        // are busy every Bl -> P hand-off takes ~55 us instead of ~5 -- their hardware queues share a microengine pipe --
+        // which made this region 190 us per panel instead of 56: GPR N = 16384 36.6 ms on Bl, 32.0 ms on Bs.)
+        Bp = aux->Bs;
+        GPK_HIP(hipStreamWaitEvent(Bp, evF[p], 0));
+        if (last_rest >= 0 && last_bulk != Bp) GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
+      } else if (strip_first) {
         Bp = aux->Bl;  // (in-order with the earlier rest-updates through evR below)
         GPK_HIP(hipEventRecord(evLate, P));
         GPK_HIP(hipStreamWaitEvent(Bp, evLate, 0));
@@ -478,7 +498,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // ---- X: the extra rows against the finished columns, in groups of up to 512 columns (so that the big
     // right-looking update is a K = 512 GEMM).  For the small sizes the groups shrink towards the end (.., n-256,
     // n-128, n): whatever is left of the extra-row work when the LAST leaf finishes is exposed latency.
-    const bool tail_zone = (nbo == NB) && (n >= 8 * NB);
+    const bool tail_zone = !large && (nbo == NB) && (n >= 8 * NB);
     const bool tail_group = tail_zone && (c1 == n - 2 * NB || c1 == n - NB);
     const bool full_group = ((c1 - xg0) >= xgroup || (large && c1 - xg0 >= nbo)) && !(tail_zone && c1 > n - 2 * NB && c1 < n);
     if (useX && (c1 == n || full_group || tail_group)) {
