@@ -63,8 +63,10 @@ extern "C" size_t gpk_invd_elems(int n, int batch) {
 //       needs a whole CU's LDS, queues behind thousands of resident GEMM workgroups (a 2 ms stall per panel at
 //       N = 16384) and the look-ahead never overlaps.  Large factorisations (n >= 4096) only: the big MFMA GEMMs of the
 //       outer trailing updates and of the extra rows;
-//   Bl  the same for the chain-bound tail of a large factorisation: leaves half the CUs to P;
-//   Bs  rest-updates of SMALL factorisations (they are ON the critical path there): all CUs;
+//   Bs  rest-updates of SMALL factorisations and of the single-leaf panels at the end of large ones (they are ON the
+//       critical path there): all CUs.  (Rounds 1-2 ran that end of a large factorisation with wide panels and a second
+//       masked stream over half the CUs; round 3 measured every hand-off from that stream to P at ~55 us while both are
+//       busy -- their hardware queues share a microengine pipe -- and replaced it: potrf_core, "Panel boundaries".)
 //   X   bulk stream of small factorisations: the right-looking solve of the extra rows (the SVGP minibatch).  Unmasked:
 //       CU-masked queues dispatch its short kernels slowly and quantise its big updates badly (profiles/r03_*).
 // One std::recursive_mutex per device serialises the ENQUEUE of factorisations (shared streams, event pool); the
@@ -74,7 +76,7 @@ struct Aux {
   std::recursive_mutex mu;
   bool ready = false;
   int init_rc = 0;  // sticky: a failed stream set-up is reported by every later call instead of being retried
-  hipStream_t P = nullptr, B = nullptr, Bs = nullptr, Bl = nullptr, X = nullptr, pad = nullptr;
+  hipStream_t P = nullptr, B = nullptr, Bs = nullptr, X = nullptr, pad = nullptr;
   hipEvent_t* ev = nullptr;
   int nev = 0;
   int ncu = 0, bulk_cus = 0;
@@ -105,7 +107,7 @@ int aux_create(Aux& a, int dev) {
   // Hence this creation order -- default stream = queue 1 (pipe 0) exists already:
   //   P -> queue 2 (pipe 1);  X -> queue 3 (pipe 2);  one unused stream, then Bs: with the usual pool of 2 the unused
   //   one shares X's queue and Bs lands on the default stream's (idle) queue 1, with a pool of 4 they open queues 4
-  //   and 5 (pipes 3 and 0);  then the masked B -> pipe 3 (or 1) and Bl -> pipe 0 (or 2).
+  //   and 5 (pipes 3 and 0);  then the masked B -> pipe 3 (or 1).
   // The chain (P), its rest-updates (Bs) and the bulk stream (X or B) are then always on three different pipes.
   GPK_HIP(hipStreamCreateWithPriority(&a.P, hipStreamNonBlocking, hi));
   GPK_HIP(hipStreamCreateWithFlags(&a.X, hipStreamNonBlocking));
@@ -116,10 +118,7 @@ int aux_create(Aux& a, int dev) {
   int rc = masked_stream(&a.B, ncu, reserved, ncu);
   if (rc) return rc;
   a.bulk_cus = ncu - reserved;
-  int late_res = GPK_TUNE(LATE_RESERVED_CUS, -1);
-  if (late_res < 0) late_res = ncu / 2;
-  if (ncu > 1024 || late_res >= ncu) late_res = 0;
-  return masked_stream(&a.Bl, ncu, late_res, ncu);
+  return 0;
 }
 
 // Cost of one cross-stream hand-off (kernel on a -> event -> kernel on b -> event -> ...), microseconds: ~5 when the two
@@ -186,7 +185,7 @@ int aux_get(int dev, int need, Aux** out) {
     if (a.init_rc) return a.init_rc;
     const int rc = aux_create(a, dev);
     if (rc) {  // no half-built stream set: give back what was created, remember the error
-      for (hipStream_t* s : {&a.P, &a.X, &a.pad, &a.Bs, &a.B, &a.Bl}) {
+      for (hipStream_t* s : {&a.P, &a.X, &a.pad, &a.Bs, &a.B}) {
         if (*s) (void)hipStreamDestroy(*s);
         *s = nullptr;
       }
@@ -194,14 +193,14 @@ int aux_get(int dev, int need, Aux** out) {
       return rc;
     }
     if (kGpkExp && GPK_TUNE(STREAM_SELFTEST, 0)) {
-      double pq = 0, pb = 0, xb = 0, pm = 0, pl = 0;
+      double pq = 0, pb = 0, xb = 0, pm = 0;
       (void)handoff_us(a.P, a.X, &pq); (void)handoff_us(a.P, a.Bs, &pb); (void)handoff_us(a.X, a.Bs, &xb);
-      (void)handoff_us(a.P, a.B, &pm); (void)handoff_us(a.P, a.Bl, &pl);
+      (void)handoff_us(a.P, a.B, &pm);
       hipStream_t trio[3] = {a.P, a.X, a.Bs};
       double cu[3] = {0, 0, 0};
       (void)concurrent_us(trio, 3, cu);
-      fprintf(stderr, "[gpk] stream hand-off us: P<->X %.1f  P<->Bs %.1f  X<->Bs %.1f  P<->B(masked) %.1f  P<->Bl(masked) %.1f | concurrent noop us/kernel: P %.1f X %.1f Bs %.1f\n",
-              pq, pb, xb, pm, pl, cu[0], cu[1], cu[2]);
+      fprintf(stderr, "[gpk] stream hand-off us: P<->X %.1f  P<->Bs %.1f  X<->Bs %.1f  P<->B(masked) %.1f | concurrent noop us/kernel: P %.1f X %.1f Bs %.1f\n",
+              pq, pb, xb, pm, cu[0], cu[1], cu[2]);
     }
     a.ready = true;
   }
@@ -426,7 +425,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
   hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
   hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1], evJoinB = aux->ev[2 * npanels + 2],
-             evJoinX = aux->ev[2 * npanels + 3], evLate = aux->ev[2 * npanels + 4];
+             evJoinX = aux->ev[2 * npanels + 3];
   if (x_prologue && !useX) {  // the extra rows ride through the panel solves: they must exist before the first one
     rc = (*x_prologue)(S);
     if (rc) return rc;
@@ -438,7 +437,6 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
   int xg0 = 0;         // first column of the current extra-row group
-  const int late_rows = GPK_TUNE(LATE_ROWS, 3072);  // A/B at N = 16384: 3072 -> 32.9 ms, 6144 -> 33.8, off -> 33.1
   const int xgroup = std::max(NB, (GPK_TUNE(XGROUP, NBO) / NB) * NB);
   for (int p = 0; p < npanels; ++p) {
     const int c0 = cuts[p], c1 = cuts[p + 1];
@@ -459,24 +457,16 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       if (rc) return rc;
     }
     // ---- B: rest of the outer trailing update  A[c2:, c2:] -= P[c2:] P[c2:]^T, lower tiles only --------
-    // While the trailing matrix is large the factorisation is bound by these GEMMs and they start as soon as
-    // panel p is solved.  Near the end it is bound by the latency chain of P instead: there the strip goes
-    // first (alone on the chip) and the rest-update overlaps the NEXT panel's chain rather than the strip.
-    const bool strip_first = large && !narrow && (n - c1 <= late_rows) && (c1 < n);
+    // While the trailing matrix is large the factorisation is bound by these GEMMs (masked stream B); they start as soon
+    // as panel p is solved.
     if (c2 < n) {
       hipStream_t Bp = B;
       if (narrow) {
-        // the unmasked stream of the SVGP-size scheme.  (The half-masked Bl would keep CUs free for the leaf, but while both
-        // are busy every Bl -> P hand-off takes ~55 us instead of ~5 -- their hardware queues share a microengine pipe --
-        // which made this region 190 us per panel instead of 56: GPR N = 16384 36.6 ms on Bl, 32.0 ms on Bs.)
+        // the unmasked stream of the SVGP-size scheme.  (A stream masked to half the CUs would keep CUs free for the leaf,
+        // but its hand-offs to P took ~55 us instead of ~5: 190 us per panel instead of 56, GPR N = 16384 36.6 vs 32.0 ms.)
         Bp = aux->Bs;
         GPK_HIP(hipStreamWaitEvent(Bp, evF[p], 0));
         if (last_rest >= 0 && last_bulk != Bp) GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
-      } else if (strip_first) {
-        Bp = aux->Bl;  // (in-order with the earlier rest-updates through evR below)
-        GPK_HIP(hipEventRecord(evLate, P));
-        GPK_HIP(hipStreamWaitEvent(Bp, evLate, 0));
-        if (last_rest >= 0) GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
       } else {
         GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));
       }
