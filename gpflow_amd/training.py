@@ -45,8 +45,8 @@ class _Adam:
 
 
 class SVGPTrainer:
-    """Adam on -ELBO for `model` (SVGP: whitened or un-whitened, full q_sqrt, SquaredExponential kernel, Gaussian likelihood with a
-    constant variance, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
+    """Adam on -ELBO for `model` (SVGP: whitened or un-whitened, full or diagonal q_sqrt, SquaredExponential / Matern kernel with
+    or without `active_dims`, Gaussian likelihood with a constant variance, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
     `Constant.c`).  A step whose Kuu factorisation fails raises and leaves variables and Adam moments untouched.
 
         trainer = SVGPTrainer(model, learning_rate=1e-3)
@@ -60,8 +60,13 @@ class SVGPTrainer:
         """natgrad_gamma: if given, (q_mu, q_sqrt) take a natural-gradient step of that size per iteration
         (optimizers/natgrad.py; natgrad.natgrad_update on the device) and Adam handles the remaining parameters -- the
         hybrid recipe of the reference's natural-gradient notebook, from ONE gradient evaluation per step."""
-        k, iv, c = model.gradient_config()      # NotImplementedError outside the scope of the reverse pass
+        # NotImplementedError outside the scope of the reverse pass
+        k, iv, c = model.gradient_config(allow_active_dims=True, allow_q_diag=True)
         lik = model.likelihood
+        self.kernel = k
+        self.q_diag = model.q_sqrt.numpy().ndim == 2
+        if self.q_diag and natgrad_gamma is not None:
+            raise NotImplementedError("natural gradients need the full q_sqrt [P, M, M] (optimizers/natgrad.py:280-368)")
         for p in (k.variance, k.lengthscales, lik.variance, iv.Z, model.q_mu, model.q_sqrt):
             if p.prior is not None:
                 raise NotImplementedError("parameter priors are not part of the trainer's objective")
@@ -86,6 +91,19 @@ class SVGPTrainer:
         self.dev = {"Z": ops.to_device(iv.Z.numpy()).clone(), "q_mu": ops.to_device(model.q_mu.numpy()).clone(),
                     "q_sqrt": ops.to_device(model.q_sqrt.numpy()).clone()}
         self.dev_params = {"Z": iv.Z, "q_mu": model.q_mu, "q_sqrt": model.q_sqrt}
+        self.q_lower = 0.0
+        if self.q_diag:
+            # q_sqrt [M, P] holds standard deviations under positive() = softplus (+ an optional lower bound,
+            # utilities/bijectors.py:27-45): the DEVICE variable is the unconstrained one, q = softplus(u) + lower is formed
+            # on the device every step and the gradient is chained through sigmoid(u) there
+            from .base import Chain, Shift, Softplus
+            t = model.q_sqrt.transform
+            if isinstance(t, Chain) and len(t.bijectors) == 2 and isinstance(t.bijectors[0], Shift) \
+                    and isinstance(t.bijectors[1], Softplus):
+                self.q_lower = float(t.bijectors[0].shift)
+            elif not isinstance(t, Softplus):
+                raise NotImplementedError("the trainer covers the softplus transform of a diagonal q_sqrt")
+            self.dev["q_sqrt"] = ops.to_device(np.asarray(model.q_sqrt.unconstrained_variable, dtype=np.float64)).clone()
         self.last_info: Optional[int] = None   # factorisation status of the last step (0 = ok), checked every step
 
     def constrained(self, name: str) -> np.ndarray:
@@ -105,11 +123,17 @@ class SVGPTrainer:
         if "mean_const" in self.host:
             self.mean_const = float(np.ravel(self.constrained("mean_const"))[0])
         fn = gradients.svgp_elbo_and_grad if self.model.whiten else gradients.svgp_elbo_and_grad_unwhitened
+        from .models.svgp import SVGP
+        Zs, Xs, scatter = SVGP._sliced(self.kernel, self.dev["Z"], Xb)          # active_dims (kernels/base.py:90-109)
+        q_sqrt = torch.nn.functional.softplus(self.dev["q_sqrt"]) + self.q_lower if self.q_diag else self.dev["q_sqrt"]
         F, g, info = fn(
-            self.dev["Z"], Xb, Yb, self.dev["q_mu"], self.dev["q_sqrt"], variance=var, lengthscales=ls,
+            Zs, Xs, Yb, self.dev["q_mu"], q_sqrt, variance=var, lengthscales=ls,
             noise_variance=noise, jitter=config.default_jitter(), scale=scale, mean_const=self.mean_const,
             kl_weight=1.0 / world, family=self.family)
         g = dict(g)
+        g["Z"] = scatter(g["Z"])
+        if self.q_diag:
+            g["q_sqrt"] = g["q_sqrt"] * torch.sigmoid(self.dev["q_sqrt"])      # d softplus(u) / du
         g["_status"] = info.to(torch.float64).reshape(-1)[:1]   # rides in the packed all-reduce: > 0 iff ANY rank failed
         F, g = distributed.all_reduce_grads(F, g, self.group)
         # The factorisation status decides whether this step may be applied at all: after a failed Cholesky of Kuu the
@@ -155,4 +179,7 @@ class SVGPTrainer:
             p.assign_unconstrained(self.u[name])
         for name, p in self.dev_params.items():
             v = self.dev[name].cpu().numpy()
-            p.assign(np.tril(v) if name == "q_sqrt" else v)
+            if name == "q_sqrt" and self.q_diag:
+                p.assign_unconstrained(v)
+            else:
+                p.assign(np.tril(v) if name == "q_sqrt" else v)

@@ -501,3 +501,40 @@ def test_unwhitened_q_diag_svgp_elbo_and_grad_vs_autograd_oracle(gpu, M, B, D, P
     scale_fix = (1000.0 / B)   # (the model scales by num_data / B itself)
     assert abs(mv - float(m.elbo((X, Y)).cpu())) <= 1e-9 * abs(mv) and abs(mv - v) <= 1e-9 * abs(v), (mv, v, scale_fix)
     np.testing.assert_allclose(mg[m.q_mu], go["q_mu"], rtol=0, atol=1e-8 * np.abs(go["q_mu"]).max())
+
+
+@pytest.mark.parametrize("whiten", [True, False])
+def test_trainer_with_q_diag_and_active_dims(gpu, whiten):
+    """The device-resident trainer on a model with a diagonal q_sqrt (softplus-constrained standard deviations, chained on
+    the device) and a kernel with `active_dims`: the value it returns is the model's own ELBO, its FIRST Adam step moves
+    every variable by lr * sign(dELBO/du) (bias-corrected Adam from zero moments) with the gradient of `SVGP.elbo_and_grad`,
+    inducing-point columns outside `active_dims` do not move, and training raises the ELBO."""
+    import gpflow_amd as gpflow
+    rng = np.random.default_rng(71)
+    N, D, M, P = 260, 4, 30, 2
+    X = rng.normal(size=(N, D)); Y = np.sin(X[:, [2]] + X[:, [0]]) + 0.1 * rng.normal(size=(N, P))
+    Z = rng.normal(size=(M, D)); q_mu = 0.2 * rng.normal(size=(M, P)); q = 0.4 + np.abs(rng.normal(size=(M, P)))
+    dims = [2, 0]
+    def make():
+        k = gpflow.kernels.Matern32(variance=1.2, lengthscales=np.array([0.9, 1.3]), active_dims=dims)
+        return gpflow.models.SVGP(k, gpflow.likelihoods.Gaussian(0.3), Z.copy(), q_mu=q_mu.copy(), q_sqrt=q.copy(), q_diag=True,
+                                  whiten=whiten, num_latent_gps=P, num_data=5 * N)
+    m = make()
+    v, g = m.elbo_and_grad((X, Y))
+    lr = 0.01
+    tr = gpflow.training.SVGPTrainer(m, learning_rate=lr)
+    u0 = np.array(m.q_sqrt.unconstrained_variable, dtype=np.float64, copy=True)
+    F0 = float(tr.step((X, Y)).cpu()[0])
+    assert abs(F0 - v) <= 1e-9 * abs(v)
+    tr.sync_to_model()
+    du = np.asarray(m.q_sqrt.unconstrained_variable) - u0
+    gq = np.asarray(g[m.q_sqrt]).reshape(u0.shape)
+    big = np.abs(gq) > 1e-3 * np.abs(gq).max()
+    np.testing.assert_allclose(du[big], lr * np.sign(gq[big]), rtol=1e-4)
+    dz = m.inducing_variable.Z.numpy() - Z
+    assert np.all(dz[:, [1, 3]] == 0.0) and np.abs(dz[:, dims]).max() > 0.5 * lr
+    for _ in range(40):
+        last = tr.step((X, Y))
+    assert float(last.cpu()[0]) > F0
+    tr.sync_to_model()
+    assert abs(float(m.elbo((X, Y)).cpu()) - float(tr.step((X, Y)).cpu()[0])) <= 1e-8 * abs(F0)
