@@ -41,6 +41,28 @@ int main(int argc, char** argv) {
   printf("  captured, ending...\n"); fflush(stdout);
   CK(hipStreamEndCapture(S, &g));
   size_t nn = 0; CK(hipGraphGetNodes(g, nullptr, &nn)); printf("  %zu nodes\n", nn); fflush(stdout);
+  {
+    // priorities: what the capture recorded, and (argv[3] = 1) the chain's kernels -- 512-thread workgroups: leaf, one-shot
+    // solve / strip -- raised to the highest priority before instantiation
+    std::vector<hipGraphNode_t> nodes(nn);
+    CK(hipGraphGetNodes(g, nodes.data(), &nn));
+    int lo = 0, hi = 0; CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    int nk = 0, nprio = 0, nset = 0;
+    for (auto nd : nodes) {
+      hipGraphNodeType ty; CK(hipGraphNodeGetType(nd, &ty));
+      if (ty != hipGraphNodeTypeKernel) continue;
+      ++nk;
+      hipKernelNodeAttrValue v{};
+      if (hipGraphKernelNodeGetAttribute(nd, hipKernelNodeAttributePriority, &v) == hipSuccess && v.priority != 0) ++nprio;
+      hipKernelNodeParams kp{}; CK(hipGraphKernelNodeGetParams(nd, &kp));
+      if (argc > 3 && atoi(argv[3]) == 1 && kp.blockDim.x == 512) {
+        v.priority = hi;
+        if (hipGraphKernelNodeSetAttribute(nd, hipKernelNodeAttributePriority, &v) == hipSuccess) ++nset;
+      }
+    }
+    printf("  %d kernel nodes, %d captured with a non-default priority, %d raised (range %d..%d)\n", nk, nprio, nset, lo, hi);
+    fflush(stdout);
+  }
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   auto replay = [&]() -> int { CK(hipGraphLaunch(ge, S)); return 0; };
   if (replay()) return 1;
