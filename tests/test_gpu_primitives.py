@@ -203,6 +203,16 @@ def test_row_stats_project_reductions(gpu):
     ssq = ops.project(_t(At), LqT).cpu().numpy()
     ref = np.stack([((At @ np.tril(q_sqrt[p])) ** 2).sum(1) for p in range(P)])
     np.testing.assert_allclose(ssq, ref, rtol=1e-12)
+    # one At PER latent (gpk_project_batched; SeparateIndependent): rows of a batched trapezoid, i.e. a strided view --
+    # bit-identical to P single-latent launches
+    T3 = _t(rng.normal(size=(P, 50 + rows, m)))
+    ssq_b = ops.project(T3[:, 50:], LqT).cpu().numpy()
+    for p in range(P):
+        one = ops.project(T3[p, 50:], LqT[p:p + 1]).cpu().numpy()[0]
+        np.testing.assert_array_equal(ssq_b[p], one)
+        np.testing.assert_allclose(ssq_b[p], ((T3[p, 50:].cpu().numpy() @ np.tril(q_sqrt[p])) ** 2).sum(1), rtol=1e-12)
+    with pytest.raises(ValueError):
+        ops.project(T3[:2, 50:], LqT)
     # scalar tails
     Y = rng.normal(size=(rows, P)); fmean = rng.normal(size=(rows, P))
     s0 = rng.uniform(0, 0.5, size=rows)
