@@ -305,8 +305,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
 //     covers the LDS latency of the first fragments of slab s+1.
 // With beta != 0 the accumulators start as (beta/alpha) C, loaded in the prologue next to the first
 // slab, so the epilogue is store-only.
+// rev != 0: the K slabs are walked from the LAST to the first (same slabs, same per-slab arithmetic; the sum over slabs is
+// taken in the opposite order).  Used by the paired triangular-K launches: see gemm_nt_fast.
 template <int EPI>
-__device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int tile_n, double* smem) {
+__device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int tile_n, double* smem, int rev = 0) {
   constexpr int BM = 128, BN = 128;
   constexpr int BUF = (BM + BN) * LDSS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -355,8 +357,9 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   const int woff = srow * LDSS + scol;
   d2 st[8];
   auto gload = [&](int s) {
-    const char* ab = abase + (long)s * (BK * 8);
-    const char* bb = bbase + (long)s * (BK * 8);
+    const long so = rev ? (long)(nk - 1 - s) : (long)s;
+    const char* ab = abase + so * (BK * 8);
+    const char* bb = bbase + so * (BK * 8);
 #pragma unroll
     for (int q = 0; q < 4; ++q) st[q] = *reinterpret_cast<const d2*>(ab + oa[q]);
 #pragma unroll
@@ -558,11 +561,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
       if (t + (int)gridDim.x < total) __syncthreads();  // both LDS buffers are about to be refilled
     }
   } else {
+    // The workgroups of one row tile (block ids tile_m + j gy: the same XCD, all resident together) read the same rows of A.
+    // Column tile j only needs K >= 128 j, so started at their own first slab they would sit at eight different K offsets
+    // and every one of them would pull its rows of A through an L2 that cannot hold them (8 row tiles x 2 MB per XCD):
+    // FETCH_SIZE of the projection was 6.8 x its algorithmic bytes.  Time-aligned instead: the first tile of every pair walks
+    // K DOWN from the common end (all eight start at the same slab), the second, short one walks UP to it (all eight
+    // finish at the same slab), so a slab of A is fetched once per XCD and hit by the other seven.  (b_tri = 1 only.)
+    const int align = (EPI == 1 && p.b_tri == 1) ? p.pair_k_align : 0;
     const int tile_m = blockIdx.x % gy, j = blockIdx.x / gy;
-    fast_tile<EPI>(p, tile_m, j, smem);
+    fast_tile<EPI>(p, tile_m, j, smem, align);
     if (gx - 1 - j != j) {
       __syncthreads();  // both LDS buffers are about to be refilled
-      fast_tile<EPI>(p, tile_m, gx - 1 - j, smem);
+      fast_tile<EPI>(p, tile_m, gx - 1 - j, smem, 0);
     }
   }
 }
@@ -602,7 +612,9 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     if (pair_ok && gx >= 4 && a.b_tri_rows >= a.n) {
       total = ((gx + 1) / 2) * gy;
       g_last_kind = 2 + 2 * EPI + 1;
-      hipLaunchKernelGGL((gemm_nt_fast<EPI, true>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, a, gx, gy,
+      GemmArgs ap = a;
+      ap.pair_k_align = GPK_TUNE(PAIR_K_ALIGN, 1);
+      hipLaunchKernelGGL((gemm_nt_fast<EPI, true>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, ap, gx, gy,
                          total, compact);
       GPK_LAUNCH_CHECK();
       return 0;

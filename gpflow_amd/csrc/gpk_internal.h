@@ -81,6 +81,7 @@ struct GemmArgs {
   int small_loop;   // K <= 128 launches with MORE than 512 row slivers may still take the one-shot latency kernel: its workgroups
                     // then walk the row blocks with their B tile staged once (the in-group updates of the extra rows)
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
+  int pair_k_align; // set by the launcher for paired triangular-K launches: time-aligned K traversal (gemm_nt_fast)
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
 
