@@ -1069,6 +1069,14 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
     const long eff = a.c_lower ? tiles / 2 : tiles;
     if (eff < GPK_TUNE(HALF_TILE_BELOW, 300)) return launch_cfg<64, 128, 1, 4>(s, a);
   }
+  if (a.epi == 1 && a.b_tri == 1 && !(a.beta != 0.0 && a.C) && a.m > 64) {
+    // under-filled projections (a rank's 1024-row shard of a strong-scaled step: 8 row tiles x 8 column pairs = 64
+    // workgroups, ONE of them per four CUs, 296 us for 4.3 GFLOP): 64-row tiles, unpaired -- four times the workgroups.
+    // tools/proj_small_probe.py: 1024 x 2048 296 -> 194 us, 300 x 1024 (P = 2) 162 -> 97 us, 2048 x 2048 306 -> 268 us;
+    // from 256 pairs on the paired 128-row tiles win (4096 x 2048: 327 us against 483)
+    const long pairs = (long)((gpk_cdiv(a.n, 128) + 1) / 2) * gpk_cdiv(a.m, 128) * (a.batch > 0 ? a.batch : 1);
+    if (pairs < GPK_TUNE(PROJ_HALF_TILE_BELOW, 200)) return launch_cfg<64, 128, 2, 2>(s, a);
+  }
   if (fast_ok(a) && (a.epi == 1 || (a.n > 64 && (tiles >= 24 || a.m <= 64)))) {
     return a.epi == 1 ? launch_fast<1>(s, a) : launch_fast<0>(s, a);
   }
