@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 8);
-        if ((lane & 15) == 0 && row < p.m) part[(long)(tile_n * 2 + wn) * p.part_ld + row] = s;
+        // one partial per 64 columns of the output: tile_n * (BN / 64) + (this wave's 64-column slot within the tile)
+        if ((lane & 15) == 0 && row < p.m) part[(long)(tile_n * (BN / 64) + (wn * WN) / 64) * p.part_ld + row] = s;
       }
   }
 }
@@ -1071,11 +1072,18 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
   }
   if (a.epi == 1 && a.b_tri == 1 && !(a.beta != 0.0 && a.C) && a.m > 64) {
     // under-filled projections (a rank's 1024-row shard of a strong-scaled step: 8 row tiles x 8 column pairs = 64
-    // workgroups, ONE of them per four CUs, 296 us for 4.3 GFLOP): 64-row tiles, unpaired -- four times the workgroups.
-    // tools/proj_small_probe.py: 1024 x 2048 296 -> 194 us, 300 x 1024 (P = 2) 162 -> 97 us, 2048 x 2048 306 -> 268 us;
-    // from 256 pairs on the paired 128-row tiles win (4096 x 2048: 327 us against 483)
+    // workgroups, ONE of them per four CUs, 296 us for 4.3 GFLOP; a CU cannot finish a 128 x 128 x 16 slab in less than
+    // 1.7 us however many workgroups it holds): 64 x 64 tiles, unpaired -- sixteen times the workgroups.
+    // tools/proj_small_probe.py (profiles/r03_projection_few_rows.txt), paired 128-row tiles / 64 x 128 / 64 x 64:
+    // 1024 x 2048: 296 / 194 / 155 us, 300 x 1024 (P = 2): 162 / 98 / 62 us, 2048 x 2048: 306 / 268 / 221 us; from 256 pairs
+    // on the paired 128-row tiles win (4096 x 2048: 327 us against 483 us on 64 x 128).
     const long pairs = (long)((gpk_cdiv(a.n, 128) + 1) / 2) * gpk_cdiv(a.m, 128) * (a.batch > 0 ? a.batch : 1);
-    if (pairs < GPK_TUNE(PROJ_HALF_TILE_BELOW, 200)) return launch_cfg<64, 128, 2, 2>(s, a);
+    if (pairs < GPK_TUNE(PROJ_SMALL_TILE_BELOW, 200)) {
+      // (every 64-column partial slot the reduction reads must be written: 64-wide tiles only if they cover the same
+      // slots as the 128-wide ones, else 64 x 128 tiles)
+      if (gpk_cdiv(a.n, 64) == 2 * gpk_cdiv(a.n, 128)) return launch_cfg<64, 64, 4, 1>(s, a);
+      return launch_cfg<64, 128, 2, 2>(s, a);
+    }
   }
   if (fast_ok(a) && (a.epi == 1 || (a.n > 64 && (tiles >= 24 || a.m <= 64)))) {
     return a.epi == 1 ? launch_fast<1>(s, a) : launch_fast<0>(s, a);
