@@ -83,7 +83,7 @@ def test_gemm_nt_tri_and_batch(gpu):
     np.testing.assert_allclose(np.tril(out), np.tril(ref), rtol=0, atol=1e-11)
 
 
-@pytest.mark.parametrize("n,extra", [(1, 0), (17, 3), (128, 0), (129, 5), (300, 40), (640, 130), (1100, 257)])
+@pytest.mark.parametrize("n,extra", [(1, 0), (17, 3), (128, 0), (129, 5), (300, 40), (640, 130), (1100, 257), (5000, 700)])
 def test_potrf_trapezoid(gpu, n, extra):
     from gpflow_amd import ops
     rng = np.random.default_rng(4)
