@@ -2,6 +2,8 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cm|c3|c4-weak|c4-strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+`python bench.py --gpus N` WITHOUT a launcher spawns the N ranks itself (torch.distributed.run, 127.0.0.1, a free port) and
+refuses to run when the node has fewer than N devices; `--dry-launch` exercises that launch / timing protocol on CPU (gloo).
 
 Metric (BASELINE.json): SVGP ELBO steps/s at N=1e6, M=2048, D=8 (config "Cm", the default workload), with the GPR
 config C2 (N=16384: K build + Cholesky + predict, GF/s vs fp64 peak) reported alongside in the same JSON line (key
@@ -207,11 +209,15 @@ def other_workloads_leg(device, with_oracle: bool, steps: int = 20):
         inf = torch.zeros(1, dtype=torch.int32, device=device)
         scale = float(n_data) / b
 
-        def step(s, Xd=Xd, Yd=Yd, Z=Z, q_mu=q_mu, q_sqrt=q_sqrt, ls=ls, ws=ws, o=o, inf=inf, b=b, scale=scale):
+        box = ops.HostMailbox(2)
+
+        def step(s, Xd=Xd, Yd=Yd, Z=Z, q_mu=q_mu, q_sqrt=q_sqrt, ls=ls, ws=ws, o=o, inf=inf, b=b, scale=scale, box=box):
             lo = (s % 8) * b
             ops.svgp_elbo_shard(Z, Xd[lo:lo + b], Yd[lo:lo + b], q_mu, q_sqrt, variance=1.0, lengthscales=ls, noise_variance=0.1,
                                 jitter=1e-6, ws=ws, out=o, info=inf)
-            h = o.cpu()
+            box.post(o, inf)  # scalars + status land in mapped host memory (gpk_publish_host), like the headline step
+            h, status = box.wait()
+            assert status == 0, status
             return float(h[0]) * scale - float(h[1])
 
         def orc_fn(i, Xh=Xh, Yh=Yh, Zh=Zh, qmh=qmh, qsh=qsh, ls=ls, b=b, n_data=n_data):
@@ -371,6 +377,61 @@ def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
     return res
 
 
+def spawn_ranks(n: int, dry: bool) -> int:
+    """Re-execute this script under torch.distributed.run with n ranks on this node (what the driver's command line does);
+    returns the launcher's exit status.  Refuses -- loudly, before starting anything -- when the node has fewer devices."""
+    import socket
+    import subprocess
+    if not dry and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} needs {n} HIP devices, this node has {torch.cuda.device_count()}; not running a "
+              f"{n}-rank job on fewer devices (use --dry-launch to exercise the launch protocol on CPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL fails without it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args, world: int, rank: int) -> None:
+    """The launch / timing protocol of the multi-GPU bench without devices: gloo process group, W warm-up + K timed
+    'steps' (each = the 8-byte SUM all-reduce of the real step on a host scalar), barrier on both sides of the timed region,
+    MAX over ranks, ONE JSON line from rank 0.  Covered by tests/test_host.py (world size 2, runs anywhere)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_data, m_ind, d_in, global_rows, strong, _ = WORKLOADS[args.workload]
+    b_rows = global_rows // world if strong else global_rows
+    acc = torch.zeros(1, dtype=torch.float64)
+
+    def step(s):
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        acc[0] = t[0]
+    for s in range(args.warmup):
+        step(s)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s)
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "svgp_elbo_steps_per_s", "value": None, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": float(el[0]) / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "none",
+                          "dry_launch": True, "allreduce_check": float(acc[0]) == world * (world + 1) / 2.0,
+                          "config": {"workload": f"launch protocol only ({args.workload}: M={m_ind}, D={d_in}, {b_rows} rows per rank)",
+                                     "name": args.workload, "parallelism": f"dp{world}"}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():  # noqa: C901
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,13 +446,28 @@ def main():  # noqa: C901
     ap.add_argument("--rccl-selftest", action="store_true",
                     help="N=1 only: bring up a world-size-1 nccl (RCCL) process group and put the 8-byte all-reduce of the "
                          "multi-GPU path behind every step -- what RCCL's own streams cost beside the library's")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="exercise ONLY the multi-rank launch protocol on CPU (gloo): rank spawn, rendezvous, barrier-bracketed "
+                         "timing, MAX over ranks, the single JSON line from rank 0 -- no device work, `value` is null")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under a launcher: become one.  `python bench.py --gpus N` starts N ranks itself (one process per GPU,
+        # torch.distributed.run on 127.0.0.1, a free port) and rank 0 prints the single JSON line with n_gpus = N.
+        raise SystemExit(spawn_ranks(args.gpus, args.dry_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it spawns the ranks itself)")
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} HIP devices, this node has {torch.cuda.device_count()}: refusing to "
+                         f"run a {world}-rank job on fewer devices")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -424,9 +500,10 @@ def main():  # noqa: C901
     scale = float(n_data) / float(rows_per_step)
     last = {}
 
-    # the step's scalars land in pinned host memory by two async copies + one stream synchronise
-    h_out = torch.empty(2, dtype=torch.float64).pin_memory()
-    h_info = torch.empty(1, dtype=torch.int32).pin_memory()
+    # the step's scalars (data term, KL) and the factorisation status land in pinned, device-mapped host memory by a
+    # kernel store behind the step (gpk_publish_host); the host spins on the sequence word written last -- no blit copies,
+    # no stream synchronise (round 3 timeline: ~130 us between the last kernel and the D2H blit, per step)
+    mailbox = ops.HostMailbox(2)
 
     def shard_lo(s: int, r: int) -> int:
         return ((s % n_batches) * world + r) * b_rows  # rank r's shard of global minibatch s
@@ -438,11 +515,10 @@ def main():  # noqa: C901
         if world > 1 or selftest:
             # RCCL over xGMI: one 8-byte all-reduce per step, enqueued behind the shard (no host sync in between)
             dist.all_reduce(out[0:1], op=dist.ReduceOp.SUM)
-        h_out.copy_(out, non_blocking=True)
-        h_info.copy_(info, non_blocking=True)
-        torch.cuda.current_stream().synchronize()  # scalar is in host memory
-        elbo = float(h_out[0]) * scale - float(h_out[1])
-        last.update(elbo=elbo, info=int(h_info[0]), step=s)
+        mailbox.post(out, info)
+        vals, inf = mailbox.wait()  # scalar is in host memory
+        elbo = float(vals[0]) * scale - float(vals[1])
+        last.update(elbo=elbo, info=inf, step=s)
         return elbo
 
     def fence():
@@ -594,8 +670,8 @@ def main():  # noqa: C901
             dY.copy_(hY[s % 4], non_blocking=True)
             ops.svgp_elbo_shard(Z, dX, dY, q_mu, q_sqrt, variance=1.0, lengthscales=ls, noise_variance=0.1, jitter=1e-6,
                                 ws=ws, out=out, info=info)
-            h_out.copy_(out, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            mailbox.post(out, info)
+            mailbox.wait()
         for s in range(3):
             host_step(s)
         torch.cuda.synchronize()

@@ -372,42 +372,64 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   };
 
   d4 acc[4][4];
-  const int row_base = m0 + wm * 64 + (lane >> 4);
-  const int col_base = n0 + wn * 64 + (lane & 15);
+  // Accumulator layout.  The MFMA's M index (D row = (lane >> 4) + 4 reg) is fed from the B tile and its N index
+  // (D column = lane & 15) from the A tile, and the B-tile row that MFMA row x = g + 4 r reads is permuted to
+  // 2 g + (r & 1) + 8 (r >> 1).  A lane (c = lane & 15, g = lane >> 4) then owns, of every 16 x 16 block (i, j), row
+  // 16 i + c and the COLUMN PAIRS {2 g, 2 g + 1} (registers 0, 1) and {8 + 2 g, 9 + 2 g} (registers 2, 3): the accumulator
+  // preload and the store are 16-byte accesses (32 + 32 per thread and tile, the four g lanes of a row covering 64
+  // contiguous bytes per instruction) instead of the 64 + 64 8-byte accesses of the plain D layout, which made the
+  // prologue / epilogue of the K = 640 trailing updates store-issue-bound (MI355X_MICROARCH.md: 8-byte accesses reach
+  // 0.54 - 0.70 of the 16-byte rate).
+  const int lane_c = lane & 15, lane_g = lane >> 4;
+  const int row_base = m0 + wm * 64 + lane_c;            // + 16 i
+  const int col_base = n0 + wn * 64 + 2 * lane_g;        // + 16 j + 8 h (+ 0 / 1)
   // (EPI = 1 with a C operand: the streamed projection's last group squares C + A B^T without storing it)
   const bool load_c = (p.beta != 0.0) && (EPI == 0 || p.C != nullptr);
   if (nk > 0) gload(0);
-  // C is addressed as  wave-uniform base + a 32-bit offset per accumulator ROW (16 of them, 4 rows apart) + a 32-bit
-  // offset per column step (4 of them, 16 doubles apart), both clamped into the matrix: 20 address registers instead of
-  // 64 address pairs -- the generic row * ldc + col form made the compiler spill 34 VGPRs around the preload (and the
-  // experimental build, whose preload could not be hoisted, ran the N = 16384 factorisation 3 % faster for it)
-  const int c_r0 = wm * 64 + (lane >> 4), c_c0 = wn * 64 + (lane & 15);
+  // C is addressed as  wave-uniform base + a 32-bit byte offset per accumulator row block (4) + one per column pair (8),
+  // both clamped into the matrix
+  const int c_r0 = wm * 64 + lane_c, c_c0 = wn * 64 + 2 * lane_g;
   const int c_rmax = p.m - 1 - m0, c_cmax = p.n - 1 - n0;  // last valid row / column of the matrix, relative to the tile
-  unsigned c_coff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = c_c0 + j * 16;
-    c_coff[j] = (unsigned)((c < c_cmax ? c : c_cmax) * 8);
-  }
-  auto c_roff = [&](int q) -> unsigned {  // q = 4 i + r: row c_r0 + 4 q
-    const int rr = c_r0 + 4 * q;
+  // (computed where they are used -- prologue and epilogue -- so that no address register lives across the K loop)
+  auto c_roff = [&](int i) -> unsigned {
+    const int rr = c_r0 + 16 * i;
     return (unsigned)(((long)(rr < c_rmax ? rr : c_rmax) * p.ldc) * 8);
   };
+  auto c_coff = [&](int j, int h) -> unsigned {
+    const int c = c_c0 + j * 16 + 8 * h;
+    return (unsigned)((c < c_cmax ? c : c_cmax) * 8);
+  };
+  // 16-byte accesses need whole column pairs inside the matrix and 16-byte aligned rows (block-uniform)
+  const bool c_vec = (EPI == 0 || p.C != nullptr) && (n0 + BN <= p.n) && !(p.ldc & 1) && !(p.strideC & 1) &&
+                     !(reinterpret_cast<uintptr_t>(p.C) & 15);
   if (load_c) {
     const double* __restrict__ C = p.C + (long)bz * p.strideC;
     const double sc = p.beta / p.alpha;
     const char* cb = reinterpret_cast<const char*>(C + (long)m0 * p.ldc + n0);
+    if (c_vec) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const char* rowp = cb + c_roff(i * 4 + r);
+      for (int i = 0; i < 4; ++i) {
+        const char* rowp = cb + c_roff(i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const double* cp = reinterpret_cast<const double*>(rowp + c_coff[j]);
-          acc[i][j][r] = sc * *cp;
+          const d2 lo = *reinterpret_cast<const d2*>(rowp + c_coff(j, 0));
+          const d2 hi = *reinterpret_cast<const d2*>(rowp + c_coff(j, 1));
+          acc[i][j] = (d4){sc * lo.x, sc * lo.y, sc * hi.x, sc * hi.y};
         }
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* rowp = cb + c_roff(i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = c_c0 + j * 16 + 8 * (r >> 1) + (r & 1);
+            acc[i][j][r] = sc * *reinterpret_cast<const double*>(rowp + (unsigned)((c < c_cmax ? c : c_cmax) * 8));
+          }
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -415,8 +437,11 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
       for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
   }
 
-  const double* as = smem + (wm * 64 + (lane & 15)) * LDSS + (lane >> 4);
-  const double* bs = smem + (BM + wn * 64 + (lane & 15)) * LDSS + (lane >> 4);
+  // B-tile row read by MFMA row x = lane & 15 (see "Accumulator layout"): a permutation inside each 16-row block, so the
+  // 32-lane ds_read_b64 groups still hit 64 distinct banks
+  const int bperm = 2 * (lane_c & 3) + ((lane_c >> 2) & 1) + 8 * (lane_c >> 3);
+  const double* as = smem + (wm * 64 + lane_c) * LDSS + lane_g;
+  const double* bs = smem + (BM + wn * 64 + bperm) * LDSS + lane_g;
   double fa[2][4], fb[2][4];
   auto fload = [&](int buf, int kk, int f) {
 #pragma unroll
@@ -426,7 +451,7 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
   };
 #define GPK_MFMA_ROW(f, i)                                                                         \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] =                                       \
-      __builtin_amdgcn_mfma_f64_16x16x4f64(fa[f][i], fb[f][j], acc[i][j], 0, 0, 0)
+      __builtin_amdgcn_mfma_f64_16x16x4f64(fb[f][j], fa[f][i], acc[i][j], 0, 0, 0)
 
   if (nk > 0) {
 #pragma unroll
@@ -494,33 +519,39 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
     const double alpha = p.alpha;
     char* cb = reinterpret_cast<char*>(C + (long)m0 * p.ldc + n0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (c_r0 + 4 * (i * 4 + r) <= c_rmax) {
-          char* rowp = cb + c_roff(i * 4 + r);
+    for (int i = 0; i < 4; ++i) {
+      if (c_r0 + 16 * i <= c_rmax) {
+        char* rowp = cb + c_roff(i);
+        if (c_vec) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (c_c0 + j * 16 <= c_cmax) {
-              double* cp = reinterpret_cast<double*>(rowp + c_coff[j]);
-              *cp = alpha * acc[i][j][r];
-            }
+            *reinterpret_cast<d2*>(rowp + c_coff(j, 0)) = (d2){alpha * acc[i][j][0], alpha * acc[i][j][1]};
+            *reinterpret_cast<d2*>(rowp + c_coff(j, 1)) = (d2){alpha * acc[i][j][2], alpha * acc[i][j][3]};
           }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int c = c_c0 + j * 16 + 8 * (r >> 1) + (r & 1);
+              if (c <= c_cmax) *reinterpret_cast<double*>(rowp + (unsigned)(c * 8)) = alpha * acc[i][j][r];
+            }
         }
       }
+    }
   } else {
     double* __restrict__ C2 = p.C2 + (long)bz * p.strideC2;
     double* __restrict__ part = p.part + (long)bz * p.stridePart;
     const double alpha = p.alpha;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      const int row = row_base + i * 16;
+      double s = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row_base + i * 16 + 4 * r;
-        double s = 0.0;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = col_base + j * 16;
+        for (int r = 0; r < 4; ++r) {
+          const int col = col_base + j * 16 + 8 * (r >> 1) + (r & 1);
           const double v = alpha * acc[i][j][r];
           if (col < p.sq_cols) {
             s += v * v;
@@ -528,12 +559,11 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
             C2[(long)row * p.ldc2 + (col - p.sq_cols)] = v;
           }
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 8);
-        if ((lane & 15) == 0 && row < p.m) part[(long)(tile_n * 2 + wn) * p.part_ld + row] = s;
-      }
+      // the four g lanes of a row hold its 64 columns of this wave
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane_g == 0 && row < p.m) part[(long)(tile_n * 2 + wn) * p.part_ld + row] = s;
+    }
   }
 }
 

@@ -545,3 +545,23 @@ int gpk_launch_transpose_shift(hipStream_t s, const double* in, int rows, int co
   GPK_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- result mailbox: device scalars -> mapped host memory, sequence word last (gpk.h) --------------------------------
+namespace {
+__global__ void publish_host_kernel(const double* __restrict__ src, int n, const int* __restrict__ info, double* vals, int* tail,
+                                    int seq) {
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < n; ++i) __hip_atomic_store(vals + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(tail, info ? info[0] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(tail + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // after everything above
+  }
+}
+}  // namespace
+
+extern "C" int gpk_publish_host(void* stream, const double* src, int n, const int* info, void* host_dst, int seq) {
+  if (!src || !host_dst || n <= 0 || n > 16) return GPK_E_ARG;
+  double* vals = (double*)host_dst;
+  hipLaunchKernelGGL(publish_host_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, n, info, vals, (int*)(vals + n), seq);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}

@@ -475,6 +475,52 @@ def gpr_lml(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, 
     return out, info
 
 
+
+class HostMailbox:
+    """Scalars of a step delivered into pinned, device-mapped host memory by a kernel store (gpk_publish_host) instead of
+    device-to-host copies + a stream synchronise: `post(src, info)` enqueues one tiny kernel behind the step on the current
+    stream, `wait()` spins on the sequence word that kernel writes last and returns (values, info).  The reference reads
+    the same scalar with `.numpy()` on the ELBO tensor (svgp.py:181 -> optimizers / monitoring); here that read costs a few
+    microseconds instead of 90 - 150 us per step (two blit copies + hipStreamSynchronize, profiles/r03_step_timeline.txt).
+    Falls back to nothing: a wait that times out raises."""
+
+    def __init__(self, n: int = 2):
+        if not 1 <= n <= 16:
+            raise ValueError("HostMailbox holds 1..16 doubles")
+        device()  # raises without a HIP device
+        self.n = int(n)
+        self._buf = torch.zeros(n + 1, dtype=torch.float64).pin_memory()
+        self._vals = self._buf.numpy()[:n]
+        self._tail = self._buf.numpy()[n:].view(np.int32)  # [info, seq]
+        self._seq = 0
+
+    def post(self, src: torch.Tensor, info: Optional[torch.Tensor] = None) -> int:
+        lib = _lib.load()
+        _chk(src, "src")
+        if src.numel() < self.n or not src.is_contiguous():
+            raise ValueError("src must be a contiguous tensor with at least n elements")
+        if info is not None and (not info.is_cuda or info.dtype != torch.int32):
+            raise _lib.GpkError("info must be an int32 tensor on the HIP device")
+        self._seq = (self._seq % 0x7FFFFFF0) + 1
+        rc = lib.gpk_publish_host(_stream(), src.data_ptr(), self.n, info.data_ptr() if info is not None else None,
+                                  self._buf.data_ptr(), self._seq)
+        _lib.check(rc, "gpk_publish_host")
+        return self._seq
+
+    def wait(self, timeout_s: float = 30.0):
+        import time as _time
+        tail, seq = self._tail, self._seq
+        spins, t0 = 0, None
+        while int(tail[1]) != seq:
+            spins += 1
+            if spins & 0x3FFF == 0:
+                now = _time.perf_counter()
+                t0 = t0 or now
+                if now - t0 > timeout_s:
+                    raise _lib.GpkError("HostMailbox.wait timed out (the publishing kernel never ran)")
+        return self._vals.copy(), int(tail[0])
+
+
 def svgp_elbo_workspace(m: int, rows: int, d: int, P: int, q_diag: bool) -> torch.Tensor:
     lib = _lib.load()
     return _ws(int(lib.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, int(q_diag))))

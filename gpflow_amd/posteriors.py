@@ -321,6 +321,9 @@ class IndependentPosterior(BasePosterior):
         Xf, lead = _flatten_rows(Xnew)
         Kfu = covariances.Kfu(self.X_data, self.kernel, Xf)
         separate = Kfu.dim() == 3
+        # Kff carries a latent axis only for separate KERNELS; a shared kernel over separate inducing variables has
+        # Kfu [L,N,M] but one Kff, broadcast over the latents (posteriors.py:794-822)
+        kff_per_latent = isinstance(self.kernel, SeparateIndependent)
         Lnum = Qinv.shape[0]
         if separate:
             mean = torch.stack([ops.row_stats(Kfu[l], V=alpha[l].contiguous(), want_sumsq=False)[1][:, 0] for l in range(Lnum)],
@@ -330,7 +333,7 @@ class IndependentPosterior(BasePosterior):
         Ws = [ops.gemm_nt(Kfu[l] if separate else Kfu, Qinv[l]) for l in range(Lnum)]  # Kfu Qinv (Qinv symmetric)
         if not full_cov:
             Kff = self._get_Kff(Xf, False)  # [N] or [L, N]
-            cov = torch.stack([(Kff[l] if separate else Kff) - ops.row_dot(Ws[l], Kfu[l] if separate else Kfu)
+            cov = torch.stack([(Kff[l] if kff_per_latent else Kff) - ops.row_dot(Ws[l], Kfu[l] if separate else Kfu)
                                for l in range(Lnum)], dim=-1)
             if len(lead) > 1:
                 mean, cov = mean.reshape(*lead, -1), cov.reshape(*lead, -1)
@@ -341,7 +344,7 @@ class IndependentPosterior(BasePosterior):
         for b in range(nb):
             r = slice(b * T, (b + 1) * T)
             Kff = self._get_Kff(Xf[r], True)  # [T, T] or [L, T, T]
-            blocks.append(torch.stack([(Kff[l] if separate else Kff)
+            blocks.append(torch.stack([(Kff[l] if kff_per_latent else Kff)
                                        - ops.gemm_nt(Ws[l][r], (Kfu[l] if separate else Kfu)[r]) for l in range(Lnum)], dim=0))
         cov = torch.stack(blocks)  # [nb, L, T, T]
         if len(lead) > 1:

@@ -234,6 +234,16 @@ int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long l
                         const double* q_sqrt, int q_diag, int whiten, double* out, int* info,
                         void* ws, size_t ws_bytes);
 
+/* ---- result mailbox in mapped host memory ------------------------------------------------------------------------
+ * Copies n doubles from device memory `src` (and one int from `info`, may be NULL) into `host_dst`, a buffer of PINNED,
+ * device-mapped host memory (hipHostMalloc / torch pin_memory) laid out as { double vals[n]; int32 info; int32 seq; },
+ * then -- after a system-scope release -- writes `seq` last.  The caller spins on host_dst's `seq` word instead of
+ * enqueueing device-to-host copies and synchronising the stream: the scalar of SVGP.elbo (svgp.py:181, read by
+ * every optimiser step and by monitoring) lands in host memory a few microseconds after the last kernel of the step.
+ * (Two blit copies + hipStreamSynchronize cost 90 - 150 us per step on MI355X, profiles/r03_step_timeline.txt.)
+ * n <= 16.  One tiny kernel on `stream`; never synchronises. */
+int gpk_publish_host(void* stream, const double* src, int n, const int* info, void* host_dst, int seq);
+
 /* Optional per-launch timing of the GEMM kernel (HIP events on the launch stream) for the roofline
  * leg of bench.py: enable(1) starts recording, collect() synchronises and returns the summed kernel
  * time, launch count and ALGORITHMIC flops (useful multiply-adds only) since enable. */

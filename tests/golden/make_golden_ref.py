@@ -201,6 +201,17 @@ def build():  # noqa: C901
             out[f"mo_sep_cached_mu_w{w}_fc{fc}"] = _n(pmu); out[f"mo_sep_cached_var_w{w}_fc{fc}"] = _n(pvar)
         mu, var = s.predict_f(Xs, full_output_cov=True)
         out[f"mo_sep_var_w{w}_foc"] = _n(var)
+    # shared KERNEL over separate inducing variables (posteriors.py:794-822: Kff [N] / [N,N] broadcast over the latents,
+    # Kuf [L,M,N]); fused and cached, marginals and full covariance
+    for w in (0, 1):
+        s = gpflow.models.SVGP(mo, gpflow.likelihoods.Gaussian(variance=0.2), ivsep, q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(),
+                               whiten=bool(w), num_latent_gps=L)
+        out[f"mo_shsep_elbo_w{w}"] = float(s.elbo((X, Y)))
+        for fc in (0, 1):
+            mu, var = s.predict_f(Xs, full_cov=bool(fc))
+            out[f"mo_shsep_mu_w{w}_fc{fc}"] = _n(mu); out[f"mo_shsep_var_w{w}_fc{fc}"] = _n(var)
+            pmu, pvar = s.posterior().predict_f(Xs, full_cov=bool(fc))
+            out[f"mo_shsep_cached_mu_w{w}_fc{fc}"] = _n(pmu); out[f"mo_shsep_cached_var_w{w}_fc{fc}"] = _n(pvar)
 
     # ---- SGPR (models/sgpr.py) ---------------------------------------------------------------------------------------------
     rng = np.random.default_rng(51)

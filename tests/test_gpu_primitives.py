@@ -411,3 +411,44 @@ def test_two_host_threads_one_device(gpu):
         for T, info in out[i]:
             assert int(info.cpu()[0]) == 0
             assert np.array_equal(T.cpu().numpy(), expected[i])
+
+
+@pytest.mark.parametrize("m,n,k,view", [(1500, 1301, 256, 0), (1300, 1290, 320, 0), (1290, 1408, 256, 1), (1409, 1282, 272, 2)])
+def test_gemm_nt_fast_path_c_access(gpu, m, n, k, view):
+    """The 128x128x16 kernel preloads / stores its accumulators with 16-byte accesses when the tile's columns lie inside
+    the matrix and C's rows are 16-byte aligned, element by element otherwise: odd n (odd leading dimension), even n that
+    is no multiple of 128 (only the last column tile falls back), C as a view that starts 8 bytes into a row (view 1) and
+    a view with an odd leading dimension (view 2).  alpha, beta != 0, 1 so that both the preload and the store count."""
+    import torch
+    from gpflow_amd import ops
+    rng = np.random.default_rng(77)
+    A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
+    if view == 0:
+        Cd = _t(C)
+    else:
+        big = torch.zeros((m, n + (2 if view == 1 else 3)), dtype=torch.float64, device=_t(A).device)
+        Cd = big[:, 1:1 + n]
+        Cd.copy_(_t(C))
+    out = ops.gemm_nt(_t(A), _t(B), alpha=0.7, beta=-1.3, C=Cd).cpu().numpy()
+    np.testing.assert_allclose(out, 0.7 * A @ B.T - 1.3 * C, rtol=0, atol=2e-11)
+    if view:
+        bo = big.cpu().numpy()
+        assert np.all(bo[:, 0] == 0) and np.all(bo[:, 1 + n:] == 0)   # nothing written outside the view
+
+
+def test_host_mailbox(gpu):
+    """gpk_publish_host: device scalars + status land in pinned host memory, sequence word last; successive posts."""
+    import torch
+    from gpflow_amd import ops
+    box = ops.HostMailbox(3)
+    dev = ops.device()
+    for i in range(5):
+        src = torch.tensor([1.5 + i, -2.0, 3.25e10], dtype=torch.float64, device=dev)
+        info = torch.tensor([i], dtype=torch.int32, device=dev)
+        box.post(src, info)
+        vals, status = box.wait()
+        np.testing.assert_array_equal(vals, [1.5 + i, -2.0, 3.25e10])
+        assert status == i
+    box.post(torch.ones(3, dtype=torch.float64, device=dev))
+    vals, status = box.wait()
+    assert status == 0 and np.all(vals == 1.0)

@@ -162,6 +162,18 @@ def test_ref_multi_output(gp):
             close(pmu, G[f"mo_sep_cached_mu_w{w}_fc{fc}"], 1e-7); close(pvar, G[f"mo_sep_cached_var_w{w}_fc{fc}"], 1e-7)
         close(s.predict_f(Xs, full_output_cov=True)[1], G[f"mo_sep_var_w{w}_foc"])
         close(post.predict_f(Xs, full_output_cov=True)[1], G[f"mo_sep_var_w{w}_foc"], 1e-7)
+    # shared kernel + separate inducing variables: Kff has no latent axis while Kfu does (the cached
+    # route indexed Kff by latent and returned a wrong full covariance)
+    for w in (0, 1):
+        s = gp.models.SVGP(mo, gp.likelihoods.Gaussian(variance=0.2), ivsep, q_mu=q_mu.copy(), q_sqrt=q_sqrt.copy(), whiten=bool(w),
+                           num_latent_gps=L)
+        np.testing.assert_allclose(float(s.elbo((X, Y))), float(G[f"mo_shsep_elbo_w{w}"]), rtol=1e-9)
+        post = s.posterior()
+        for fc in (0, 1):
+            mu, var = s.predict_f(Xs, full_cov=bool(fc))
+            close(mu, G[f"mo_shsep_mu_w{w}_fc{fc}"]); close(var, G[f"mo_shsep_var_w{w}_fc{fc}"])
+            pmu, pvar = post.predict_f(Xs, full_cov=bool(fc))
+            close(pmu, G[f"mo_shsep_cached_mu_w{w}_fc{fc}"], 1e-7); close(pvar, G[f"mo_shsep_cached_var_w{w}_fc{fc}"], 1e-7)
 
 
 def test_ref_sgpr(gp):

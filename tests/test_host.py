@@ -244,3 +244,37 @@ def test_adam_state_matches_tf_keras_rule():
         lr_t = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
         np.testing.assert_allclose(p_new, p - lr_t * m / (np.sqrt(v) + 1e-7), rtol=1e-14)
         p = p_new
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself and rank 0 prints ONE JSON line with n_gpus = 2
+    (the launch / barrier / MAX-over-ranks protocol, exercised on CPU through --dry-launch: gloo, no device work)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "4", "--warmup", "1",
+                        "--workload", "c4-strong"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1 and rec["scaling"] == "strong"
+    assert rec["dry_launch"] is True and rec["allreduce_check"] is True
+
+
+def test_bench_refuses_fewer_devices_than_ranks():
+    """Without enough devices a multi-rank bench must fail loudly, not run a silent 1-GPU job."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("node has two devices")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0
+    assert "needs 2 HIP devices" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
