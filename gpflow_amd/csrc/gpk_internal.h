@@ -92,6 +92,17 @@ int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo,
 int gpk_gemm_tiles_n(int n);   // number of column tiles the launcher will use for n columns
 int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg)
 
+// ---- single-launch SVGP step (mega.hip) ---------------------------------------------------------------------------
+#ifndef GPK_MEGA_DEFAULT
+#define GPK_MEGA_DEFAULT 0
+#endif
+size_t gpk_mega_flag_ints(int m);
+int gpk_mega_supported(int m, int rows, int P, int ncu);
+int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, int m, int rows, double* invd, const double* LqT,
+                         long ldl, double* Cacc, const double* q_mu, int P, const double* Y, long ldy, double* s0, double* fmean,
+                         double* ssq, double* partial, int* flags, int* info, double* out, double variance, double noise,
+                         double mean_const, int min_wgs);
+
 // ---- leaf (leaf.hip): NB x NB Cholesky + inverse of the diagonal block --------------------------
 // A: pointer to the diagonal block (row-major, lda); nb <= NB valid rows/cols.
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,

@@ -1,0 +1,616 @@
+// Single-launch SVGP step ("step kernel"): the whole dependent part of SVGP.elbo (svgp.py:166-181) -- Cholesky of Kuu
+// (conditionals/util.py:67), A^T = Kfu Lm^-T (util.py:125), fmean / sum A^2 (util.py:133,144), the projection onto q_sqrt
+// (util.py:151-164) and the Gaussian variational expectations (likelihoods/scalar_continuous.py:139-148) -- as ONE
+// persistent kernel with one workgroup per compute unit.
+//
+// Why.  Rounds 1-3 ran this as ~80 launches on four streams: a latency chain (leaf -> panel solve -> strip, 16 panels)
+// beside bulk GEMM launches.  Every variant lost time to the same two things: the chain's kernels need EMPTY
+// compute units and wait for the bulk launches to end, and every bulk launch pays ~40 us of ramp and drain.  Here nothing
+// is launched while the step runs: a workgroup owns a compute unit for the whole step and interleaves its share of the
+// factorisation with its share of the minibatch rows, so the chain never queues behind bulk work and bulk work has no
+// launch boundaries.
+//
+// Work decomposition.  Everything is the right-looking row recurrence of the trapezoidal factorisation
+//     for panel q:   X[r, q] = X[r, q] inv(L_qq)^T                      ("FIN":  finish column block q of row block r)
+//                    X[r, n] -= X[r, q] L[n, q]^T   for n > q            ("UPD":  update the columns still to come)
+// applied to 32-row blocks r of (i) the square part (rows of Kuu below panel q: "chain tasks", which together with the
+// 128 x 128 leaf ARE the Cholesky factorisation) and (ii) the minibatch rows of Kfu (each workgroup owns one block for
+// the whole step: "bulk"), where it is followed by the projection
+//                    C_p[r, n] += X[r, q] Lq_p[q, n]   for n <= q        ("PROJ": right-looking too, so that the work of a
+//                                                                         step is the same for every q: M + 128 B-rows)
+// One primitive serves all of it: a 32 x 128 A panel resident in LDS, B streamed in slabs of 32 rows (1 KiB rows,
+// LDS-DMA, double-buffered), each slab a 32 x 32 x 128 product on four "consumer" waves (one per SIMD: MFMA-bound) while
+// the four "producer" waves move the next slab and poll the flags.  Per step and workgroup: 68 slabs.
+//
+// Scheduling.  Chain tasks of panel p, in dependency order: LEAF(p) | FIN(p+1, 4 quarters) | UPD(p+1, .) | FIN(i>p+1, .)
+// | UPD(i>p+1, .), dealt round-robin to the workgroups; a workgroup runs its chain tasks in that global order, polls
+// their readiness between (and, through a producer wave, DURING) its bulk streams, and leaves a bulk stream at a slab
+// boundary when a task becomes ready.  Every wait is a non-blocking poll of flags in global memory, every task only
+// depends on tasks earlier in the global order, so the earliest unfinished task can always run: no deadlock.  All polls
+// are bounded by a wall-clock timeout that makes every workgroup leave (info = INT_MAX) instead of hanging the device.
+//
+// Coherence (8 XCDs, private L2s).  Protocol 0: producers finish a task with an agent-scope release fence (L2 write-back)
+// before raising its flag, consumers run an agent-scope acquire fence (L1 / L2 invalidate) after seeing it -- the
+// documented sequences.  Protocol 1: chain data is written with agent-scope write-through stores and read with
+// agent-scope loads / LDS-DMA (no L2 flush, no invalidate by chain tasks); bulk workgroups still acquire once per phase.
+// Bulk rows (A^T, C) are private to their workgroup: plain accesses.
+//
+// Numerics: identical recurrence and block inverses as the multi-launch path (gpk_potrf); summation order inside a
+// 128-block differs (two alternating accumulators over K = 128), results agree to ~1e-13 relative (tests).
+#include "gpk_internal.h"
+#include "leaf_device.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int NBK = GPK_NB;      // 128: panel width
+constexpr int MB = 32;           // rows of a row block (A panel)
+constexpr int NS = 32;           // B rows per slab
+constexpr int LDP = NBK + 2;     // LDS row stride (doubles): fragment reads of 16 rows x 2 k hit 64 distinct banks
+constexpr int PAN = MB * LDP;    // doubles per panel / slab buffer
+constexpr int OFF_PA = 0, OFF_PB = PAN, OFF_S0 = 2 * PAN, OFF_S1 = 3 * PAN, OFF_MISC = 4 * PAN;
+constexpr int MEGA_THREADS = 512;
+constexpr size_t MEGA_LDS = gpk_leaf::LEAF_LDS > (size_t)(OFF_MISC + 256) * 8 ? gpk_leaf::LEAF_LDS : (size_t)(OFF_MISC + 256) * 8;
+
+struct MegaArgs {
+  double* T; long ld;            // [m + rows, ld]: Kuu (+ jitter) on top, Kfu below (becomes L / A^T in place)
+  double* invd;                  // [nb][128][128]
+  const double* LqT; long ldl;   // [P][m][ldl] = tril(q_sqrt_p)^T
+  double* Cacc;                  // [P][rows][ld] projection accumulator
+  const double* q_mu;            // [m][P]
+  const double* Y; long ldy;     // [rows][P]
+  double* s0; double* fmean; double* ssq;   // [rows], [rows][P], [P][rows]
+  double* partial;               // [nbulk]
+  int* flags;
+  long long* stamps;             // [nb][2]: wall clock at the start / publication of every leaf (diagnostics, 16 bytes per panel)
+  int* info;
+  double* out;
+  int m, nb, rows, P, nbulk;
+  double variance, noise, mean_const;
+  long long timeout_ticks;
+};
+
+// flag words (ints, zeroed before the launch)
+__device__ __forceinline__ int f_leaf(int p) { return p; }
+__device__ __forceinline__ int f_finc(int nb, int p, int i) { return nb + p * nb + i; }
+__device__ __forceinline__ int f_fint(int nb, int p) { return nb + nb * nb + p; }
+__device__ __forceinline__ int f_rowd(int nb, int i, int u) { return 2 * nb + nb * nb + 4 * i + u; }
+__device__ __forceinline__ int f_done(int nb) { return 6 * nb + nb * nb; }
+__device__ __forceinline__ int f_abort(int nb) { return 6 * nb + nb * nb + 1; }
+
+__device__ __forceinline__ int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_flag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int add_flag(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+typedef __attribute__((address_space(1))) double gdouble;          // explicitly GLOBAL doubles: inside the non-inlined
+typedef __attribute__((address_space(1))) const double cgdouble;   // functions a plain pointer is a flat one, and flat
+                                                                    // stores are ordered against every LDS access
+struct Cond { const int* a[4]; int thr[4]; int n; };
+__device__ __forceinline__ bool cond_ok(const Cond& c) {
+  int v[4] = {0, 0, 0, 0};
+  for (int k = 0; k < c.n; ++k) v[k] = ld_flag(c.a[k]);   // independent loads: one round trip, not c.n
+  bool ok = true;
+  for (int k = 0; k < c.n; ++k) ok = ok && (v[k] >= c.thr[k]);
+  return ok;
+}
+
+template <bool COH>
+__device__ __forceinline__ void dma_row(const double* src, double* dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, COH ? 16 : 0);
+}
+template <bool COH>
+__device__ __forceinline__ double ld_c(cgdouble* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_c(gdouble* p, double v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// 32 rows x 128 doubles of global memory -> an LDS panel (one LDS-DMA row per wave instruction); rows >= nrows repeat the
+// last valid row (their outputs are never stored).  The caller synchronises.
+template <bool COH>
+__device__ __forceinline__ void load_panel(double* S, int off, const double* src, long ld, int nrows, int wave, int lane) {
+  for (int q = wave; q < MB; q += MEGA_THREADS / 64) {
+    const int r = q < nrows ? q : nrows - 1;
+    dma_row<COH>(src + (long)r * ld + 2 * lane, S + off + q * LDP);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, i.e. it also
+// waits for every outstanding GLOBAL store of the wave -- inside the slab loop that would expose the latency of the C
+// stores once per slab (the consumer waves never read those stores back; the end of a task waits for them once).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+enum { MODE_FIN = 0, MODE_SUB = 1, MODE_ADD = 2, MODE_SQ = 3 };
+struct Stream {
+  const double* B; long ldb;   // B row n at B + n * ldb (128 contiguous doubles = the K segment)
+  int n0, n1;                  // B-row range (n0 a multiple of 32)
+  double* C; long ldc;         // C[r][n] at C + r * ldc + n, r = 0 .. 31 local rows
+  int nrows;                   // valid local rows
+  int mode;
+  int nfresh;                  // MODE_ADD / MODE_SQ: columns n >= nfresh carry no earlier contribution
+  int pa_off;                  // LDS offset of the A panel
+};
+
+// Runs slabs [slab_begin, nslabs) of a stream; returns the index of the first slab NOT run (== nslabs when complete).  With
+// `intr` the producer wave polls that condition while the slabs run and the workgroup leaves at the next slab boundary once
+// it holds.  sq: per-lane row sums of squares (MODE_SQ), rows 16 mt + g + 4 r of this wave's column half.
+template <bool COH>
+__device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Cond* intr_in, int* ctl_flat, d4& sq_io) {
+  extern __shared__ __attribute__((aligned(16))) double S[];
+  __attribute__((address_space(3))) int* ctl = (__attribute__((address_space(3))) int*)ctl_flat;
+  gdouble* Cg = (gdouble*)st.C;
+  // (everything the loops use is copied into registers first: with the descriptors left in memory the compiler orders
+  // every LDS-DMA instruction against their reloads and the eight rows of a slab are fetched one after the other)
+  const bool has_intr = intr_in != nullptr;
+  Cond ic{};
+  if (has_intr) ic = *intr_in;
+  const Cond* intr = has_intr ? &ic : nullptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nslabs = (st.n1 - st.n0 + NS - 1) / NS;
+  if (slab_begin >= nslabs) return nslabs;
+  const int c = lane & 15, g = lane >> 4;
+  const int mt = wave & 1, nt = (wave >> 1) & 1;
+  auto dma_slab = [&](int s, int buf) {
+    for (int q = 0; q < NS / 4; ++q) {
+      const int lr = (wave - 4) * (NS / 4) + q;
+      int n = st.n0 + s * NS + lr;
+      n = n < st.n1 ? n : st.n1 - 1;
+      dma_row<COH>(st.B + (long)n * st.ldb + 2 * lane, S + (buf ? OFF_S1 : OFF_S0) + lr * LDP);
+    }
+  };
+  if (tid == 0) { ctl[1] = 0; ctl[2] = 0; }
+  if (wave >= 4) {
+    dma_slab(slab_begin, slab_begin & 1);
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  __syncthreads();
+  // Two loops with the same trip count and one barrier per slab: the producer waves' and the consumer waves'.  (One loop
+  // with a role branch inside made every wave carry -- and copy around, behind waits -- the other role's registers.)
+  if (wave >= 4) {
+    for (int s = slab_begin; s < nslabs; ++s) {
+      if (s + 1 < nslabs) dma_slab(s + 1, (s & 1) ^ 1);
+      if (intr && wave == 4 && lane == 0) ctl[1 + (s & 1)] = cond_ok(*intr) ? 1 : 0;
+      __builtin_amdgcn_s_waitcnt(0);
+      lds_barrier();
+      if (intr && s + 1 < nslabs && ctl[1 + (s & 1)]) return s + 1;
+    }
+    return nslabs;
+  }
+  double fa[NBK / 4];   // this lane's A fragments (row 16 mt + c, k = 4 kk + g), fixed for the whole stream
+  {
+    const double* pa = S + st.pa_off + (16 * mt + c) * LDP + g;
+#pragma unroll
+    for (int kk = 0; kk < NBK / 4; ++kk) fa[kk] = pa[4 * kk];
+  }
+  d4 sq = sq_io;
+  for (int s = slab_begin; s < nslabs; ++s) {
+    const int buf = s & 1;
+    const int n = st.n0 + s * NS + 16 * nt + c;
+    const bool nvalid = n < st.n1;
+    const bool has_old = (st.mode == MODE_SUB) || ((st.mode == MODE_ADD || st.mode == MODE_SQ) && n < st.nfresh);
+    double cold[4] = {0.0, 0.0, 0.0, 0.0};
+    if (has_old && nvalid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * mt + g + 4 * r;
+        if (rr < st.nrows) cold[r] = ld_c<COH>(Cg + (long)rr * st.ldc + n);
+      }
+    }
+    // B fragments of the slab in four groups of eight k-steps, group G + 1 in flight under the MFMAs of group G (LDS
+    // returns in order, so the wait before a group only covers that group); the A fragments live in registers
+    const double* pb = S + (buf ? OFF_S1 : OFF_S0) + (16 * nt + c) * LDP + g;
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    double fb[2][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fb[0][k] = pb[4 * k];
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+      if (grp + 1 < 4) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fb[(grp + 1) & 1][k] = pb[4 * (8 * (grp + 1) + k)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[8 * grp + k], fb[grp & 1][k], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[8 * grp + k + 1], fb[grp & 1][k + 1], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // all four results first, then the stores: nothing loaded is consumed after the first store, so the stores of a slab
+    // are issued back to back (a use of `cold` behind a store made the compiler wait for that store)
+    double outv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double o = acc0[r] + acc1[r];
+      outv[r] = st.mode == MODE_FIN ? o : (st.mode == MODE_SUB ? cold[r] - o : cold[r] + o);
+    }
+    if (st.mode == MODE_SQ) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = nvalid ? outv[r] : 0.0;
+        sq[r] += v * v;
+      }
+    } else {
+      if (st.mode == MODE_FIN && nvalid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[OFF_PB + (16 * mt + g + 4 * r) * LDP + (n - st.n0)] = outv[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * mt + g + 4 * r;
+        if (nvalid && rr < st.nrows) st_c<COH>(Cg + (long)rr * st.ldc + n, outv[r]);
+      }
+    }
+    lds_barrier();
+    if (intr && s + 1 < nslabs && ctl[1 + (s & 1)]) { sq_io = sq; return s + 1; }
+  }
+  sq_io = sq;
+  return nslabs;
+}
+
+// ---- chain task bookkeeping -------------------------------------------------------------------------------------------
+// Tasks of panel p, in dependency order:  LEAF(p);  then for block rows i = p+1 .. nb-1 the four quarter tasks FIN(i, u, p)
+// (rows 128 i + 32 u .. + 31:  X[r, p] <- X[r, p] inv(L_pp)^T) and UPD(i, u, p) (X[r, n] -= X[r, p] L[n, p]^T for the
+// columns n after panel p up to the rows' own diagonal).  Two classes, two pools of workgroups:
+//   NEAR  LEAF(p) and the block rows p+1 .. p+3: short tasks (<= 12 slabs) on or next to the critical path
+//         leaf -> FIN(p+1) -> UPD(p+1) -> leaf; dealt to the first GA workgroups;
+//   FAR   block rows p+4 ..: long tasks (up to 60 slabs) that have several panels of slack; dealt to the other workgroups.
+// A workgroup runs its tasks in the global (panel, slot) order.  Keeping the classes apart keeps a near task from waiting
+// behind a far one of an earlier panel in the same workgroup's list (first version: one pool, the factorisation of
+// n = 2048 took 170 us per panel instead of ~55).
+enum { T_LEAF = 0, T_FIN = 1, T_UPD = 2 };
+struct Task { int type, p, i, u; };
+constexpr int NEAR_ROWS = 3;
+
+__device__ __forceinline__ int near_rows(int nb, int p) { const int r = nb - 1 - p; return r < NEAR_ROWS ? r : NEAR_ROWS; }
+__device__ __forceinline__ int ntasks_near(int nb, int p) { return 1 + 8 * near_rows(nb, p); }
+__device__ __forceinline__ int ntasks_far(int nb, int p) { const int r = nb - 1 - p - NEAR_ROWS; return r > 0 ? 8 * r : 0; }
+__device__ __forceinline__ int slot_owner_offset(int p) { return 29 * p; }
+__device__ __forceinline__ Task decode_near(int p, int t) {
+  Task k{T_LEAF, p, p, 0};
+  if (t == 0) return k;
+  const int rem = t - 1;                 // block row p + 1 + rem / 8: FIN x 4 then UPD x 4
+  k.i = p + 1 + rem / 8;
+  k.type = (rem % 8) < 4 ? T_FIN : T_UPD;
+  k.u = rem % 4;
+  return k;
+}
+__device__ __forceinline__ Task decode_far(int nb, int p, int t) {
+  const int nrest = nb - 1 - p - NEAR_ROWS;   // block rows p + 4 ..: all FIN first, then all UPD
+  Task k{T_FIN, p, 0, 0};
+  if (t < 4 * nrest) { k.i = p + 1 + NEAR_ROWS + t / 4; k.u = t % 4; return k; }
+  t -= 4 * nrest;
+  k.type = T_UPD; k.i = p + 1 + NEAR_ROWS + t / 4; k.u = t % 4;
+  return k;
+}
+// flags: leaf[p] = 1 once LEAF(p) is published; finc[p][i] = number of published FIN tasks of panel p in block rows
+// p+1 .. i (every FIN(i', ., p) adds one to finc[p][i] for all i >= i'); rowd[i][u] = panels applied to row quarter (i, u)
+__device__ __forceinline__ void task_cond(const MegaArgs& a, const Task& k, Cond& c) {
+  const int nb = a.nb;
+  c.n = 0;
+  if (k.type == T_LEAF) {
+    if (k.p > 0)
+      for (int u = 0; u < 4; ++u) { c.a[c.n] = a.flags + f_rowd(nb, k.p, u); c.thr[c.n] = k.p; ++c.n; }
+  } else if (k.type == T_FIN) {
+    c.a[0] = a.flags + f_leaf(k.p); c.thr[0] = 1;
+    c.a[1] = a.flags + f_rowd(nb, k.i, k.u); c.thr[1] = k.p;
+    c.n = 2;
+  } else {
+    c.a[0] = a.flags + f_finc(nb, k.p, k.i); c.thr[0] = 4 * (k.i - k.p);   // the B rows it reads: block rows p+1 .. i
+    c.n = 1;
+  }
+}
+
+// (the leaf and the stream are real calls: each gets the whole register file instead of sharing it with the scheduler's state)
+template <bool WT>
+__device__ __noinline__ void mega_leaf(double* A, long lda, double* inv, int* info, int col0) {
+  extern __shared__ __attribute__((aligned(16))) double S[];
+  gpk_leaf::leaf_body<false, WT>(S, A, lda, NBK, inv, info, col0, nullptr);
+}
+
+template <int PROTO>
+__device__ __forceinline__ void acquire_all() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// end of a task: every store of the workgroup is performed device-wide before thread 0 raises the flag
+template <int PROTO>
+__device__ __forceinline__ void publish_barrier() {
+  __builtin_amdgcn_s_waitcnt(0);
+  if constexpr (PROTO == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+}
+
+template <int PROTO>
+__global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double S[];
+  __shared__ int ctl[8];
+  constexpr bool WT = PROTO == 1;   // chain data: write-through stores, agent-scope loads
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x, G = gridDim.x;
+  const int nb = a.nb, m = a.m, P = a.P;
+  const long ld = a.ld;
+  double* E = a.T + (long)m * ld;
+  const bool has_rows = wg < a.nbulk;
+  const int r0 = wg * MB;
+  const int nr = has_rows ? (a.rows - r0 < MB ? a.rows - r0 : MB) : 0;
+  double* E0 = E + (long)r0 * ld;
+  int* abortf = a.flags + f_abort(nb);
+
+  int q = 0, ph = 0, pos = 0;   // bulk: panel, phase (0 FIN, 1..P PROJ of latent ph-1, P+1 UPD), next slab
+  bool panel_ok = false;        // the A panel of the bulk row block (A^T[:, q]) is resident in LDS (OFF_PB)
+  int cp = 0, ct = -1;          // chain: panel cursor, slot cursor within the panel (-1: not yet computed)
+  // near pool: workgroups [0, GA); far pool: [GA, G) (one pool for tiny grids: then everybody takes near AND far tasks,
+  // far ones as extra slots behind the near ones -- handled by giving such grids the near decode over both ranges)
+  const int GA = G >= 16 ? (G / 4 > 32 ? G / 4 : 32 < G / 2 ? 32 : G / 2) : G;
+  const bool two_pools = GA < G;
+  const bool is_near = !two_pools || wg < GA;
+  const int pool_n = is_near ? GA : G - GA;
+  const int pool_id = is_near ? wg : wg - GA;
+  d4 sq = {0.0, 0.0, 0.0, 0.0};
+  const long long t_start = wall_clock64();
+  bool aborted = false;
+
+  for (;;) {
+    // ---- my next chain task ---------------------------------------------------------------------------------------
+    bool have_task = false;
+    Task tk{};
+    while (cp < nb) {
+      const int nt_p = is_near ? ntasks_near(nb, cp) : ntasks_far(nb, cp);
+      if (ct < 0) ct = ((pool_id - slot_owner_offset(cp)) % pool_n + pool_n) % pool_n;
+      if (ct < nt_p) { tk = is_near ? decode_near(cp, ct) : decode_far(nb, cp, ct); have_task = true; break; }
+      ++cp; ct = -1;
+    }
+    const bool bulk_left = has_rows && q < nb;
+    if (!have_task && !bulk_left) break;
+    Cond tc{};
+    if (have_task) task_cond(a, tk, tc);
+    // ---- decide: 1 chain task, 2 bulk quantum, 0 nothing ready, 3 abort -------------------------------------------
+    if (tid == 0) {
+      int d = 0;
+      if (ld_flag(abortf)) d = 3;
+      else if (have_task && cond_ok(tc)) d = 1;
+      else if (bulk_left) {
+        bool ok = true;
+        if (ph == 0) ok = ld_flag(a.flags + f_leaf(q)) >= 1;
+        else if (ph == P + 1 && q < nb - 1) ok = ld_flag(a.flags + f_finc(nb, q, nb - 1)) >= 4 * (nb - q - 1);
+        if (ok) d = 2;
+      }
+      if (d == 0 && wall_clock64() - t_start > a.timeout_ticks) { st_flag(abortf, 1); d = 3; }
+      ctl[0] = d;
+    }
+    __syncthreads();
+    const int d = ctl[0];
+    __syncthreads();
+    if (d == 3) { aborted = true; break; }
+    if (d == 0) { __builtin_amdgcn_s_sleep(8); continue; }
+
+    // One stream per loop iteration, described by the branch that owns it and run at a single call site per coherence
+    // variant (the leaf and the stream body are large: one inlined copy each keeps the kernel's register budget for them).
+    const int p = tk.p;
+    Stream st{};
+    st.nrows = MB; st.pa_off = OFF_PA; st.nfresh = 0;
+    bool coh = false, run = true;
+    int begin = 0;
+    const Cond* intr = nullptr;
+    int what;   // 0 leaf, 1 chain FIN, 2 chain UPD, 3 bulk FIN, 4 bulk PROJ, 5 bulk UPD, 6 bulk final
+    if (d == 1) {
+      // ================= chain task =================
+      if (tk.type == T_LEAF) {
+        what = 0; run = false;
+        if (tid == 0) a.stamps[2 * p] = wall_clock64();
+        acquire_all<PROTO>();
+        mega_leaf<WT>(a.T + (long)(NBK * p) * (ld + 1), ld, a.invd + (long)p * NBK * NBK, a.info, NBK * p);
+      } else {
+        double* R = a.T + (long)(NBK * tk.i + MB * tk.u) * ld;   // the task's 32 rows of the square part
+        coh = WT;
+        if constexpr (!WT) acquire_all<PROTO>();
+        if (WT) load_panel<true>(S, OFF_PA, R + NBK * p, ld, MB, wave, lane);
+        else load_panel<false>(S, OFF_PA, R + NBK * p, ld, MB, wave, lane);
+        __syncthreads();
+        if (tk.type == T_FIN) {
+          what = 1;
+          st.B = a.invd + (long)p * NBK * NBK; st.ldb = NBK; st.n0 = 0; st.n1 = NBK;
+          st.C = R + NBK * p; st.ldc = ld; st.mode = MODE_FIN;
+        } else {
+          what = 2;
+          st.B = a.T + NBK * p; st.ldb = ld; st.n0 = NBK * (p + 1); st.n1 = NBK * tk.i + MB * tk.u + MB;
+          st.C = R; st.ldc = ld; st.mode = MODE_SUB;
+        }
+      }
+    } else {
+      // ================= bulk quantum (d == 2) =================
+      st.nrows = nr;
+      if (ph == 0) {
+        // FIN: A^T[:, q] = E[:, q] inv(L_qq)^T
+        what = 3;
+        acquire_all<PROTO>();
+        load_panel<false>(S, OFF_PA, E0 + NBK * q, ld, nr, wave, lane);
+        __syncthreads();
+        st.B = a.invd + (long)q * NBK * NBK; st.ldb = NBK; st.n0 = 0; st.n1 = NBK;
+        st.C = E0 + NBK * q; st.ldc = ld; st.mode = MODE_FIN;
+      } else {
+        if (!panel_ok) {
+          load_panel<false>(S, OFF_PB, E0 + NBK * q, ld, nr, wave, lane);   // own rows, written by this workgroup
+          __syncthreads();
+          panel_ok = true;
+        }
+        st.pa_off = OFF_PB;
+        begin = pos;
+        if (ph <= P) {
+          // PROJ, latent pl: C_pl[:, 0 : 128 (q+1)] += A^T[:, q] Lq_pl[q, :]; the last panel squares instead of storing
+          what = 4;
+          const int pl = ph - 1;
+          const bool last = q == nb - 1;
+          st.B = a.LqT + (long)pl * m * a.ldl + NBK * q; st.ldb = a.ldl; st.n0 = 0; st.n1 = NBK * (q + 1);
+          st.C = a.Cacc + ((long)pl * a.rows + r0) * ld; st.ldc = ld;
+          st.mode = last ? MODE_SQ : MODE_ADD; st.nfresh = NBK * q;
+          intr = (have_task && !last) ? &tc : nullptr;
+        } else if (q < nb - 1) {
+          // UPD: E[:, n] -= A^T[:, q] L[n, q]^T for the columns still to come
+          what = 5;
+          if (pos == 0) acquire_all<PROTO>();
+          st.B = a.T + NBK * q; st.ldb = ld; st.n0 = NBK * (q + 1); st.n1 = m;
+          st.C = E0; st.ldc = ld; st.mode = MODE_SUB;
+          intr = have_task ? &tc : nullptr;
+        } else {
+          what = 6; run = false;
+        }
+      }
+    }
+    int endpos = 0;
+    const int nslabs = run ? (st.n1 - st.n0 + NS - 1) / NS : 0;
+    if (run) {
+      if (coh) endpos = stream_run<true>(st, begin, intr, ctl, sq);
+      else endpos = stream_run<false>(st, begin, intr, ctl, sq);
+    }
+    // ---- what follows the stream ----------------------------------------------------------------------------------
+    if (what <= 2) {
+      publish_barrier<PROTO>();
+      if (tid == 0) {
+        if (what == 0) { st_flag(a.flags + f_leaf(p), 1); a.stamps[2 * p + 1] = wall_clock64(); }
+        // (FIN: the cumulative counters of the block rows i .. nb-1, one lane each -- below)
+        else st_flag(a.flags + f_rowd(nb, tk.i, tk.u), p + 1);
+      }
+      if (what == 1 && tid < nb - tk.i) add_flag(a.flags + f_finc(nb, p, tk.i + tid), 1);
+      panel_ok = false;
+      ct += pool_n;
+      if (ct >= (is_near ? ntasks_near(nb, cp) : ntasks_far(nb, cp))) { ++cp; ct = -1; }
+    } else if (what == 3) {
+      // s0[row] (+)= sum_k A^2, fmean[row][p] (+)= sum_k A[row][k] q_mu[128 q + k][p]: 16 threads per row
+      const int row = tid >> 4, sub = tid & 15;
+      const double* ap = S + OFF_PB + row * LDP + sub * 8;
+      double s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s2 += ap[k] * ap[k];
+      s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
+      if (sub == 0 && row < nr) a.s0[r0 + row] = (q == 0 ? 0.0 : a.s0[r0 + row]) + s2;
+      for (int pp = 0; pp < P; ++pp) {
+        double mv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mv += ap[k] * a.q_mu[(long)(NBK * q + sub * 8 + k) * P + pp];
+        mv += __shfl_xor(mv, 1); mv += __shfl_xor(mv, 2); mv += __shfl_xor(mv, 4); mv += __shfl_xor(mv, 8);
+        if (sub == 0 && row < nr) {
+          double* fm = a.fmean + (long)(r0 + row) * P + pp;
+          *fm = (q == 0 ? 0.0 : *fm) + mv;
+        }
+      }
+      panel_ok = true; ph = 1; pos = 0;
+      sq = (d4){0.0, 0.0, 0.0, 0.0};
+    } else if (what == 4) {
+      pos = endpos;
+      if (endpos >= nslabs) {
+        if (q == nb - 1) {
+          // ssq[pl][row]: the 16 column lanes of a row, then the two column halves (waves nt = 0, 1) in a fixed order
+          double* red = S + OFF_MISC;
+          if (wave < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              double v = sq[r];
+              v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+              if ((lane & 15) == 0) red[((wave >> 1) & 1) * MB + 16 * (wave & 1) + (lane >> 4) + 4 * r] = v;
+            }
+          }
+          __syncthreads();
+          if (tid < nr) a.ssq[(long)(ph - 1) * a.rows + r0 + tid] = red[tid] + red[MB + tid];
+          __syncthreads();
+          sq = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+        ++ph; pos = 0;
+      }
+    } else if (what == 5) {
+      pos = endpos;
+      if (endpos >= nslabs) { ++q; ph = 0; pos = 0; panel_ok = false; }
+    } else {
+      // ---- variational expectations of the row block (likelihoods/scalar_continuous.py:139-148), summed --------------
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();   // this workgroup's ssq / s0 / fmean stores are performed
+      double* red = S + OFF_MISC;
+      if (tid < MB) {
+        double acc = 0.0;
+        if (tid < nr) {
+          const double c0 = -0.5 * 1.8378770664093453 - 0.5 * log(a.noise);
+          const long b = r0 + tid;
+          for (int pp = 0; pp < P; ++pp) {
+            const double fv = a.variance - a.s0[b] + a.ssq[(long)pp * a.rows + b];
+            const double dy = a.Y[b * a.ldy + pp] - (a.fmean[b * P + pp] + a.mean_const);
+            acc += c0 - 0.5 * (dy * dy + fv) / a.noise;
+          }
+        }
+        red[tid] = acc;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < MB; ++i) tot += red[i];
+        __hip_atomic_store(a.partial + wg, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int prev = add_flag(a.flags + f_done(nb), 1);
+        if (prev == a.nbulk - 1) {   // the last row block: the step's data term, summed in workgroup order
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          double o = 0.0;
+          for (int i = 0; i < a.nbulk; ++i) o += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          a.out[0] = o;
+        }
+      }
+      __syncthreads();
+      q = nb;
+    }
+  }
+  if (aborted && tid == 0 && a.info) a.info[0] = INT_MAX;   // timed out: the caller sees a failed factorisation
+}
+
+}  // namespace
+
+// flags + partials the step kernel needs (bytes), and the launch.  The caller has built Kuu (+ jitter) into T[0:m], Kfu into
+// T[m:m+rows], LqT, and zeroes `flags` on the same stream before this launch.
+size_t gpk_mega_flag_ints(int m) {
+  const int nb = m / NBK;
+  return (size_t)nb * nb + 6 * nb + 8 + 4 * (size_t)nb + 2;   // flag words, then (8-byte aligned) the leaf time stamps
+}
+int gpk_mega_supported(int m, int rows, int P, int ncu) {
+  if (m < NBK || (m % NBK) || m / NBK > 64 || rows < 1 || P < 1 || P > 16) return 0;
+  if ((rows + MB - 1) / MB > ncu) return 0;   // one row block per resident workgroup
+  return 1;
+}
+int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, int m, int rows, double* invd, const double* LqT,
+                         long ldl, double* Cacc, const double* q_mu, int P, const double* Y, long ldy, double* s0, double* fmean,
+                         double* ssq, double* partial, int* flags, int* info, double* out, double variance, double noise,
+                         double mean_const, int min_wgs) {
+  if (!gpk_mega_supported(m, rows, P, ncu)) return GPK_E_UNSUPPORTED;
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(svgp_step_kernel<0>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MEGA_LDS);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(svgp_step_kernel<1>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MEGA_LDS);
+  GPK_HIP(attr0);
+  GPK_HIP(attr1);
+  MegaArgs a{};
+  a.T = T; a.ld = ld; a.invd = invd; a.LqT = LqT; a.ldl = ldl; a.Cacc = Cacc; a.q_mu = q_mu; a.Y = Y; a.ldy = ldy;
+  a.s0 = s0; a.fmean = fmean; a.ssq = ssq; a.partial = partial; a.flags = flags; a.info = info; a.out = out;
+  {
+    const size_t nflag = (size_t)(m / NBK) * (m / NBK) + 6 * (m / NBK) + 8;
+    a.stamps = (long long*)(flags + ((nflag + 1) & ~(size_t)1));
+  }
+  a.m = m; a.nb = m / NBK; a.rows = rows; a.P = P; a.nbulk = (rows + MB - 1) / MB;
+  a.variance = variance; a.noise = noise; a.mean_const = mean_const;
+  a.timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+  int G = a.nbulk;
+  if (G < min_wgs) G = min_wgs;
+  if (G < 16) G = 16;   // two task pools need a few workgroups each
+  if (G > ncu) G = ncu;
+  if (G < 16) return GPK_E_UNSUPPORTED;
+  GPK_HIP(hipMemsetAsync(flags, 0, gpk_mega_flag_ints(m) * sizeof(int), s));
+  if (proto == 1) hipLaunchKernelGGL((svgp_step_kernel<1>), dim3((unsigned)G), dim3(MEGA_THREADS), MEGA_LDS, s, a);
+  else hipLaunchKernelGGL((svgp_step_kernel<0>), dim3((unsigned)G), dim3(MEGA_THREADS), MEGA_LDS, s, a);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}

@@ -689,7 +689,7 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
 namespace {
 struct ElboLayout {
   long ld; int nt;
-  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, total;
+  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_C, off_flags, total;
 };
 
 ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
@@ -706,10 +706,34 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   l.off_proj = o; o += q_diag ? 0 : gpk_align_up(gpk_project_workspace_bytes(rows, m, P), 256);
   l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
+  // single-launch step kernel (mega.hip): projection accumulator [P, rows, ld] and its flag words
+  l.off_C = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)P * rows * l.ld * sizeof(double), 256) : 0;
+  l.off_flags = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up(gpk_mega_flag_ints(m) * sizeof(int), 256) : 0;
   l.total = o;
   return l;
 }
+
+int device_cus(int* ncu) {
+  static int cached[16] = {0};
+  int dev = 0;
+  GPK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return GPK_E_UNSUPPORTED;
+  if (!cached[dev]) {
+    hipDeviceProp_t prop;
+    GPK_HIP(hipGetDeviceProperties(&prop, dev));
+    cached[dev] = prop.multiProcessorCount;
+  }
+  *ncu = cached[dev];
+  return 0;
+}
 }  // namespace
+
+#ifdef GPK_EXPERIMENTAL
+// (A/B build only) byte offset of the step kernel's flag words / leaf time stamps inside the fused driver's workspace
+extern "C" __attribute__((visibility("default"))) long gpk_exp_svgp_flags_offset(int m, int rows, int P) {
+  return (long)elbo_layout(m, rows, P, 0).off_flags;
+}
+#endif
 
 extern "C" size_t gpk_svgp_elbo_workspace_bytes(int m, int rows, int d, int P, int q_diag) {
   (void)d;
@@ -745,6 +769,32 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   // and the panel chain starts right after the much smaller Kuu build.  Work that depends on neither factorisation
   // nor minibatch solve -- tril(q_sqrt)^T for the projection and the whole KL term -- goes to that stream too, which
   // idles until the first 512 columns of Lm exist; gpk_potrf joins it.
+  // ---- single-launch route (mega.hip): builds + KL on the caller's stream, then ONE persistent kernel for everything
+  // that depends on the factorisation.  Taken when the shapes fit one row block per compute unit.
+  if (!q_diag && GPK_TUNE(MEGA, GPK_MEGA_DEFAULT) && rows > 0) {
+    int ncu = 0;
+    rc = device_cus(&ncu);
+    if (rc) return rc;
+    if (gpk_mega_supported(m, rows, P, ncu)) {
+      rc = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter, 1, T, l.ld);
+      if (rc) return rc;
+      rc = gpk_kernel_matrix(stream, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0, Kfu, l.ld);
+      if (rc) return rc;
+      rc = gpk_transpose(stream, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
+      if (rc) return rc;
+      int ck = 0;
+      rc = gpk_launch_kl_white_stage1(s, q_mu, q_sqrt, m, P, q_diag, part1, &ck);
+      if (rc) return rc;
+      const double* pk[1] = {part1};
+      const double halfk = 0.5;
+      rc = gpk_launch_final(s, 1, pk, &ck, &halfk, -0.5 * (double)m * (double)P, out + 1);
+      if (rc) return rc;
+      GPK_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
+      return gpk_launch_svgp_mega(s, GPK_TUNE(MEGA_PROTO, 0), ncu, T, l.ld, m, rows, invd, LqT, l.ld, (double*)(w + l.off_C), q_mu, P,
+                                  Yb, ldyb, s0, fmean, ssq, part0, (int*)(w + l.off_flags), info, out, variance, noise_variance,
+                                  mean_const, GPK_TUNE(MEGA_MIN_WGS, 96));
+    }
+  }
   const bool side = m > GPK_NB && m < 4096 && rows > 256;
   // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only: the chain's first leaf waits for
   // nothing else, so it is the first thing enqueued
