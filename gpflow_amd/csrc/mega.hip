@@ -62,10 +62,12 @@ struct MegaArgs {
   double* s0; double* fmean; double* ssq;   // [rows], [rows][P], [P][rows]
   double* partial;               // [nbulk]
   int* flags;
+  long long* trace;              // A/B build: [1 + 8 * cap] task trace (count, then records), else NULL
   long long* stamps;             // [nb][2]: wall clock at the start / publication of every leaf (diagnostics, 16 bytes per panel)
   int* info;
   double* out;
   int m, nb, rows, P, nbulk;
+  int one_pool;                  // A/B: deal near and far chain tasks to all workgroups alike
   double variance, noise, mean_const;
   long long timeout_ticks;
 };
@@ -85,13 +87,18 @@ __device__ __forceinline__ int add_flag(int* p, int v) { return __hip_atomic_fet
 typedef __attribute__((address_space(1))) double gdouble;          // explicitly GLOBAL doubles: inside the non-inlined
 typedef __attribute__((address_space(1))) const double cgdouble;   // functions a plain pointer is a flat one, and flat
                                                                     // stores are ordered against every LDS access
-struct Cond { const int* a[4]; int thr[4]; int n; };
+// A readiness condition: up to four flag words that must have reached their thresholds.  Always four entries -- unused ones
+// point at a valid word with threshold INT_MIN -- so that the test is four unconditional, independent loads and no
+// dynamically indexed private array (the first version looped over `n` entries of a private array; the leaf's four-flag
+// condition then evaluated true before its flags were set: the leaf ran 10 us ahead of the updates it depends on).
+struct Cond { const int* a0; const int* a1; const int* a2; const int* a3; int t0, t1, t2, t3; };
+__device__ __forceinline__ void cond_init(Cond& c, const int* valid) {
+  c.a0 = c.a1 = c.a2 = c.a3 = valid;
+  c.t0 = c.t1 = c.t2 = c.t3 = INT_MIN;
+}
 __device__ __forceinline__ bool cond_ok(const Cond& c) {
-  int v[4] = {0, 0, 0, 0};
-  for (int k = 0; k < c.n; ++k) v[k] = ld_flag(c.a[k]);   // independent loads: one round trip, not c.n
-  bool ok = true;
-  for (int k = 0; k < c.n; ++k) ok = ok && (v[k] >= c.thr[k]);
-  return ok;
+  const int v0 = ld_flag(c.a0), v1 = ld_flag(c.a1), v2 = ld_flag(c.a2), v3 = ld_flag(c.a3);
+  return (v0 >= c.t0) & (v1 >= c.t1) & (v2 >= c.t2) & (v3 >= c.t3);
 }
 
 template <bool COH>
@@ -148,8 +155,9 @@ __device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Co
   // (everything the loops use is copied into registers first: with the descriptors left in memory the compiler orders
   // every LDS-DMA instruction against their reloads and the eight rows of a slab are fetched one after the other)
   const bool has_intr = intr_in != nullptr;
-  Cond ic{};
+  Cond ic;
   if (has_intr) ic = *intr_in;
+  else { ic.a0 = ic.a1 = ic.a2 = ic.a3 = nullptr; ic.t0 = ic.t1 = ic.t2 = ic.t3 = 0; }
   const Cond* intr = has_intr ? &ic : nullptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -295,17 +303,18 @@ __device__ __forceinline__ Task decode_far(int nb, int p, int t) {
 // p+1 .. i (every FIN(i', ., p) adds one to finc[p][i] for all i >= i'); rowd[i][u] = panels applied to row quarter (i, u)
 __device__ __forceinline__ void task_cond(const MegaArgs& a, const Task& k, Cond& c) {
   const int nb = a.nb;
-  c.n = 0;
+  cond_init(c, a.flags);
   if (k.type == T_LEAF) {
-    if (k.p > 0)
-      for (int u = 0; u < 4; ++u) { c.a[c.n] = a.flags + f_rowd(nb, k.p, u); c.thr[c.n] = k.p; ++c.n; }
+    if (k.p > 0) {
+      c.a0 = a.flags + f_rowd(nb, k.p, 0); c.a1 = a.flags + f_rowd(nb, k.p, 1);
+      c.a2 = a.flags + f_rowd(nb, k.p, 2); c.a3 = a.flags + f_rowd(nb, k.p, 3);
+      c.t0 = c.t1 = c.t2 = c.t3 = k.p;
+    }
   } else if (k.type == T_FIN) {
-    c.a[0] = a.flags + f_leaf(k.p); c.thr[0] = 1;
-    c.a[1] = a.flags + f_rowd(nb, k.i, k.u); c.thr[1] = k.p;
-    c.n = 2;
+    c.a0 = a.flags + f_leaf(k.p); c.t0 = 1;
+    c.a1 = a.flags + f_rowd(nb, k.i, k.u); c.t1 = k.p;
   } else {
-    c.a[0] = a.flags + f_finc(nb, k.p, k.i); c.thr[0] = 4 * (k.i - k.p);   // the B rows it reads: block rows p+1 .. i
-    c.n = 1;
+    c.a0 = a.flags + f_finc(nb, k.p, k.i); c.t0 = 4 * (k.i - k.p);   // the B rows it reads: block rows p+1 .. i
   }
 }
 
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
   int cp = 0, ct = -1;          // chain: panel cursor, slot cursor within the panel (-1: not yet computed)
   // near pool: workgroups [0, GA); far pool: [GA, G) (one pool for tiny grids: then everybody takes near AND far tasks,
   // far ones as extra slots behind the near ones -- handled by giving such grids the near decode over both ranges)
-  const int GA = G >= 16 ? (G / 4 > 32 ? G / 4 : 32 < G / 2 ? 32 : G / 2) : G;
+  const int GA = (G >= 16 && !a.one_pool) ? (G / 4 > 32 ? G / 4 : 32 < G / 2 ? 32 : G / 2) : G;
   const bool two_pools = GA < G;
   const bool is_near = !two_pools || wg < GA;
   const int pool_n = is_near ? GA : G - GA;
@@ -364,14 +373,21 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
     bool have_task = false;
     Task tk{};
     while (cp < nb) {
-      const int nt_p = is_near ? ntasks_near(nb, cp) : ntasks_far(nb, cp);
+      const int nn = ntasks_near(nb, cp), nf = ntasks_far(nb, cp);
+      const int nt_p = two_pools ? (is_near ? nn : nf) : nn + nf;   // one pool: the far slots follow the near ones
       if (ct < 0) ct = ((pool_id - slot_owner_offset(cp)) % pool_n + pool_n) % pool_n;
-      if (ct < nt_p) { tk = is_near ? decode_near(cp, ct) : decode_far(nb, cp, ct); have_task = true; break; }
+      if (ct < nt_p) {
+        if (two_pools) tk = is_near ? decode_near(cp, ct) : decode_far(nb, cp, ct);
+        else tk = ct < nn ? decode_near(cp, ct) : decode_far(nb, cp, ct - nn);
+        have_task = true;
+        break;
+      }
       ++cp; ct = -1;
     }
     const bool bulk_left = has_rows && q < nb;
     if (!have_task && !bulk_left) break;
-    Cond tc{};
+    Cond tc;
+    cond_init(tc, a.flags);
     if (have_task) task_cond(a, tk, tc);
     // ---- decide: 1 chain task, 2 bulk quantum, 0 nothing ready, 3 abort -------------------------------------------
     if (tid == 0) {
@@ -396,6 +412,7 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
     // One stream per loop iteration, described by the branch that owns it and run at a single call site per coherence
     // variant (the leaf and the stream body are large: one inlined copy each keeps the kernel's register budget for them).
     const int p = tk.p;
+    const long long t_task0 = wall_clock64();
     Stream st{};
     st.nrows = MB; st.pa_off = OFF_PA; st.nfresh = 0;
     bool coh = false, run = true;
@@ -481,9 +498,19 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
         else st_flag(a.flags + f_rowd(nb, tk.i, tk.u), p + 1);
       }
       if (what == 1 && tid < nb - tk.i) add_flag(a.flags + f_finc(nb, p, tk.i + tid), 1);
+#ifdef GPK_EXPERIMENTAL
+      if (a.trace && tid == 0) {
+        const long long idx = __hip_atomic_fetch_add((unsigned long long*)a.trace, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (idx < 4096) {
+          long long* r = a.trace + 1 + 8 * idx;
+          r[0] = t_task0; r[1] = wall_clock64(); r[2] = wg; r[3] = what; r[4] = p; r[5] = tk.i; r[6] = tk.u;
+          r[7] = (what == 2) ? ld_flag(a.flags + f_finc(nb, p, tk.i)) : (what == 1 ? ld_flag(a.flags + f_rowd(nb, tk.i, tk.u)) : 0);
+        }
+      }
+#endif
       panel_ok = false;
       ct += pool_n;
-      if (ct >= (is_near ? ntasks_near(nb, cp) : ntasks_far(nb, cp))) { ++cp; ct = -1; }
+      if (ct >= (two_pools ? (is_near ? ntasks_near(nb, cp) : ntasks_far(nb, cp)) : ntasks_near(nb, cp) + ntasks_far(nb, cp))) { ++cp; ct = -1; }
     } else if (what == 3) {
       // s0[row] (+)= sum_k A^2, fmean[row][p] (+)= sum_k A[row][k] q_mu[128 q + k][p]: 16 threads per row
       const int row = tid >> 4, sub = tid & 15;
@@ -582,6 +609,26 @@ int gpk_mega_supported(int m, int rows, int P, int ncu) {
   if ((rows + MB - 1) / MB > ncu) return 0;   // one row block per resident workgroup
   return 1;
 }
+#ifdef GPK_EXPERIMENTAL
+namespace { long long* g_trace = nullptr; }
+extern "C" __attribute__((visibility("default"))) int gpk_exp_mega_trace_dump(void) {
+  if (!g_trace) return 0;
+  static long long host[1 + 8 * 4096];
+  if (hipMemcpy(host, g_trace, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const long long n = host[0] < 4096 ? host[0] : 4096;
+  long long t0 = 0;
+  for (long long i = 0; i < n; ++i) if (i == 0 || host[1 + 8 * i] < t0) t0 = host[1 + 8 * i];
+  printf("# chain task trace: start_us dur_us wg what(0 leaf,1 FIN,2 UPD) p i u flag_at_end   (%lld records)\n", host[0]);
+  for (long long i = 0; i < n; ++i) {
+    const long long* r = host + 1 + 8 * i;
+    printf("T %8.1f %6.1f wg=%3lld what=%lld p=%lld i=%lld u=%lld flag=%lld\n", (r[0] - t0) / 100.0, (r[1] - r[0]) / 100.0, r[2], r[3], r[4], r[5],
+           r[6], r[7]);
+  }
+  fflush(stdout);
+  return (int)n;
+}
+#endif
+
 int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, int m, int rows, double* invd, const double* LqT,
                          long ldl, double* Cacc, const double* q_mu, int P, const double* Y, long ldy, double* s0, double* fmean,
                          double* ssq, double* partial, int* flags, int* info, double* out, double variance, double noise,
@@ -603,12 +650,20 @@ int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, 
   a.m = m; a.nb = m / NBK; a.rows = rows; a.P = P; a.nbulk = (rows + MB - 1) / MB;
   a.variance = variance; a.noise = noise; a.mean_const = mean_const;
   a.timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+  a.one_pool = GPK_TUNE(MEGA_ONE_POOL, 0);
   int G = a.nbulk;
   if (G < min_wgs) G = min_wgs;
   if (G < 16) G = 16;   // two task pools need a few workgroups each
   if (G > ncu) G = ncu;
   if (G < 16) return GPK_E_UNSUPPORTED;
   GPK_HIP(hipMemsetAsync(flags, 0, gpk_mega_flag_ints(m) * sizeof(int), s));
+#ifdef GPK_EXPERIMENTAL
+  if (GPK_TUNE(MEGA_TRACE, 0)) {
+    if (!g_trace) GPK_HIP(hipMalloc(&g_trace, sizeof(long long) * (1 + 8 * 4096)));
+    GPK_HIP(hipMemsetAsync(g_trace, 0, sizeof(long long) * (1 + 8 * 4096), s));
+    a.trace = g_trace;
+  }
+#endif
   if (proto == 1) hipLaunchKernelGGL((svgp_step_kernel<1>), dim3((unsigned)G), dim3(MEGA_THREADS), MEGA_LDS, s, a);
   else hipLaunchKernelGGL((svgp_step_kernel<0>), dim3((unsigned)G), dim3(MEGA_THREADS), MEGA_LDS, s, a);
   GPK_LAUNCH_CHECK();

@@ -213,6 +213,73 @@ def build():  # noqa: C901
             pmu, pvar = s.posterior().predict_f(Xs, full_cov=bool(fc))
             out[f"mo_shsep_cached_mu_w{w}_fc{fc}"] = _n(pmu); out[f"mo_shsep_cached_var_w{w}_fc{fc}"] = _n(pvar)
 
+    # ---- gradients of the reference's own objectives (what optimizers/scipy.py:174-221, 322-331 differentiates) ------------
+    # tf.GradientTape is not emulated by the stand-ins, so the gradients are taken by Richardson-extrapolated central
+    # differences of the REFERENCE'S forward code (SVGP.elbo, GPR.log_marginal_likelihood, SGPR.elbo) with respect to the
+    # constrained quantities -- kernel variance, ARD lengthscales, noise variance, Z, q_mu, tril(q_sqrt) -- each model
+    # rebuilt from perturbed values.  (h = 2e-3 and h / 2: truncation O(h^4), rounding ~1e-11; the oracle's autograd and the
+    # HIP reverse pass are then tested against these numbers at 1e-7 of the largest entry.)
+    def richardson(f, x, h=2e-3):
+        x = np.array(x, dtype=np.float64)
+        g = np.zeros_like(x)
+        it = np.nditer(x, flags=["multi_index"])
+        for _ in it:
+            i = it.multi_index
+            d = []
+            for hh in (h, h / 2):
+                xp, xm = x.copy(), x.copy()
+                xp[i] += hh; xm[i] -= hh
+                d.append((f(xp) - f(xm)) / (2 * hh))
+            g[i] = (4.0 * d[1] - d[0]) / 3.0
+        return g
+
+    rng = np.random.default_rng(61)
+    Mg, Bg, Dg, Pg = 7, 19, 2, 2
+    Xg = rng.normal(size=(Bg, Dg)); Yg = np.sin(Xg.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(Bg, Pg))
+    Zg = Xg[:Mg] + 0.05 * rng.normal(size=(Mg, Dg))
+    qmg = 0.3 * rng.normal(size=(Mg, Pg)); qsg = np.tril(0.2 * rng.normal(size=(Pg, Mg, Mg))) + 0.6 * np.eye(Mg)
+    th = dict(variance=np.array(1.3), lengthscales=np.array([0.9, 1.4]), noise_variance=np.array(0.15))
+    out.update(g_X=Xg, g_Y=Yg, g_Z=Zg, g_q_mu=qmg, g_q_sqrt=qsg, g_variance=th["variance"], g_lengthscales=th["lengthscales"],
+               g_noise_variance=th["noise_variance"])
+    tril_mask = np.tril(np.ones((Mg, Mg), dtype=bool))
+
+    def svgp_elbo_of(whiten, **kw):
+        v = dict(Z=Zg, q_mu=qmg, q_sqrt=qsg, **th); v.update(kw)
+        mdl = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=float(v["variance"]), lengthscales=np.array(v["lengthscales"])),
+                                 gpflow.likelihoods.Gaussian(variance=float(v["noise_variance"])), np.array(v["Z"]),
+                                 q_mu=np.array(v["q_mu"]), q_sqrt=np.array(v["q_sqrt"]), whiten=bool(whiten), num_latent_gps=Pg, num_data=500)
+        return float(mdl.elbo((Xg, Yg)))
+
+    for w in (1, 0):
+        out[f"g_svgp_elbo_w{w}"] = svgp_elbo_of(w)
+        for name in ("variance", "lengthscales", "noise_variance"):
+            out[f"g_svgp_d{name}_w{w}"] = richardson(lambda x, n=name: svgp_elbo_of(w, **{n: x}), th[name])
+        out[f"g_svgp_dZ_w{w}"] = richardson(lambda x: svgp_elbo_of(w, Z=x), Zg)
+        out[f"g_svgp_dq_mu_w{w}"] = richardson(lambda x: svgp_elbo_of(w, q_mu=x), qmg)
+        gq = richardson(lambda x: svgp_elbo_of(w, q_sqrt=x), qsg)
+        out[f"g_svgp_dq_sqrt_w{w}"] = gq * tril_mask[None]   # (the strict upper triangle is ignored by band_part: exact zeros)
+
+    def gpr_lml_of(**kw):
+        v = dict(th); v.update(kw)
+        mdl = gpflow.models.GPR((Xg, Yg[:, :1]), gpflow.kernels.SquaredExponential(variance=float(v["variance"]),
+                                                                                 lengthscales=np.array(v["lengthscales"])),
+                                noise_variance=float(v["noise_variance"]))
+        return float(mdl.log_marginal_likelihood())
+    out["g_gpr_lml"] = gpr_lml_of()
+    for name in ("variance", "lengthscales", "noise_variance"):
+        out[f"g_gpr_d{name}"] = richardson(lambda x, n=name: gpr_lml_of(**{n: x}), th[name])
+
+    def sgpr_elbo_of(**kw):
+        v = dict(Z=Zg, **th); v.update(kw)
+        mdl = gpflow.models.SGPR((Xg, Yg[:, :1]), gpflow.kernels.SquaredExponential(variance=float(v["variance"]),
+                                                                                  lengthscales=np.array(v["lengthscales"])),
+                                 np.array(v["Z"]), noise_variance=float(v["noise_variance"]))
+        return float(mdl.elbo())
+    out["g_sgpr_elbo"] = sgpr_elbo_of()
+    for name in ("variance", "lengthscales", "noise_variance"):
+        out[f"g_sgpr_d{name}"] = richardson(lambda x, n=name: sgpr_elbo_of(**{n: x}), th[name])
+    out["g_sgpr_dZ"] = richardson(lambda x: sgpr_elbo_of(Z=x), Zg)
+
     # ---- SGPR (models/sgpr.py) ---------------------------------------------------------------------------------------------
     rng = np.random.default_rng(51)
     X = rng.normal(size=(60, 2)); Y = np.sin(X[:, :1]) + 0.1 * rng.normal(size=(60, 1)); Z = X[:9].copy(); Xs = rng.normal(size=(5, 2))

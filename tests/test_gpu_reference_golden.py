@@ -185,3 +185,34 @@ def test_ref_sgpr(gp):
     close(mu, G["sgpr_mu"], 1e-8); close(var, G["sgpr_var"], 1e-8)
     qmu, qcov = sg.compute_qu()
     close(qmu, G["sgpr_qu_mu"], 1e-7); close(qcov, G["sgpr_qu_cov"], 1e-7)
+
+
+def test_ref_gradients(gp):
+    """The hand-written reverse pass (gpflow_amd/gradients.py, every product a libgpk call) against gradients of the
+    reference's own SVGP.elbo (whitened and not) / GPR.log_marginal_likelihood / SGPR.elbo obtained by Richardson central
+    differences of the unmodified GPflow source (make_golden_ref.py).  1e-7 of each gradient's largest entry."""
+    from gpflow_amd import gradients, ops
+    X, Y, Z, qm, qs = (ops.to_device(G[k]) for k in ("g_X", "g_Y", "g_Z", "g_q_mu", "g_q_sqrt"))
+    kw = dict(variance=float(G["g_variance"]), lengthscales=G["g_lengthscales"], noise_variance=float(G["g_noise_variance"]))
+    B = X.shape[0]
+
+    def chk(g, ref, tol=1e-7):
+        g = _np(g).reshape(ref.shape)
+        assert np.abs(g - ref).max() <= tol * max(np.abs(ref).max(), 1e-300), (np.abs(g - ref).max(), np.abs(ref).max())
+    for w, fn in ((1, gradients.svgp_elbo_and_grad), (0, gradients.svgp_elbo_and_grad_unwhitened)):
+        F, g, info = fn(Z, X, Y, qm, qs, jitter=1e-6, scale=500.0 / B, **kw)
+        assert int(_np(info).ravel()[0]) == 0
+        np.testing.assert_allclose(float(_np(F).ravel()[0]), float(G[f"g_svgp_elbo_w{w}"]), rtol=1e-10)
+        for n in ("variance", "lengthscales", "noise_variance", "Z", "q_mu"):
+            chk(g[n], G[f"g_svgp_d{n}_w{w}"])
+        chk(np.tril(_np(g["q_sqrt"])), G[f"g_svgp_dq_sqrt_w{w}"])
+    Y1 = Y[:, :1].contiguous()
+    F, g, info = gradients.gpr_lml_and_grad(X, Y1, **kw)
+    np.testing.assert_allclose(float(_np(F).ravel()[0]), float(G["g_gpr_lml"]), rtol=1e-10)
+    for n in ("variance", "lengthscales", "noise_variance"):
+        chk(g[n], G[f"g_gpr_d{n}"])
+    F, g, info = gradients.sgpr_elbo_and_grad(Z, X, Y1, jitter=1e-6, **kw)
+    np.testing.assert_allclose(float(_np(F).ravel()[0]), float(G["g_sgpr_elbo"]), rtol=1e-10)
+    for n in ("variance", "lengthscales", "noise_variance", "Z"):
+        chk(g[n], G[f"g_sgpr_d{n}"])
+

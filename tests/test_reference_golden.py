@@ -173,3 +173,32 @@ def test_sgpr():
     close(mu, G["sgpr_mu"]); close(var, G["sgpr_var"], 1e-11)
     qmu, qcov = orc.sgpr_compute_qu(X, Y, Z, **kw)
     close(qmu, G["sgpr_qu_mu"], 1e-10); close(qcov, G["sgpr_qu_cov"], 1e-10)
+
+
+def test_gradient_oracle_pinned_to_reference_finite_differences():
+    """oracle/gp_oracle_grad.py (torch autograd over the restated algorithm) against gradients of the REFERENCE'S OWN
+    SVGP.elbo / GPR.log_marginal_likelihood / SGPR.elbo, taken by Richardson-extrapolated central differences of the
+    unmodified GPflow source (tests/golden/make_golden_ref.py; what optimizers/scipy.py:174-221, 322-331 differentiates
+    with tf.GradientTape).  1e-7 of each gradient's largest entry: the finite differences themselves carry ~1e-8."""
+    from oracle import gp_oracle_grad as og
+    X, Y, Z, qm, qs = G["g_X"], G["g_Y"], G["g_Z"], G["g_q_mu"], G["g_q_sqrt"]
+    kw = dict(variance=float(G["g_variance"]), lengthscales=G["g_lengthscales"], noise_variance=float(G["g_noise_variance"]))
+
+    def chk(g, ref, tol=1e-7):
+        g = np.asarray(g, dtype=np.float64).reshape(ref.shape)
+        assert np.abs(g - ref).max() <= tol * max(np.abs(ref).max(), 1e-300), (np.abs(g - ref).max(), np.abs(ref).max())
+    for w in (1, 0):
+        F, g = og.svgp_elbo_value_and_grads(X, Y, Z, qm, qs, num_data=500, whiten=bool(w), **kw)
+        np.testing.assert_allclose(F, float(G[f"g_svgp_elbo_w{w}"]), rtol=1e-12)
+        for n in ("variance", "lengthscales", "noise_variance", "Z", "q_mu"):
+            chk(g[n], G[f"g_svgp_d{n}_w{w}"])
+        chk(np.tril(g["q_sqrt"]), G[f"g_svgp_dq_sqrt_w{w}"])
+    F, g = og.gpr_lml_value_and_grads(X, Y[:, :1], **kw)
+    np.testing.assert_allclose(F, float(G["g_gpr_lml"]), rtol=1e-12)
+    for n in ("variance", "lengthscales", "noise_variance"):
+        chk(g[n], G[f"g_gpr_d{n}"])
+    F, g = og.sgpr_elbo_value_and_grads(X, Y[:, :1], Z, **kw)
+    np.testing.assert_allclose(F, float(G["g_sgpr_elbo"]), rtol=1e-12)
+    for n in ("variance", "lengthscales", "noise_variance", "Z"):
+        chk(g[n], G[f"g_sgpr_d{n}"])
+

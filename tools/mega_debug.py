@@ -78,6 +78,8 @@ def main():
             ld = (m + 7) // 8 * 8
             T = ws[:(m + rows) * ld].reshape(m + rows, ld).cpu().numpy().copy()
             o, inf = out.cpu().numpy().copy(), int(info.cpu()[0])
+            if name == "mega" and os.environ.get("GPK_MEGA_TRACE"):
+                lib.gpk_exp_mega_trace_dump()
             if name == "mega":
                 nbp = m // 128
                 off = int(lib.gpk_exp_svgp_flags_offset(m, rows, P)) // 8
