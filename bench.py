@@ -562,7 +562,7 @@ def main():  # noqa: C901
                                              ctypes.byref(n_launch), ctypes.byref(fl))
             return ms.value, n_launch.value, fl.value
         kinds = {1: "gemm_nt_small", 2: "gemm_nt_fast<0,false>", 3: "gemm_nt_fast<0,true>", 4: "gemm_nt_fast<1,false>",
-                 5: "gemm_nt_fast<1,true>", 6: "gemm_nt_kernel"}
+                 5: "gemm_nt_fast<1,true>", 6: "gemm_nt_kernel", 7: "svgp_step_kernel"}
         per_kernel = {}
         for kd, nm in kinds.items():
             ms_k, n_k, fl_k = by_kind(kd)
@@ -592,7 +592,9 @@ def main():  # noqa: C901
         except Exception:
             traffic = None
         step_tf = svgp_step_flops(m_ind, b_rows, P_LAT) * (args.steps / elapsed) / 1e12
-        roof = {"bound": "mfma", "kernel": f"{dom}: v_mfma_f64_16x16x4_f64, 128x128x16 tiles",
+        dom_desc = ("svgp_step_kernel: ONE persistent launch per step (factorisation chain + minibatch rows, 32 x 32 x 128 "
+                    "v_mfma_f64_16x16x4_f64 slabs)") if dom == "svgp_step_kernel" else f"{dom}: v_mfma_f64_16x16x4_f64, 128x128x16 tiles"
+        roof = {"bound": "mfma", "kernel": dom_desc,
                 "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
                 "traffic": traffic, "launches_per_step": n_dom / nprof, "avg_launch_us": ms_dom * 1e3 / max(n_dom, 1),
                 "algorithmic_gflop_per_launch": fl_dom / max(n_dom, 1) / 1e9,

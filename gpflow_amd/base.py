@@ -276,11 +276,31 @@ class Parameter:
         return self._device_cache
 
     def log_prior_density(self) -> float:
+        """gpflow/base.py:201-224: log density of the prior, evaluated on the constrained value, or -- `prior_on=UNCONSTRAINED`
+        -- on the unconstrained one plus the log|Jacobian| of the inverse transform (the density is reported in the
+        constrained space either way)."""
         if self.prior is None:
             return 0.0
         if self.prior_on == PriorOn.CONSTRAINED:
             return float(np.sum(self.prior.log_prob(self.numpy())))
-        raise NotImplementedError("priors on the unconstrained value are out of scope")
+        x = self._unconstrained
+        # inverse_log_det_jacobian(y) = log |dx/dy| = -log |d forward(x)/dx|, elementwise transforms
+        return float(np.sum(self.prior.log_prob(x))) - float(np.sum(np.log(np.abs(self._transform.forward_grad(x)))))
+
+    def log_prior_density_grad(self) -> np.ndarray:
+        """d log_prior_density / d(unconstrained value): what TF autodiff adds to every training-loss gradient in the
+        reference (models/model.py:47-76 -> optimizers/scipy.py:322-331).  Shape of the unconstrained value."""
+        from .priors import grad_log_prob
+        x = self._unconstrained
+        if self.prior is None:
+            return np.zeros_like(x)
+        fg = self._transform.forward_grad(x)   # raises for non-elementwise transforms (FillTriangular)
+        if self.prior_on == PriorOn.CONSTRAINED:
+            return grad_log_prob(self.prior, self._transform.forward(x)) * fg
+        # unconstrained prior: d/dx [ log p(x) - log |fg(x)| ]; the second term by central differences of the transform
+        h = 1e-5 * np.maximum(1.0, np.abs(x))
+        dlogfg = (np.log(np.abs(self._transform.forward_grad(x + h))) - np.log(np.abs(self._transform.forward_grad(x - h)))) / (2.0 * h)
+        return grad_log_prob(self.prior, x) - dlogfg
 
     def __repr__(self) -> str:
         return f"<Parameter name={self.name} shape={self.shape} value={self.numpy()!r}>"

@@ -1066,6 +1066,29 @@ extern "C" int gpk_profile_gemm_collect(double* total_ms, long* launches, double
 
 static int launch_select(hipStream_t s, const GemmArgs& a);
 
+// the same per-launch timing for kernels outside this file (kind 7: the single-launch SVGP step kernel, mega.hip)
+int gpk_prof_begin(hipStream_t s, double flops, int kind) {
+  if (!g_prof_on) return -1;
+  if (g_prof_n == g_prof_cap) {
+    const int cap = g_prof_cap ? 2 * g_prof_cap : 1024;
+    ProfRec* p = (ProfRec*)realloc(g_prof, sizeof(ProfRec) * cap);
+    if (!p) return -1;
+    for (int i = g_prof_cap; i < cap; ++i) {
+      if (hipEventCreate(&p[i].e0) != hipSuccess || hipEventCreate(&p[i].e1) != hipSuccess) return -1;
+    }
+    g_prof = p;
+    g_prof_cap = cap;
+  }
+  ProfRec& r = g_prof[g_prof_n];
+  r.flops = flops;
+  r.kind = kind;
+  if (hipEventRecord(r.e0, s) != hipSuccess) return -1;
+  return g_prof_n++;
+}
+void gpk_prof_end(int idx, hipStream_t s) {
+  if (idx >= 0 && idx < g_prof_n) (void)hipEventRecord(g_prof[idx].e1, s);
+}
+
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
   if (a.m <= 0 || a.n <= 0) return 0;
   if (!g_prof_on) return launch_select(s, a);

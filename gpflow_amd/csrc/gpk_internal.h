@@ -91,6 +91,8 @@ int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo,
                            const double* X, int nb);
 int gpk_gemm_tiles_n(int n);   // number of column tiles the launcher will use for n columns
 int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg)
+int gpk_prof_begin(hipStream_t s, double flops, int kind);   // same facility for other kernels; returns a record index or -1
+void gpk_prof_end(int idx, hipStream_t s);
 
 // ---- single-launch SVGP step (mega.hip) ---------------------------------------------------------------------------
 #ifndef GPK_MEGA_DEFAULT
@@ -98,7 +100,7 @@ int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline
 #endif
 size_t gpk_mega_flag_ints(int m);
 int gpk_mega_supported(int m, int rows, int P, int ncu);
-int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, int m, int rows, double* invd, const double* LqT,
+int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, int m, int rows, double* invd, double* Lfin, const double* LqT,
                          long ldl, double* Cacc, const double* q_mu, int P, const double* Y, long ldy, double* s0, double* fmean,
                          double* ssq, double* partial, int* flags, int* info, double* out, double variance, double noise,
                          double mean_const, int min_wgs);

@@ -29,7 +29,12 @@
 // depends on tasks earlier in the global order, so the earliest unfinished task can always run: no deadlock.  All polls
 // are bounded by a wall-clock timeout that makes every workgroup leave (info = INT_MAX) instead of hanging the device.
 //
-// Coherence (8 XCDs, private L2s).  Protocol 0: producers finish a task with an agent-scope release fence (L2 write-back)
+// Coherence (8 XCDs, private L2s).  What the minibatch rows read from the factorisation -- the finished rows of L and the
+// block inverses -- is WRITE-ONCE data in buffers of its own (Lfin, invd): an address is written (write-through) exactly
+// once per step and is never read before that, so after one invalidate at kernel start a plain, cached load can only miss
+// and fetch the final value.  No cache is invalidated while the step runs, and the B rows that all 32 workgroups of an
+// XCD stream stay in its L2 (first version: two L2 invalidates per workgroup and step, every B row came from the fabric,
+// 2.3 - 2.7 us per slab against 0.9 us of MFMA work).  Protocol 0 (reference, slower): producers finish a task with an agent-scope release fence (L2 write-back)
 // before raising its flag, consumers run an agent-scope acquire fence (L1 / L2 invalidate) after seeing it -- the
 // documented sequences.  Protocol 1: chain data is written with agent-scope write-through stores and read with
 // agent-scope loads / LDS-DMA (no L2 flush, no invalidate by chain tasks); bulk workgroups still acquire once per phase.
@@ -55,6 +60,8 @@ constexpr size_t MEGA_LDS = gpk_leaf::LEAF_LDS > (size_t)(OFF_MISC + 256) * 8 ? 
 struct MegaArgs {
   double* T; long ld;            // [m + rows, ld]: Kuu (+ jitter) on top, Kfu below (becomes L / A^T in place)
   double* invd;                  // [nb][128][128]
+  double* Lfin;                  // [m, ld]: the FINISHED rows of L below the diagonal blocks, each element written exactly once
+                                 // (by the FIN task that finishes it) -- what the minibatch rows read as B operand
   const double* LqT; long ldl;   // [P][m][ldl] = tril(q_sqrt_p)^T
   double* Cacc;                  // [P][rows][ld] projection accumulator
   const double* q_mu;            // [m][P]
@@ -63,11 +70,14 @@ struct MegaArgs {
   double* partial;               // [nbulk]
   int* flags;
   long long* trace;              // A/B build: [1 + 8 * cap] task trace (count, then records), else NULL
+  int trace_wg;                  // A/B build: the workgroup whose bulk quanta are traced too
   long long* stamps;             // [nb][2]: wall clock at the start / publication of every leaf (diagnostics, 16 bytes per panel)
   int* info;
   double* out;
   int m, nb, rows, P, nbulk;
   int one_pool;                  // A/B: deal near and far chain tasks to all workgroups alike
+  int dbg;                       // A/B build: what-if bits for the bulk streams (Stream::dbg)
+  int role_map;                  // 1: consumer / producer roles from the waves' SIMD ids (default), 0: waves 0..3 / 4..7
   double variance, noise, mean_const;
   long long timeout_ticks;
 };
@@ -106,15 +116,18 @@ __device__ __forceinline__ void dma_row(const double* src, double* dst_wave_unif
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, COH ? 16 : 0);
 }
+// C / E traffic of a stream.  COH: agent-scope accesses (chain data shared between XCDs).  Otherwise the rows are private to
+// the workgroup and only streamed through once per step: non-temporal, so that 16 KB per slab and workgroup of read-modify-
+// write traffic does not push the B rows -- which all 32 workgroups of an XCD read -- out of the 4 MB L2.
 template <bool COH>
 __device__ __forceinline__ double ld_c(cgdouble* p) {
   if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
+  else return __builtin_nontemporal_load(p);
 }
 template <bool COH>
 __device__ __forceinline__ void st_c(gdouble* p, double v) {
   if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
+  else __builtin_nontemporal_store(v, p);
 }
 
 // 32 rows x 128 doubles of global memory -> an LDS panel (one LDS-DMA row per wave instruction); rows >= nrows repeat the
@@ -138,20 +151,26 @@ struct Stream {
   const double* B; long ldb;   // B row n at B + n * ldb (128 contiguous doubles = the K segment)
   int n0, n1;                  // B-row range (n0 a multiple of 32)
   double* C; long ldc;         // C[r][n] at C + r * ldc + n, r = 0 .. 31 local rows
+  double* C2;                  // MODE_FIN: optional second destination (same ldc): the write-once copy of finished L rows
   int nrows;                   // valid local rows
   int mode;
   int nfresh;                  // MODE_ADD / MODE_SQ: columns n >= nfresh carry no earlier contribution
   int pa_off;                  // LDS offset of the A panel
+  long long* tacc;             // A/B build: per-phase cycle counters of the consumer loop (traced workgroup), else NULL
+  int dbg;                     // A/B build: what-if bits (results wrong): 1 no C loads, 2 no C stores, 4 no B DMA, 8 no MFMA
+  const double* pan_src; long pan_ld;   // if set: the A panel is fetched (32 LDS-DMA rows) in the stream's own prologue,
+                                        // together with the first slabs -- one memory round trip instead of two
 };
 
 // Runs slabs [slab_begin, nslabs) of a stream; returns the index of the first slab NOT run (== nslabs when complete).  With
 // `intr` the producer wave polls that condition while the slabs run and the workgroup leaves at the next slab boundary once
 // it holds.  sq: per-lane row sums of squares (MODE_SQ), rows 16 mt + g + 4 r of this wave's column half.
-template <bool COH>
-__device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Cond* intr_in, int* ctl_flat, d4& sq_io) {
+template <bool COH, int MODE>
+__device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Cond* intr_in, int* ctl_flat, d4& sq_io, int vw) {
   extern __shared__ __attribute__((aligned(16))) double S[];
   __attribute__((address_space(3))) int* ctl = (__attribute__((address_space(3))) int*)ctl_flat;
   gdouble* Cg = (gdouble*)st.C;
+  gdouble* Cg2 = (gdouble*)st.C2;
   // (everything the loops use is copied into registers first: with the descriptors left in memory the compiler orders
   // every LDS-DMA instruction against their reloads and the eight rows of a slab are fetched one after the other)
   const bool has_intr = intr_in != nullptr;
@@ -160,35 +179,81 @@ __device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Co
   else { ic.a0 = ic.a1 = ic.a2 = ic.a3 = nullptr; ic.t0 = ic.t1 = ic.t2 = ic.t3 = 0; }
   const Cond* intr = has_intr ? &ic : nullptr;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);   // physical wave index: only for splitting the panel rows
+  const int wave = __builtin_amdgcn_readfirstlane(vw);          // ROLE index: 0..3 consumers (one per SIMD), 4..7 producers
   const int nslabs = (st.n1 - st.n0 + NS - 1) / NS;
   if (slab_begin >= nslabs) return nslabs;
   const int c = lane & 15, g = lane >> 4;
   const int mt = wave & 1, nt = (wave >> 1) & 1;
-  auto dma_slab = [&](int s, int buf) {
-    for (int q = 0; q < NS / 4; ++q) {
-      const int lr = (wave - 4) * (NS / 4) + q;
+  // Slab ring.  Only one of the two panels holds the A operand of a non-FIN stream; the other one serves as a third slab
+  // buffer: slabs are then fetched TWO ahead.  Measured with two buffers (one slab ahead): 2.3 us per slab against 0.85 us of MFMA
+  // work -- a slab's DMA (L2 miss -> fabric) takes longer than one slab of arithmetic, so the loop ran at memory latency.
+  const int nbuf = MODE != MODE_FIN ? 3 : 2;   // (MODE_FIN writes the other panel: OFF_PB is its output)
+  const int depth = nbuf - 1;
+  const int third = st.pa_off == OFF_PB ? OFF_PA : OFF_PB;
+  auto buf_off = [&](int s) -> int { const int b = s % nbuf; return b == 0 ? OFF_S0 : (b == 1 ? OFF_S1 : third); };
+  // producer roles: 4, 5, 6 move the slabs (rows lr = role - 4, + 3, + 6, ...: 11 / 11 / 10 rows), 7 only polls
+  const int nd = wave == 6 ? 10 : 11;   // LDS-DMA instructions of this wave per slab
+  auto dma_slab = [&](int s) {
+    const int off = buf_off(s);
+    for (int lr = wave - 4; lr < NS; lr += 3) {
       int n = st.n0 + s * NS + lr;
       n = n < st.n1 ? n : st.n1 - 1;
-      dma_row<COH>(st.B + (long)n * st.ldb + 2 * lane, S + (buf ? OFF_S1 : OFF_S0) + lr * LDP);
+      dma_row<COH>(st.B + (long)n * st.ldb + 2 * lane, S + off + lr * LDP);
     }
   };
   if (tid == 0) { ctl[1] = 0; ctl[2] = 0; }
-  if (wave >= 4) {
-    dma_slab(slab_begin, slab_begin & 1);
-    __builtin_amdgcn_s_waitcnt(0);
+  if (st.pan_src) {   // the A panel: 4 rows per wave
+    for (int q = pwave; q < MB; q += MEGA_THREADS / 64) {
+      const int r = q < st.nrows ? q : st.nrows - 1;
+      dma_row<COH>(st.pan_src + (long)r * st.pan_ld + 2 * lane, S + st.pa_off + q * LDP);
+    }
   }
+  if (wave >= 4 && wave <= 6) {
+    for (int d = 0; d < depth; ++d)
+      if (slab_begin + d < nslabs) dma_slab(slab_begin + d);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  // Two loops with the same trip count and one barrier per slab: the producer waves' and the consumer waves'.  (One loop
-  // with a role branch inside made every wave carry -- and copy around, behind waits -- the other role's registers.)
-  if (wave >= 4) {
+  // Three loops with the same trip count and one barrier per slab: the poller's, the movers' and the consumers'.
+  if (wave == 7) {
+    // The poller.  A flag read is a round trip to memory (~2 us): waiting for one per slab made EVERY slab 2 us long (all
+    // eight waves meet at the slab barrier).  So: one set of four reads every third slab, tested two slabs later -- this
+    // wave has nothing else in flight, the wait the compiler puts in front of the test only covers those reads.
+    int v0 = INT_MIN, v1 = INT_MIN, v2 = INT_MIN, v3 = INT_MIN;
     for (int s = slab_begin; s < nslabs; ++s) {
-      if (s + 1 < nslabs) dma_slab(s + 1, (s & 1) ^ 1);
-      if (intr && wave == 4 && lane == 0) ctl[1 + (s & 1)] = cond_ok(*intr) ? 1 : 0;
-      __builtin_amdgcn_s_waitcnt(0);
+      const int ph3 = (s - slab_begin) % 3;
+      int ready = 0;
+      if (intr && lane == 0) {
+        if (ph3 == 0) { v0 = ld_flag(intr->a0); v1 = ld_flag(intr->a1); v2 = ld_flag(intr->a2); v3 = ld_flag(intr->a3); }
+        if (ph3 == 2) ready = ((v0 >= intr->t0) & (v1 >= intr->t1) & (v2 >= intr->t2) & (v3 >= intr->t3)) ? 1 : 0;
+        ctl[1 + (s & 1)] = ready;
+      }
       lds_barrier();
       if (intr && s + 1 < nslabs && ctl[1 + (s & 1)]) return s + 1;
     }
+    if constexpr (MODE == MODE_FIN) lds_barrier();
+    return nslabs;
+  }
+  if (wave >= 4) {
+    for (int s = slab_begin; s < nslabs; ++s) {
+      const bool more = s + depth < nslabs;
+      if (more && !(st.dbg & 4)) dma_slab(s + depth);
+      // slab s + 1 must have landed before the barrier; the slab just requested (nd instructions of this wave) may stay in
+      // flight when the ring is three deep
+      if (more && depth == 2 && !(st.dbg & 4)) {
+        if (nd == 11) __builtin_amdgcn_s_waitcnt(0x0F7B);   // vmcnt(11)
+        else __builtin_amdgcn_s_waitcnt(0x0F7A);            // vmcnt(10)
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+      }
+      lds_barrier();
+      if (intr && s + 1 < nslabs && ctl[1 + (s & 1)]) {
+        __builtin_amdgcn_s_waitcnt(0);   // (nothing of this stream may still be landing in LDS when the caller reuses it)
+        return s + 1;
+      }
+    }
+    if constexpr (MODE == MODE_FIN) lds_barrier();
     return nslabs;
   }
   double fa[NBK / 4];   // this lane's A fragments (row 16 mt + c, k = 4 kk + g), fixed for the whole stream
@@ -198,26 +263,90 @@ __device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Co
     for (int kk = 0; kk < NBK / 4; ++kk) fa[kk] = pa[4 * kk];
   }
   d4 sq = sq_io;
-  for (int s = slab_begin; s < nslabs; ++s) {
-    const int buf = s & 1;
-    const int n = st.n0 + s * NS + 16 * nt + c;
-    const bool nvalid = n < st.n1;
-    const bool has_old = (st.mode == MODE_SUB) || ((st.mode == MODE_ADD || st.mode == MODE_SQ) && n < st.nfresh);
-    double cold[4] = {0.0, 0.0, 0.0, 0.0};
-    if (has_old && nvalid) {
+  long long t_top = 0, acc_pre = 0, acc_mma = 0, acc_post = 0, acc_bar = 0;   // A/B build: where a slab's time goes (role 0)
+  // Everything per-lane that does not change from slab to slab is computed once: the four row pointers of this lane's C
+  // elements (rows 16 mt + g + 4 r, column 16 nt + c of the slab), advanced by NS columns per slab, and the rows' validity.
+  // (First version: 64-bit multiply-adds and four-way mode branches per element and slab -- 800 + 1100 cycles of VALU work
+  // around 2300 cycles of MFMAs, profiles/r04_mega_consumer_cycles.txt.)  The stream's B-row range is whole slabs.
+  gdouble* cp[4];
+  gdouble* cp2[4];
+  bool rv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 16 * mt + g + 4 * r;
-        if (rr < st.nrows) cold[r] = ld_c<COH>(Cg + (long)rr * st.ldc + n);
+  for (int r = 0; r < 4; ++r) {
+    const int rr = 16 * mt + g + 4 * r;
+    rv[r] = rr < st.nrows;
+    const long off = (long)(rv[r] ? rr : 0) * st.ldc + st.n0 + (long)slab_begin * NS + 16 * nt + c;
+    cp[r] = Cg + off;
+    cp2[r] = Cg2 ? Cg2 + off : nullptr;
+  }
+  const int s_fresh = (MODE == MODE_SUB) ? nslabs : (st.nfresh - st.n0) / NS;   // slabs >= s_fresh carry no earlier contribution
+  // C values are read CD slabs ahead of their use (an HBM round trip under a chip-wide read-modify-write stream is longer
+  // than one slab of MFMAs)
+  constexpr int CD = 3;
+  double cq[CD][4];
+  auto load_cold = [&](int s, int ahead, double* cold) {
+    const bool has_old = (MODE != MODE_FIN) && s < s_fresh && s < nslabs && !(st.dbg & 1);   // (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cold[r] = 0.0;
+      if (has_old && rv[r]) cold[r] = ld_c<COH>(cp[r] + ahead * NS);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < CD; ++d) load_cold(slab_begin + d, d, cq[d]);
+  const int pb_lane = (16 * nt + c) * LDP + g;
+  // The epilogue of slab s - 1 (adds, stores, pointer bumps) is issued AFTER the first fragment reads of slab s: it then runs
+  // in the shadow of that LDS round trip and of the first MFMAs instead of between two slabs.
+  double pend[4] = {0.0, 0.0, 0.0, 0.0};   // results of the previous slab, not stored yet
+  bool have_pend = false;
+  int pend_s = 0;
+  auto epilogue = [&]() {
+    if constexpr (MODE == MODE_SQ) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq[r] += pend[r] * pend[r];
+    } else {
+      if constexpr (MODE == MODE_FIN) {
+        const int nl = pend_s * NS + 16 * nt + c;   // column inside the 128-wide output panel
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[OFF_PB + (16 * mt + g + 4 * r) * LDP + nl] = pend[r];
+      }
+      if (!(st.dbg & 2)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (rv[r]) st_c<COH>(cp[r], pend[r]);
+        if constexpr (MODE == MODE_FIN) {
+          if (Cg2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (rv[r]) st_c<COH>(cp2[r], pend[r]);
+          }
+        }
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cp[r] += NS; if constexpr (MODE == MODE_FIN) cp2[r] += NS; }
+  };
+  for (int s = slab_begin; s < nslabs; ++s) {
+    if (kGpkExp && st.tacc) t_top = __builtin_readcyclecounter();
     // B fragments of the slab in four groups of eight k-steps, group G + 1 in flight under the MFMAs of group G (LDS
     // returns in order, so the wait before a group only covers that group); the A fragments live in registers
-    const double* pb = S + (buf ? OFF_S1 : OFF_S0) + (16 * nt + c) * LDP + g;
-    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const double* pb = S + buf_off(s) + pb_lane;
     double fb[2][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) fb[0][k] = pb[4 * k];
+    __builtin_amdgcn_sched_barrier(0);
+    if (have_pend) epilogue();          // (cp points at slab s - 1 until here)
+    double cold[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cold[r] = cq[0][r];
+#pragma unroll
+    for (int d = 0; d + 1 < CD; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cq[d][r] = cq[d + 1][r];
+    load_cold(s + CD, CD, cq[CD - 1]);   // (cp now points at slab s)
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    long long t_a = 0, t_b = 0, t_c = 0;
+    if (kGpkExp && st.tacc) { __builtin_amdgcn_sched_barrier(0); t_a = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
       if (grp + 1 < 4) {
@@ -225,41 +354,39 @@ __device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Co
         for (int k = 0; k < 8; ++k) fb[(grp + 1) & 1][k] = pb[4 * (8 * (grp + 1) + k)];
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (!(st.dbg & 8)) {
 #pragma unroll
-      for (int k = 0; k < 8; k += 2) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[8 * grp + k], fb[grp & 1][k], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[8 * grp + k + 1], fb[grp & 1][k + 1], acc1, 0, 0, 0);
+        for (int k = 0; k < 8; k += 2) {
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[8 * grp + k], fb[grp & 1][k], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[8 * grp + k + 1], fb[grp & 1][k + 1], acc1, 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // all four results first, then the stores: nothing loaded is consumed after the first store, so the stores of a slab
-    // are issued back to back (a use of `cold` behind a store made the compiler wait for that store)
-    double outv[4];
+    if (kGpkExp && st.tacc) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const double o = acc0[r] + acc1[r];
-      outv[r] = st.mode == MODE_FIN ? o : (st.mode == MODE_SUB ? cold[r] - o : cold[r] + o);
+      pend[r] = MODE == MODE_FIN ? o : (MODE == MODE_SUB ? cold[r] - o : cold[r] + o);
     }
-    if (st.mode == MODE_SQ) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double v = nvalid ? outv[r] : 0.0;
-        sq[r] += v * v;
-      }
-    } else {
-      if (st.mode == MODE_FIN && nvalid) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[OFF_PB + (16 * mt + g + 4 * r) * LDP + (n - st.n0)] = outv[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 16 * mt + g + 4 * r;
-        if (nvalid && rr < st.nrows) st_c<COH>(Cg + (long)rr * st.ldc + n, outv[r]);
-      }
-    }
+    have_pend = true;
+    pend_s = s;
+    if (kGpkExp && st.tacc) { __builtin_amdgcn_sched_barrier(0); t_c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     lds_barrier();
-    if (intr && s + 1 < nslabs && ctl[1 + (s & 1)]) { sq_io = sq; return s + 1; }
+    if (kGpkExp && st.tacc) {
+      const long long t_d = __builtin_readcyclecounter();
+      acc_pre += t_a - t_top; acc_mma += t_b - t_a; acc_post += t_c - t_b; acc_bar += t_d - t_c;
+      if (tid == 0) { st.tacc[0] += acc_pre; st.tacc[1] += acc_mma; st.tacc[2] += acc_post; st.tacc[3] += acc_bar; st.tacc[4] += 1; }
+      acc_pre = acc_mma = acc_post = acc_bar = 0;
+    }
+    if (intr && s + 1 < nslabs && ctl[1 + (s & 1)]) {
+      epilogue();
+      sq_io = sq;
+      return s + 1;
+    }
   }
+  if (have_pend) epilogue();
+  if constexpr (MODE == MODE_FIN) lds_barrier();   // the last slab's part of the output panel (OFF_PB) is in LDS for everybody
   sq_io = sq;
   return nslabs;
 }
@@ -275,15 +402,30 @@ __device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Co
 // behind a far one of an earlier panel in the same workgroup's list (first version: one pool, the factorisation of
 // n = 2048 took 170 us per panel instead of ~55).
 enum { T_LEAF = 0, T_FIN = 1, T_UPD = 2 };
-struct Task { int type, p, i, u; };
+struct Task { int type, p, i, u, c; };   // c: column chunk of a far UPD
 constexpr int NEAR_ROWS = 3;
+constexpr int CH = 16;   // slabs per far UPD task: a far update is split along its columns into independent chunks, so that
+                         // the chain FIN(i,u,p) -> UPD(i,u,p) -> FIN(i,u,p+1) of one row quarter costs a chunk, not up to 60
+                         // slabs, per panel (unsplit, block row 15 alone needed 2.4 ms for a 2048 factorisation)
 
 __device__ __forceinline__ int near_rows(int nb, int p) { const int r = nb - 1 - p; return r < NEAR_ROWS ? r : NEAR_ROWS; }
 __device__ __forceinline__ int ntasks_near(int nb, int p) { return 1 + 8 * near_rows(nb, p); }
-__device__ __forceinline__ int ntasks_far(int nb, int p) { const int r = nb - 1 - p - NEAR_ROWS; return r > 0 ? 8 * r : 0; }
+// number of UPD tasks of row quarter (i, .) at panel p: 1 for a near block row, ceil(4 (i - p) / CH) chunks for a far one
+__device__ __forceinline__ int upd_chunks(int i, int p) { return (i - p <= NEAR_ROWS) ? 1 : (4 * (i - p) + CH - 1) / CH; }
+// completed UPD tasks of row quarter (i, .) once panels 0 .. p are applied (the threshold its next FIN / its LEAF waits for)
+__device__ __forceinline__ int upd_cum(int i, int p) {
+  int c = 0;
+  for (int pp = 0; pp <= p; ++pp) c += upd_chunks(i, pp);
+  return c;
+}
+__device__ __forceinline__ int ntasks_far(int nb, int p) {
+  int n = 0;
+  for (int i = p + 1 + NEAR_ROWS; i < nb; ++i) n += 4 + 4 * upd_chunks(i, p);
+  return n;
+}
 __device__ __forceinline__ int slot_owner_offset(int p) { return 29 * p; }
 __device__ __forceinline__ Task decode_near(int p, int t) {
-  Task k{T_LEAF, p, p, 0};
+  Task k{T_LEAF, p, p, 0, 0};
   if (t == 0) return k;
   const int rem = t - 1;                 // block row p + 1 + rem / 8: FIN x 4 then UPD x 4
   k.i = p + 1 + rem / 8;
@@ -292,15 +434,20 @@ __device__ __forceinline__ Task decode_near(int p, int t) {
   return k;
 }
 __device__ __forceinline__ Task decode_far(int nb, int p, int t) {
-  const int nrest = nb - 1 - p - NEAR_ROWS;   // block rows p + 4 ..: all FIN first, then all UPD
-  Task k{T_FIN, p, 0, 0};
+  const int nrest = nb - 1 - p - NEAR_ROWS;   // block rows p + 4 ..: all FIN first, then the UPD chunks row by row
+  Task k{T_FIN, p, 0, 0, 0};
   if (t < 4 * nrest) { k.i = p + 1 + NEAR_ROWS + t / 4; k.u = t % 4; return k; }
   t -= 4 * nrest;
-  k.type = T_UPD; k.i = p + 1 + NEAR_ROWS + t / 4; k.u = t % 4;
+  k.type = T_UPD;
+  for (int i = p + 1 + NEAR_ROWS; i < nb; ++i) {
+    const int n = 4 * upd_chunks(i, p);
+    if (t < n) { k.i = i; k.c = t / 4; k.u = t % 4; return k; }
+    t -= n;
+  }
   return k;
 }
 // flags: leaf[p] = 1 once LEAF(p) is published; finc[p][i] = number of published FIN tasks of panel p in block rows
-// p+1 .. i (every FIN(i', ., p) adds one to finc[p][i] for all i >= i'); rowd[i][u] = panels applied to row quarter (i, u)
+// p+1 .. i (every FIN(i', ., p) adds one to finc[p][i] for all i >= i'); rowd[i][u] = published UPD tasks of row quarter (i, u)
 __device__ __forceinline__ void task_cond(const MegaArgs& a, const Task& k, Cond& c) {
   const int nb = a.nb;
   cond_init(c, a.flags);
@@ -308,11 +455,11 @@ __device__ __forceinline__ void task_cond(const MegaArgs& a, const Task& k, Cond
     if (k.p > 0) {
       c.a0 = a.flags + f_rowd(nb, k.p, 0); c.a1 = a.flags + f_rowd(nb, k.p, 1);
       c.a2 = a.flags + f_rowd(nb, k.p, 2); c.a3 = a.flags + f_rowd(nb, k.p, 3);
-      c.t0 = c.t1 = c.t2 = c.t3 = k.p;
+      c.t0 = c.t1 = c.t2 = c.t3 = upd_cum(k.p, k.p - 1);
     }
   } else if (k.type == T_FIN) {
     c.a0 = a.flags + f_leaf(k.p); c.t0 = 1;
-    c.a1 = a.flags + f_rowd(nb, k.i, k.u); c.t1 = k.p;
+    c.a1 = a.flags + f_rowd(nb, k.i, k.u); c.t1 = k.p > 0 ? upd_cum(k.i, k.p - 1) : 0;
   } else {
     c.a0 = a.flags + f_finc(nb, k.p, k.i); c.t0 = 4 * (k.i - k.p);   // the B rows it reads: block rows p+1 .. i
   }
@@ -367,6 +514,44 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
   d4 sq = {0.0, 0.0, 0.0, 0.0};
   const long long t_start = wall_clock64();
   bool aborted = false;
+  // Roles.  The four waves that issue the MFMAs of a slab must sit on four DIFFERENT SIMDs (a SIMD has one matrix pipe): the
+  // hardware places the eight waves of a workgroup two per SIMD but in no documented order, so every wave reads its SIMD id
+  // and the lower-numbered wave of each SIMD becomes a consumer (role 0..3), the other one a producer (role 4..7).  (With
+  // the roles fixed as waves 0..3 / 4..7 a slab took 2.2 us against 0.9 us of MFMA issue time: pairs of consumers shared a pipe.)
+  int vw = wave;
+  {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (lane == 0) ctl[wave] = (int)((hw >> 4) & 3u);
+    __syncthreads();
+    int simd[8], cons[8], ncons = 0;
+    for (int w2 = 0; w2 < 8; ++w2) simd[w2] = ctl[w2];
+    for (int w2 = 0; w2 < 8; ++w2) {
+      cons[w2] = 1;
+      for (int w3 = 0; w3 < w2; ++w3) cons[w2] &= (simd[w3] != simd[w2]);
+      ncons += cons[w2];
+    }
+    if (ncons == 4 && a.role_map) {
+      int rank = 0;
+      for (int w2 = 0; w2 < wave; ++w2) rank += (cons[w2] == cons[wave]);
+      vw = cons[wave] ? rank : 4 + rank;
+    }
+    __syncthreads();
+  }
+#ifdef GPK_EXPERIMENTAL
+  if (a.trace && wg == a.trace_wg && lane == 0) {
+    const long long idx = __hip_atomic_fetch_add((unsigned long long*)a.trace, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (idx < 4096) {
+      long long* r = a.trace + 1 + 8 * idx;
+      unsigned hw2;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw2));
+      r[0] = wall_clock64(); r[1] = r[0]; r[2] = wg; r[3] = 9; r[4] = wave; r[5] = (hw2 >> 4) & 3; r[6] = vw; r[7] = hw2;
+    }
+  }
+#endif
+  // whatever an earlier kernel left in this XCD's L2 / this CU's L1 of the buffers that are rewritten below is dropped once,
+  // here; after that, protocol 1 never invalidates a cache on behalf of the minibatch rows again
+  acquire_all<PROTO>();
 
   for (;;) {
     // ---- my next chain task ---------------------------------------------------------------------------------------
@@ -413,8 +598,11 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
     // variant (the leaf and the stream body are large: one inlined copy each keeps the kernel's register budget for them).
     const int p = tk.p;
     const long long t_task0 = wall_clock64();
+    const long long c_task0 = (long long)__builtin_readcyclecounter();
     Stream st{};
     st.nrows = MB; st.pa_off = OFF_PA; st.nfresh = 0;
+    st.dbg = (d == 2) ? a.dbg : 0;
+    st.tacc = (kGpkExp && a.trace && d == 2 && wg == a.trace_wg) ? a.trace + 1 + 8 * 4096 : nullptr;   // (what-if switches act on the minibatch rows only: the factorisation stays exact)
     bool coh = false, run = true;
     int begin = 0;
     const Cond* intr = nullptr;
@@ -430,16 +618,21 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
         double* R = a.T + (long)(NBK * tk.i + MB * tk.u) * ld;   // the task's 32 rows of the square part
         coh = WT;
         if constexpr (!WT) acquire_all<PROTO>();
-        if (WT) load_panel<true>(S, OFF_PA, R + NBK * p, ld, MB, wave, lane);
-        else load_panel<false>(S, OFF_PA, R + NBK * p, ld, MB, wave, lane);
-        __syncthreads();
+        st.pan_src = R + NBK * p; st.pan_ld = ld;   // the task's A panel: its rows of column block p
         if (tk.type == T_FIN) {
           what = 1;
           st.B = a.invd + (long)p * NBK * NBK; st.ldb = NBK; st.n0 = 0; st.n1 = NBK;
           st.C = R + NBK * p; st.ldc = ld; st.mode = MODE_FIN;
+          st.C2 = a.Lfin + (long)(NBK * tk.i + MB * tk.u) * ld + NBK * p;
         } else {
           what = 2;
-          st.B = a.T + NBK * p; st.ldb = ld; st.n0 = NBK * (p + 1); st.n1 = NBK * tk.i + MB * tk.u + MB;
+          const int n_end = NBK * tk.i + MB * tk.u + MB;   // the rows' own diagonal
+          st.B = a.T + NBK * p; st.ldb = ld; st.n0 = NBK * (p + 1); st.n1 = n_end;
+          if (tk.i - p > NEAR_ROWS) {                     // far: column chunk tk.c of CH slabs (may be empty for small u)
+            st.n0 += NS * CH * tk.c;
+            st.n1 = st.n0 + NS * CH < n_end ? st.n0 + NS * CH : n_end;
+            if (st.n1 <= st.n0) { run = false; st.pan_src = nullptr; }
+          }
           st.C = R; st.ldc = ld; st.mode = MODE_SUB;
         }
       }
@@ -449,18 +642,16 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
       if (ph == 0) {
         // FIN: A^T[:, q] = E[:, q] inv(L_qq)^T
         what = 3;
-        acquire_all<PROTO>();
-        load_panel<false>(S, OFF_PA, E0 + NBK * q, ld, nr, wave, lane);
-        __syncthreads();
+        if constexpr (!WT) acquire_all<PROTO>();   // (protocol 1: inv(L_qq) is write-once data, see "Coherence")
+        st.pan_src = E0 + NBK * q; st.pan_ld = ld;
         st.B = a.invd + (long)q * NBK * NBK; st.ldb = NBK; st.n0 = 0; st.n1 = NBK;
         st.C = E0 + NBK * q; st.ldc = ld; st.mode = MODE_FIN;
       } else {
-        if (!panel_ok) {
-          load_panel<false>(S, OFF_PB, E0 + NBK * q, ld, nr, wave, lane);   // own rows, written by this workgroup
-          __syncthreads();
+        st.pa_off = OFF_PB;
+        if (!panel_ok) {   // A^T[:, q] again (own rows, written by this workgroup), fetched in the stream's prologue
+          st.pan_src = E0 + NBK * q; st.pan_ld = ld;
           panel_ok = true;
         }
-        st.pa_off = OFF_PB;
         begin = pos;
         if (ph <= P) {
           // PROJ, latent pl: C_pl[:, 0 : 128 (q+1)] += A^T[:, q] Lq_pl[q, :]; the last panel squares instead of storing
@@ -474,8 +665,8 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
         } else if (q < nb - 1) {
           // UPD: E[:, n] -= A^T[:, q] L[n, q]^T for the columns still to come
           what = 5;
-          if (pos == 0) acquire_all<PROTO>();
-          st.B = a.T + NBK * q; st.ldb = ld; st.n0 = NBK * (q + 1); st.n1 = m;
+          if constexpr (!WT) { if (pos == 0) acquire_all<PROTO>(); }
+          st.B = (WT ? a.Lfin : a.T) + NBK * q; st.ldb = ld; st.n0 = NBK * (q + 1); st.n1 = m;
           st.C = E0; st.ldc = ld; st.mode = MODE_SUB;
           intr = have_task ? &tc : nullptr;
         } else {
@@ -486,16 +677,22 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
     int endpos = 0;
     const int nslabs = run ? (st.n1 - st.n0 + NS - 1) / NS : 0;
     if (run) {
-      if (coh) endpos = stream_run<true>(st, begin, intr, ctl, sq);
-      else endpos = stream_run<false>(st, begin, intr, ctl, sq);
+      // (one instantiation per coherence variant and epilogue: the mode is a compile-time constant inside the slab loop)
+      if (coh) {
+        if (st.mode == MODE_FIN) endpos = stream_run<true, MODE_FIN>(st, begin, intr, ctl, sq, vw);
+        else endpos = stream_run<true, MODE_SUB>(st, begin, intr, ctl, sq, vw);
+      } else if (st.mode == MODE_FIN) endpos = stream_run<false, MODE_FIN>(st, begin, intr, ctl, sq, vw);
+      else if (st.mode == MODE_SUB) endpos = stream_run<false, MODE_SUB>(st, begin, intr, ctl, sq, vw);
+      else if (st.mode == MODE_ADD) endpos = stream_run<false, MODE_ADD>(st, begin, intr, ctl, sq, vw);
+      else endpos = stream_run<false, MODE_SQ>(st, begin, intr, ctl, sq, vw);
     }
     // ---- what follows the stream ----------------------------------------------------------------------------------
     if (what <= 2) {
       publish_barrier<PROTO>();
       if (tid == 0) {
         if (what == 0) { st_flag(a.flags + f_leaf(p), 1); a.stamps[2 * p + 1] = wall_clock64(); }
-        // (FIN: the cumulative counters of the block rows i .. nb-1, one lane each -- below)
-        else st_flag(a.flags + f_rowd(nb, tk.i, tk.u), p + 1);
+        else if (what == 2) add_flag(a.flags + f_rowd(nb, tk.i, tk.u), 1);
+        // (what == 1, FIN: the cumulative counters of the block rows i .. nb-1, one lane each -- below)
       }
       if (what == 1 && tid < nb - tk.i) add_flag(a.flags + f_finc(nb, p, tk.i + tid), 1);
 #ifdef GPK_EXPERIMENTAL
@@ -511,6 +708,18 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
       panel_ok = false;
       ct += pool_n;
       if (ct >= (two_pools ? (is_near ? ntasks_near(nb, cp) : ntasks_far(nb, cp)) : ntasks_near(nb, cp) + ntasks_far(nb, cp))) { ++cp; ct = -1; }
+    }
+#ifdef GPK_EXPERIMENTAL
+    if (what >= 3 && a.trace && tid == 0 && wg == a.trace_wg) {
+      const long long idx = __hip_atomic_fetch_add((unsigned long long*)a.trace, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (idx < 4096) {
+        long long* r = a.trace + 1 + 8 * idx;
+        r[0] = t_task0; r[1] = wall_clock64(); r[2] = wg; r[3] = what; r[4] = q; r[5] = begin; r[6] = endpos;
+        r[7] = (long long)__builtin_readcyclecounter() - c_task0;   // shader-clock cycles of the quantum: cycles / us = clock in MHz
+      }
+    }
+#endif
+    if (what <= 2) {
     } else if (what == 3) {
       // s0[row] (+)= sum_k A^2, fmean[row][p] (+)= sum_k A[row][k] q_mu[128 q + k][p]: 16 threads per row
       const int row = tid >> 4, sub = tid & 15;
@@ -538,12 +747,12 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
         if (q == nb - 1) {
           // ssq[pl][row]: the 16 column lanes of a row, then the two column halves (waves nt = 0, 1) in a fixed order
           double* red = S + OFF_MISC;
-          if (wave < 4) {
+          if (vw < 4) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               double v = sq[r];
               v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-              if ((lane & 15) == 0) red[((wave >> 1) & 1) * MB + 16 * (wave & 1) + (lane >> 4) + 4 * r] = v;
+              if ((lane & 15) == 0) red[((vw >> 1) & 1) * MB + 16 * (vw & 1) + (lane >> 4) + 4 * r] = v;
             }
           }
           __syncthreads();
@@ -613,12 +822,18 @@ int gpk_mega_supported(int m, int rows, int P, int ncu) {
 namespace { long long* g_trace = nullptr; }
 extern "C" __attribute__((visibility("default"))) int gpk_exp_mega_trace_dump(void) {
   if (!g_trace) return 0;
-  static long long host[1 + 8 * 4096];
+  static long long host[1 + 8 * 4096 + 8];
   if (hipMemcpy(host, g_trace, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   const long long n = host[0] < 4096 ? host[0] : 4096;
   long long t0 = 0;
   for (long long i = 0; i < n; ++i) if (i == 0 || host[1 + 8 * i] < t0) t0 = host[1 + 8 * i];
-  printf("# chain task trace: start_us dur_us wg what(0 leaf,1 FIN,2 UPD) p i u flag_at_end   (%lld records)\n", host[0]);
+  {
+    const long long* t = host + 1 + 8 * 4096;
+    if (t[4] > 0)
+      printf("# consumer loop of the traced workgroup, shader-clock cycles per slab over %lld slabs: before MFMA %.0f, MFMA section %.0f, "
+             "epilogue %.0f, barrier wait %.0f\n", t[4], (double)t[0] / t[4], (double)t[1] / t[4], (double)t[2] / t[4], (double)t[3] / t[4]);
+  }
+  printf("# task trace: start_us dur_us wg what(0 leaf,1 FIN,2 UPD | 3 bulk FIN,4 PROJ,5 UPD,6 final: p=q i=first slab u=end slab flag=slabs)   (%lld records)\n", host[0]);
   for (long long i = 0; i < n; ++i) {
     const long long* r = host + 1 + 8 * i;
     printf("T %8.1f %6.1f wg=%3lld what=%lld p=%lld i=%lld u=%lld flag=%lld\n", (r[0] - t0) / 100.0, (r[1] - r[0]) / 100.0, r[2], r[3], r[4], r[5],
@@ -629,7 +844,7 @@ extern "C" __attribute__((visibility("default"))) int gpk_exp_mega_trace_dump(vo
 }
 #endif
 
-int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, int m, int rows, double* invd, const double* LqT,
+int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, int m, int rows, double* invd, double* Lfin, const double* LqT,
                          long ldl, double* Cacc, const double* q_mu, int P, const double* Y, long ldy, double* s0, double* fmean,
                          double* ssq, double* partial, int* flags, int* info, double* out, double variance, double noise,
                          double mean_const, int min_wgs) {
@@ -641,7 +856,7 @@ int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, 
   GPK_HIP(attr0);
   GPK_HIP(attr1);
   MegaArgs a{};
-  a.T = T; a.ld = ld; a.invd = invd; a.LqT = LqT; a.ldl = ldl; a.Cacc = Cacc; a.q_mu = q_mu; a.Y = Y; a.ldy = ldy;
+  a.T = T; a.ld = ld; a.invd = invd; a.Lfin = Lfin; a.LqT = LqT; a.ldl = ldl; a.Cacc = Cacc; a.q_mu = q_mu; a.Y = Y; a.ldy = ldy;
   a.s0 = s0; a.fmean = fmean; a.ssq = ssq; a.partial = partial; a.flags = flags; a.info = info; a.out = out;
   {
     const size_t nflag = (size_t)(m / NBK) * (m / NBK) + 6 * (m / NBK) + 8;
@@ -651,6 +866,8 @@ int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, 
   a.variance = variance; a.noise = noise; a.mean_const = mean_const;
   a.timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
   a.one_pool = GPK_TUNE(MEGA_ONE_POOL, 0);
+  a.role_map = GPK_TUNE(MEGA_ROLE_MAP, 1);
+  a.dbg = kGpkExp ? GPK_TUNE(MEGA_DBG, 0) : 0;
   int G = a.nbulk;
   if (G < min_wgs) G = min_wgs;
   if (G < 16) G = 16;   // two task pools need a few workgroups each
@@ -659,13 +876,17 @@ int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, 
   GPK_HIP(hipMemsetAsync(flags, 0, gpk_mega_flag_ints(m) * sizeof(int), s));
 #ifdef GPK_EXPERIMENTAL
   if (GPK_TUNE(MEGA_TRACE, 0)) {
-    if (!g_trace) GPK_HIP(hipMalloc(&g_trace, sizeof(long long) * (1 + 8 * 4096)));
-    GPK_HIP(hipMemsetAsync(g_trace, 0, sizeof(long long) * (1 + 8 * 4096), s));
+    if (!g_trace) GPK_HIP(hipMalloc(&g_trace, sizeof(long long) * (1 + 8 * 4096 + 8)));
+    GPK_HIP(hipMemsetAsync(g_trace, 0, sizeof(long long) * (1 + 8 * 4096 + 8), s));
     a.trace = g_trace;
+    a.trace_wg = GPK_TUNE(MEGA_TRACE_WG, 100);
   }
 #endif
+  // (bench roofline leg: HIP events around the launch; algorithmic flops of everything the kernel does, M^3/3 + M^2 B (1 + P))
+  const int prof = gpk_prof_begin(s, (double)m * m * m / 3.0 + (double)m * m * (double)rows * (1.0 + P), 7);
   if (proto == 1) hipLaunchKernelGGL((svgp_step_kernel<1>), dim3((unsigned)G), dim3(MEGA_THREADS), MEGA_LDS, s, a);
   else hipLaunchKernelGGL((svgp_step_kernel<0>), dim3((unsigned)G), dim3(MEGA_THREADS), MEGA_LDS, s, a);
   GPK_LAUNCH_CHECK();
+  gpk_prof_end(prof, s);
   return 0;
 }

@@ -689,7 +689,7 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
 namespace {
 struct ElboLayout {
   long ld; int nt;
-  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_C, off_flags, total;
+  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_C, off_flags, off_Lfin, total;
 };
 
 ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
@@ -709,6 +709,7 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   // single-launch step kernel (mega.hip): projection accumulator [P, rows, ld] and its flag words
   l.off_C = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)P * rows * l.ld * sizeof(double), 256) : 0;
   l.off_flags = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up(gpk_mega_flag_ints(m) * sizeof(int), 256) : 0;
+  l.off_Lfin = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)m * l.ld * sizeof(double), 256) : 0;
   l.total = o;
   return l;
 }
@@ -790,7 +791,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
       rc = gpk_launch_final(s, 1, pk, &ck, &halfk, -0.5 * (double)m * (double)P, out + 1);
       if (rc) return rc;
       GPK_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
-      return gpk_launch_svgp_mega(s, GPK_TUNE(MEGA_PROTO, 0), ncu, T, l.ld, m, rows, invd, LqT, l.ld, (double*)(w + l.off_C), q_mu, P,
+      return gpk_launch_svgp_mega(s, GPK_TUNE(MEGA_PROTO, 1), ncu, T, l.ld, m, rows, invd, (double*)(w + l.off_Lfin), LqT, l.ld, (double*)(w + l.off_C), q_mu, P,
                                   Yb, ldyb, s0, fmean, ssq, part0, (int*)(w + l.off_flags), info, out, variance, noise_variance,
                                   mean_const, GPK_TUNE(MEGA_MIN_WGS, 96));
     }

@@ -85,9 +85,8 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
             if par.trainable:
                 u = par.unconstrained_variable
                 out[par] = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
-        if any(p.prior is not None for p in out):
-            raise NotImplementedError("parameter priors are not differentiated here")
-        return float(lml.cpu()[0]), out
+        # with parameter priors this is the log POSTERIOR density and its gradient: -training_loss (model.py:56-76)
+        return self._add_log_prior(float(lml.cpu()[0]), out)
 
     objective_and_grad = log_marginal_likelihood_and_grad   # what optimizers.Scipy calls
 

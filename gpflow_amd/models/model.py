@@ -8,6 +8,7 @@ import torch
 
 from .. import ops
 from ..base import Module
+from ..config import default_jitter
 from ..kernels import Kernel, MultioutputKernel
 from ..likelihoods import Likelihood
 from ..mean_functions import MeanFunction, Zero
@@ -18,6 +19,18 @@ class BayesianModel(Module, metaclass=abc.ABCMeta):
     def log_prior_density(self) -> float:
         """model.py:47-54"""
         return float(sum(p.log_prior_density() for p in self.trainable_parameters))
+
+    def _add_log_prior(self, value: float, grads: dict):
+        """MAP estimation (model.py:47-76): every training loss is -(objective + log_prior_density) with the priors of ALL
+        trainable parameters; the device reverse pass returns d objective / d(unconstrained), this adds the prior part
+        (Parameter.log_prior_density_grad, host arithmetic on a few scalars).  `grads` is {Parameter: gradient}."""
+        missing = [q for q in self.trainable_parameters if q.prior is not None and q not in grads]
+        if missing:
+            raise NotImplementedError(f"a trainable parameter with a prior is outside this model's reverse pass: {missing[0]!r}")
+        for par in grads:
+            if par.prior is not None:
+                grads[par] = grads[par] + par.log_prior_density_grad()
+        return value + self.log_prior_density(), grads
 
     def log_posterior_density(self, *args, **kwargs):
         return self.maximum_log_likelihood_objective(*args, **kwargs) + self.log_prior_density()
@@ -70,7 +83,7 @@ class GPModel(BayesianModel):
             P, N, _ = cov.shape
             T = cov.clone()
             idx = torch.arange(N, device=cov.device)
-            T[:, idx, idx] += 1e-6  # default jitter, conditionals/util.py:201
+            T[:, idx, idx] += default_jitter()  # conditionals/util.py:196-201
             _, info = ops.potrf_(T, N, zero_upper=True)
             ops.check_info(info)
             epsT = torch.randn((P, S, N), dtype=torch.float64, device=cov.device)
@@ -78,7 +91,7 @@ class GPModel(BayesianModel):
             samples = (mean.t()[:, None, :] + zT).permute(1, 2, 0).contiguous()  # [S,N,P]
         else:
             eps = torch.randn((S,) + tuple(mean.shape), dtype=torch.float64, device=mean.device)
-            samples = mean[None] + eps * torch.sqrt(torch.clamp(cov, min=0.0))[None]
+            samples = mean[None] + eps * torch.sqrt(cov)[None]  # (no clamp: conditionals/util.py:193 takes tf.sqrt(cov) as is)
         return samples[0] if num_samples is None else samples
 
     def predict_y(self, Xnew, full_cov: bool = False, full_output_cov: bool = False):

@@ -183,11 +183,9 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         out = {}
         for par, gc in pairs:
             if par.trainable:
-                if par.prior is not None:
-                    raise NotImplementedError("parameter priors are not differentiated here")
                 u = par.unconstrained_variable
                 out[par] = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
-        return float(F.cpu()[0]), out
+        return self._add_log_prior(float(F.cpu()[0]), out)   # (+ log prior density: -training_loss, model.py:56-76)
 
     # ---- prediction ------------------------------------------------------------------------------
     def predict_f(self, Xnew, full_cov: bool = False, full_output_cov: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -232,15 +232,13 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         for par, gc in pairs:
             if not par.trainable:
                 continue
-            if par.prior is not None:
-                raise NotImplementedError("parameter priors are not differentiated here")
             u = par.unconstrained_variable
             if isinstance(par.transform, FillTriangular):   # linear embedding: the vector entries are the lower-triangular ones
                 gu = par.transform.inverse(np.asarray(gc, dtype=np.float64)).reshape(u.shape)
             else:
                 gu = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
             out[par] = out[par] + gu if par in out else gu
-        return Fv, out
+        return self._add_log_prior(Fv, out)   # (+ log prior density of the trainable parameters: model.py:56-76)
 
     def posterior(self, precompute_cache=posteriors.PrecomputeCacheType.TENSOR):
         """svgp.py:210-240"""

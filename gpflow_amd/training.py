@@ -67,9 +67,11 @@ class SVGPTrainer:
         self.q_diag = model.q_sqrt.numpy().ndim == 2
         if self.q_diag and natgrad_gamma is not None:
             raise NotImplementedError("natural gradients need the full q_sqrt [P, M, M] (optimizers/natgrad.py:280-368)")
-        for p in (k.variance, k.lengthscales, lik.variance, iv.Z, model.q_mu, model.q_sqrt):
+        # priors (MAP, model.py:56-76): on the host-side hyper-parameters their gradient is added on the host every step; the
+        # device-resident variables (Z, q_mu, q_sqrt) would need it on the device
+        for p in (iv.Z, model.q_mu, model.q_sqrt):
             if p.prior is not None:
-                raise NotImplementedError("parameter priors are not part of the trainer's objective")
+                raise NotImplementedError("the trainer supports priors on kernel / likelihood / mean parameters, not on Z, q_mu, q_sqrt")
         self.model, self.group = model, group
         self.natgrad_gamma = None if natgrad_gamma is None else float(natgrad_gamma)
         self.mean_const = float(c)
@@ -81,8 +83,6 @@ class SVGPTrainer:
         mf = model.mean_function
         if isinstance(mf, Constant):
             # Constant.c is a trainable Parameter like any other (gpflow/functions.py:173-192): it joins the host set
-            if mf.c.prior is not None:
-                raise NotImplementedError("parameter priors are not part of the trainer's objective")
             if np.size(mf.c.numpy()) != 1:
                 raise NotImplementedError("the reverse pass covers a scalar Constant mean")
             self.host["mean_const"] = mf.c
@@ -171,6 +171,9 @@ class SVGPTrainer:
             if not p.trainable:
                 continue
             gu = -parts[name].reshape(self.u[name].shape) * p.transform.forward_grad(self.u[name])
+            if p.prior is not None:   # loss = -(ELBO + log prior): the prior's part, evaluated at the trainer's current value
+                p.assign_unconstrained(self.u[name])
+                gu = gu - p.log_prior_density_grad()
             self.u[name] = self.opt.update_host(name, self.u[name], gu)
         return F
 

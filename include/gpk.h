@@ -252,7 +252,7 @@ int gpk_profile_gemm_collect(double* total_ms, long* launches, double* flops);
 /* same, restricted to launches with at least min_flops algorithmic flops; keep != 0 keeps the records */
 int gpk_profile_gemm_collect_min(double min_flops, int keep, double* total_ms, long* launches, double* flops);
 /* same, restricted to launches of ONE kernel -- kind 1 gemm_nt_small, 2 gemm_nt_fast<0,false>, 3 <0,true>, 4 <1,false>,
- * 5 <1,true>, 6 gemm_nt_kernel -- so that the HIP-event average can be compared with rocprofv3's per-kernel average;
+ * 5 <1,true>, 6 gemm_nt_kernel, 7 the single-launch SVGP step kernel (mega.hip; its flops = the whole step's) -- so that the HIP-event average can be compared with rocprofv3's per-kernel average;
  * records are kept */
 int gpk_profile_gemm_collect_kind(int kind, double min_flops, double* total_ms, long* launches, double* flops);
 /* phase spanned by the launches with >= min_flops (first start .. last end) and the algorithmic flops of ALL recorded

@@ -4,21 +4,22 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``gpflow_amd/`` may import this file; o
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do, and
 there only as the checker / timed CPU baseline -- never as the thing shipped.
 
-Parity status: the reference (GPflow 2.9.2) does its arithmetic in TensorFlow, which is not
-installable in the build container (no tensorflow / tensorflow_probability / check_shapes /
-multipledispatch wheels, no network), and the reference tests hold NO stored golden vectors
-for this path -- only relational checks and in-test NumPy/SciPy restatements.  This oracle
-is therefore pinned by (tests/test_oracle.py):
+Parity status: PINNED to the reference's own source.  The reference (GPflow 2.9.2) does its arithmetic in TensorFlow,
+which is not installable in the build container, and its tests hold no stored golden vectors for this path; so
+tests/golden/refshim/ provides NumPy stand-ins for exactly the third-party surface GPflow touches, the UNMODIFIED package
+under /root/reference is imported over them, and tests/golden/make_golden_ref.py writes what its public API returns --
+kernels, GPR / SVGP / SGPR objectives and predictions, conditionals, all seven gauss_kl forms, multi-output posteriors,
+and (round 4) finite-difference gradients of the three objectives -- to tests/golden/ref_golden.npz.  This oracle
+reproduces every one of those arrays at 1e-12 and its autograd twin (gp_oracle_grad.py) the gradients at 1e-7
+(tests/test_reference_golden.py).  It is additionally pinned by (tests/test_oracle.py):
   * every in-test restatement the reference's own tests use (loop RBF kernel
     tests/gpflow/kernels/reference.py:13-27, scipy mvn.logpdf tests/gpflow/test_logdensities.py:113-129,
     explicit-inverse conditional tests/gpflow/conditionals/test_conditionals.py:166-214,
     by-hand 1-D KL tests/gpflow/test_kullback_leiblers.py:94-98,213-229, slogdet KL
     tests/gpflow/models/test_variational.py:92-120),
   * the reference's relational tests (q_diag == diag-embedded q_sqrt, whitened == unwhitened
-    after V = L^-1 mu, K vs K_cholesky, GPR LML == SVGP ELBO at Z = X with the optimal q),
-  * committed golden .npz vectors generated FROM this oracle on the reference's own test
-    fixtures (tests/golden/make_golden.py).
-"absolute values vs TensorFlow itself" remain unpinned -- stated in DESIGN.md.
+    after V = L^-1 mu, K vs K_cholesky, GPR LML == SVGP ELBO at Z = X with the optimal q).
+What stays unpinned is TensorFlow's own rounding (Eigen LLT against LAPACK dpotrf: both IEEE fp64) -- stated in DESIGN.md.
 
 Each function cites the reference file:line it restates (paths relative to the GPflow tree).
 """

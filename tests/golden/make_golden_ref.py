@@ -280,6 +280,36 @@ def build():  # noqa: C901
         out[f"g_sgpr_d{name}"] = richardson(lambda x, n=name: sgpr_elbo_of(**{n: x}), th[name])
     out["g_sgpr_dZ"] = richardson(lambda x: sgpr_elbo_of(Z=x), Zg)
 
+    # ---- MAP objective: parameter priors (base.py:201-224, models/model.py:47-76) ---------------------------------------------
+    # a prior on the constrained value (Gamma / LogNormal) and one on the UNCONSTRAINED value (Normal + log|Jacobian|); value
+    # of log_prior_density / log_posterior_density / training_loss from the reference's statements, and the gradient of the
+    # log posterior w.r.t. the unconstrained variables by the same Richardson differences
+    import tensorflow_probability as tfp
+
+    def gpr_with_priors():
+        mdl = gpflow.models.GPR((Xg, Yg[:, :1]), gpflow.kernels.SquaredExponential(variance=float(th["variance"]),
+                                                                                 lengthscales=np.array(th["lengthscales"])),
+                                noise_variance=float(th["noise_variance"]))
+        mdl.kernel.lengthscales.prior = tfp.distributions.Gamma(np.float64(2.0), np.float64(3.0))
+        mdl.kernel.variance.prior = tfp.distributions.LogNormal(np.float64(0.1), np.float64(0.8))
+        mdl.likelihood.variance.prior = tfp.distributions.Normal(np.float64(-1.0), np.float64(2.0))
+        mdl.likelihood.variance.prior_on = gpflow.base.PriorOn.UNCONSTRAINED
+        return mdl
+    mp = gpr_with_priors()
+    out.update(g_map_log_prior=float(mp.log_prior_density()), g_map_log_posterior=float(mp.log_posterior_density()),
+               g_map_training_loss=float(mp.training_loss()))
+    for pname, getp in (("lengthscales", lambda mm: mm.kernel.lengthscales), ("variance", lambda mm: mm.kernel.variance),
+                        ("noise_variance", lambda mm: mm.likelihood.variance)):
+        u0 = _n(getp(mp).unconstrained_variable)
+        out[f"g_map_u_{pname}"] = u0
+
+        def f_of_u(u, getp=getp):
+            mm = gpr_with_priors()
+            par = getp(mm)
+            par.assign(_n(par.transform.forward(tf.convert_to_tensor(np.asarray(u, dtype=np.float64)))))
+            return float(mm.log_posterior_density())
+        out[f"g_map_d{pname}"] = richardson(f_of_u, u0, h=1e-3)
+
     # ---- SGPR (models/sgpr.py) ---------------------------------------------------------------------------------------------
     rng = np.random.default_rng(51)
     X = rng.normal(size=(60, 2)); Y = np.sin(X[:, :1]) + 0.1 * rng.normal(size=(60, 1)); Z = X[:9].copy(); Xs = rng.normal(size=(5, 2))

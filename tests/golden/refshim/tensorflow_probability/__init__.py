@@ -30,6 +30,17 @@ class Bijector(tf.Module):
     def __call__(self, x):
         return self.forward(x)
 
+    def inverse_log_det_jacobian(self, y, event_ndims=None, name=None, **kw):
+        """log |d inverse(y) / dy|, summed over the rightmost `event_ndims` axes (elementwise bijectors only)."""
+        v = np.asarray(self._ildj(_np(y)), dtype=np.float64)
+        nd = 0 if event_ndims is None else int(event_ndims)
+        if nd:
+            v = v.sum(axis=tuple(range(v.ndim - nd, v.ndim)))
+        return tf.Tensor(v)
+
+    def _ildj(self, y):
+        raise NotImplementedError(f"{type(self).__name__}: no inverse_log_det_jacobian in the stand-in")
+
 
 class Identity(Bijector):
     def __init__(self, validate_args=False, name="identity"):
@@ -40,6 +51,9 @@ class Identity(Bijector):
 
     def _inverse(self, y):
         return y
+
+    def _ildj(self, y):
+        return np.zeros_like(y)
 
 
 class Softplus(Bijector):
@@ -57,6 +71,11 @@ class Softplus(Bijector):
             y = y - _np(self.low)
         return y + np.log(-np.expm1(-y))  # log(exp(y) - 1), the form TFP uses
 
+    def _ildj(self, y):
+        if self.low is not None:
+            y = y - _np(self.low)
+        return -np.log(-np.expm1(-y))  # dx/dy = 1 / (1 - exp(-y))
+
 
 class Exp(Bijector):
     def __init__(self, validate_args=False, name="exp"):
@@ -67,6 +86,9 @@ class Exp(Bijector):
 
     def _inverse(self, y):
         return np.log(y)
+
+    def _ildj(self, y):
+        return -np.log(y)
 
 
 class Shift(Bijector):
@@ -80,6 +102,9 @@ class Shift(Bijector):
     def _inverse(self, y):
         return y - _np(self.shift)
 
+    def _ildj(self, y):
+        return np.zeros_like(y)
+
 
 class Scale(Bijector):
     def __init__(self, scale, validate_args=False, name="scale"):
@@ -91,6 +116,9 @@ class Scale(Bijector):
 
     def _inverse(self, y):
         return y / _np(self.scale)
+
+    def _ildj(self, y):
+        return np.zeros_like(y) - np.log(np.abs(_np(self.scale)))
 
 
 class Sigmoid(Bijector):
@@ -128,6 +156,13 @@ class Chain(Bijector):
         for b in self.bijectors:
             y = b._inverse(y)
         return y
+
+    def _ildj(self, y):
+        tot = np.zeros_like(y)
+        for b in self.bijectors:
+            tot = tot + b._ildj(y)
+            y = b._inverse(y)
+        return tot
 
 
 class FillTriangular(Bijector):
@@ -197,6 +232,40 @@ class Distribution:
         pass
 
 
+class _NpDist(Distribution):
+    """the few tfp.distributions GPflow's documentation hangs on Parameters as priors: log_prob only"""
+
+    def log_prob(self, value, name=None):
+        return tf.Tensor(np.asarray(self._lp(_np(value)), dtype=np.float64))
+
+
+class Normal(_NpDist):
+    def __init__(self, loc, scale, **kw):
+        self.loc, self.scale = _np(loc), _np(scale)
+
+    def _lp(self, x):
+        z = (x - self.loc) / self.scale
+        return -0.5 * z * z - np.log(self.scale) - 0.5 * np.log(2.0 * np.pi)
+
+
+class Gamma(_NpDist):
+    def __init__(self, concentration, rate=None, **kw):
+        self.a, self.b = _np(concentration), _np(rate)
+
+    def _lp(self, x):
+        from scipy.special import gammaln
+        return (self.a - 1.0) * np.log(x) - self.b * x + self.a * np.log(self.b) - gammaln(self.a)
+
+
+class LogNormal(_NpDist):
+    def __init__(self, loc, scale, **kw):
+        self.loc, self.scale = _np(loc), _np(scale)
+
+    def _lp(self, x):
+        z = (np.log(x) - self.loc) / self.scale
+        return -0.5 * z * z - np.log(self.scale * x) - 0.5 * np.log(2.0 * np.pi)
+
+
 def _mod(name, **attrs):
     m = types.ModuleType(__name__ + "." + name)
     for k, v in attrs.items():
@@ -214,7 +283,7 @@ def _mod(name, **attrs):
 bijectors = _mod("bijectors", Bijector=Bijector, Identity=Identity, Softplus=Softplus, Exp=Exp, Shift=Shift, Scale=Scale,
                  Sigmoid=Sigmoid, Chain=Chain, FillTriangular=FillTriangular)
 util = _mod("util", TransformedVariable=TransformedVariable)
-distributions = _mod("distributions", Distribution=Distribution)
+distributions = _mod("distributions", Distribution=Distribution, Normal=Normal, Gamma=Gamma, LogNormal=LogNormal)
 mcmc = _mod("mcmc")
 stats = _mod("stats")
 math = _mod("math")

@@ -538,3 +538,64 @@ def test_trainer_with_q_diag_and_active_dims(gpu, whiten):
     assert float(last.cpu()[0]) > F0
     tr.sync_to_model()
     assert abs(float(m.elbo((X, Y)).cpu()) - float(tr.step((X, Y)).cpu()[0])) <= 1e-8 * abs(F0)
+
+
+def test_parameter_priors_enter_value_and_gradient(gpu):
+    """MAP estimation (gpflow/models/model.py:47-76, gpflow/base.py:201-224): with priors on trainable parameters the
+    objective handed to the optimisers is the log POSTERIOR density -- objective + sum of log prior densities -- and its
+    gradient carries the priors' part, for a prior on the constrained value (Gamma on lengthscales / variance) and for one
+    on the unconstrained value (Normal, with the log|Jacobian| of the transform).  GPR, SGPR and SVGP; checked against
+    central differences of the models' own `log_posterior_density` in the unconstrained space; a user prior object without
+    `grad_log_prob` goes through the numerical fallback; Scipy's MAP fit differs from the ML fit."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import priors
+    from gpflow_amd.base import PriorOn
+    rng = np.random.default_rng(23)
+    X = rng.uniform(-2, 2, size=(60, 2)); Y = np.sin(2 * X[:, :1]) + 0.1 * rng.normal(size=(60, 1))
+
+    class OnlyLogProb:   # e.g. a tfp distribution wrapped by the user: no derivative supplied
+        def log_prob(self, x):
+            return -0.5 * ((np.asarray(x) - 0.7) / 0.3) ** 2
+
+    def put_priors(m):
+        m.kernel.lengthscales.prior = priors.Gamma(2.0, 3.0)
+        m.kernel.variance.prior = priors.LogNormal(0.1, 0.8)
+        m.likelihood.variance.prior = priors.Normal(-1.0, 2.0)
+        m.likelihood.variance.prior_on = PriorOn.UNCONSTRAINED
+        return m
+
+    def check(m, objective, value_fn):
+        v, g = objective()
+        lp = m.log_prior_density()
+        assert abs(lp) > 1e-3
+        assert abs(v - (value_fn() + lp)) <= 1e-9 * max(1.0, abs(v))
+        h = 1e-5
+        for par in (m.kernel.lengthscales, m.kernel.variance, m.likelihood.variance):
+            u0 = np.array(par.unconstrained_variable, dtype=np.float64, copy=True)
+            for idx in np.ndindex(*u0.shape) if u0.shape else [()]:
+                vals = []
+                for d in (h, -h):
+                    u = u0.copy(); u[idx] += d
+                    par.assign_unconstrained(u)
+                    vals.append(value_fn() + m.log_prior_density())
+                par.assign_unconstrained(u0)
+                fd = (vals[0] - vals[1]) / (2 * h)
+                got = float(np.asarray(g[par])[idx])
+                assert abs(got - fd) <= 2e-5 * max(1.0, abs(fd)), (par.name, idx, got, fd)
+
+    gpr = put_priors(gpflow.models.GPR((X, Y), gpflow.kernels.SquaredExponential(lengthscales=[0.9, 1.3]), noise_variance=0.3))
+    check(gpr, gpr.objective_and_grad, lambda: float(gpr.log_marginal_likelihood().cpu()))
+    sg = put_priors(gpflow.models.SGPR((X, Y), gpflow.kernels.SquaredExponential(lengthscales=[0.9, 1.3]), X[:9].copy(), noise_variance=0.3))
+    check(sg, sg.objective_and_grad, lambda: float(sg.elbo().cpu()))
+    sv, Xs, Ys = _small_model(20, 60, 2, 1, 5)
+    put_priors(sv)
+    check(sv, lambda: sv.elbo_and_grad((Xs, Ys)), lambda: float(sv.elbo((Xs, Ys)).cpu()))
+    # numerical fallback for a prior without grad_log_prob
+    gpr.kernel.variance.prior = OnlyLogProb()
+    check(gpr, gpr.objective_and_grad, lambda: float(gpr.log_marginal_likelihood().cpu()))
+    # the MAP optimum is not the ML optimum, and training_loss == -log posterior there
+    ml = gpflow.models.GPR((X, Y), gpflow.kernels.SquaredExponential(lengthscales=[0.9, 1.3]), noise_variance=0.3)
+    gpflow.optimizers.Scipy().minimize(ml, options=dict(maxiter=200))
+    res = gpflow.optimizers.Scipy().minimize(gpr, options=dict(maxiter=200))
+    assert abs(res.fun - float(gpr.training_loss())) <= 1e-8 * abs(res.fun)
+    assert np.max(np.abs(gpr.kernel.lengthscales.numpy() - ml.kernel.lengthscales.numpy())) > 1e-3

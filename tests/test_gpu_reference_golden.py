@@ -216,3 +216,29 @@ def test_ref_gradients(gp):
     for n in ("variance", "lengthscales", "noise_variance", "Z"):
         chk(g[n], G[f"g_sgpr_d{n}"])
 
+
+
+def test_ref_map_objective_with_priors(gp):
+    """MAP objective against the reference's own statements (gpflow/base.py:201-224, models/model.py:47-76 run through the
+    shim): log_prior_density with a prior on the constrained value (Gamma, LogNormal) and one on the unconstrained value
+    (Normal + log|Jacobian| of the transform), log_posterior_density, training_loss, and the gradient of the log posterior
+    w.r.t. the unconstrained variables (reference side: Richardson differences of its forward code)."""
+    from gpflow_amd import priors
+    from gpflow_amd.base import PriorOn
+    m = gp.models.GPR((G["g_X"], G["g_Y"][:, :1]), gp.kernels.SquaredExponential(variance=float(G["g_variance"]),
+                                                                               lengthscales=G["g_lengthscales"]),
+                      noise_variance=float(G["g_noise_variance"]))
+    m.kernel.lengthscales.prior = priors.Gamma(2.0, 3.0)
+    m.kernel.variance.prior = priors.LogNormal(0.1, 0.8)
+    m.likelihood.variance.prior = priors.Normal(-1.0, 2.0)
+    m.likelihood.variance.prior_on = PriorOn.UNCONSTRAINED
+    np.testing.assert_allclose(m.log_prior_density(), float(G["g_map_log_prior"]), rtol=1e-12)
+    np.testing.assert_allclose(float(_np(m.log_posterior_density())), float(G["g_map_log_posterior"]), rtol=1e-10)
+    np.testing.assert_allclose(float(_np(m.training_loss())), float(G["g_map_training_loss"]), rtol=1e-10)
+    for name, par in (("lengthscales", m.kernel.lengthscales), ("variance", m.kernel.variance), ("noise_variance", m.likelihood.variance)):
+        np.testing.assert_allclose(np.asarray(par.unconstrained_variable), G[f"g_map_u_{name}"], rtol=1e-12)
+    v, g = m.objective_and_grad()
+    np.testing.assert_allclose(v, float(G["g_map_log_posterior"]), rtol=1e-10)
+    for name, par in (("lengthscales", m.kernel.lengthscales), ("variance", m.kernel.variance), ("noise_variance", m.likelihood.variance)):
+        ref = G[f"g_map_d{name}"]
+        assert np.abs(np.asarray(g[par]).reshape(ref.shape) - ref).max() <= 1e-7 * np.abs(ref).max(), name
