@@ -660,7 +660,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     // (A/B, 16384^2 x 512, beta = 1: 60.7 -> 63.0 TFLOP/s; lower-only 55.8 -> 58.8; percent of a half tile, 0 = off)
     const int stagger_on = GPK_TUNE(GEMM_STAGGER, 100);
     if (b.stagger_first <= 0) b.stagger_first = 256;
-    b.stagger_ticks = (stagger_on && EPI == 0 && !a.b_tri && total >= 1024 && nwg == (unsigned)total)
+    b.stagger_ticks = (stagger_on && EPI == 0 && !a.b_tri && total >= 1024 && (nwg == (unsigned)total || nwg >= 2u * (unsigned)b.stagger_first))
                           ? (int)((a.k / 16) * 170 * stagger_on / 200)
                           : 0;
   }

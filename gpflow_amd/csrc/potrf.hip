@@ -474,7 +474,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       GemmArgs u = gemm_base(R - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
-      if (Bp == aux->B && large) u.stagger_first = aux->bulk_cus;
+      if (Bp == aux->B && large) {
+        u.stagger_first = aux->bulk_cus;
+        // persistent workgroups (two per CU of the masked stream) that walk the tile list: no workgroup launch per tile
+        if (GPK_TUNE(TRAIL_PERSIST, 0)) u.max_wgs = GPK_TUNE(TRAIL_PERSIST, 0) * aux->bulk_cus;
+      }
       rc = gpk_launch_gemm(Bp, u);
       if (rc) return rc;
       GPK_HIP(hipEventRecord(evR[p], Bp));

@@ -56,8 +56,15 @@ class NaturalGradient:
 
     (SVGP, whitened or not, SquaredExponential / Matern kernel, Gaussian likelihood, full q_sqrt -- the scope of the reverse pass)."""
 
-    def __init__(self, gamma: float = 1.0):
+    def __init__(self, gamma: float = 1.0, xi_transform: str = "XiNat"):
+        """xi_transform: "XiNat" (natural parameters, the default of the reference) or "XiSqrtMeanVar" (steps taken in
+        (q_mu, q_sqrt) itself, natgrad.py:139-173); objects named like the reference's classes are accepted too."""
+        from . import natgrad
         self.gamma = float(gamma)
+        name = xi_transform if isinstance(xi_transform, str) else type(xi_transform).__name__
+        if name not in natgrad.XI_TRANSFORMS:
+            raise NotImplementedError(f"xi_transform {name!r}: only {natgrad.XI_TRANSFORMS}")
+        self.xi_transform = name
 
     def minimize(self, model, data) -> None:
         from . import config, gradients, natgrad, ops
@@ -72,6 +79,7 @@ class NaturalGradient:
                                                   noise_variance=lik.noise_variance(), jitter=config.default_jitter(),
                                                   scale=scale, mean_const=float(c), family=family)
         ops.check_info(info)
-        mu, sq = natgrad.natgrad_update(q_mu, q_sqrt, -g["q_mu"], -g["q_sqrt"], self.gamma)   # loss = -ELBO
+        mu, sq = natgrad.natgrad_update(q_mu, q_sqrt, -g["q_mu"], -g["q_sqrt"], self.gamma,
+                                        xi_transform=self.xi_transform)   # loss = -ELBO
         model.q_mu.assign(mu.cpu().numpy())
         model.q_sqrt.assign(sq.cpu().numpy())

@@ -121,7 +121,34 @@ def gpr_lml_value_and_grads(X, Y, *, variance, lengthscales, noise_variance, mea
 
 
 # ----------------------------------------------------------------------------- natural gradient
-def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma):
+def natural_to_meanvarsqrt_torch(nat1, nat2):
+    """gpflow/optimizers/natgrad.py:429-441 on [P, M, 1] / [P, M, M] torch tensors"""
+    vsi = torch.linalg.cholesky(-2 * nat2)
+    vs = torch.linalg.solve_triangular(vsi, torch.eye(vsi.shape[1], dtype=torch.float64).expand_as(vsi), upper=False)
+    S = vs.transpose(1, 2) @ vs
+    return S @ nat1, torch.linalg.cholesky(S)
+
+
+def natgrad_conversions(q_mu, q_sqrt):
+    """The parameter conversions of gpflow/optimizers/natgrad.py:429-516 on NumPy q_mu [M, P], q_sqrt [P, M, M] (in the
+    reference's [N, D] / [D, N, N] layout): returns a dict with nat1, nat2 (meanvarsqrt_to_natural :444-455), eta1, eta2
+    (meanvarsqrt_to_expectation :490-498) and the round trips natural_to_meanvarsqrt (:429-441) /
+    expectation_to_meanvarsqrt (:479-487).  Pinned to the reference's own functions (tests/test_reference_golden.py)."""
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64)  # noqa: E731
+    mu = t(q_mu).T[:, :, None]
+    Ls = torch.tril(t(q_sqrt))
+    Linv = torch.linalg.solve_triangular(Ls, torch.eye(Ls.shape[1], dtype=torch.float64).expand_as(Ls), upper=False)
+    s_inv = Linv.transpose(1, 2) @ Linv
+    nat1, nat2 = s_inv @ mu, -0.5 * s_inv
+    eta1, eta2 = mu, Ls @ Ls.transpose(1, 2) + mu @ mu.transpose(1, 2)
+    m_b, s_b = natural_to_meanvarsqrt_torch(nat1, nat2)
+    s_c = torch.linalg.cholesky(eta2 - eta1 @ eta1.transpose(1, 2))
+    back = lambda v: v[:, :, 0].T.numpy().copy()  # noqa: E731
+    return {"nat1": back(nat1), "nat2": nat2.numpy().copy(), "eta1": back(eta1), "eta2": eta2.numpy().copy(),
+            "back_mu": back(m_b), "back_sqrt": s_b.numpy().copy(), "back2_mu": back(eta1), "back2_sqrt": s_c.numpy().copy()}
+
+
+def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma, xi_transform="XiNat"):
     """One XiNat step of gpflow/optimizers/natgrad.py:280-368, restated literally with torch autograd standing in for
     the TF tapes: dL/deta through expectation_to_meanvarsqrt (:484-487), theta <- theta - gamma dL/deta (:341-343),
     natural_to_meanvarsqrt (:429-441).  q_mu [M, P], q_sqrt [P, M, M]; g_* = loss gradients w.r.t. them."""
@@ -138,6 +165,12 @@ def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma):
     Linv = torch.linalg.solve_triangular(Ls, torch.eye(Ls.shape[1], dtype=torch.float64).expand_as(Ls), upper=False)
     s_inv = Linv.transpose(1, 2) @ Linv                                                  # :452-454
     nat1, nat2 = s_inv @ mu, -0.5 * s_inv
+    if xi_transform == "XiSqrtMeanVar":
+        # xi = natural_to_meanvarsqrt(theta) (:139-173): nat_dL_xi = (d xi / d theta) dL/deta, a forward-mode product (:323-339)
+        (_, _), (dxi1, dxi2) = torch.func.jvp(natural_to_meanvarsqrt_torch, (nat1.detach(), nat2.detach()),
+                                              (dL_deta1.detach(), dL_deta2.detach()))
+        mun, Ln = mu - gamma * dxi1, Ls - gamma * dxi2                                   # :341-347 with xi = (mean, varsqrt)
+        return mun[:, :, 0].T.numpy().copy(), Ln.numpy().copy()
     nat1n, nat2n = nat1 - gamma * dL_deta1, nat2 - gamma * dL_deta2                      # :341-343
     vsi = torch.linalg.cholesky(-2 * nat2n)                                              # :435
     vs = torch.linalg.solve_triangular(vsi, torch.eye(vsi.shape[1], dtype=torch.float64).expand_as(vsi), upper=False)

@@ -310,6 +310,19 @@ def build():  # noqa: C901
             return float(mm.log_posterior_density())
         out[f"g_map_d{pname}"] = richardson(f_of_u, u0, h=1e-3)
 
+    # ---- natural-gradient parameter conversions (optimizers/natgrad.py:429-516): pure linear algebra, run as they are -----------
+    from gpflow.optimizers import natgrad as ref_ng
+    rng = np.random.default_rng(71)
+    Mn, Pn = 6, 3
+    ng_mu = rng.normal(size=(Mn, Pn)); ng_sqrt = np.tril(0.3 * rng.normal(size=(Pn, Mn, Mn))) + 0.7 * np.eye(Mn)
+    out.update(ng_mu=ng_mu, ng_sqrt=ng_sqrt)
+    n1, n2 = ref_ng.meanvarsqrt_to_natural(T(ng_mu), T(ng_sqrt))
+    e1, e2 = ref_ng.meanvarsqrt_to_expectation(T(ng_mu), T(ng_sqrt))
+    m_b, s_b = ref_ng.natural_to_meanvarsqrt(n1, n2)
+    m_c, s_c = ref_ng.expectation_to_meanvarsqrt(e1, e2)
+    out.update(ng_nat1=_n(n1), ng_nat2=_n(n2), ng_eta1=_n(e1), ng_eta2=_n(e2), ng_back_mu=_n(m_b), ng_back_sqrt=_n(s_b),
+               ng_back2_mu=_n(m_c), ng_back2_sqrt=_n(s_c))
+
     # ---- SGPR (models/sgpr.py) ---------------------------------------------------------------------------------------------
     rng = np.random.default_rng(51)
     X = rng.normal(size=(60, 2)); Y = np.sin(X[:, :1]) + 0.1 * rng.normal(size=(60, 1)); Z = X[:9].copy(); Xs = rng.normal(size=(5, 2))

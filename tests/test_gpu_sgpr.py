@@ -6,6 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import gp_oracle as orc  # noqa: E402  (checker only)
+from oracle import gp_oracle_grad as orcg  # noqa: E402  (checker only)
 
 
 def _data(N, M, D, P, seed):
@@ -186,3 +187,25 @@ def test_trainer_natgrad_hybrid(gpu):
     for _ in range(25):
         fa, fb = a.step((X, Y)), b.step((X, Y))
     assert float(fa.cpu()[0]) > float(fb.cpu()[0])
+
+
+@pytest.mark.parametrize("M,P", [(96, 3), (300, 2)])
+def test_natgrad_batched_over_latents_and_xi_sqrt_mean_var(gpu, M, P):
+    """natgrad.natgrad_update runs all P latents as batched launches (one gpk_potrf(batch = P) per factorisation, batched
+    triangular-K GEMMs; optimizers/natgrad.py:429-516 is batched [P, M, M] too) for both xi transforms -- XiNat (:98-136) and
+    XiSqrtMeanVar (:139-173) -- against the literal restatement with torch autograd (reverse mode through
+    expectation_to_meanvarsqrt, forward mode through natural_to_meanvarsqrt); and through gpflow.optimizers.NaturalGradient."""
+    from gpflow_amd import natgrad, ops
+    rng = np.random.default_rng(M + P)
+    q_mu = rng.normal(size=(M, P))
+    q_sqrt = np.tril(0.1 * rng.normal(size=(P, M, M))) + np.eye(M) * (0.6 + 0.3 * rng.random(size=(P, 1, 1)))
+    g_mu = rng.normal(size=(M, P))
+    g_sqrt = np.tril(0.05 * rng.normal(size=(P, M, M)))   # (small enough that the XiNat precision stays positive definite)
+    t = ops.to_device
+    for xi in ("XiNat", "XiSqrtMeanVar"):
+        for gamma in (0.05, 0.3):
+            mu_n, sq_n = natgrad.natgrad_update(t(q_mu), t(q_sqrt), t(g_mu), t(g_sqrt), gamma, xi_transform=xi)
+            mu_r, sq_r = orcg.natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma, xi_transform=xi)
+            np.testing.assert_allclose(mu_n.cpu().numpy(), mu_r, rtol=0, atol=1e-8 * max(1.0, np.abs(mu_r).max()), err_msg=xi)
+            np.testing.assert_allclose(sq_n.cpu().numpy(), sq_r, rtol=0, atol=1e-8 * max(1.0, np.abs(sq_r).max()), err_msg=xi)
+            assert np.all(np.triu(sq_n.cpu().numpy(), 1) == 0)

@@ -257,6 +257,14 @@ def test_natgrad_update_on_emulated_primitives_and_svgp_vs_sgpr(monkeypatch):
         mu_r, sq_r = orcg.natgrad_step(q_mu, q_sqrt, -g["q_mu"], -g["q_sqrt"], gamma)
         np.testing.assert_allclose(mu_n.numpy(), mu_r, rtol=0, atol=1e-9 * max(1.0, np.abs(mu_r).max()))
         np.testing.assert_allclose(sq_n.numpy(), sq_r, rtol=0, atol=1e-9)
+        # XiSqrtMeanVar (natgrad.py:139-173): the step in (q_mu, q_sqrt) itself, = S g_mu and L Phi(L^T g_L) written out,
+        # against forward-mode autograd through the restated natural_to_meanvarsqrt
+        mu_x, sq_x = natgrad.natgrad_update(t(q_mu), t(q_sqrt), t(-g["q_mu"]), t(-g["q_sqrt"]), gamma, xi_transform="XiSqrtMeanVar")
+        mu_xr, sq_xr = orcg.natgrad_step(q_mu, q_sqrt, -g["q_mu"], -g["q_sqrt"], gamma, xi_transform="XiSqrtMeanVar")
+        np.testing.assert_allclose(mu_x.numpy(), mu_xr, rtol=0, atol=1e-9 * max(1.0, np.abs(mu_xr).max()))
+        np.testing.assert_allclose(sq_x.numpy(), sq_xr, rtol=0, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        natgrad.natgrad_update(t(q_mu), t(q_sqrt), t(-g["q_mu"]), t(-g["q_sqrt"]), 0.1, xi_transform="XiSomethingElse")
     after = orc.svgp_elbo(X, Y, Z, mu_n.numpy(), sq_n.numpy(), whiten=True, num_data=N, **kw)
     sgpr = orc.sgpr_elbo(X, Y, Z, **kw)
     assert abs(v - sgpr) > 1.0                   # different before

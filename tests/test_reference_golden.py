@@ -202,3 +202,15 @@ def test_gradient_oracle_pinned_to_reference_finite_differences():
     for n in ("variance", "lengthscales", "noise_variance", "Z"):
         chk(g[n], G[f"g_sgpr_d{n}"])
 
+
+def test_natgrad_conversions_pinned_to_reference():
+    """The natural-gradient parameter conversions restated in oracle/gp_oracle_grad.py (which the natural-gradient oracle
+    differentiates) against the reference's own functions run through the shim (optimizers/natgrad.py:429-516)."""
+    from oracle import gp_oracle_grad as og
+    c = og.natgrad_conversions(G["ng_mu"], G["ng_sqrt"])
+    for k in ("nat1", "nat2", "eta1", "eta2", "back_mu", "back_sqrt", "back2_mu", "back2_sqrt"):
+        ref = G[f"ng_{k}"]
+        np.testing.assert_allclose(np.asarray(c[k]).reshape(ref.shape), ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max()), err_msg=k)
+    np.testing.assert_allclose(c["back_mu"], G["ng_mu"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(c["back_sqrt"], G["ng_sqrt"], rtol=0, atol=1e-10)
+
