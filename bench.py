@@ -225,6 +225,24 @@ def other_workloads_leg(device, with_oracle: bool, steps: int = 20):
                                  noise_variance=0.1, whiten=True, num_data=n_data)
         run(name, note, step, svgp_step_flops(m, b, 1), orc_fn)
         del Xd, Yd, ws
+    # Cm variants ("also report whiten=False, q_diag=True"): the headline shape through gpflow_amd.models.SVGP.elbo --
+    # the un-whitened model is composed on the host from the primitives (one more triangular solve + the KL against Kuu),
+    # the diagonal q goes through the fused driver with its row-statistics epilogue instead of the projection GEMM
+    m, b, d = 2048, 8192, 8
+    Xh, Yh, Zh, qmh, qsh, ls = pool(19, b, d, 1, m)
+    Xd, Yd = ops.to_device(Xh), ops.to_device(Yh)
+    qdh = 0.5 + 0.05 * np.abs(np.random.default_rng(20).normal(size=(m, 1)))
+    for name, note, kwm, qs, okw, fl in (
+            ("cm_unwhitened", "Cm shape, whiten=False (full q_sqrt): SVGP.elbo through the model surface, composed from the primitives",
+             dict(whiten=False), qsh, dict(whiten=False), m ** 3 / 3.0 + 3.0 * float(m) * m * b + 2.0 * m ** 3 / 3.0),
+            ("cm_q_diag", "Cm shape, q_diag=True (whitened): SVGP.elbo through the model surface (fused driver, no projection GEMM)",
+             dict(whiten=True, q_diag=True), qdh, dict(whiten=True), m ** 3 / 3.0 + float(m) * m * b)):
+        mv = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=1.0, lengthscales=ls), gpflow.likelihoods.Gaussian(0.1), Zh,
+                                q_mu=qmh, q_sqrt=qs, num_data=1_000_000, **kwm)
+        run(name, note, lambda s, mv=mv: float(mv.elbo((Xd[(s % 8) * b:(s % 8 + 1) * b], Yd[(s % 8) * b:(s % 8 + 1) * b]))), fl,
+            lambda i, qs=qs, okw=okw: orc.svgp_elbo(Xh[i * b:(i + 1) * b], Yh[i * b:(i + 1) * b], Zh, qmh, qs, variance=1.0, lengthscales=ls,
+                                                    noise_variance=0.1, num_data=1_000_000, **okw))
+    del Xd, Yd
     # C5: multi-output SVGP, 4 latent GPs, M = 1024, through gpflow_amd.models.SVGP
     m, b, d, p = 1024, 8192, 8, 4
     Xh, Yh, Zh, qmh, qsh, ls = pool(18, b, d, p, m)

@@ -142,11 +142,85 @@ def stationary_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Ten
 se_kernel_adjoint = stationary_kernel_adjoint   # (the name of rounds 1-2)
 
 
+class KernelSpec:
+    """What the reverse pass needs to know about the covariance function: ONE stationary kernel, or a flat Sum / Product of
+    stationary kernels over the same input columns (gpflow/kernels/base.py:216-220 `Sum`, :305-315 `Product`; the reference
+    differentiates `tf.add_n` / `tf.multiply` of the member matrices with autodiff).  members: [(family, variance,
+    lengthscales)], op: None | "add" | "mul".
+
+      build    the combined matrix, members folded in place by `gpk_kernel_matrix_combine` (no second matrix);
+      kdiag    K(x, x): sum or product of the variances (stationary members), dkdiag[i] = d kdiag / d variance_i;
+      adjoint  member i sees  Kbar (Sum)  or  Kbar .* prod_{j != i} k_j  (Product: formed by the same in-place combine pass)
+               and goes through `stationary_kernel_adjoint`; the input gradients of the members add up."""
+
+    def __init__(self, members, op=None):
+        self.members = [(f, float(v), np.asarray(ls, dtype=np.float64)) for f, v, ls in members]
+        self.op = op if len(self.members) > 1 else None
+        if len(self.members) > 1 and op not in ("add", "mul"):
+            raise ValueError("a kernel combination needs op 'add' or 'mul'")
+
+    @staticmethod
+    def single(variance, lengthscales, family="SquaredExponential"):
+        return KernelSpec([(family, variance, lengthscales)], None)
+
+    @property
+    def n(self) -> int:
+        return len(self.members)
+
+    def build(self, X1, X2, out, diag_add: float = 0.0):
+        last = self.n - 1
+        f, v, ls = self.members[0]
+        ops.kernel_matrix(X1, X2, variance=v, lengthscales=ls, family=f, diag_add=diag_add if last == 0 else 0.0,
+                          lower_only=False, out=out)
+        for i, (f, v, ls) in enumerate(self.members[1:], start=1):
+            ops.kernel_matrix_combine(X1, X2, out, op=self.op, variance=v, lengthscales=ls, family=f,
+                                      diag_add=diag_add if i == last else 0.0, out=out)
+        return out
+
+    def kdiag(self) -> float:
+        vs = [v for _, v, _ in self.members]
+        return float(np.prod(vs)) if self.op == "mul" else float(np.sum(vs))
+
+    def dkdiag(self):
+        if self.op == "mul":
+            kd = self.kdiag()
+            return [kd / v for _, v, _ in self.members]
+        return [1.0] * self.n
+
+    def adjoint(self, A, Bm, Kbar, symmetric: bool):
+        dvs, dls, Abar = [], [], None
+        for i, (f, v, ls) in enumerate(self.members):
+            Kb = Kbar
+            if self.op == "mul":
+                Kb = Kbar.clone()
+                for j, (fj, vj, lj) in enumerate(self.members):
+                    if j != i:
+                        ops.kernel_matrix_combine(A, None if symmetric else Bm, Kb, op="mul", variance=vj, lengthscales=lj,
+                                                  family=fj, out=Kb)
+            dv, dl, Ab = stationary_kernel_adjoint(A, Bm, Kb, symmetric=symmetric, variance=v, lengthscales=ls, family=f)
+            if np.ndim(ls) == 0 or np.size(ls) == 1:
+                dl = dl.sum().reshape(1)
+            dvs.append(dv.reshape(1))
+            dls.append(dl)
+            Abar = Ab if Abar is None else Abar + Ab
+        return dvs, dls, Abar
+
+    def pack(self, dvs, dls):
+        """gradient entries: one member -> ("variance" [1], "lengthscales" [D or 1]) as before; several -> "variance" [n] and
+        "lengthscales" a list of per-member tensors"""
+        if self.n == 1:
+            return dvs[0], dls[0]
+        return torch.cat(dvs), list(dls)
+
+
+
 def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor, q_sqrt: torch.Tensor,
-                       *, variance: float, lengthscales, noise_variance: float, jitter: float, scale: float = 1.0,
-                       mean_const: float = 0.0, kl_weight: float = 1.0, family: str = "SquaredExponential"
+                       *, variance: float = None, lengthscales=None, noise_variance: float, jitter: float, scale: float = 1.0,
+                       mean_const: float = 0.0, kl_weight: float = 1.0, family: str = "SquaredExponential",
+                       kernel_spec: "KernelSpec" = None
                        ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
-    """F = scale * sum_b var_exp_b - kl_weight * KL for the whitened SVGP with a SquaredExponential kernel, a Gaussian likelihood
+    """F = scale * sum_b var_exp_b - kl_weight * KL for the whitened SVGP with a stationary kernel (or, `kernel_spec`, a Sum /
+    Product of stationary kernels: then grads["variance"] is [n_members] and grads["lengthscales"] a list), a Gaussian likelihood
     and a full q_sqrt [P, M, M], and dF/d{variance, lengthscales, noise_variance, Z, q_mu, q_sqrt, mean_const}.
 
     Returns (F [1], grads, info).  `scale` = num_data / minibatch size (svgp.py:176-180).  For a row shard of a
@@ -159,14 +233,14 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     if tuple(q_sqrt.shape) not in ((P, M, M), (M, P)):
         raise ValueError("svgp_elbo_and_grad needs q_sqrt [P, M, M] or, for q_diag, [M, P]")
     dev = Z.device
-    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+    spec = kernel_spec if kernel_spec is not None else KernelSpec.single(variance, lengthscales, family)
 
     # ---------------------------------------------------------------- forward (intermediates kept)
     # trapezoid = [Kuu + jitter I ; Kfu ; I]: the factorisation returns Lm, At = Kfu Lm^-T and, from the identity
     # rows, Lm^-T itself -- the explicit inverse that turns every triangular solve of the backward into one GEMM
     T = torch.empty((M + B + M, M), dtype=torch.float64, device=dev)
-    ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)       # Kuu + jitter I
-    ops.kernel_matrix(Xb, Z, out=T[M:M + B], **kw)                                      # Kfu
+    spec.build(Z, None, T[:M], diag_add=jitter)                                         # Kuu + jitter I
+    spec.build(Xb, Z, T[M:M + B])                                                       # Kfu
     invd, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)                  # (the last M rows: I -> Lm^-T)
     L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
     if q_diag:   # q_sqrt [M, P] holds standard deviations (svgp.py:90-148, conditionals/util.py:149,164)
@@ -178,7 +252,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
         s0, fmean, _ = ops.row_stats(At, V=q_mu)                                        # rowsum(At^2), At q_mu
         W = ops.gemm_nt(At, LqT, b_tri=1)                                               # [P, B, M]: W_p = At Lq_p
         ssq = torch.stack([ops.row_stats(W[p])[0] for p in range(P)])                   # [P, B]
-    ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
+    ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[spec.kdiag()], noise_variance=noise_variance,
                                     mean_const=mean_const)
     kl = ops.gauss_kl_white(q_mu, q_sqrt)
     F = scale * ve - kl_weight * kl
@@ -221,8 +295,8 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     try:
         Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)            # -tril(Kfu_bar^T At)
         Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
-        dv1, dl1, Zb1 = stationary_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
-        dv2, dl2, Zb2 = stationary_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
+        dv1, dl1, Zb1 = spec.adjoint(Z, Xb, Kuf_bar, symmetric=False)
+        dv2, dl2, Zb2 = spec.adjoint(Z, Z, Kuu_bar, symmetric=True)
     finally:
         if side is not None:
             main.wait_stream(side)
@@ -231,21 +305,19 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
         g_qs.record_stream(main)
     else:
         g_qmu, g_qs = branch_q()
-    g_var = dv1 + dv2 + c * B * P                                                       # Knn = variance in every fvar
-    g_ls = dl1 + dl2
-    if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
-        g_ls = g_ls.sum().reshape(1)
+    dkd = spec.dkdiag()                                                                 # Knn = kdiag in every fvar
+    g_var, g_ls = spec.pack([a + b + c * B * P * dk for a, b, dk in zip(dv1, dv2, dkd)], [a + b for a, b in zip(dl1, dl2)])
     # sum_bp ((y - f)^2 + fvar) recovered from the forward value:  ve = B P k0 - Q / (2 s2)
     k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
     Q = 2.0 * noise_variance * (B * P * k0 - ve)
     g_noise = scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)
-    grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
+    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
              "Z": Zb1 + Zb2, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
     return F, grads, info
 
 
-def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
-                     mean_const: float = 0.0, family: str = "SquaredExponential"
+def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float = None, lengthscales=None, noise_variance: float,
+                     mean_const: float = 0.0, family: str = "SquaredExponential", kernel_spec: "KernelSpec" = None
                      ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """GPR.log_marginal_likelihood (gpr.py:91-107) and its gradient w.r.t. {variance, lengthscales, noise_variance,
     mean_const} for a SquaredExponential kernel -- what `optimizers/scipy.py:322-331` asks TF autodiff for.
@@ -258,9 +330,9 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
     N, D = X.shape
     P = Y.shape[1]
     dev = X.device
-    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+    spec = kernel_spec if kernel_spec is not None else KernelSpec.single(variance, lengthscales, family)
     T = torch.empty((N + P + N, N), dtype=torch.float64, device=dev)
-    ops.kernel_matrix(X, None, diag_add=noise_variance, lower_only=False, out=T[:N], **kw)
+    spec.build(X, None, T[:N], diag_add=noise_variance)
     T[N:N + P] = (Y - mean_const).t()
     invd, info = ops.potrf_(T, N, zero_upper=True, identity_rows=True)                  # (the last N rows: I -> L^-T, N^3/3)
     L, alphat, LinvT = T[:N], T[N:N + P], T[N + P:]
@@ -273,10 +345,9 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengt
     ops.gemm_nt(beta, beta, alpha=0.5, beta=-0.5 * P, C=Kbar, c_lower=True)             # 0.5 beta beta^T - 0.5 P K^-1
     low = torch.tril(Kbar)
     Kbar = low + torch.tril(low, -1).t()                                                # symmetric, full
-    dvar, dls, _ = stationary_kernel_adjoint(X, X, Kbar, symmetric=True, **kw)
-    if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
-        dls = dls.sum().reshape(1)
-    grads = {"variance": dvar.reshape(1), "lengthscales": dls, "noise_variance": torch.diagonal(Kbar).sum().reshape(1),
+    dvs, dlss, _ = spec.adjoint(X, X, Kbar, symmetric=True)
+    dvar, dls = spec.pack(dvs, dlss)
+    grads = {"variance": dvar, "lengthscales": dls, "noise_variance": torch.diagonal(Kbar).sum().reshape(1),
              "mean_const": betat.sum().reshape(1)}
     return lml.reshape(1), grads, info
 

@@ -163,6 +163,23 @@ class Combination(Kernel):
         return self.K_diag(X) if not full_cov else self.K(X, X2)
 
 
+def gradient_spec(kernel):
+    """gradients.KernelSpec + [(variance Parameter, lengthscales Parameter)] for the kernels the reverse pass covers beyond a
+    single stationary one: a flat Sum / Product of isotropic-stationary members that all see every input column (members
+    with their own `active_dims` are refused: their input gradients would have to be scattered member by member).  None if
+    `kernel` is not such a combination."""
+    from .stationaries import IsotropicStationary
+    from .. import gradients
+    if not isinstance(kernel, Combination):
+        return None
+    ks = list(kernel.kernels)
+    if not all(isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES and k.has_default_active_dims for k in ks):
+        raise NotImplementedError("gradients of a kernel combination: Sum / Product of SquaredExponential / Matern members over all "
+                                  "input columns (kernels/base.py:216-220, 305-315)")
+    spec = gradients.KernelSpec([k.hyper() for k in ks], kernel._op)
+    return spec, [(k.variance, k.lengthscales) for k in ks]
+
+
 class Sum(Combination):
     """gpflow/kernels/base.py:318-321"""
     _op = "add"

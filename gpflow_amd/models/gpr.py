@@ -67,17 +67,31 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
         from ..mean_functions import Constant
         k, lik, mf = self.kernel, self.likelihood, self.mean_function
         c = mf.constant_value()
-        if not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES) or c is None or lik.variance is None:
-            raise NotImplementedError("gradients: SquaredExponential / Matern kernel, constant mean, Gaussian "
-                                      "likelihood with a variance parameter")
+        from ..kernels.base import gradient_spec
+        combo = gradient_spec(k)            # Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315)
+        if combo is None and not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES) or c is None or lik.variance is None:
+            raise NotImplementedError("gradients: SquaredExponential / Matern kernel (or a Sum / Product of them), constant mean, "
+                                      "Gaussian likelihood with a variance parameter")
         X, Y = self.data
-        X, _ = k.slice(X, None)    # active_dims (kernels/base.py:90-109); nothing is differentiated w.r.t. X
-        family, var, ls = k.hyper()
-        lml, g, info = gradients.gpr_lml_and_grad(X.contiguous(), Y, variance=var, lengthscales=ls,
-                                                  noise_variance=lik.noise_variance(), mean_const=c, family=family)
-        ops.check_info(info)
-        host = {n: t.cpu().numpy() for n, t in g.items()}
-        pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (lik.variance, host["noise_variance"])]
+        if combo is not None:
+            spec, members = combo
+            lml, g, info = gradients.gpr_lml_and_grad(ops.to_device(X).contiguous(), Y, noise_variance=lik.noise_variance(),
+                                                      mean_const=c, kernel_spec=spec)
+            ops.check_info(info)
+            gv = g["variance"].cpu().numpy()
+            pairs = []
+            for i, (pv, pl) in enumerate(members):
+                pairs += [(pv, gv[i]), (pl, g["lengthscales"][i].cpu().numpy())]
+            host = {"noise_variance": g["noise_variance"].cpu().numpy(), "mean_const": g["mean_const"].cpu().numpy()}
+            pairs.append((lik.variance, host["noise_variance"]))
+        else:
+            X, _ = k.slice(X, None)    # active_dims (kernels/base.py:90-109); nothing is differentiated w.r.t. X
+            family, var, ls = k.hyper()
+            lml, g, info = gradients.gpr_lml_and_grad(X.contiguous(), Y, variance=var, lengthscales=ls,
+                                                      noise_variance=lik.noise_variance(), mean_const=c, family=family)
+            ops.check_info(info)
+            host = {n: t.cpu().numpy() for n, t in g.items()}
+            pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (lik.variance, host["noise_variance"])]
         if isinstance(mf, Constant):
             pairs.append((mf.c, host["mean_const"]))
         out = {}

@@ -184,6 +184,10 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         lik, mf = self.likelihood, self.mean_function
         # scope checks first: a model outside the reverse pass is refused before anything touches the device
         sep = self._separate_gradient_config()
+        from ..kernels.base import gradient_spec
+        combo = gradient_spec(self.kernel) if sep is None else None   # Sum / Product of stationary kernels
+        if combo is not None:
+            return self._elbo_and_grad_combination(data, combo)
         single = self.gradient_config(allow_active_dims=True, allow_q_diag=True) if sep is None else None
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
@@ -239,6 +243,45 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                 gu = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
             out[par] = out[par] + gu if par in out else gu
         return self._add_log_prior(Fv, out)   # (+ log prior density of the trainable parameters: model.py:56-76)
+
+    def _elbo_and_grad_combination(self, data, combo):
+        """elbo_and_grad for a Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315): the whitened reverse
+        pass with the members' adjoints taken one by one (gradients.KernelSpec)."""
+        from .. import gradients
+        from ..base import FillTriangular
+        from ..mean_functions import Constant
+        spec, members = combo
+        lik, mf, iv = self.likelihood, self.mean_function, self.inducing_variable
+        c = mf.constant_value()
+        if not (self.whiten and isinstance(lik, Gaussian) and lik.variance is not None and isinstance(iv, InducingPoints)
+                and c is not None and self.q_sqrt.numpy().ndim == 3):
+            raise NotImplementedError("gradients with a kernel combination: whitened SVGP, Gaussian likelihood, InducingPoints, "
+                                      "full q_sqrt, constant mean")
+        X, Y = ops.to_device(data[0]), ops.to_device(data[1])
+        scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
+        F, g, info = gradients.svgp_elbo_and_grad(iv.Z.device_value(), X, Y, self.q_mu.device_value(), self.q_sqrt.device_value(),
+                                                  noise_variance=lik.noise_variance(), jitter=config.default_jitter(), scale=scale,
+                                                  mean_const=float(c), kernel_spec=spec)
+        ops.check_info(info)
+        gv = g["variance"].cpu().numpy()
+        pairs = []
+        for i, (pv, pl) in enumerate(members):
+            pairs += [(pv, gv[i]), (pl, g["lengthscales"][i].cpu().numpy())]
+        pairs += [(iv.Z, g["Z"].cpu().numpy()), (lik.variance, g["noise_variance"].cpu().numpy()),
+                  (self.q_mu, g["q_mu"].cpu().numpy()), (self.q_sqrt, g["q_sqrt"].cpu().numpy())]
+        if isinstance(mf, Constant):
+            pairs.append((mf.c, g["mean_const"].cpu().numpy()))
+        out = {}
+        for par, gc in pairs:
+            if not par.trainable:
+                continue
+            u = par.unconstrained_variable
+            if isinstance(par.transform, FillTriangular):
+                gu = par.transform.inverse(np.asarray(gc, dtype=np.float64)).reshape(u.shape)
+            else:
+                gu = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+            out[par] = out[par] + gu if par in out else gu
+        return self._add_log_prior(float(F.cpu()[0]), out)
 
     def posterior(self, precompute_cache=posteriors.PrecomputeCacheType.TENSOR):
         """svgp.py:210-240"""

@@ -41,13 +41,34 @@ def _rbf(X, X2, variance, ls, family="SquaredExponential"):
     raise KeyError(family)
 
 
+def combination_kernel(members, op):
+    """(k(A, B), k_diag) of a flat Sum ("add") / Product ("mul") of stationary members [(family, variance, lengthscales)] on
+    torch tensors: kernels/base.py:216-220 (tf.add_n of the member matrices), :305-315 (their elementwise product)."""
+    def kfun(A, Bm):
+        mats = [_rbf(A, Bm, v, ls, f) for f, v, ls in members]
+        out = mats[0]
+        for m_ in mats[1:]:
+            out = out + m_ if op == "add" else out * m_
+        return out
+    vs = [v for _, v, _ in members]
+    kd = vs[0]
+    for v in vs[1:]:
+        kd = kd + v if op == "add" else kd * v
+    return kfun, kd
+
+
 def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_variance, *, num_data=None, jitter=1e-6,
-                    mean=0.0, whiten=True, family="SquaredExponential"):
-    """SVGP.elbo (svgp.py:166-181) on torch fp64 tensors; q_sqrt [P, M, M]; whiten as in the reference."""
+                    mean=0.0, whiten=True, family="SquaredExponential", kfun=None, kdiag=None):
+    """SVGP.elbo (svgp.py:166-181) on torch fp64 tensors; q_sqrt [P, M, M]; whiten as in the reference.  kfun / kdiag: a
+    kernel combination (combination_kernel) instead of the single stationary kernel."""
     M = Z.shape[0]
     B = X.shape[0]
-    Kmm = _rbf(Z, Z, variance, lengthscales, family) + jitter * torch.eye(M, dtype=torch.float64)   # covariances/kuus.py:29-34
-    Kmn = _rbf(Z, X, variance, lengthscales, family)                                         # kufs.py:31-34
+    if kfun is None:
+        kfun = lambda A_, B_: _rbf(A_, B_, variance, lengthscales, family)  # noqa: E731
+    else:
+        variance = kdiag
+    Kmm = kfun(Z, Z) + jitter * torch.eye(M, dtype=torch.float64)                            # covariances/kuus.py:29-34
+    Kmn = kfun(Z, X)                                                                         # kufs.py:31-34
     Lm = torch.linalg.cholesky(Kmm)                                                         # conditionals/util.py:67
     A = torch.linalg.solve_triangular(Lm, Kmn, upper=False)                                 # :125
     fvar = variance - (A * A).sum(0)                                                        # :133 (Knn = K_diag)
@@ -101,10 +122,11 @@ def svgp_elbo_value_and_grads(X, Y, Z, q_mu, q_sqrt, *, variance, lengthscales, 
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}
 
 
-def gpr_lml_torch(X, Y, variance, lengthscales, noise_variance, mean=0.0, family="SquaredExponential"):
+def gpr_lml_torch(X, Y, variance, lengthscales, noise_variance, mean=0.0, family="SquaredExponential", kfun=None):
     """GPR.log_marginal_likelihood (gpr.py:91-107; logdensities.py:139-156) on torch fp64 tensors."""
     N = X.shape[0]
-    K = _rbf(X, X, variance, lengthscales, family) + noise_variance * torch.eye(N, dtype=torch.float64)   # gpr.py:100-101
+    Kxx = kfun(X, X) if kfun is not None else _rbf(X, X, variance, lengthscales, family)
+    K = Kxx + noise_variance * torch.eye(N, dtype=torch.float64)                                  # gpr.py:100-101
     L = torch.linalg.cholesky(K)                                                                 # :102
     alpha = torch.linalg.solve_triangular(L, Y - mean, upper=False)                              # logdensities.py:150
     P = Y.shape[1]
@@ -118,6 +140,30 @@ def gpr_lml_value_and_grads(X, Y, *, variance, lengthscales, noise_variance, mea
     F.backward()
     g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "mean_const": mc.grad}
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}
+
+
+def combination_value_and_grads(model, X, Y, members, op, *, noise_variance, Z=None, q_mu=None, q_sqrt=None, num_data=None,
+                                jitter=1e-6, mean=0.0):
+    """Value and gradients of GPR.log_marginal_likelihood ("gpr") or the whitened SVGP.elbo ("svgp") under a Sum / Product of
+    stationary kernels, by autograd: {"variance": [n], "lengthscales": [per member], "noise_variance", "Z", "q_mu", "q_sqrt"}."""
+    t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
+    vs = [t(v, True) for _, v, _ in members]
+    lss = [t(np.atleast_1d(ls), True) for _, _, ls in members]
+    kfun, kd = combination_kernel([(f, v, ls) for (f, _, _), v, ls in zip(members, vs, lss)], op)
+    nv = t(noise_variance, True)
+    out = {}
+    if model == "gpr":
+        F = gpr_lml_torch(t(X), t(Y), None, None, nv, t(mean), kfun=kfun)
+    else:
+        Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
+        F = svgp_elbo_torch(t(X), t(Y), Zt, qm, qs, None, None, nv, num_data=num_data, jitter=jitter, mean=t(mean), whiten=True,
+                            kfun=kfun, kdiag=kd)
+    F.backward()
+    out.update(variance=np.array([float(v.grad) for v in vs]), lengthscales=[ls.grad.numpy().copy() for ls in lss],
+               noise_variance=float(nv.grad))
+    if model != "gpr":
+        out.update(Z=Zt.grad.numpy().copy(), q_mu=qm.grad.numpy().copy(), q_sqrt=qs.grad.numpy().copy())
+    return float(F.detach()), out
 
 
 # ----------------------------------------------------------------------------- natural gradient (SURVEY 8f row 3)

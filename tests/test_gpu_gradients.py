@@ -599,3 +599,64 @@ def test_parameter_priors_enter_value_and_gradient(gpu):
     res = gpflow.optimizers.Scipy().minimize(gpr, options=dict(maxiter=200))
     assert abs(res.fun - float(gpr.training_loss())) <= 1e-8 * abs(res.fun)
     assert np.max(np.abs(gpr.kernel.lengthscales.numpy() - ml.kernel.lengthscales.numpy())) > 1e-3
+
+
+@pytest.mark.parametrize("op", ["add", "mul"])
+def test_sum_and_product_kernels_in_the_reverse_pass(gpu, op):
+    """Sum / Product of stationary kernels (gpflow/kernels/base.py:216-220, 305-315; the reference differentiates the
+    tf.add_n / tf.multiply of the member matrices): GPR.log_marginal_likelihood and the whitened SVGP.elbo with their
+    gradients w.r.t. EVERY member's variance and lengthscales (plus noise, Z, q_mu, q_sqrt) against torch autograd over the
+    restated kernels; through the model surface in the unconstrained space, and Scipy improves the objective."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import gradients, ops
+    rng = np.random.default_rng(31)
+    N, D, M, P = 260, 3, 70, 2
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P))
+    Z = X[:M] + 0.05 * rng.normal(size=(M, D))
+    q_mu = 0.2 * rng.normal(size=(M, P)); q_sqrt = np.tril(0.1 * rng.normal(size=(P, M, M))) + 0.5 * np.eye(M)
+    members = [("SquaredExponential", 1.2, np.array([0.9, 1.1, 1.3])), ("Matern32", 0.7, np.array(0.8)), ("Matern52", 0.9, np.array([1.5, 0.7, 1.0]))]
+    spec = gradients.KernelSpec(members, op)
+    t = ops.to_device
+
+    def chk(got, ref, tol=1e-8):
+        got = np.asarray(got.cpu().numpy() if hasattr(got, "cpu") else got, dtype=np.float64).reshape(np.shape(ref))
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (np.abs(got - ref).max(), np.abs(ref).max())
+    # GPR
+    F, g, info = gradients.gpr_lml_and_grad(t(X), t(Y[:, :1]), noise_variance=0.2, mean_const=0.1, kernel_spec=spec)
+    rv, rg = orcg.combination_value_and_grads("gpr", X, Y[:, :1], members, op, noise_variance=0.2, mean=0.1)
+    assert int(info.cpu()[0]) == 0 and abs(float(F.cpu()[0]) - rv) <= 1e-9 * abs(rv)
+    chk(g["variance"], rg["variance"]); chk(g["noise_variance"], rg["noise_variance"])
+    for i in range(3):
+        chk(g["lengthscales"][i], rg["lengthscales"][i])
+    # SVGP (whitened)
+    F, g, info = gradients.svgp_elbo_and_grad(t(Z), t(X), t(Y), t(q_mu), t(q_sqrt), noise_variance=0.2, jitter=1e-6, scale=5.0,
+                                              kernel_spec=spec)
+    rv, rg = orcg.combination_value_and_grads("svgp", X, Y, members, op, noise_variance=0.2, Z=Z, q_mu=q_mu, q_sqrt=q_sqrt, num_data=5 * N)
+    assert int(info.cpu()[0]) == 0 and abs(float(F.cpu()[0]) - rv) <= 1e-9 * abs(rv)
+    chk(g["variance"], rg["variance"]); chk(g["noise_variance"], rg["noise_variance"]); chk(g["Z"], rg["Z"]); chk(g["q_mu"], rg["q_mu"])
+    chk(np.tril(g["q_sqrt"].cpu().numpy()), np.tril(rg["q_sqrt"]))
+    for i in range(3):
+        chk(g["lengthscales"][i], rg["lengthscales"][i])
+    # model surface: unconstrained gradients of every member parameter; then Scipy
+    ks = [gpflow.kernels.SquaredExponential(variance=1.2, lengthscales=[0.9, 1.1, 1.3]), gpflow.kernels.Matern32(variance=0.7, lengthscales=0.8)]
+    kc = ks[0] + ks[1] if op == "add" else ks[0] * ks[1]
+    m = gpflow.models.GPR((X, Y[:, :1]), kc, noise_variance=0.2)
+    v, gm = m.objective_and_grad()
+    assert abs(v - float(m.log_marginal_likelihood().cpu())) <= 1e-9 * abs(v)
+    assert set(gm) == {ks[0].variance, ks[0].lengthscales, ks[1].variance, ks[1].lengthscales, m.likelihood.variance}
+    h = 1e-5
+    for par, idx in [(ks[0].variance, ()), (ks[0].lengthscales, (1,)), (ks[1].variance, ()), (ks[1].lengthscales, ())]:
+        u0 = np.array(par.unconstrained_variable, dtype=np.float64, copy=True)
+        vals = []
+        for dlt in (h, -h):
+            u = u0.copy(); u[idx] += dlt
+            par.assign_unconstrained(u)
+            vals.append(float(m.log_marginal_likelihood().cpu()))
+        par.assign_unconstrained(u0)
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(float(np.asarray(gm[par])[idx]) - fd) <= 2e-5 * max(1.0, abs(fd)), (par.name, fd)
+    res = gpflow.optimizers.Scipy().minimize(m, options=dict(maxiter=20))
+    assert -res.fun > v
+    sv = gpflow.models.SVGP(kc, gpflow.likelihoods.Gaussian(0.2), Z.copy(), q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=P, num_data=5 * N)
+    v2, g2 = sv.elbo_and_grad((X, Y))
+    assert abs(v2 - float(sv.elbo((X, Y)).cpu())) <= 1e-9 * abs(v2) and ks[1].lengthscales in g2 and sv.inducing_variable.Z in g2
