@@ -225,10 +225,14 @@ def test_gradient_entry_points_refuse_unsupported_models_before_touching_the_dev
     for m in (summed, qdiag, sliced):
         with pytest.raises(NotImplementedError):
             gpflow.optimizers.NaturalGradient(1.0).minimize(m, data)
-    # (round 3: SVGP.elbo_and_grad itself covers q_diag, active_dims and the Matern families -- tests/test_gpu_gradients.py;
-    #  kernel sums / products stay out)
-    with pytest.raises(NotImplementedError):
-        summed.elbo_and_grad(data)
+    # (round 3: SVGP.elbo_and_grad itself covers q_diag, active_dims and the Matern families; round 4: Sum / Product of
+    #  stationary kernels over all input columns, whitened -- tests/test_gpu_gradients.py.  Still out: combinations whose
+    #  members have their own active_dims, and un-whitened combinations)
+    mixed = gpflow.models.SVGP(gpflow.kernels.Matern32(active_dims=[0]) + gpflow.kernels.SquaredExponential(), lik, Z)
+    unwhite = gpflow.models.SVGP(gpflow.kernels.Matern32() * gpflow.kernels.SquaredExponential(), lik, Z, whiten=False)
+    for m in (mixed, unwhite):
+        with pytest.raises(NotImplementedError):
+            m.elbo_and_grad(data)
     with pytest.raises(NotImplementedError):
         gpflow.optimizers.Scipy().minimize(object())
 
