@@ -395,6 +395,16 @@ def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
     return res
 
 
+def stream_selfcheck(lib):
+    """The library's init-time check of its stream -> hardware-queue layout (gpk_stream_selfcheck): a slow process is detected
+    (and repaired) instead of benchmarked."""
+    now, first, rec = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), ctypes.c_int()
+    if lib.gpk_stream_selfcheck(now, first, ctypes.byref(rec)) != 0:
+        return None
+    return {"handoff_us_P_X_Bs_pairs": [round(v, 1) for v in now], "first_layout_us": [round(v, 1) for v in first],
+            "streams_recreated": bool(rec.value), "limit_us": 30}
+
+
 def spawn_ranks(n: int, dry: bool) -> int:
     """Re-execute this script under torch.distributed.run with n ranks on this node (what the driver's command line does);
     returns the launcher's exit status.  Refuses -- loudly, before starting anything -- when the node has fewer devices."""
@@ -660,6 +670,7 @@ def main():  # noqa: C901
         "step_frac_of_fp64_peak": svgp_step_flops(m_ind, b_rows, P_LAT) * steps_per_s / 1e12 / FP64_PEAK_TFLOPS,
         "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
         "library": lib.gpk_version().decode(),
+        "stream_selfcheck": stream_selfcheck(lib),
         "roofline": roof,
     }
     if selftest:

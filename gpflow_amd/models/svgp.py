@@ -168,7 +168,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
 
         def scatter(gz):
             full = torch.zeros_like(Z)
-            full.index_copy_(1, cols, gz)
+            full.index_add_(1, cols, gz)   # (a repeated active column collects both contributions, like tf.gather's gradient)
             return full
         return Zs, Xs, scatter
 

@@ -18,17 +18,20 @@
  *
  * Internal state and threading (the complete list; nothing else in the library is mutable)
  *   - gpk_potrf with n > 128 (and the two fused drivers, which call it) uses per-device state created lazily on the
- *     first such call: six internal HIP streams (panel, high priority / side / one placeholder that fixes the
- *     stream-to-hardware-queue layout / bulk-small / bulk and bulk-late, both CU-masked) and a pool of timing-disabled
- *     events that grows to 3 * panels + 8.  No device memory is allocated and nothing synchronises: work is forked
- *     from and joined to the caller's stream with events only.  (The streams are created in an order that keeps the
- *     panel and bulk streams on different microengine pipes -- INTEGRATION.md section 4: create this state, i.e. make
- *     one such call, before other libraries of the process create their streams.)
+ *     first such call: five internal HIP streams (P panel, high priority / X side / one placeholder that fixes the
+ *     stream-to-hardware-queue layout / Bs bulk-small / B bulk, CU-masked) and a pool of timing-disabled events that grows
+ *     to 2 * panels + 8.  That first call also runs a ~1 ms self-check of the stream layout (a few hundred empty kernels;
+ *     the ONLY place the library synchronises) and creates the streams again if a pair of them hands kernels over slowly
+ *     (gpk_stream_selfcheck).  Afterwards no device memory is allocated and nothing synchronises: work is forked from and
+ *     joined to the caller's stream with events only.  (The streams are created in an order that keeps the panel and bulk
+ *     streams on different microengine pipes -- INTEGRATION.md section 4: create this state, i.e. make one such call,
+ *     before other libraries of the process create their streams.)
  *   - One recursive mutex per device serialises the ENQUEUE section of these calls, so they may be issued from any
  *     number of host threads and on any caller streams; factorisations of one device share the internal streams and
  *     therefore execute one after the other on the GPU.
  *   - Every other entry point is stateless and reentrant (kernel attributes are set through thread-safe function-local
- *     statics).  The library never reads the environment.
+ *     statics; the GEMM launcher keeps the id of the kernel it picked last in a thread_local for the profiling facility).
+ *     The library never reads the environment.
  *   - gpk_profile_gemm_* is a measurement facility for bench.py: process-global, not thread-safe, off by default.
  */
 #ifndef GPK_H
@@ -106,6 +109,12 @@ int gpk_kernel_matrix_hadamard(void* stream, int family, const double* X1, int n
 size_t gpk_invd_elems(int n, int batch);
 int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch, long strideA,
               double* invd, int zero_upper, int* info);
+
+/* Result of the init-time stream-layout self-check (see "Internal state and threading"): microseconds per cross-stream
+ * kernel hand-off between the library's panel / side / bulk-small streams, as measured now (us_now[3]) and on the first
+ * stream set (us_first[3]); *recreated = 1 if the first set was slow (> 30 us: two active hardware queues on one
+ * microengine pipe) and the streams were created again.  GPK_E_UNSUPPORTED before the first factorisation with n > 128. */
+int gpk_stream_selfcheck(double* us_now, double* us_first, int* recreated);
 
 /* gpk_potrf for callers that also need the explicit inverse factor (the reverse pass: gradients.py; the reference
  * gets the same quantities from the triangular solves inside TF's Cholesky gradient).  A is [n + extra + n, lda]:
