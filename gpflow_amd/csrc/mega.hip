@@ -54,8 +54,11 @@ constexpr int NS = 32;           // B rows per slab
 constexpr int LDP = NBK + 2;     // LDS row stride (doubles): fragment reads of 16 rows x 2 k hit 64 distinct banks
 constexpr int PAN = MB * LDP;    // doubles per panel / slab buffer
 constexpr int OFF_PA = 0, OFF_PB = PAN, OFF_S0 = 2 * PAN, OFF_S1 = 3 * PAN, OFF_MISC = 4 * PAN;
+constexpr int OFF_CS = OFF_MISC + 256;   // three 32 x 32 blocks of old C values (the ring of the flag-synchronised stream)
+constexpr int LDS_DOUBLES_MEGA = OFF_CS + 3 * MB * NS;
 constexpr int MEGA_THREADS = 512;
-constexpr size_t MEGA_LDS = gpk_leaf::LEAF_LDS > (size_t)(OFF_MISC + 256) * 8 ? gpk_leaf::LEAF_LDS : (size_t)(OFF_MISC + 256) * 8;
+constexpr size_t MEGA_LDS = gpk_leaf::LEAF_LDS > (size_t)LDS_DOUBLES_MEGA * 8 ? gpk_leaf::LEAF_LDS : (size_t)LDS_DOUBLES_MEGA * 8;
+static_assert(MEGA_LDS + 64 <= 160 * 1024, "LDS budget of one compute unit");
 
 struct MegaArgs {
   double* T; long ld;            // [m + rows, ld]: Kuu (+ jitter) on top, Kfu below (becomes L / A^T in place)
@@ -75,9 +78,11 @@ struct MegaArgs {
   int* info;
   double* out;
   int m, nb, rows, P, nbulk;
+  int rows_pad;                  // rows rounded up to whole row blocks: the caller's T / Cacc have that many minibatch rows
   int one_pool;                  // A/B: deal near and far chain tasks to all workgroups alike
   int dbg;                       // A/B build: what-if bits for the bulk streams (Stream::dbg)
   int role_map;                  // 1: consumer / producer roles from the waves' SIMD ids (default), 0: waves 0..3 / 4..7
+  int sync_mode;                 // 0: one workgroup barrier per slab (default), 1: slab hand-over through LDS counters
   double variance, noise, mean_const;
   long long timeout_ticks;
 };
@@ -115,6 +120,12 @@ template <bool COH>
 __device__ __forceinline__ void dma_row(const double* src, double* dst_wave_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, COH ? 16 : 0);
+}
+// the old C values of a slab: private rows streamed once (non-temporal) unless they are chain data (agent scope)
+template <bool COH>
+__device__ __forceinline__ void dma_row_nt(const double* src, double* dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, COH ? 16 : 2);
 }
 // C / E traffic of a stream.  COH: agent-scope accesses (chain data shared between XCDs).  Otherwise the rows are private to
 // the workgroup and only streamed through once per step: non-temporal, so that 16 KB per slab and workgroup of read-modify-
@@ -391,6 +402,380 @@ __device__ __noinline__ int stream_run(const Stream st, int slab_begin, const Co
   return nslabs;
 }
 
+// ---- the same stream without a workgroup barrier per slab (A/B: GPK_MEGA_SYNC=1; correct, and SLOWER: 3.28 against 3.10 ms) ----
+// The barrier version above costs ~3400 consumer cycles per slab of which 2300 are MFMAs (profiles/r04_mega_task_trace_and_
+// consumer_cycles.txt): after the slab barrier every consumer first waits for its fragment reads (676 cycles), and the barrier
+// itself collects the skew of eight waves (322 cycles).  Here the slab hand-over goes through counters in LDS instead:
+//   c_land[j] slabs of which mover wave j's rows are in LDS                     (slab r landed:  every c_land[j] >= r + 1)
+//   c_read[i] slabs of which consumer wave i has ISSUED all fragment reads (LDS executes a wave's operations in order, so the
+//             store is performed after the reads)                              (slab r free:    every c_read[i] >= r + 1)
+//             -- one word per wave: a sum could reach the threshold while one wave is still behind
+//   c_issue   number of slabs the LEAD mover has decided to fetch; the other movers follow it
+//   c_stop_at first slab that is NOT run: written once by the lead mover when the polling wave has raised c_stop_req -- the
+//             lead mover is the only wave that decides where a stream ends, so the four consumers agree on it by construction
+// A consumer only blocks when the next slab has not landed; in the steady state it would find it landed while its last MFMA
+// group of the current slab is still to be issued and load the first fragments of the next slab under those MFMAs.  Every spin
+// loop is bounded (c_abort): the stream then returns -1 and the step fails with info = INT_MAX instead of hanging the device.
+//
+// What the measurement says (profiles/r04_mega_flag_sync_whatif.txt): the instruction stream is what it should be -- no wait on an
+// MFMA result, no global load in the consumers, every LDS wait three MFMA pairs behind its request -- and a slab still takes 4080
+// cycles, 1216 of them in the blocking wait: 1002 of 1088 slabs are NOT in LDS when they are needed.  With the B-slab DMA
+// switched off 3088 cycles, with the old-C DMA off 3397, with both off 2868: the stream runs at the latency of its LDS-DMA
+// (the first workgroup of an XCD to touch a B row fetches it from memory, ~2 - 3 us; the ring holds two slabs ahead = ~2 us of
+// cover) and a deeper ring does not fit: four 33-KB slab buffers + four 8-KB old-C blocks are 166 KB.  The barrier version hides
+// part of that latency behind its own inefficiency.  Kept as the A/B variant it is; not the way to 1.8 ms.
+typedef __attribute__((address_space(3))) int lint;
+__device__ __forceinline__ int lds_ld(lint* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(lint* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_add(lint* p, int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// A store the compiler does not see as an LDS access: behind an LDS-DMA instruction it orders every DS instruction after ALL
+// outstanding DMA (vmcnt(0)) -- the movers publish "slab t - 1 has landed" while slab t is still in flight.
+__device__ __forceinline__ void lds_st_raw(lint* p, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void cfence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }   // compiler-only ordering
+enum { C_STOPREQ = 3, C_STOPAT = 4, C_ISSUE = 5, C_FIN = 6, C_ABORT = 7, C_READ0 = 8, C_LAND0 = 12 };   // (ctl has 16 words)
+constexpr int NMOV = 3;
+constexpr long long SPIN_TICKS = 50000000LL;   // 0.5 s of the 100 MHz clock
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+struct TagTrue { static constexpr bool value = true; };
+struct TagFalse { static constexpr bool value = false; };
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// All row blocks are FULL here (the fused driver pads the minibatch rows of its workspace to a multiple of 32; the padding rows
+// carry garbage through the arithmetic and are left out of the final sum), so the loop has no per-row predicates and everything
+// that controls it is wave-uniform (scalar branches).
+//
+// The OLD C values of a read-modify-write stream travel with the B slab: the movers fetch the slab's 32 x 32 C block by LDS-DMA
+// into a ring of its own (OFF_CS) and the consumers read it from LDS.  A consumer wave therefore issues no global LOADS at all,
+// only stores -- which matters because loads and stores share one counter (vmcnt) and complete out of order with respect to
+// each other: with both in flight the compiler has to wait for ALL of them before it may use a loaded value, i.e. every slab
+// waited for the stores of the previous one (part of the 676 cycles "before the MFMAs" of the barrier version).
+template <bool COH, int MODE>
+__device__ __noinline__ int stream_run_flags(const Stream st, int slab_begin_in, const Cond* intr_in, int* ctl_flat, d4& sq_io, int vw) {
+  extern __shared__ __attribute__((aligned(16))) double S[];
+  lint* ctl = (lint*)ctl_flat;
+  gdouble* Cg = (gdouble*)st.C;
+  gdouble* Cg2 = (gdouble*)st.C2;
+  const bool has_intr = intr_in != nullptr;
+  Cond ic;
+  if (has_intr) ic = *intr_in;
+  else { ic.a0 = ic.a1 = ic.a2 = ic.a3 = nullptr; ic.t0 = ic.t1 = ic.t2 = ic.t3 = 0; }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int pwave = rfl(tid >> 6);
+  const int wave = rfl(vw);          // ROLE: 0..3 consumers (one per SIMD), 4..6 movers (4 leads), 7 poller
+  const int slab_begin = rfl(slab_begin_in);
+  const int n0 = rfl(st.n0), n1 = rfl(st.n1), pa_off = rfl(st.pa_off);
+  const int nslabs = (n1 - n0 + NS - 1) / NS;
+  if (slab_begin >= nslabs) return nslabs;
+  const int c = lane & 15, g = lane >> 4;
+  const int mt = wave & 1, nt = (wave >> 1) & 1;
+  const int nbuf = MODE != MODE_FIN ? 3 : 2;
+  const int depth = nbuf - 1;
+  const int third = pa_off == OFF_PB ? OFF_PA : OFF_PB;
+  auto buf_off = [&](int s) -> int { const int b = s % nbuf; return b == 0 ? OFF_S0 : (b == 1 ? OFF_S1 : third); };
+  auto cbuf_off = [&](int s) -> int { return OFF_CS + (s % 3) * (MB * NS); };
+  const int s_fresh = (MODE == MODE_FIN) ? 0 : ((MODE == MODE_SUB) ? nslabs : (rfl(st.nfresh) - n0) / NS);   // slabs >= s_fresh: no old C
+  // mover wave j = wave - 4 moves B rows j, j + 3, ... (11 / 11 / 10 LDS-DMA instructions) and C row quads j, j + 3, ... of 8 (3 / 3 / 2)
+  const int dbg = kGpkExp ? rfl(st.dbg) : 0;   // A/B build what-if bits (results wrong): 1 no old-C DMA, 2 no C stores, 4 no B DMA
+  auto dma_slab = [&](int s) {
+    if (dbg & 4) return;
+    const int off = buf_off(s);
+    const double* src = st.B + (long)(n0 + s * NS + (wave - 4)) * st.ldb + 2 * lane;
+    for (int lr = wave - 4; lr < NS; lr += 3) {
+      dma_row<COH>(src, S + off + lr * LDP);
+      src += 3 * st.ldb;
+    }
+  };
+  auto dma_cslab = [&](int s) {   // lane l of quad i: row 4 i + (l >> 4), columns 2 (l & 15) .. + 1 of the slab
+    if (dbg & 1) return;
+    const int off = cbuf_off(s);
+    const double* src = st.C + (long)(4 * (wave - 4) + (lane >> 4)) * st.ldc + n0 + s * NS + 2 * (lane & 15);
+    for (int i = wave - 4; i < MB / 4; i += 3) {
+      dma_row_nt<COH>(src, S + off + i * (4 * NS));
+      src += 12 * st.ldc;
+    }
+  };
+  const int npre = nslabs - slab_begin < depth ? nslabs - slab_begin : depth;   // slabs fetched in the prologue
+  if (tid == 0) {
+    for (int j = 0; j < NMOV; ++j) lds_st(ctl + C_LAND0 + j, npre);
+    for (int i = 0; i < 4; ++i) lds_st(ctl + C_READ0 + i, 0);
+    lds_st(ctl + C_STOPREQ, 0); lds_st(ctl + C_STOPAT, INT_MAX);
+    lds_st(ctl + C_ISSUE, slab_begin + npre); lds_st(ctl + C_FIN, 0); lds_st(ctl + C_ABORT, 0);
+  }
+  if (st.pan_src) {
+    for (int q = pwave; q < MB; q += MEGA_THREADS / 64)
+      dma_row<COH>(st.pan_src + (long)q * st.pan_ld + 2 * lane, S + pa_off + q * LDP);
+  }
+  if (wave >= 4 && wave <= 6) {
+    for (int d = 0; d < npre; ++d) {
+      dma_slab(slab_begin + d);
+      if (slab_begin + d < s_fresh) dma_cslab(slab_begin + d);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  const long long t_spin0 = wall_clock64();
+
+  if (wave == 7) {
+    // ---- the poller: raises c_stop_req when the workgroup's next chain task has become ready
+    if (has_intr) {
+      for (;;) {
+        const int fin = rfl(lds_ld(ctl + C_FIN) | lds_ld(ctl + C_ABORT));
+        if (fin) break;
+        int ok = 0;
+        if (lane == 0) ok = cond_ok(ic) ? 1 : 0;
+        ok = rfl(ok);
+        if (ok) { if (lane == 0) lds_st(ctl + C_STOPREQ, 1); break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+  } else if (wave >= 4) {
+    // ---- the movers
+    const bool lead = wave == 4;
+    int pub = npre;          // slabs of this wave published in c_land
+    int issued = npre;       // slabs of this wave issued
+    bool stopped = false;
+    for (int t = slab_begin + npre; t < nslabs; ++t) {
+      if (lead) {
+        const int need = t - nbuf - slab_begin + 1;   // every consumer has read the slab whose buffer slab t reuses
+        int it = 0;
+        for (;;) {
+          cfence();
+          const int r0 = lds_ld(ctl + C_READ0), r1 = lds_ld(ctl + C_READ0 + 1), r2 = lds_ld(ctl + C_READ0 + 2), r3 = lds_ld(ctl + C_READ0 + 3);
+          const int rq = rfl(lds_ld(ctl + C_STOPREQ) | lds_ld(ctl + C_ABORT));
+          const int rd = rfl(min(min(r0, r1), min(r2, r3)));
+          cfence();
+          if (rq) { stopped = true; break; }
+          if (rd >= need) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++it & 1023) == 0 && wall_clock64() - t_spin0 > SPIN_TICKS) { if (lane == 0) lds_st(ctl + C_ABORT, 1); stopped = true; break; }
+        }
+        if (stopped) {
+          if (lane == 0) lds_st(ctl + C_STOPAT, t);
+          cfence();
+          if (lane == 0) lds_st(ctl + C_FIN, 1);
+          break;
+        }
+        if (lane == 0) lds_st(ctl + C_ISSUE, t + 1);
+      } else {
+        int it = 0;
+        for (;;) {
+          cfence();
+          const int is = rfl(lds_ld(ctl + C_ISSUE)), fin = rfl(lds_ld(ctl + C_FIN) | lds_ld(ctl + C_ABORT));
+          cfence();
+          if (is > t) break;
+          if (fin) { stopped = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+          if ((++it & 1023) == 0 && wall_clock64() - t_spin0 > SPIN_TICKS) { if (lane == 0) lds_st(ctl + C_ABORT, 1); stopped = true; break; }
+        }
+        if (stopped) break;
+      }
+      dma_slab(t);
+      // everything older than the instructions just issued has landed (LDS-DMA loads complete in order)
+      if (t < s_fresh) {
+        dma_cslab(t);
+        if (wave == 6) __builtin_amdgcn_s_waitcnt(0x0F7C); else __builtin_amdgcn_s_waitcnt(0x0F7E);   // vmcnt(12) / vmcnt(14)
+      } else {
+        if (wave == 6) __builtin_amdgcn_s_waitcnt(0x0F7A); else __builtin_amdgcn_s_waitcnt(0x0F7B);   // vmcnt(10) / vmcnt(11)
+      }
+      ++issued;
+      cfence();
+      if (issued - 1 > pub) { pub = issued - 1; lds_st_raw(ctl + C_LAND0 + (wave - 4), pub); }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the last slab(s) of this wave
+    cfence();
+    if (lane == 0 && issued > pub) lds_st(ctl + C_LAND0 + (wave - 4), issued);
+    if (lead && !stopped && lane == 0) lds_st(ctl + C_FIN, 1);
+  } else {
+    // ---- the consumers
+    double fa[NBK / 4];
+    {
+      const double* pa = S + pa_off + (16 * mt + c) * LDP + g;
+#pragma unroll
+      for (int kk = 0; kk < NBK / 4; ++kk) fa[kk] = pa[4 * kk];
+    }
+    d4 sq = sq_io;
+    long long acc_wait = 0, acc_all = 0, nslab_run = 0, nslow = 0;
+    gdouble* cp[4];
+    gdouble* cp2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long off = (long)(16 * mt + g + 4 * r) * st.ldc + n0 + (long)slab_begin * NS + 16 * nt + c;
+      cp[r] = Cg + off;
+      cp2[r] = Cg2 ? Cg2 + off : nullptr;
+    }
+    const int pb_lane = (16 * nt + c) * LDP + g;
+    const int pc_lane = (16 * mt + g) * NS + 16 * nt + c;   // this lane's element of row r: + 4 r NS
+    double pend[4] = {0.0, 0.0, 0.0, 0.0};
+    auto finish_prev = [&](const d4& P0, const d4& P1, const double* cold, int ps) {   // ps: the slab these sums belong to
+      const bool has_old = MODE == MODE_SUB || ps < s_fresh;   // (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double o = P0[r] + P1[r];
+        const double cv = has_old ? cold[r] : 0.0;
+        pend[r] = MODE == MODE_FIN ? o : (MODE == MODE_SUB ? cv - o : cv + o);
+      }
+    };
+    auto store_r = [&](int r, int ps) {   // ps: the slab the pending values belong to
+      if constexpr (MODE == MODE_SQ) {
+        sq[r] += pend[r] * pend[r];
+      } else {
+        if constexpr (MODE == MODE_FIN) S[OFF_PB + (16 * mt + g + 4 * r) * LDP + ps * NS + 16 * nt + c] = pend[r];
+        if (!(dbg & 2)) st_c<COH>(cp[r], pend[r]);
+        if constexpr (MODE == MODE_FIN) { if (Cg2) st_c<COH>(cp2[r], pend[r]); }
+      }
+      cp[r] += NS;
+      if constexpr (MODE == MODE_FIN) cp2[r] += NS;
+    };
+    double fb[2][8];
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    // Blocks until slab t has landed; false when the stream ends before it (stop / abort / bounded spin ran out).
+    auto wait_landed = [&](int t) -> bool {
+      const int need = t - slab_begin + 1;
+      int it = 0;
+      bool ok = true;
+      long long t_w0 = 0;
+      if (kGpkExp && st.tacc) t_w0 = __builtin_readcyclecounter();
+      for (;;) {
+        cfence();
+        const int l0 = lds_ld(ctl + C_LAND0), l1 = lds_ld(ctl + C_LAND0 + 1), l2 = lds_ld(ctl + C_LAND0 + 2);
+        const int sa = rfl(lds_ld(ctl + C_STOPAT)), ab = rfl(lds_ld(ctl + C_ABORT));
+        const int ln = rfl(min(l0, min(l1, l2)));
+        cfence();
+        if ((t >= sa) | ab) { ok = false; break; }
+        if (ln >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++it & 1023) == 0) {
+          const bool late = wall_clock64() - t_spin0 > SPIN_TICKS;
+          // (the clock read is a scalar-memory access; they complete out of order, so with one possibly in flight every later
+          // LDS wait would have to be a full one -- settle it here, on the slow path)
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          if (late) { if (lane == 0) lds_st(ctl + C_ABORT, 1); ok = false; break; }
+        }
+      }
+      if (kGpkExp && st.tacc) { acc_wait += __builtin_readcyclecounter() - t_w0; nslow += 1; __builtin_amdgcn_s_waitcnt(0xC07F); }
+      return ok;
+    };
+    // One slab.  CUR accumulates it; PRV still holds the sums of slab s - 1, which are folded into C under the first MFMAs of this
+    // slab (no MFMA result is ever waited for inside the loop); coldc / coldp: the old C values of this / the previous slab.
+    // fb[0] holds this slab's first fragments on entry (requested by the previous slab; the first slab of a call requests its
+    // own).  Returns 0 when the next slab's first fragments are on their way, -1 when the stream ends with this slab.
+    auto body = [&](auto first_tag, int s_in, d4& cur0, d4& cur1, const d4& prv0, const d4& prv1, double* coldc, const double* coldp) -> int {
+      constexpr bool have_prev = !decltype(first_tag)::value;   // the first slab of a call is peeled: nothing to fold yet
+      const int s = rfl(s_in);
+      long long t_top = 0;
+      if (kGpkExp && st.tacc) t_top = __builtin_readcyclecounter();
+      const double* pb = S + buf_off(s) + pb_lane;
+      if constexpr (!have_prev) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fb[0][k] = pb[4 * k];
+      }
+      // The compiler waits for ALL outstanding LDS traffic at the first use of any LDS result (it does not count past a loop
+      // header), so every group issues its first MFMA pair BEFORE the LDS requests of the next group: at the next group's first
+      // MFMA the youngest request is then three MFMA pairs (~400 cycles) old and the full wait falls through.
+#define MFMA2(K, FB)                                                                     \
+  cur0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[(K)], FB[(K) & 7], cur0, 0, 0, 0);      \
+  cur1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[(K) + 1], FB[((K) & 7) + 1], cur1, 0, 0, 0)
+      // ---- group 0 (k = 0 .. 7): fragments of group 1 requested, the previous slab folded into C in the MFMAs' shadow
+      SB();
+      cur0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0][0], zero, 0, 0, 0);
+      cur1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1], fb[0][1], zero, 0, 0, 0);
+      SB();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fb[1][k] = pb[4 * (8 + k)];
+      if constexpr (have_prev) finish_prev(prv0, prv1, coldp, s - 1);
+      SB();
+      MFMA2(2, fb[0]);
+      SB();
+      if constexpr (have_prev) { store_r(0, s - 1); store_r(1, s - 1); }
+      SB();
+      MFMA2(4, fb[0]);
+      SB();
+      if constexpr (have_prev) { store_r(2, s - 1); store_r(3, s - 1); }
+      SB();
+      MFMA2(6, fb[0]);
+      SB();
+      // ---- group 1 (k = 8 .. 15): fragments of group 2 and this slab's old C values requested
+      MFMA2(8, fb[1]);
+      SB();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fb[0][k] = pb[4 * (16 + k)];
+      if constexpr (MODE != MODE_FIN) {   // (unconditional: a slab without old values reads stale LDS and drops it in finish_prev)
+        const double* pc = S + cbuf_off(s) + pc_lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) coldc[r] = pc[4 * r * NS];
+      }
+      SB();
+      MFMA2(10, fb[1]);
+      MFMA2(12, fb[1]);
+      MFMA2(14, fb[1]);
+      SB();
+      // ---- group 2 (k = 16 .. 23): the last fragments of the slab requested -> its buffers may be refilled; the next slab's
+      // state is read here and looked at one group later
+      MFMA2(16, fb[0]);
+      SB();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fb[1][k] = pb[4 * (24 + k)];
+      cfence();
+      if (lane == 0) lds_st(ctl + C_READ0 + wave, s - slab_begin + 1);
+      const int q0 = lds_ld(ctl + C_LAND0), q1 = lds_ld(ctl + C_LAND0 + 1), q2 = lds_ld(ctl + C_LAND0 + 2);
+      const int qs = lds_ld(ctl + C_STOPAT), qa = lds_ld(ctl + C_ABORT);
+      cfence();
+      SB();
+      MFMA2(18, fb[0]);
+      MFMA2(20, fb[0]);
+      MFMA2(22, fb[0]);
+      SB();
+      // ---- group 3 (k = 24 .. 31): the next slab's first fragments requested (in the steady state it landed long ago)
+      MFMA2(24, fb[1]);
+      SB();
+      int nx = -1;
+      if (s + 1 < nslabs) {
+        const bool fast = (rfl(min(q0, min(q1, q2))) >= s + 2 - slab_begin) & (s + 1 < rfl(qs)) & (rfl(qa) == 0);
+        if (fast || wait_landed(s + 1)) nx = 0;
+      }
+      {
+        // (requested unconditionally -- when there is no next slab the values are never used)
+        const double* pbn = S + buf_off(s + 1) + pb_lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fb[0][k] = pbn[4 * k];
+      }
+      SB();
+      MFMA2(26, fb[1]);
+      MFMA2(28, fb[1]);
+      MFMA2(30, fb[1]);
+      SB();
+#undef MFMA2
+      if (kGpkExp && st.tacc) { acc_all += __builtin_readcyclecounter() - t_top; nslab_run += 1; }
+      return nx;
+    };
+    d4 a0 = zero, a1 = zero, b0 = zero, b1 = zero;
+    double ca[4] = {0.0, 0.0, 0.0, 0.0}, cb[4] = {0.0, 0.0, 0.0, 0.0};
+    int s = slab_begin;
+    if (wait_landed(s)) {
+      // (slab k = s - slab_begin: accumulators / old-C registers a for even k, b for odd k)
+      int h = rfl(body(TagTrue{}, s, a0, a1, b0, b1, ca, cb));
+      ++s;
+      while (h >= 0) {
+        h = rfl(body(TagFalse{}, s, b0, b1, a0, a1, cb, ca)); ++s; if (h < 0) break;
+        h = rfl(body(TagFalse{}, s, a0, a1, b0, b1, ca, cb)); ++s;
+      }
+    }
+    if (s > slab_begin) {   // the last slab run (s - 1) is still in its accumulators
+      const int k = s - 1 - slab_begin;
+      if ((k & 1) == 0) finish_prev(a0, a1, ca, s - 1); else finish_prev(b0, b1, cb, s - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) store_r(r, s - 1);
+    }
+    if (kGpkExp && st.tacc && tid == 0) { st.tacc[0] += acc_wait; st.tacc[1] += acc_all; st.tacc[2] += nslow; st.tacc[4] += nslab_run; }
+    sq_io = sq;
+  }
+  __syncthreads();
+  const int sa = rfl(lds_ld(ctl + C_STOPAT)), ab = rfl(lds_ld(ctl + C_ABORT));
+  if (ab) return -1;
+  return sa < nslabs ? sa : nslabs;
+}
+
 // ---- chain task bookkeeping -------------------------------------------------------------------------------------------
 // Tasks of panel p, in dependency order:  LEAF(p);  then for block rows i = p+1 .. nb-1 the four quarter tasks FIN(i, u, p)
 // (rows 128 i + 32 u .. + 31:  X[r, p] <- X[r, p] inv(L_pp)^T) and UPD(i, u, p) (X[r, n] -= X[r, p] L[n, p]^T for the
@@ -487,7 +872,7 @@ __device__ __forceinline__ void publish_barrier() {
 template <int PROTO>
 __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) double S[];
-  __shared__ int ctl[8];
+  __shared__ __attribute__((aligned(16))) int ctl[16];
   constexpr bool WT = PROTO == 1;   // chain data: write-through stores, agent-scope loads
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -659,7 +1044,7 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
           const int pl = ph - 1;
           const bool last = q == nb - 1;
           st.B = a.LqT + (long)pl * m * a.ldl + NBK * q; st.ldb = a.ldl; st.n0 = 0; st.n1 = NBK * (q + 1);
-          st.C = a.Cacc + ((long)pl * a.rows + r0) * ld; st.ldc = ld;
+          st.C = a.Cacc + ((long)pl * a.rows_pad + r0) * ld; st.ldc = ld;
           st.mode = last ? MODE_SQ : MODE_ADD; st.nfresh = NBK * q;
           intr = (have_task && !last) ? &tc : nullptr;
         } else if (q < nb - 1) {
@@ -678,13 +1063,28 @@ __global__ __launch_bounds__(MEGA_THREADS) void svgp_step_kernel(MegaArgs a) {
     const int nslabs = run ? (st.n1 - st.n0 + NS - 1) / NS : 0;
     if (run) {
       // (one instantiation per coherence variant and epilogue: the mode is a compile-time constant inside the slab loop)
-      if (coh) {
-        if (st.mode == MODE_FIN) endpos = stream_run<true, MODE_FIN>(st, begin, intr, ctl, sq, vw);
-        else endpos = stream_run<true, MODE_SUB>(st, begin, intr, ctl, sq, vw);
-      } else if (st.mode == MODE_FIN) endpos = stream_run<false, MODE_FIN>(st, begin, intr, ctl, sq, vw);
-      else if (st.mode == MODE_SUB) endpos = stream_run<false, MODE_SUB>(st, begin, intr, ctl, sq, vw);
-      else if (st.mode == MODE_ADD) endpos = stream_run<false, MODE_ADD>(st, begin, intr, ctl, sq, vw);
-      else endpos = stream_run<false, MODE_SQ>(st, begin, intr, ctl, sq, vw);
+      if (a.sync_mode == 0) {   // (A/B: the barrier-per-slab version)
+        if (coh) {
+          if (st.mode == MODE_FIN) endpos = stream_run<true, MODE_FIN>(st, begin, intr, ctl, sq, vw);
+          else endpos = stream_run<true, MODE_SUB>(st, begin, intr, ctl, sq, vw);
+        } else if (st.mode == MODE_FIN) endpos = stream_run<false, MODE_FIN>(st, begin, intr, ctl, sq, vw);
+        else if (st.mode == MODE_SUB) endpos = stream_run<false, MODE_SUB>(st, begin, intr, ctl, sq, vw);
+        else if (st.mode == MODE_ADD) endpos = stream_run<false, MODE_ADD>(st, begin, intr, ctl, sq, vw);
+        else endpos = stream_run<false, MODE_SQ>(st, begin, intr, ctl, sq, vw);
+      } else {
+        if (coh) {
+          if (st.mode == MODE_FIN) endpos = stream_run_flags<true, MODE_FIN>(st, begin, intr, ctl, sq, vw);
+          else endpos = stream_run_flags<true, MODE_SUB>(st, begin, intr, ctl, sq, vw);
+        } else if (st.mode == MODE_FIN) endpos = stream_run_flags<false, MODE_FIN>(st, begin, intr, ctl, sq, vw);
+        else if (st.mode == MODE_SUB) endpos = stream_run_flags<false, MODE_SUB>(st, begin, intr, ctl, sq, vw);
+        else if (st.mode == MODE_ADD) endpos = stream_run_flags<false, MODE_ADD>(st, begin, intr, ctl, sq, vw);
+        else endpos = stream_run_flags<false, MODE_SQ>(st, begin, intr, ctl, sq, vw);
+      }
+      if (endpos < 0) {   // a bounded spin inside the stream ran out: give up device-wide
+        if (tid == 0) st_flag(abortf, 1);
+        aborted = true;
+        break;
+      }
     }
     // ---- what follows the stream ----------------------------------------------------------------------------------
     if (what <= 2) {
@@ -831,7 +1231,8 @@ extern "C" __attribute__((visibility("default"))) int gpk_exp_mega_trace_dump(vo
     const long long* t = host + 1 + 8 * 4096;
     if (t[4] > 0)
       printf("# consumer loop of the traced workgroup, shader-clock cycles per slab over %lld slabs: before MFMA %.0f, MFMA section %.0f, "
-             "epilogue %.0f, barrier wait %.0f\n", t[4], (double)t[0] / t[4], (double)t[1] / t[4], (double)t[2] / t[4], (double)t[3] / t[4]);
+             "epilogue %.0f, barrier wait %.0f   (flag-synchronised stream: waiting %.0f of %.0f cycles per slab, %lld blocking waits)\n", t[4],
+             (double)t[0] / t[4], (double)t[1] / t[4], (double)t[2] / t[4], (double)t[3] / t[4], (double)t[0] / t[4], (double)t[1] / t[4], t[2]);
   }
   printf("# task trace: start_us dur_us wg what(0 leaf,1 FIN,2 UPD | 3 bulk FIN,4 PROJ,5 UPD,6 final: p=q i=first slab u=end slab flag=slabs)   (%lld records)\n", host[0]);
   for (long long i = 0; i < n; ++i) {
@@ -863,10 +1264,12 @@ int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, 
     a.stamps = (long long*)(flags + ((nflag + 1) & ~(size_t)1));
   }
   a.m = m; a.nb = m / NBK; a.rows = rows; a.P = P; a.nbulk = (rows + MB - 1) / MB;
+  a.rows_pad = a.nbulk * MB;
   a.variance = variance; a.noise = noise; a.mean_const = mean_const;
   a.timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
   a.one_pool = GPK_TUNE(MEGA_ONE_POOL, 0);
   a.role_map = GPK_TUNE(MEGA_ROLE_MAP, 1);
+  a.sync_mode = GPK_TUNE(MEGA_SYNC, 0);   // (measured: the barrier version is the faster one, 3.10 against 3.28 ms at Cm)
   a.dbg = kGpkExp ? GPK_TUNE(MEGA_DBG, 0) : 0;
   int G = a.nbulk;
   if (G < min_wgs) G = min_wgs;

@@ -746,7 +746,10 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   l.ld = (long)gpk_align_up((size_t)m, 8);
   l.nt = 2 * gpk_gemm_tiles_n(m);
   size_t o = 0;
-  l.off_T = o; o += gpk_align_up((size_t)(m + rows) * l.ld * sizeof(double), 256);
+  // (minibatch rows padded to whole 32-row blocks: the single-launch step kernel runs full blocks only; the padding rows are
+  // never initialised, never read by the multi-launch route and left out of the step kernel's final sum)
+  const size_t rows_pad = gpk_align_up((size_t)rows, 32);
+  l.off_T = o; o += gpk_align_up((size_t)(m + rows_pad) * l.ld * sizeof(double), 256);
   l.off_invd = o; o += gpk_align_up(gpk_invd_elems(m, 1) * sizeof(double), 256);
   l.off_LqT = o; o += q_diag ? 0 : gpk_align_up((size_t)P * m * l.ld * sizeof(double), 256);
   l.off_s0 = o; o += gpk_align_up((size_t)rows * sizeof(double), 256);
@@ -756,7 +759,7 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   // single-launch step kernel (mega.hip): projection accumulator [P, rows, ld] and its flag words
-  l.off_C = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)P * rows * l.ld * sizeof(double), 256) : 0;
+  l.off_C = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)P * rows_pad * l.ld * sizeof(double), 256) : 0;
   l.off_flags = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up(gpk_mega_flag_ints(m) * sizeof(int), 256) : 0;
   l.off_Lfin = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)m * l.ld * sizeof(double), 256) : 0;
   l.total = o;
