@@ -66,6 +66,10 @@ _SIGS = {
     "gpk_svgp_elbo_shard": (c_int, [c_void_p, c_int, _dp, c_int, c_long, _dp, _dp, c_int, c_long, c_long,
                                     c_int, c_int, C.POINTER(c_double), c_int, c_double, c_double,
                                     c_double, c_double, _dp, _dp, c_int, c_int, _dp, _dp, _dp, c_size_t]),
+    "gpk_svgp_elbo_sep_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "gpk_svgp_elbo_shard_sep": (c_int, [c_void_p, C.POINTER(c_int), _dp, c_int, c_long, c_long, _dp, _dp, c_int, c_long, c_long,
+                                        c_int, c_int, C.POINTER(c_double), c_int, C.POINTER(c_double), c_double, c_double,
+                                        c_double, _dp, _dp, _dp, _dp, _dp, c_size_t]),
     "gpk_publish_host": (c_int, [c_void_p, _dp, c_int, _dp, c_void_p, c_int]),
     "gpk_profile_gemm_enable": (None, [c_int]),
     "gpk_profile_gemm_collect": (c_int, [C.POINTER(c_double), C.POINTER(c_long), C.POINTER(c_double)]),

@@ -811,10 +811,15 @@ struct GroupSolveArgs {
   const double* L; long ldl;     // L[c0, c0]: top-left element of the group's diagonal block
   const double* X;               // block inverses of the group, consecutive [nb][128][128]
   int rows, nb;
+  long strideE, strideEo, strideL, strideX;   // batched form (blockIdx.y = problem): element offsets between problems
 };
 
 __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
   constexpr int LDK = 130, NBK = 128;
+  {
+    const long b = blockIdx.y;
+    p.E += b * p.strideE; p.Eo += b * p.strideEo; p.L += b * p.strideL; p.X += b * p.strideX;
+  }
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -898,17 +903,20 @@ __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
 }
 
 int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
-                       const double* X, int nb) {
+                       const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX) {
   if (rows <= 0) return 0;
+  if (batch < 1) batch = 1;
   if (!E || !Eo || !Lgg || !X || nb < 1 || nb > 4) return GPK_E_ARG;
   if ((ldl & 1) || (reinterpret_cast<uintptr_t>(Lgg) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return GPK_E_UNSUPPORTED;
+  if (batch > 1 && ((strideL & 1) || (strideX & 1))) return GPK_E_UNSUPPORTED;   // (16-byte LDS-DMA of every problem's tiles)
   constexpr size_t LDS = (size_t)(16 + 128) * 130 * sizeof(double);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(group_solve_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
   GPK_HIP(attr);
   GroupSolveArgs a{};
   a.E = E; a.lde = lde; a.Eo = Eo; a.ldeo = ldeo; a.L = Lgg; a.ldl = ldl; a.X = X; a.rows = rows; a.nb = nb;
-  hipLaunchKernelGGL(group_solve_kernel, dim3((unsigned)gpk_cdiv(rows, 16)), dim3(512), LDS, s, a);
+  a.strideE = strideE; a.strideEo = strideEo; a.strideL = strideL; a.strideX = strideX;
+  hipLaunchKernelGGL(group_solve_kernel, dim3((unsigned)gpk_cdiv(rows, 16), (unsigned)batch), dim3(512), LDS, s, a);
   GPK_LAUNCH_CHECK();
   return 0;
 }
@@ -959,8 +967,8 @@ int launch_cfg(hipStream_t s, const GemmArgs& a) {
 int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
 
 int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
-                           const double* X, int nb) {
-  return launch_group_solve(s, E, lde, Eo, ldeo, rows, Lgg, ldl, X, nb);
+                           const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX) {
+  return launch_group_solve(s, E, lde, Eo, ldeo, rows, Lgg, ldl, X, nb, batch, strideE, strideEo, strideL, strideX);
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events around every GEMM launch, on the

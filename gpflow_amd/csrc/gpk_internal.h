@@ -87,8 +87,10 @@ int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
 
 // fused in-group solve of `rows` right-hand-side rows against nb <= 4 leaf blocks of the factor (gemm.hip); E / Eo point at
 // the group's first column, Lgg at L[c0, c0], X at the group's first block inverse
+// (batch > 1: blockIdx.y walks the problems, strides in elements)
 int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
-                           const double* X, int nb);
+                           const double* X, int nb, int batch = 1, long strideE = 0, long strideEo = 0, long strideL = 0,
+                           long strideX = 0);
 int gpk_gemm_tiles_n(int n);   // number of column tiles the launcher will use for n columns
 int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg)
 int gpk_prof_begin(hipStream_t s, double flops, int kind);   // same facility for other kernels; returns a record index or -1
@@ -115,7 +117,7 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
 
 // ---- reduce.hip: small kernels -------------------------------------------------------------------
 int gpk_launch_zero_upper(hipStream_t s, double* A, int n, long lda, int batch, long strideA);
-int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda);
+int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda, int batch = 1, long strideA = 0);
 int gpk_launch_noop(hipStream_t s);  // empty kernel (stream hand-off probe)
 int gpk_launch_sum_parts(hipStream_t s, const double* part, int nt, int rows, long stridePart, int P,
                          double* ssq);
@@ -129,6 +131,8 @@ int gpk_launch_varexp_stage1(hipStream_t s, const double* Y, long ldy, const dou
                              double mean_const, double* fvar_out, double* part, int* count);
 int gpk_launch_kl_white_stage1(hipStream_t s, const double* q_mu, const double* q_sqrt, int m, int P,
                                int q_diag, double* part, int* count);
+int gpk_launch_row_stats_sep(hipStream_t s, const double* At, long strideAt, int rows, int m, long ldat, const double* V, int P,
+                             double* sumsq, double* mv);
 int gpk_launch_transpose_shift(hipStream_t s, const double* in, int rows, int cols, long ldin,
                                double* out, long ldout, double shift);
 #define GPK_REDUCE_MAXPART 1024

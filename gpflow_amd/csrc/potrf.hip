@@ -301,13 +301,15 @@ int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, double
                     long strideEo, long strideL) {
   int rc;
   const int nbk = (c1 - c0) / NB;
-  if (batch <= 1 && nbk >= 2 && nbk <= 4 && nbk * NB == c1 - c0 && (c0 % NB) == 0 && rows >= GPK_TUNE(GROUP_FUSED_MIN_ROWS, 1024) &&
+  // (a batch of problems: blockIdx.y walks them; C5 with separate kernels 2.14 -> 2.07 ms against the tiled per-block launches)
+  const bool batch_ok = batch <= 1 || (GPK_TUNE(GROUP_FUSED_BATCH, 1) && !(strideL & 1) && !(strideInv & 1));
+  if (batch_ok && nbk >= 2 && nbk <= 4 && nbk * NB == c1 - c0 && (c0 % NB) == 0 && rows >= GPK_TUNE(GROUP_FUSED_MIN_ROWS, 1024) &&
       !(ldl & 1) && !(reinterpret_cast<uintptr_t>(L + (long)c0 * ldl + c0) & 15) &&
       !(reinterpret_cast<uintptr_t>(invd + (long)(c0 / NB) * NB * NB) & 15) && GPK_TUNE(GROUP_FUSED, 1)) {
     // (the fused kernel stages its operand tiles by 16-byte LDS-DMA: an 8-byte-aligned factor takes the per-block loop below)
     // the whole in-group phase (nbk solves + nbk - 1 updates of the latency kernel) as ONE launch with the same arithmetic
     rc = gpk_launch_group_solve(s, E + c0, lde, Eo + c0, ldeo, rows, L + (long)c0 * ldl + c0, ldl, invd + (long)(c0 / NB) * NB * NB,
-                                nbk);
+                                nbk, batch, strideE, strideEo, strideL, strideInv);
     if (rc) return rc;
   } else {
     for (int j0 = c0; j0 < c1; j0 += NB) {
@@ -467,7 +469,9 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
   int xg0 = 0;         // first column of the current extra-row group
-  const int xgroup = std::max(NB, (GPK_TUNE(XGROUP, NBO) / NB) * NB);
+  // (512 columns for M = 2048: 256 / 384 measured slower there; 256 for M <= 1024, where the extra-row stream otherwise starts
+  // after half of the chain: C5 shared 1.376 -> 1.331 ms, C5 separate 2.036 -> 1.977 ms, profiles/r04_ab_c5.log)
+  const int xgroup = std::max(NB, ((n <= 1024 ? GPK_TUNE(XGROUP_SMALL, 256) : GPK_TUNE(XGROUP, NBO)) / NB) * NB);
   for (int p = 0; p < npanels; ++p) {
     const int c0 = cuts[p], c1 = cuts[p + 1];
     const int c2 = (p + 2 <= npanels) ? cuts[p + 2] : n;
@@ -904,4 +908,109 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   const double* p1[1] = {part1};
   const double half = 0.5;
   return gpk_launch_final(s, 1, p1, &c1, &half, -0.5 * (double)m * (double)P, out + 1);
+}
+
+// ---- fused driver: one shard of SVGP.elbo with SEPARATE kernels per latent (SeparateIndependent, whitened, full q_sqrt) --------
+namespace {
+struct ElboSepLayout {
+  long ld, strideT;
+  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, total;
+};
+ElboSepLayout elbo_sep_layout(int m, int rows, int P) {
+  ElboSepLayout l{};
+  l.ld = (long)gpk_align_up((size_t)m, 8);
+  l.strideT = (long)(m + rows) * l.ld;
+  size_t o = 0;
+  l.off_T = o; o += gpk_align_up((size_t)P * l.strideT * sizeof(double), 256);
+  l.off_invd = o; o += gpk_align_up(gpk_invd_elems(m, P) * sizeof(double), 256);
+  l.off_LqT = o; o += gpk_align_up((size_t)P * m * l.ld * sizeof(double), 256);
+  l.off_s0 = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
+  l.off_fmean = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
+  l.off_ssq = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
+  l.off_proj = o; o += gpk_align_up(gpk_project_workspace_bytes(rows, m, P), 256);
+  l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
+  l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
+  l.total = o;
+  return l;
+}
+}  // namespace
+
+extern "C" size_t gpk_svgp_elbo_sep_workspace_bytes(int m, int rows, int d, int P) {
+  (void)d;
+  return elbo_sep_layout(m, rows, P).total;
+}
+
+// The P problems of conditionals/util.py:566-629 (tf.map_fn over the latents) share nothing but the minibatch: P covariance
+// pairs built straight into ONE batched trapezoid [P][(m + rows) x ld], one batched factorisation with the minibatch rows riding
+// along (gpk_potrf, batch = P), one batched row-statistics launch, one batched projection, one reduction.  Composed from the
+// Python mirror the same step issues ~50 launches with host gaps between them (profiles/r04_c5sep_timeline_composed.txt).
+// (Measured and not kept: the extra rows solved out of place against EXPLICIT 512-column group inverses -- nine short launches
+// for the inverses + one triangular-K GEMM per group instead of the fused in-group kernel: 2.15 / 2.16 against 2.14 ms.)
+extern "C" int gpk_svgp_elbo_shard_sep(void* stream, const int* family_host, const double* Z, int m, long ldz, long strideZ,
+                                       const double* Xb, const double* Yb, int rows, long ldxb, long ldyb, int d, int P,
+                                       const double* ls_host, int ard, const double* variance_host, double noise_variance,
+                                       double jitter, double mean_const, const double* q_mu, const double* q_sqrt, double* out,
+                                       int* info, void* ws, size_t ws_bytes) {
+  if (!family_host || !Z || !Xb || !Yb || !q_mu || !q_sqrt || !ls_host || !variance_host || !out || !info || m <= 0 || rows < 0 ||
+      P <= 0 || P > 16 || d <= 0 || strideZ < 0)
+    return GPK_E_ARG;
+  const ElboSepLayout l = elbo_sep_layout(m, rows, P);
+  if (!ws || ws_bytes < l.total) return GPK_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)ws;
+  double* T = (double*)(w + l.off_T);
+  double* invd = (double*)(w + l.off_invd);
+  double* LqT = (double*)(w + l.off_LqT);
+  double* s0 = (double*)(w + l.off_s0);
+  double* fmean = (double*)(w + l.off_fmean);
+  double* ssq = (double*)(w + l.off_ssq);
+  double* part0 = (double*)(w + l.off_part0);
+  double* part1 = (double*)(w + l.off_part1);
+  const int nls = ard ? d : 1;
+  int rc;
+  // Kuu_p + jitter I (lower tiles): the chain's first (batched) leaf waits for nothing else
+  for (int p = 0; p < P; ++p) {
+    rc = gpk_kernel_matrix(stream, family_host[p], Z + (long)p * strideZ, m, ldz, nullptr, 0, 0, d, ls_host + (long)p * nls, ard,
+                           variance_host[p], jitter, 1, T + (long)p * l.strideT, l.ld);
+    if (rc) return rc;
+  }
+  const bool side = m > GPK_NB && m < 4096 && rows > 256;
+  int c1 = 0;
+  auto kl_and_transpose = [&](hipStream_t xs) -> int {
+    int r = gpk_transpose((void*)xs, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
+    if (r) return r;
+    r = gpk_launch_kl_white_stage1(xs, q_mu, q_sqrt, m, P, 0, part1, &c1);
+    if (r) return r;
+    const double* p1s[1] = {part1};
+    const double halfs = 0.5;
+    return gpk_launch_final(xs, 1, p1s, &c1, &halfs, -0.5 * (double)m * (double)P, out + 1);
+  };
+  const std::function<int(hipStream_t)> prologue = [&](hipStream_t xs) -> int {
+    for (int p = 0; p < P; ++p) {
+      const int r = gpk_kernel_matrix((void*)xs, family_host[p], Xb, rows, ldxb, Z + (long)p * strideZ, m, ldz, d,
+                                      ls_host + (long)p * nls, ard, variance_host[p], 0.0, 0, T + (long)p * l.strideT + (long)m * l.ld,
+                                      l.ld);
+      if (r) return r;
+    }
+    return side ? kl_and_transpose(xs) : 0;
+  };
+  rc = potrf_core(s, T, m, rows, l.ld, P, l.strideT, invd, 0, info, &prologue);
+  if (rc) return rc;
+  if (!side) {
+    rc = kl_and_transpose(s);
+    if (rc) return rc;
+  }
+  const double* At = T + (long)m * l.ld;
+  rc = gpk_launch_row_stats_sep(s, At, l.strideT, rows, m, l.ld, q_mu, P, s0, fmean);
+  if (rc) return rc;
+  rc = gpk_project_batched(stream, At, rows, m, l.ld, l.strideT, LqT, l.ld, P, ssq, w + l.off_proj,
+                           gpk_project_workspace_bytes(rows, m, P));
+  if (rc) return rc;
+  int c0 = 0;
+  rc = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean, rows, P, s0, 1, ssq, variance_host, 1, noise_variance, mean_const, nullptr, part0,
+                                &c0);
+  if (rc) return rc;
+  const double* p0[1] = {part0};
+  const double one = 1.0;
+  return gpk_launch_final(s, 1, p0, &c0, &one, 0.0, out);
 }

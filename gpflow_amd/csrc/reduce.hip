@@ -139,6 +139,29 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const double* __restrict
   }
 }
 
+// ---- the same for P separate At_p (SeparateIndependent latents): sumsq[p, b] = sum_k At_p[b,k]^2, mv[b, p] = sum_k At_p[b,k] V[k,p];
+// one wave per (row, latent), blockIdx.y = p: ONE launch instead of P (plus P strided-column copies of V on the host side)
+__global__ __launch_bounds__(256) void row_stats_sep_kernel(const double* __restrict__ At, long strideAt, int rows, int m, long ldat,
+                                                            const double* __restrict__ V, int P, double* __restrict__ sumsq,
+                                                            double* __restrict__ mv) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w, p = blockIdx.y;
+  if (row >= rows) return;
+  const double* a = At + (long)p * strideAt + (long)row * ldat;
+  double s = 0.0, dv = 0.0;
+  for (int k = lane; k < m; k += 64) {
+    const double x = a[k];
+    s = fma(x, x, s);
+    dv = fma(x, V[(long)k * P + p], dv);
+  }
+  s = wave_sum(s);
+  dv = wave_sum(dv);
+  if (lane == 0) {
+    sumsq[(long)p * rows + row] = s;
+    mv[(long)row * P + p] = dv;
+  }
+}
+
 // ---- out[i] = beta*out[i] + alpha * sum_j A[i,j] B[i,j]  (one wave per row) --------------------------
 __global__ __launch_bounds__(256) void row_dot_kernel(const double* __restrict__ A, long lda,
                                                       const double* __restrict__ B, long ldb, int rows,
@@ -315,9 +338,10 @@ int nblocks_for(long elems) {
 
 // ================================================================================================
 namespace {
-__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int n, long lda) {
+__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int n, long lda, long strideA) {
   const int row = blockIdx.y;
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) A[(long)row * lda + c] = (c == row) ? 1.0 : 0.0;
+  double* a = A + (long)blockIdx.z * strideA;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) a[(long)row * lda + c] = (c == row) ? 1.0 : 0.0;
 }
 }  // namespace
 namespace {
@@ -329,10 +353,10 @@ int gpk_launch_noop(hipStream_t s) {
   return 0;
 }
 
-int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda) {
+int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda, int batch, long strideA) {
   if (n <= 0) return 0;
-  dim3 grid((unsigned)gpk_cdiv(n, 256), (unsigned)n, 1);
-  hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, A, n, lda);
+  dim3 grid((unsigned)gpk_cdiv(n, 256), (unsigned)n, (unsigned)(batch > 0 ? batch : 1));
+  hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, A, n, lda, strideA);
   GPK_LAUNCH_CHECK();
   return 0;
 }
@@ -380,6 +404,16 @@ extern "C" int gpk_row_stats(void* stream, const double* At, int rows, int m, lo
     GPK_LAUNCH_CHECK();
     p0 += 4;
   } while (p0 < np);
+  return 0;
+}
+
+int gpk_launch_row_stats_sep(hipStream_t s, const double* At, long strideAt, int rows, int m, long ldat, const double* V, int P,
+                             double* sumsq, double* mv) {
+  if (!At || !V || !sumsq || !mv || rows < 0 || m < 0 || P <= 0) return GPK_E_ARG;
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(row_stats_sep_kernel, dim3((unsigned)gpk_cdiv(rows, 4), (unsigned)P), dim3(256), 0, s, At, strideAt, rows, m,
+                     ldat, V, P, sumsq, mv);
+  GPK_LAUNCH_CHECK();
   return 0;
 }
 

@@ -77,6 +77,29 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             return None
         return k, iv.Z.device_value(), c
 
+    def _fused_separate_config(self):
+        """(member kernels, Z [m, d] | [P, m, d], mean constant) when the ELBO shard of a SeparateIndependent model is one
+        C-ABI call (gpk_svgp_elbo_shard_sep): whitened, Gaussian likelihood, constant mean, full q_sqrt, stationary members
+        over all input columns, inducing POINTS shared by the latents or one equally sized set per latent."""
+        from ..kernels import SeparateIndependent
+        from ..inducing_variables import SeparateIndependentInducingVariables
+        if not self.whiten or not isinstance(self.likelihood, Gaussian) or self.q_sqrt.device_value().dim() != 3:
+            return None
+        c = self.mean_function.constant_value()
+        k, iv = self.kernel, self.inducing_variable
+        if c is None or not isinstance(k, SeparateIndependent):
+            return None
+        if not all(isinstance(kk, Stationary) and kk.has_default_active_dims for kk in k.kernels):
+            return None
+        if isinstance(iv, SharedIndependentInducingVariables) and isinstance(iv.inducing_variable, InducingPoints):
+            return k.kernels, iv.inducing_variable.Z.device_value().contiguous(), c
+        if isinstance(iv, SeparateIndependentInducingVariables) and len(iv.inducing_variable_list) == len(k.kernels) \
+                and all(isinstance(v, InducingPoints) for v in iv.inducing_variable_list):
+            Zs = [v.Z.device_value() for v in iv.inducing_variable_list]
+            if len({tuple(z.shape) for z in Zs}) == 1:
+                return k.kernels, torch.stack(Zs).contiguous(), c
+        return None
+
     def elbo_terms(self, data):
         """(sum_b var_exp_b over the given rows, KL) as a 2-element device tensor -- the two pieces
         svgp.py:172-174 combines; the first is what gets all-reduced when the minibatch is sharded."""
@@ -95,6 +118,25 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                                             lengthscales=ls, noise_variance=self.likelihood.noise_variance(),
                                             jitter=config.default_jitter(), mean_const=c, family=family,
                                             ws=self._ws[1])
+            ops.check_info(info)
+            return out
+        sep = self._fused_separate_config()
+        if sep is not None:
+            kernels, Zs, c = sep
+            hyp = [k.hyper() for k in kernels]
+            P, m, d, rows = len(kernels), Zs.shape[-2], Zs.shape[-1], X.shape[0]
+            ls = [np.atleast_1d(h[2]) for h in hyp]
+            if any(l.size > 1 for l in ls):   # mixed isotropic / ARD members: every row spelled out
+                ls = np.stack([np.broadcast_to(l, (d,)) for l in ls])
+            else:
+                ls = np.concatenate(ls)
+            key = ("sep", m, rows, d, P)
+            if self._ws is None or self._ws[0] != key:
+                self._ws = (key, ops.svgp_elbo_sep_workspace(m, rows, d, P))
+            out, info = ops.svgp_elbo_shard_sep(Zs, X.contiguous(), Y, self.q_mu.device_value(), self.q_sqrt.device_value(),
+                                                variances=[h[1] for h in hyp], lengthscales=ls, families=[h[0] for h in hyp],
+                                                noise_variance=self.likelihood.noise_variance(),
+                                                jitter=config.default_jitter(), mean_const=c, ws=self._ws[1])
             ops.check_info(info)
             return out
         kl = self.prior_kl()

@@ -521,6 +521,54 @@ class HostMailbox:
         return self._vals.copy(), int(tail[0])
 
 
+def svgp_elbo_sep_workspace(m: int, rows: int, d: int, P: int) -> torch.Tensor:
+    lib = _lib.load()
+    return _ws(int(lib.gpk_svgp_elbo_sep_workspace_bytes(m, rows, d, P)))
+
+
+def svgp_elbo_shard_sep(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor, q_sqrt: torch.Tensor, *,
+                        variances, lengthscales, families, noise_variance: float, jitter: float, mean_const: float = 0.0,
+                        ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                        info: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Whitened shard with one kernel PER latent (SeparateIndependent): Z [m, d] (shared) or [P, m, d]; variances [P],
+    lengthscales [P] (isotropic) or [P, d], families [P] names; q_sqrt [P, m, m].  out[0] = sum_b var_exp_b, out[1] = KL;
+    info [P].  Returns (out, info)."""
+    lib = _lib.load()
+    for name, t in (("Xb", Xb), ("Yb", Yb), ("q_mu", q_mu)):
+        _chk(t, name, 2)
+    _chk(Z, "Z")
+    _chk(q_sqrt, "q_sqrt", 3)
+    P = q_mu.shape[1]
+    shared = Z.dim() == 2
+    m, d = Z.shape[-2], Z.shape[-1]
+    rows = Xb.shape[0]
+    if (not shared and (Z.dim() != 3 or Z.shape[0] != P)) or Xb.shape[1] != d or Yb.shape[0] != rows or Yb.shape[1] != P \
+            or q_mu.shape[0] != m or tuple(q_sqrt.shape) != (P, m, m) or len(families) != P:
+        raise ValueError("inconsistent shapes")
+    if not (Z.is_contiguous() and q_mu.is_contiguous() and q_sqrt.is_contiguous()):
+        raise ValueError("Z / q_mu / q_sqrt must be contiguous")
+    ls = np.asarray(lengthscales, dtype=np.float64)
+    var = np.asarray(variances, dtype=np.float64).reshape(-1)
+    if var.size != P or ls.shape[0] != P or (ls.ndim == 2 and ls.shape[1] != d) or ls.ndim > 2:
+        raise ValueError("variances / lengthscales: one entry (row) per latent")
+    ard = int(ls.ndim == 2)
+    nbytes = int(lib.gpk_svgp_elbo_sep_workspace_bytes(m, rows, d, P))
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = _ws(nbytes)
+    if out is None:
+        out = torch.empty(2, dtype=torch.float64, device=Xb.device)
+    if info is None:
+        info = torch.zeros(P, dtype=torch.int32, device=Xb.device)
+    fam = (_lib.C.c_int * P)(*[KERNEL_FAMILIES[f] for f in families])
+    rc = lib.gpk_svgp_elbo_shard_sep(_stream(), fam, Z.data_ptr(), m, d, 0 if shared else m * d, Xb.data_ptr(), Yb.data_ptr(), rows,
+                                     _rowmajor(Xb, "Xb"), _rowmajor(Yb, "Yb"), d, P, _lib.host_doubles(ls.reshape(-1).tolist()), ard,
+                                     _lib.host_doubles(var.tolist()), float(noise_variance), float(jitter), float(mean_const),
+                                     q_mu.data_ptr(), q_sqrt.data_ptr(), out.data_ptr(), info.data_ptr(), ws.data_ptr(),
+                                     ws.numel() * 8)
+    _lib.check(rc, "gpk_svgp_elbo_shard_sep")
+    return out, info
+
+
 def svgp_elbo_workspace(m: int, rows: int, d: int, P: int, q_diag: bool) -> torch.Tensor:
     lib = _lib.load()
     return _ws(int(lib.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, int(q_diag))))

@@ -243,6 +243,18 @@ int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long l
                         const double* q_sqrt, int q_diag, int whiten, double* out, int* info,
                         void* ws, size_t ws_bytes);
 
+/* The same for SEPARATE kernels per latent (SeparateIndependent, conditionals/util.py:566-629 behind
+ * SeparateIndependentPosterior posteriors.py:863-887), whitened, full q_sqrt [P,m,m]: P covariance pairs into one batched
+ * trapezoid, ONE batched factorisation / row-statistics / projection launch sequence instead of the reference's tf.map_fn.
+ * family_host [P], variance_host [P], ls_host [P][d] (ard) or [P]: HOST arrays.  Z: latent p's inducing points at
+ * Z + p * strideZ (strideZ = 0: shared).  info: P device ints (one factorisation status per latent). */
+size_t gpk_svgp_elbo_sep_workspace_bytes(int m, int rows, int d, int P);
+int gpk_svgp_elbo_shard_sep(void* stream, const int* family_host, const double* Z, int m, long ldz, long strideZ,
+                            const double* Xb, const double* Yb, int rows, long ldxb, long ldyb, int d, int P,
+                            const double* ls_host, int ard, const double* variance_host, double noise_variance,
+                            double jitter, double mean_const, const double* q_mu, const double* q_sqrt, double* out,
+                            int* info, void* ws, size_t ws_bytes);
+
 /* ---- result mailbox in mapped host memory ------------------------------------------------------------------------
  * Copies n doubles from device memory `src` (and one int from `info`, may be NULL) into `host_dst`, a buffer of PINNED,
  * device-mapped host memory (hipHostMalloc / torch pin_memory) laid out as { double vals[n]; int32 info; int32 seq; },

@@ -331,6 +331,39 @@ def gpr_lml(X, Y, *, variance, lengthscales, noise_variance, mean_const=0.0, fam
     return lml.reshape(1), info
 
 
+def svgp_elbo_sep_workspace(m, rows, d, P):
+    return torch.empty(1, dtype=torch.float64)
+
+
+def svgp_elbo_shard_sep(Z, Xb, Yb, q_mu, q_sqrt, *, variances, lengthscales, families, noise_variance, jitter, mean_const=0.0,
+                        ws=None, out=None, info=None):
+    """gpk_svgp_elbo_shard_sep emulated by its chain of primitives (whitened; one kernel per latent; full q_sqrt)."""
+    P = q_mu.shape[1]
+    M, rows = Z.shape[-2], Xb.shape[0]
+    ls = np.asarray(lengthscales, dtype=np.float64)
+    T = torch.empty((P, M + rows, M), dtype=torch.float64)
+    for p in range(P):
+        Zp = Z if Z.dim() == 2 else Z[p]
+        kw = dict(variance=float(variances[p]), lengthscales=ls[p], family=families[p])
+        kernel_matrix(Zp, None, diag_add=jitter, lower_only=True, out=T[p, :M], **kw)
+        if rows:
+            kernel_matrix(Xb, Zp, out=T[p, M:], **kw)
+    _, inf = potrf_(T, M)
+    res = torch.zeros(2, dtype=torch.float64)
+    if not bool((inf != 0).any()):
+        s0 = torch.stack([row_stats(T[p, M:].contiguous(), V=q_mu[:, p:p + 1].contiguous())[0] for p in range(P)])
+        fmean = torch.stack([row_stats(T[p, M:].contiguous(), V=q_mu[:, p:p + 1].contiguous())[1][:, 0] for p in range(P)], dim=1)
+        ssq = project(T[:, M:], transpose(q_sqrt, mode=1))
+        ve, _ = gaussian_varexp_sum(Yb, fmean.contiguous(), s0=s0, ssq=ssq, knn=[float(v) for v in variances],
+                                    noise_variance=noise_variance, mean_const=mean_const, s0_per_latent=True)
+        res[0] = ve[0]
+        res[1] = gauss_kl_white(q_mu, q_sqrt)[0]
+    if out is not None:
+        out.copy_(res)
+        res = out
+    return res, inf
+
+
 def svgp_elbo_workspace(m, rows, d, P, q_diag):
     return torch.empty(1, dtype=torch.float64)
 
