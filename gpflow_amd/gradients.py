@@ -25,6 +25,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Tuple
 
+import collections
+
 import numpy as np
 import torch
 
@@ -100,6 +102,25 @@ def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor) 
     return S.add_(ops.transpose(S)).mul_(0.5)
 
 
+_ls_cache: "collections.OrderedDict" = collections.OrderedDict()
+
+
+def ls_device(lengthscales, D: int, device) -> torch.Tensor:
+    """Lengthscales as a [D] device tensor.  A host array -> device copy from pageable memory BLOCKS the host until the stream
+    has drained; in the tail of a reverse pass that serialised ~80 short launches behind an idle GPU (1 ms of a 6.5-ms training
+    step, profiles/r04_train_timeline_before.txt).  The tensors are therefore made once per set of values -- the gradient entry
+    points ask for them BEFORE they enqueue their first kernel -- and found here by the adjoints."""
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(lengthscales, dtype=np.float64), (D,)))
+    key = (a.tobytes(), str(device))
+    t = _ls_cache.get(key)
+    if t is None:
+        t = torch.as_tensor(a.copy(), device=device)
+        _ls_cache[key] = t
+        while len(_ls_cache) > 32:
+            _ls_cache.popitem(last=False)
+    return t
+
+
 def stationary_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, variance: float, lengthscales,
                               symmetric: bool, family: str = "SquaredExponential"):
     """Adjoint of K = variance * f(r(A / ls, Bm / ls)) [n1, n2] given Kbar [n1, n2], f one of the stationary families of
@@ -113,7 +134,7 @@ def stationary_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Ten
     SquaredExponential -2 dK/dr2 = K, so G also carries d/dvariance = sum(Kbar .* K) / variance; the Matern families
     take that sum from a second pass (op 1)."""
     n1, D = A.shape
-    ls = torch.as_tensor(np.broadcast_to(np.asarray(lengthscales, dtype=np.float64), (D,)).copy(), device=A.device)
+    ls = ls_device(lengthscales, D, A.device)
     if family == "SquaredExponential":
         G = ops.kernel_matrix_hadamard(A, Bm, Kbar, variance=variance, lengthscales=lengthscales)   # Kbar .* K
         sum_kbar_k = None
@@ -187,6 +208,12 @@ class KernelSpec:
             return [kd / v for _, v, _ in self.members]
         return [1.0] * self.n
 
+    def warm(self, device, D: int) -> "KernelSpec":
+        """device copies of the members' lengthscales, made now (see `ls_device`)"""
+        for _, _, ls in self.members:
+            ls_device(ls, D, device)
+        return self
+
     def adjoint(self, A, Bm, Kbar, symmetric: bool):
         dvs, dls, Abar = [], [], None
         for i, (f, v, ls) in enumerate(self.members):
@@ -234,6 +261,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
         raise ValueError("svgp_elbo_and_grad needs q_sqrt [P, M, M] or, for q_diag, [M, P]")
     dev = Z.device
     spec = kernel_spec if kernel_spec is not None else KernelSpec.single(variance, lengthscales, family)
+    spec.warm(dev, D)   # (device copies of the lengthscales BEFORE the first kernel is enqueued: see ls_device)
 
     # ---------------------------------------------------------------- forward (intermediates kept)
     # trapezoid = [Kuu + jitter I ; Kfu ; I]: the factorisation returns Lm, At = Kfu Lm^-T and, from the identity
@@ -331,6 +359,7 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float = None
     P = Y.shape[1]
     dev = X.device
     spec = kernel_spec if kernel_spec is not None else KernelSpec.single(variance, lengthscales, family)
+    spec.warm(dev, D)   # (device copies of the lengthscales BEFORE the first kernel is enqueued: see ls_device)
     T = torch.empty((N + P + N, N), dtype=torch.float64, device=dev)
     spec.build(X, None, T[:N], diag_add=noise_variance)
     T[N:N + P] = (Y - mean_const).t()
@@ -378,6 +407,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     if not sharded and N != n:
         raise ValueError("num_data differs from the number of rows of a model that is not sharded")
     kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+    ls_device(lengthscales, D, Z.device)   # (before the first kernel is enqueued: see ls_device)
 
     def all_reduce(t):
         if sharded:
@@ -481,6 +511,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
         raise ValueError("svgp_elbo_and_grad_unwhitened needs q_sqrt [P, M, M] or, for q_diag, [M, P]")
     dev = Z.device
     kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+    ls_device(lengthscales, D, Z.device)   # (before the first kernel is enqueued: see ls_device)
     k = float(kl_weight)
     T = torch.empty((M + B + M, M), dtype=torch.float64, device=dev)
     ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)

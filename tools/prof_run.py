@@ -1,5 +1,6 @@
 """Workload for rocprofv3 --kernel-trace --stats: a few SVGP steps (Cm), one N=16384 GPR LML, or (c5sep) a few ELBO
-evaluations of BASELINE config C5 with SeparateIndependent kernels through the model surface."""
+evaluations of BASELINE config C5 with SeparateIndependent kernels through the model surface, or (train) a few forward +
+reverse evaluations of the SVGP step at Cm."""
 import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 import sys
@@ -51,3 +52,17 @@ if which == "c5sep":
     for _ in range(4):
         v = float(mp.elbo((X, Y)))
     print("c5sep", v)
+if which == "train":
+    from gpflow_amd import gradients
+    m, B, d = 2048, 8192, 8
+    Z = ops.to_device(rng.normal(size=(m, d)))
+    Xb = ops.to_device(rng.normal(size=(B, d)))
+    Yb = ops.to_device(np.sin(rng.normal(size=(B, 1))))
+    q_mu = ops.to_device(0.1 * rng.normal(size=(m, 1)))
+    q_sqrt = ops.to_device((np.tril(0.05 * rng.normal(size=(m, m))) + 0.5 * np.eye(m))[None])
+    ls = np.sqrt(d) * (0.8 + 0.05 * np.arange(d))
+    for _ in range(4):
+        out = gradients.svgp_elbo_and_grad(Z, Xb, Yb, q_mu, q_sqrt, variance=1.0, lengthscales=ls, noise_variance=0.1, jitter=1e-6,
+                                           scale=100.0)
+    torch.cuda.synchronize()
+    print("train", float(out[0]))
