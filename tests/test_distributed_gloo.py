@@ -258,6 +258,18 @@ def _product_worker(rank, world, port, q, backend):
                                gpflow.likelihoods.Gaussian(0.2), Z, q_mu=q_mu, q_sqrt=q_sqrt, num_data=7000)
         elbo = float(distributed.svgp_elbo_data_parallel(m, (ops.to_device(X), ops.to_device(Y))))
         ref = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt, variance=1.1, lengthscales=ls, noise_variance=0.2, num_data=7000)
+        # the same exchange with one kernel per latent (gpk_svgp_elbo_shard_sep behind SVGP.elbo_terms)
+        vs, lss = [1.1, 0.8], [0.9 * np.sqrt(D), 1.2 * np.sqrt(D)]
+        ksep = gpflow.kernels.SeparateIndependent([gpflow.kernels.SquaredExponential(variance=v, lengthscales=l)
+                                                   for v, l in zip(vs, lss)])
+        iv = gpflow.inducing_variables.SharedIndependentInducingVariables(gpflow.inducing_variables.InducingPoints(Z))
+        ms = gpflow.models.SVGP(ksep, gpflow.likelihoods.Gaussian(0.2), iv, q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=P,
+                                num_data=7000)
+        assert ms._fused_separate_config() is not None
+        elbo_s = float(distributed.svgp_elbo_data_parallel(ms, (ops.to_device(X), ops.to_device(Y))))
+        ref_s = orc.svgp_elbo_separate(X, Y, [Z] * P, q_mu, q_sqrt, variances=vs, lengthscales_list=lss, noise_variance=0.2,
+                                       whiten=True, num_data=7000)
+        np.testing.assert_allclose(elbo_s, ref_s, rtol=1e-9)
         q.put((rank, elbo, ref))
     finally:
         dist.destroy_process_group()
