@@ -100,6 +100,50 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                 return k.kernels, torch.stack(Zs).contiguous(), c
         return None
 
+    def _unwhitened_shared_factor_config(self):
+        """(stationary kernel, Z) when the un-whitened ELBO can run on ONE factorisation of Kuu: one stationary kernel
+        shared by the latents over inducing points, full q_sqrt."""
+        if self.whiten or self.q_sqrt.device_value().dim() != 3:
+            return None
+        k, iv = self.kernel, self.inducing_variable
+        if isinstance(k, SharedIndependent) and isinstance(iv, SharedIndependentInducingVariables):
+            k, iv = k.kernel, iv.inducing_variable
+        if not (isinstance(k, Stationary) and isinstance(iv, InducingPoints)):
+            return None
+        return k, iv.Z.device_value()
+
+    def _elbo_terms_unwhitened(self, X, Y, k, Z):
+        """whiten=False on one trapezoid.  The reference factors Kuu twice per ELBO -- `prior_kl` -> `gauss_kl(K=Kuu)`
+        (kullback_leiblers.py:107) and the conditional (conditionals/util.py:67) -- and so did the composed path here: two
+        latency chains of 16 panels each (profiles/r04_unwhitened_timeline_before.txt).  Here [Kuu + jitter I ; Kfu ; q_mu^T ;
+        tril(q_sqrt_p)^T] goes through ONE factorisation: the minibatch rows come back as A^T = Kfu Lm^-T (util.py:125), the
+        others as (Lm^-1 q_mu)^T and (Lm^-1 Lq_p)^T, i.e. the Mahalanobis and trace terms of the KL (:114, :152).  Same
+        arithmetic per term, one chain."""
+        from ..conditionals import Factor, conditional_tail
+        Xs, Zs = k.slice(X, Z)
+        q_mu, q_sqrt = self.q_mu.device_value(), self.q_sqrt.device_value()
+        M, P = q_mu.shape
+        B = Xs.shape[0]
+        T = torch.empty((M + B + P + P * M, M), dtype=torch.float64, device=Xs.device)
+        k.K_into(Zs, None, T[:M], diag_add=config.default_jitter(), lower_only=True)
+        if B:
+            k.K_into(Xs, Zs, T[M:M + B])
+        T[M + B:M + B + P] = q_mu.t()
+        ops.transpose(q_sqrt.contiguous(), mode=1, out=T[M + B + P:].view(P, M, M))       # tril(q_sqrt_p)^T
+        invd, info = ops.potrf_(T, M, zero_upper=True)
+        fac = Factor(T[:M], invd)
+        # KL[q || N(0, Kuu)]  (kullback_leiblers.py:98-165)
+        mahalanobis = ops.sumsq(T[M + B:M + B + P])[0]
+        trace = ops.sumsq(T[M + B + P:])[0]
+        logdet_qcov = torch.log(torch.diagonal(q_sqrt, dim1=-2, dim2=-1) ** 2).sum()
+        kl = 0.5 * (mahalanobis - float(M * P) - logdet_qcov + trace + float(P) * 2.0 * ops.sum_log_diag(T[:M])[0])
+        # q(f) at the minibatch (posteriors.py:828-841 -> conditionals/util.py:128-167), then the likelihood's expectations
+        f_mean, f_var = conditional_tail(T[M:M + B], fac, k.K_diag(Xs), q_mu, full_cov=False, q_sqrt=q_sqrt, white=False)
+        f_mean = f_mean + self.mean_function(X)
+        var_exp = self.likelihood.variational_expectations(X, f_mean, f_var, Y)
+        ops.check_info(info)
+        return torch.stack([var_exp.sum(), kl])
+
     def elbo_terms(self, data):
         """(sum_b var_exp_b over the given rows, KL) as a 2-element device tensor -- the two pieces
         svgp.py:172-174 combines; the first is what gets all-reduced when the minibatch is sharded."""
@@ -139,6 +183,9 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                                                 jitter=config.default_jitter(), mean_const=c, ws=self._ws[1])
             ops.check_info(info)
             return out
+        shared = self._unwhitened_shared_factor_config()
+        if shared is not None:
+            return self._elbo_terms_unwhitened(X, Y, *shared)
         kl = self.prior_kl()
         f_mean, f_var = self.predict_f(X, full_cov=False, full_output_cov=False)
         var_exp = self.likelihood.variational_expectations(X, f_mean, f_var, Y)

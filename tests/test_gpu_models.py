@@ -502,6 +502,31 @@ def test_separate_independent_fused_driver_matches_composed_path(gp):
     assert m._fused_separate_config() is None
 
 
+def test_unwhitened_elbo_on_one_factorisation_matches_the_two_factorisation_path(gp):
+    """whiten=False: SVGP.elbo on ONE trapezoid [Kuu ; Kfu ; q_mu^T ; tril(q_sqrt)^T] (KL and conditional share the Cholesky
+    of Kuu) against the reference's structure -- prior_kl with its own factorisation + predict_f with another -- and against
+    the oracle; shared multi-output kernel, constant mean, Matern member."""
+    rng = np.random.default_rng(23)
+    X, Y, Z, q_mu, q_sqrt = _svgp_data(rng, 260, 3, 2, 150)
+    for kern, okw in ((gp.kernels.SquaredExponential(variance=1.2, lengthscales=[0.9, 1.3, 1.1]), None),
+                      (gp.kernels.SharedIndependent(gp.kernels.Matern52(variance=0.9, lengthscales=1.4), output_dim=2), None)):
+        iv = Z if not isinstance(kern, gp.kernels.SharedIndependent) else \
+            gp.inducing_variables.SharedIndependentInducingVariables(gp.inducing_variables.InducingPoints(Z))
+        m = gp.models.SVGP(kern, gp.likelihoods.Gaussian(0.15), iv, q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=2, whiten=False,
+                           num_data=4000, mean_function=gp.mean_functions.Constant(-0.2))
+        assert m._unwhitened_shared_factor_config() is not None
+        one = float(m.elbo((X, Y)))
+        m._unwhitened_shared_factor_config = lambda: None
+        two = float(m.elbo((X, Y)))
+        np.testing.assert_allclose(one, two, rtol=1e-10)
+    ref = orc.svgp_elbo(X, Y - (-0.2), Z, q_mu, q_sqrt, variance=1.2, lengthscales=np.array([0.9, 1.3, 1.1]), noise_variance=0.15,
+                        whiten=False, num_data=4000)
+    m = gp.models.SVGP(gp.kernels.SquaredExponential(variance=1.2, lengthscales=[0.9, 1.3, 1.1]), gp.likelihoods.Gaussian(0.15), Z,
+                       q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=2, whiten=False, num_data=4000,
+                       mean_function=gp.mean_functions.Constant(-0.2))
+    np.testing.assert_allclose(float(m.elbo((X, Y))), ref, rtol=1e-9)
+
+
 def test_golden_vectors(gp):
     """The committed golden fixtures (tests/golden/*.npz, generated from the oracle on the reference's
     own test fixtures) reproduce on the device."""

@@ -66,3 +66,17 @@ if which == "train":
                                            scale=100.0)
     torch.cuda.synchronize()
     print("train", float(out[0]))
+if which == "unwh":
+    import gpflow_amd as gpflow
+    m, B, d = 2048, 8192, 8
+    Zh = rng.normal(size=(m, d))
+    X = ops.to_device(rng.normal(size=(B, d)))
+    Y = ops.to_device(np.sin(rng.normal(size=(B, 1))))
+    qm = 0.1 * rng.normal(size=(m, 1))
+    qs = (np.tril(0.05 * rng.normal(size=(m, m))) + 0.5 * np.eye(m))[None]
+    ls = np.sqrt(d) * (0.8 + 0.05 * np.arange(d))
+    mu = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=1.0, lengthscales=ls), gpflow.likelihoods.Gaussian(0.1), Zh,
+                            q_mu=qm, q_sqrt=qs, whiten=False, num_data=1_000_000)
+    for _ in range(4):
+        v = float(mu.elbo((X, Y)))
+    print("unwh", v)
