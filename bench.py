@@ -711,6 +711,27 @@ def main():  # noqa: C901
             host_step(s)
         torch.cuda.synchronize()
         res["pcie_inclusive_steps_per_s"] = 30.0 / (time.perf_counter() - t1)
+        # the same steps with the read-back one step late (never `value`): step s + 1 is enqueued before the host waits for
+        # the scalars of step s -- what a monitoring loop that does not feed the value back can do; it removes the host's
+        # turn-around (wait, then ~80 enqueues before the first kernel of the next step) from the GPU's critical path
+        boxes = [ops.HostMailbox(2), ops.HostMailbox(2)]
+
+        def piped(n):
+            for s in range(n):
+                lo = shard_lo(s, 0)
+                ops.svgp_elbo_shard(Z, X[lo:lo + b_rows], Y[lo:lo + b_rows], q_mu, q_sqrt, variance=1.0, lengthscales=ls,
+                                    noise_variance=0.1, jitter=1e-6, ws=ws, out=out, info=info)
+                boxes[s & 1].post(out, info)
+                if s:
+                    boxes[(s - 1) & 1].wait()
+            return boxes[(n - 1) & 1].wait()
+        piped(4)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pv, pinf = piped(40)
+        torch.cuda.synchronize()
+        res["readback_one_step_late_steps_per_s"] = 40.0 / (time.perf_counter() - t1)
+        assert pinf == 0 and np.isfinite(pv[0])
         # the same step through the Python mirror (gpflow_amd.models.SVGP.elbo: Parameters with cached device values,
         # hyper-parameters converted on the host every call, ctypes into the same fused driver, float() of the result)
         import gpflow_amd as gpflow

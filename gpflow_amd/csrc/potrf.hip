@@ -469,9 +469,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
   int xg0 = 0;         // first column of the current extra-row group
-  // (512 columns for M = 2048: 256 / 384 measured slower there; 256 for M <= 1024, where the extra-row stream otherwise starts
-  // after half of the chain: C5 shared 1.376 -> 1.331 ms, C5 separate 2.036 -> 1.977 ms, profiles/r04_ab_c5.log)
-  const int xgroup = std::max(NB, ((n <= 1024 ? GPK_TUNE(XGROUP_SMALL, 256) : GPK_TUNE(XGROUP, NBO)) / NB) * NB);
+  // (512 columns for M = 2048: 256 / 384 measured slower there.  For M <= 1024 the extra-row stream would start after half of
+  // the chain: 256 columns for a batch of problems -- C5 separate 2.036 -> 1.977 ms -- and 128 for a single one -- C3 0.834 ->
+  // 0.803 ms, C5 shared 1.314 -> 1.30 ms, but C5 separate 1.97 -> 2.11; profiles/r04_ab_c5.log, r04_ab_xgroup_small.log)
+  const int xgroup_small = batch > 1 ? GPK_TUNE(XGROUP_SMALL_BATCH, 256) : GPK_TUNE(XGROUP_SMALL, 128);
+  const int xgroup = std::max(NB, ((n <= 1024 ? xgroup_small : GPK_TUNE(XGROUP, NBO)) / NB) * NB);
   for (int p = 0; p < npanels; ++p) {
     const int c0 = cuts[p], c1 = cuts[p + 1];
     const int c2 = (p + 2 <= npanels) ? cuts[p + 2] : n;
