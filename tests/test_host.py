@@ -32,6 +32,12 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert built_lib.gpk_version().decode().startswith("gpk")
     assert built_lib.gpk_invd_elems(300, 2) == 2 * 3 * 128 * 128
     assert built_lib.gpk_svgp_elbo_workspace_bytes(2048, 8192, 8, 1, 0) > (2048 + 8192) * 2048 * 8
+    # the separate-kernel driver keeps one trapezoid PER latent (config C5: 4 x (1024 + 8192) x 1024 doubles) + its tails
+    sep = built_lib.gpk_svgp_elbo_sep_workspace_bytes(1024, 8192, 8, 4)
+    assert 4 * (1024 + 8192) * 1024 * 8 < sep < 2 * 4 * (1024 + 8192) * 1024 * 8
+    # argument errors are reported before anything touches a device (GPK_E_ARG = -1)
+    assert built_lib.gpk_svgp_elbo_shard_sep(None, None, None, 1024, 8, 0, None, None, 8192, 8, 4, 8, 4, None, 1, None, 0.1, 1e-6, 0.0,
+                                             None, None, None, None, None, 0) == -1
 
 
 def test_header_is_plain_c_and_a_c_client_links(built_lib, tmp_path):
