@@ -233,8 +233,10 @@ def other_workloads_leg(device, with_oracle: bool, steps: int = 20):
     Xd, Yd = ops.to_device(Xh), ops.to_device(Yh)
     qdh = 0.5 + 0.05 * np.abs(np.random.default_rng(20).normal(size=(m, 1)))
     for name, note, kwm, qs, okw, fl in (
-            ("cm_unwhitened", "Cm shape, whiten=False (full q_sqrt): SVGP.elbo through the model surface, composed from the primitives",
-             dict(whiten=False), qsh, dict(whiten=False), m ** 3 / 3.0 + 3.0 * float(m) * m * b + 2.0 * m ** 3 / 3.0),
+            ("cm_unwhitened", "Cm shape, whiten=False (full q_sqrt): SVGP.elbo through the model surface -> gpk_svgp_elbo_shard(whiten=0): "
+             "KL against N(0, Kuu) and the conditional on ONE factorisation, no second solve of the minibatch rows "
+             "(algorithmic flops of THIS form: M^3/3 + 2 M^2 B + M^3/3 for the M rows of tril(q_sqrt)^T)",
+             dict(whiten=False), qsh, dict(whiten=False), m ** 3 / 3.0 + 2.0 * float(m) * m * b + m ** 3 / 3.0),
             ("cm_q_diag", "Cm shape, q_diag=True (whitened): SVGP.elbo through the model surface (fused driver, no projection GEMM)",
              dict(whiten=True, q_diag=True), qdh, dict(whiten=True), m ** 3 / 3.0 + float(m) * m * b)):
         mv = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=1.0, lengthscales=ls), gpflow.likelihoods.Gaussian(0.1), Zh,

@@ -131,6 +131,7 @@ int gpk_launch_varexp_stage1(hipStream_t s, const double* Y, long ldy, const dou
                              double mean_const, double* fvar_out, double* part, int* count);
 int gpk_launch_kl_white_stage1(hipStream_t s, const double* q_mu, const double* q_sqrt, int m, int P,
                                int q_diag, double* part, int* count);
+int gpk_launch_sum_log_diag_sq(hipStream_t s, const double* L, int n, long ldl, int batch, long strideL, double* out);
 int gpk_launch_row_stats_sep(hipStream_t s, const double* At, long strideAt, int rows, int m, long ldat, const double* V, int P,
                              double* sumsq, double* mv);
 int gpk_launch_transpose_shift(hipStream_t s, const double* in, int rows, int cols, long ldin,

@@ -744,7 +744,7 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
 namespace {
 struct ElboLayout {
   long ld; int nt;
-  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_C, off_flags, off_Lfin, total;
+  size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_part2, off_V, off_C, off_flags, off_Lfin, total;
 };
 
 ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
@@ -755,15 +755,19 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   // (minibatch rows padded to whole 32-row blocks: the single-launch step kernel runs full blocks only; the padding rows are
   // never initialised, never read by the multi-launch route and left out of the step kernel's final sum)
   const size_t rows_pad = gpk_align_up((size_t)rows, 32);
-  l.off_T = o; o += gpk_align_up((size_t)(m + rows_pad) * l.ld * sizeof(double), 256);
+  // T [m + rows_pad rows], then -- directly behind it, so that the un-whitened form can use ONE trapezoid [Kuu ; Kfu ; q_mu^T ;
+  // tril(q_sqrt_p)^T] with the minibatch rows unpadded -- room for P + P m more rows; the whitened form keeps its LqT there
+  l.off_T = o; o += (size_t)(m + rows_pad) * l.ld * sizeof(double);
+  l.off_LqT = o; o = gpk_align_up(o + (q_diag ? 0 : (size_t)(P + (size_t)P * m + 32) * l.ld * sizeof(double)), 256);
   l.off_invd = o; o += gpk_align_up(gpk_invd_elems(m, 1) * sizeof(double), 256);
-  l.off_LqT = o; o += q_diag ? 0 : gpk_align_up((size_t)P * m * l.ld * sizeof(double), 256);
   l.off_s0 = o; o += gpk_align_up((size_t)rows * sizeof(double), 256);
   l.off_fmean = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
   l.off_ssq = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
   l.off_proj = o; o += q_diag ? 0 : gpk_align_up(gpk_project_workspace_bytes(rows, m, P), 256);
   l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
+  l.off_part2 = o; o += gpk_align_up((size_t)(GPK_REDUCE_MAXPART + 64) * sizeof(double), 256);
+  l.off_V = o; o += gpk_align_up((size_t)m * P * sizeof(double), 256);
   // single-launch step kernel (mega.hip): projection accumulator [P, rows, ld] and its flag words
   l.off_C = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)P * rows_pad * l.ld * sizeof(double), 256) : 0;
   l.off_flags = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up(gpk_mega_flag_ints(m) * sizeof(int), 256) : 0;
@@ -808,14 +812,75 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
                                    size_t ws_bytes) {
   if (!Z || !Xb || !Yb || !q_mu || !q_sqrt || !out || !info || m <= 0 || rows < 0 || P <= 0 || P > 16)
     return GPK_E_ARG;
-  if (!whiten) return GPK_E_UNSUPPORTED;  // composed from the primitives by the Python host
+  if (!whiten && q_diag) return GPK_E_UNSUPPORTED;  // composed from the primitives by the Python host
   const ElboLayout l = elbo_layout(m, rows, P, q_diag);
   if (!ws || ws_bytes < l.total) return GPK_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   char* w = (char*)ws;
   double* T = (double*)(w + l.off_T);
+  if (!whiten) {
+    // ---- whiten = 0 (kullback_leiblers.py:98-165 with K = Kuu, conditionals/util.py:128-167 with white = False) on ONE
+    // trapezoid [Kuu + jitter I ; Kfu ; q_mu^T ; tril(q_sqrt_p)^T].  The reference factors Kuu twice (once for the KL, once for
+    // the conditional) and solves the minibatch columns twice (Lm^-1, then Lm^-T).  Here the extra rows come back as
+    //     A^T = Kfu Lm^-T,   a^T = (Lm^-1 q_mu)^T,   G_p^T = (Lm^-1 Lq_p)^T   (G_p lower triangular again)
+    // which are the Mahalanobis / trace terms of the KL AND the whitened parameters of the same q(u): fmean = A^T a,
+    // sum_j (Lq^T Lm^-T A)_j^2 = sum_j (G^T A)_j^2 -- the projection kernel of the whitened path with G^T in place of Lq^T,
+    // no second triangular solve of the minibatch rows.
+    double* invd_u = (double*)(w + l.off_invd);
+    double* s0_u = (double*)(w + l.off_s0);
+    double* fmean_u = (double*)(w + l.off_fmean);
+    double* ssq_u = (double*)(w + l.off_ssq);
+    double* pa = (double*)(w + l.off_part0);
+    double* pb = (double*)(w + l.off_part1);
+    double* pc = (double*)(w + l.off_part2);          // [MAXPART] trace partials, then [P] log det q, then [1] log det Lm
+    double* V = (double*)(w + l.off_V);
+    double* Kfu_u = T + (long)m * l.ld;
+    double* arow = Kfu_u + (long)rows * l.ld;          // [P, m]
+    double* GT = arow + (long)P * l.ld;                // [P][m][ld]
+    int rcu = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter, 1, T, l.ld);
+    if (rcu) return rcu;
+    const std::function<int(hipStream_t)> pro = [&](hipStream_t xs) -> int {
+      int r = gpk_kernel_matrix((void*)xs, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0, Kfu_u, l.ld);
+      if (r) return r;
+      r = gpk_transpose((void*)xs, q_mu, m, P, P, arow, l.ld, 0, 1, 0, 0);
+      if (r) return r;
+      return gpk_transpose((void*)xs, q_sqrt, m, m, m, GT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
+    };
+    rcu = potrf_core(s, T, m, rows + P + P * m, l.ld, 1, 0, invd_u, 0, info, &pro);
+    if (rcu) return rcu;
+    rcu = gpk_transpose(stream, arow, P, m, l.ld, V, P, 0, 1, 0, 0);           // a = Lm^-1 q_mu as [m, P]
+    if (rcu) return rcu;
+    rcu = gpk_row_stats(stream, Kfu_u, rows, m, l.ld, V, nullptr, P, 1.0, 0.0, s0_u, fmean_u, nullptr);
+    if (rcu) return rcu;
+    rcu = gpk_project(stream, Kfu_u, rows, m, l.ld, GT, l.ld, P, ssq_u, w + l.off_proj, gpk_project_workspace_bytes(rows, m, P));
+    if (rcu) return rcu;
+    int ca = 0;
+    rcu = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean_u, rows, P, s0_u, 0, ssq_u, &variance, 0, noise_variance, mean_const, nullptr,
+                                   pa, &ca);
+    if (rcu) return rcu;
+    const double* q0[1] = {pa};
+    const double one_u = 1.0;
+    rcu = gpk_launch_final(s, 1, q0, &ca, &one_u, 0.0, out);
+    if (rcu) return rcu;
+    // KL = 0.5 |a|^2 + 0.5 sum_p |G_p|_F^2 - 0.5 M P - 0.5 sum log diag(Lq)^2 + P sum log diag(Lm)
+    int cm_ = 0, ct = 0;
+    rcu = gpk_launch_sumsq_stage1(s, arow, P, m, l.ld, 0, pb, &cm_);
+    if (rcu) return rcu;
+    rcu = gpk_launch_sumsq_stage1(s, GT, P * m, m, l.ld, 0, pc, &ct);
+    if (rcu) return rcu;
+    double* ldq = pc + GPK_REDUCE_MAXPART;
+    double* ldl = ldq + P;
+    rcu = gpk_launch_sum_log_diag_sq(s, q_sqrt, m, m, P, (long)m * m, ldq);
+    if (rcu) return rcu;
+    rcu = gpk_sum_log_diag(stream, T, m, l.ld, 1, 0, ldl);
+    if (rcu) return rcu;
+    const double* kp[4] = {pb, pc, ldq, ldl};
+    const int kc[4] = {cm_, ct, P, 1};
+    const double ks[4] = {0.5, 0.5, -0.5, (double)P};
+    return gpk_launch_final(s, 4, kp, kc, ks, -0.5 * (double)m * (double)P, out + 1);
+  }
   double* invd = (double*)(w + l.off_invd);
-  double* LqT = (double*)(w + l.off_LqT);
+  double* LqT = (double*)(w + l.off_LqT) + (q_diag ? 0 : (long)P * l.ld);   // (behind the P rows the un-whitened form keeps there)
   double* s0 = (double*)(w + l.off_s0);
   double* fmean = (double*)(w + l.off_fmean);
   double* ssq = (double*)(w + l.off_ssq);

@@ -308,6 +308,17 @@ __global__ __launch_bounds__(RB) void sum_log_diag_kernel(const double* L, int n
   if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
+// out[b] = sum_i log(M_b[i,i]^2): the log-determinant of a covariance from a square root whose diagonal may carry either sign
+// (kullback_leiblers.py:124: tf.math.log(tf.square(Lq_diag)))
+__global__ __launch_bounds__(RB) void sum_log_diag_sq_kernel(const double* L, int n, long ldl, long strideL, double* out) {
+  __shared__ double sh[4];
+  const double* M = L + (long)blockIdx.x * strideL;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += RB) { const double v = M[(long)i * ldl + i]; acc += log(v * v); }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
 // ---- sum of squares of a matrix, stage 1 -----------------------------------------------------------------
 __global__ __launch_bounds__(RB) void sumsq_kernel(const double* A, int rows, int cols, long lda,
                                                    int upper_only, double* part) {
@@ -506,6 +517,13 @@ extern "C" int gpk_sum_log_diag(void* stream, const double* L, int n, long ldl, 
   if (!L || !out || n <= 0) return GPK_E_ARG;
   hipLaunchKernelGGL(sum_log_diag_kernel, dim3((unsigned)(batch > 0 ? batch : 1)), dim3(RB), 0,
                      (hipStream_t)stream, L, n, ldl, strideL, out);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpk_launch_sum_log_diag_sq(hipStream_t s, const double* L, int n, long ldl, int batch, long strideL, double* out) {
+  if (!L || !out || n <= 0) return GPK_E_ARG;
+  hipLaunchKernelGGL(sum_log_diag_sq_kernel, dim3((unsigned)(batch > 0 ? batch : 1)), dim3(RB), 0, s, L, n, ldl, strideL, out);
   GPK_LAUNCH_CHECK();
   return 0;
 }

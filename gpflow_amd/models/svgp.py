@@ -63,9 +63,12 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
     # ---- fused device path ---------------------------------------------------------------------
     def _fused_config(self):
         """(stationary kernel, Z tensor, mean constant) when the whole ELBO shard is one C-ABI call:
-        whitened, Gaussian likelihood, constant mean, and one stationary kernel shared by all latents
-        (plain kernel + InducingPoints, or SharedIndependent + SharedIndependentInducingVariables)."""
-        if not self.whiten or not isinstance(self.likelihood, Gaussian):
+        Gaussian likelihood, constant mean, and one stationary kernel shared by all latents (plain kernel +
+        InducingPoints, or SharedIndependent + SharedIndependentInducingVariables); whitened, or un-whitened with a
+        full q_sqrt."""
+        if not isinstance(self.likelihood, Gaussian):
+            return None
+        if not self.whiten and self.q_sqrt.device_value().dim() != 3:
             return None
         c = self.mean_function.constant_value()
         if c is None:
@@ -169,7 +172,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             out, info = ops.svgp_elbo_shard(Zs, Xs, Y, self.q_mu.device_value(), q_sqrt, variance=var,
                                             lengthscales=ls, noise_variance=self.likelihood.noise_variance(),
                                             jitter=config.default_jitter(), mean_const=c, family=family,
-                                            ws=self._ws[1])
+                                            ws=self._ws[1], whiten=self.whiten)
             ops.check_info(info)
             return out
         sep = self._fused_separate_config()

@@ -578,8 +578,9 @@ def svgp_elbo_shard(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: t
                     q_sqrt: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
                     jitter: float, mean_const: float = 0.0, family: str = "SquaredExponential",
                     ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                    info: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Whitened shard: out[0] = sum_b var_exp_b over this shard, out[1] = KL.  Returns (out, info)."""
+                    info: Optional[torch.Tensor] = None, whiten: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One shard of SVGP.elbo: out[0] = sum_b var_exp_b over this shard, out[1] = KL.  Returns (out, info).
+    whiten=False (full q_sqrt only): KL against N(0, Kuu) and the un-whitened conditional, on one factorisation."""
     lib = _lib.load()
     for name, t in (("Z", Z), ("Xb", Xb), ("Yb", Yb), ("q_mu", q_mu)):
         _chk(t, name, 2)
@@ -604,7 +605,7 @@ def svgp_elbo_shard(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: t
                                  Xb.data_ptr(), Yb.data_ptr(), rows, _rowmajor(Xb, "Xb"),
                                  _rowmajor(Yb, "Yb"), d, P, ls, ard, float(variance),
                                  float(noise_variance), float(jitter), float(mean_const),
-                                 q_mu.data_ptr(), q_sqrt.data_ptr(), int(q_diag), 1, out.data_ptr(),
+                                 q_mu.data_ptr(), q_sqrt.data_ptr(), int(q_diag), int(bool(whiten)), out.data_ptr(),
                                  info.data_ptr(), ws.data_ptr(), ws.numel() * 8)
     _lib.check(rc, "gpk_svgp_elbo_shard")
     return out, info

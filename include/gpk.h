@@ -233,8 +233,11 @@ int gpk_gpr_lml(void* stream, int family, const double* X, int n, int d, long ld
  * (IndependentPosteriorSingleOutput posteriors.py:828-841 and the SharedIndependent branch :849-861):
  *   out[0] = sum over this shard's rows of var_exp   (all-reduced across ranks by the caller)
  *   out[1] = KL (replicated; identical on every rank)
- * q_diag: q_sqrt is [m,P] instead of [P,m,m].  whiten = 0 returns GPK_E_UNSUPPORTED (the host
- * composes that case from the primitives above). */
+ * q_diag: q_sqrt is [m,P] instead of [P,m,m].
+ * whiten = 0 (full q_sqrt): KL against N(0, Kuu) (kullback_leiblers.py:98-165 with K) and the un-whitened conditional
+ * (conditionals/util.py:128-167, white = False) on ONE factorisation -- [Kuu ; Kfu ; q_mu^T ; tril(q_sqrt_p)^T] as one
+ * trapezoid; the reference factors Kuu twice and solves the minibatch columns twice.  whiten = 0 with q_diag returns
+ * GPK_E_UNSUPPORTED (the host composes that case from the primitives above). */
 size_t gpk_svgp_elbo_workspace_bytes(int m, int rows, int d, int P, int q_diag);
 int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long ldz, const double* Xb,
                         const double* Yb, int rows, long ldxb, long ldyb, int d, int P,

@@ -369,10 +369,38 @@ def svgp_elbo_workspace(m, rows, d, P, q_diag):
 
 
 def svgp_elbo_shard(Z, Xb, Yb, q_mu, q_sqrt, *, variance, lengthscales, noise_variance, jitter, mean_const=0.0,
-                    family="SquaredExponential", ws=None, out=None, info=None):
-    """gpk_svgp_elbo_shard emulated by its own chain of primitives (whitened; shared kernel)."""
+                    family="SquaredExponential", ws=None, out=None, info=None, whiten=True):
+    """gpk_svgp_elbo_shard emulated by its own chain of primitives (shared kernel; whitened, or un-whitened on one trapezoid)."""
     M, rows, P = Z.shape[0], Xb.shape[0], q_mu.shape[1]
     kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+    if not whiten:
+        if q_sqrt.dim() != 3:
+            raise RuntimeError("gpk_svgp_elbo_shard: unsupported (rc -4)")
+        T = torch.empty((M + rows + P + P * M, M), dtype=torch.float64)
+        kernel_matrix(Z, None, diag_add=jitter, lower_only=True, out=T[:M], **kw)
+        if rows:
+            kernel_matrix(Xb, Z, out=T[M:M + rows], **kw)
+        T[M + rows:M + rows + P] = q_mu.t()
+        T[M + rows + P:] = transpose(q_sqrt, mode=1).reshape(P * M, M)
+        _, inf = potrf_(T, M)
+        res = torch.zeros(2, dtype=torch.float64)
+        if int(inf[0]) == 0:
+            At = T[M:M + rows].contiguous()
+            V = T[M + rows:M + rows + P].t().contiguous()
+            GT = T[M + rows + P:].reshape(P, M, M).contiguous()
+            s0, fmean, _ = row_stats(At, V=V)
+            ssq = project(At, GT)
+            ve, _ = gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
+                                        mean_const=mean_const)
+            res[0] = ve[0]
+            Lq = np.tril(_np(q_sqrt))
+            res[1] = 0.5 * float((_np(T[M + rows:M + rows + P]) ** 2).sum()) + 0.5 * float((_np(GT) ** 2).sum()) - 0.5 * M * P \
+                - 0.5 * float(np.log(np.diagonal(Lq, axis1=1, axis2=2) ** 2).sum()) \
+                + P * float(np.log(np.diagonal(_np(T[:M]))).sum())
+        if out is not None:
+            out.copy_(res)
+            res = out
+        return res, inf
     T = torch.empty((M + rows, M), dtype=torch.float64)
     kernel_matrix(Z, None, diag_add=jitter, lower_only=True, out=T[:M], **kw)
     if rows:

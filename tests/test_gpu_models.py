@@ -514,10 +514,13 @@ def test_unwhitened_elbo_on_one_factorisation_matches_the_two_factorisation_path
             gp.inducing_variables.SharedIndependentInducingVariables(gp.inducing_variables.InducingPoints(Z))
         m = gp.models.SVGP(kern, gp.likelihoods.Gaussian(0.15), iv, q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=2, whiten=False,
                            num_data=4000, mean_function=gp.mean_functions.Constant(-0.2))
-        assert m._unwhitened_shared_factor_config() is not None
-        one = float(m.elbo((X, Y)))
+        assert m._fused_config() is not None and m._unwhitened_shared_factor_config() is not None
+        fused = float(m.elbo((X, Y)))                      # gpk_svgp_elbo_shard(whiten = 0): one C-ABI call
+        m._fused_config = lambda: None
+        one = float(m.elbo((X, Y)))                        # the same on one trapezoid, composed by the host mirror
         m._unwhitened_shared_factor_config = lambda: None
-        two = float(m.elbo((X, Y)))
+        two = float(m.elbo((X, Y)))                        # prior_kl + predict_f: two factorisations, as the reference
+        np.testing.assert_allclose(fused, two, rtol=1e-10)
         np.testing.assert_allclose(one, two, rtol=1e-10)
     ref = orc.svgp_elbo(X, Y - (-0.2), Z, q_mu, q_sqrt, variance=1.2, lengthscales=np.array([0.9, 1.3, 1.1]), noise_variance=0.15,
                         whiten=False, num_data=4000)
