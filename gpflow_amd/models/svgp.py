@@ -86,21 +86,33 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         over all input columns, inducing POINTS shared by the latents or one equally sized set per latent."""
         from ..kernels import SeparateIndependent
         from ..inducing_variables import SeparateIndependentInducingVariables
-        if not self.whiten or not isinstance(self.likelihood, Gaussian) or self.q_sqrt.device_value().dim() != 3:
+        if not self.whiten or not isinstance(self.likelihood, Gaussian):
             return None
         c = self.mean_function.constant_value()
+        if c is None:
+            return None
+        sep = self._separate_stationary_members()
+        return None if sep is None else sep + (c,)
+
+    def _separate_stationary_members(self):
+        """(member kernels, Z [m, d] | [P, m, d]) for SeparateIndependent stationary members over all input columns and
+        inducing points (shared, or one equally sized set per latent), full q_sqrt; else None."""
+        from ..kernels import SeparateIndependent
+        from ..inducing_variables import SeparateIndependentInducingVariables
+        if self.q_sqrt.device_value().dim() != 3:
+            return None
         k, iv = self.kernel, self.inducing_variable
-        if c is None or not isinstance(k, SeparateIndependent):
+        if not isinstance(k, SeparateIndependent):
             return None
         if not all(isinstance(kk, Stationary) and kk.has_default_active_dims for kk in k.kernels):
             return None
         if isinstance(iv, SharedIndependentInducingVariables) and isinstance(iv.inducing_variable, InducingPoints):
-            return k.kernels, iv.inducing_variable.Z.device_value().contiguous(), c
+            return k.kernels, iv.inducing_variable.Z.device_value().contiguous()
         if isinstance(iv, SeparateIndependentInducingVariables) and len(iv.inducing_variable_list) == len(k.kernels) \
                 and all(isinstance(v, InducingPoints) for v in iv.inducing_variable_list):
             Zs = [v.Z.device_value() for v in iv.inducing_variable_list]
             if len({tuple(z.shape) for z in Zs}) == 1:
-                return k.kernels, torch.stack(Zs).contiguous(), c
+                return k.kernels, torch.stack(Zs).contiguous()
         return None
 
     def _unwhitened_shared_factor_config(self):
@@ -155,6 +167,42 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         ops.check_info(info)
         return torch.stack([var_exp.sum(), kl])
 
+    def _elbo_terms_unwhitened_separate(self, X, Y, kernels, Z):
+        """`_elbo_terms_unwhitened` for one kernel PER latent (SeparateIndependent): the P trapezoids [Kuu_p ; Kfu_p ; q_mu_p^T ;
+        tril(q_sqrt_p)^T] go through ONE batched factorisation; per latent the extra rows are A_p^T, (Lm_p^-1 q_mu_p)^T and
+        G_p^T = (Lm_p^-1 Lq_p)^T -- KL terms and whitened parameters of the same q at once (kullback_leiblers.py:98-165 batched
+        over K [L,M,M]; conditionals/util.py:566-629 with white = False)."""
+        q_mu, q_sqrt = self.q_mu.device_value(), self.q_sqrt.device_value()
+        M, P = q_mu.shape
+        B = X.shape[0]
+        T = torch.empty((P, M + B + 1 + M, M), dtype=torch.float64, device=X.device)
+        for p, kp in enumerate(kernels):
+            Zp = Z if Z.dim() == 2 else Z[p]
+            kp.K_into(Zp, None, T[p, :M], diag_add=config.default_jitter(), lower_only=True)
+            if B:
+                kp.K_into(X, Zp, T[p, M:M + B])
+        T[:, M + B] = q_mu.t()
+        ops.transpose(q_sqrt.contiguous(), mode=1, out=T[:, M + B + 1:])                 # tril(q_sqrt_p)^T
+        _, info = ops.potrf_(T, M)
+        arow = T[:, M + B].contiguous()                                                  # [P, M]: (Lm_p^-1 q_mu_p)^T
+        GT = T[:, M + B + 1:].contiguous()                                               # [P, M, M]: G_p^T (upper)
+        mahalanobis = ops.sumsq(arow)[0]
+        trace = ops.sumsq(GT.reshape(P * M, M))[0]
+        logdet_qcov = torch.log(torch.diagonal(q_sqrt, dim1=-2, dim2=-1) ** 2).sum()
+        kl = 0.5 * (mahalanobis - float(M * P) - logdet_qcov + trace + 2.0 * ops.sum_log_diag(T[:, :M]).sum())
+        s0s, mus = [], []
+        for p in range(P):
+            s0, mu, _ = ops.row_stats(T[p, M:M + B], V=arow[p].reshape(M, 1).contiguous())
+            s0s.append(s0)
+            mus.append(mu[:, 0])
+        ssq = ops.project(T[:, M:M + B], GT)                                             # [P, B]: sum_j (G_p^T A_p)_j^2
+        kdiag = torch.stack([kp.K_diag(X) for kp in kernels])                            # [P, B]
+        f_var = (kdiag - torch.stack(s0s) + ssq).t().contiguous()
+        f_mean = torch.stack(mus, dim=-1) + self.mean_function(X)
+        var_exp = self.likelihood.variational_expectations(X, f_mean, f_var, Y)
+        ops.check_info(info)
+        return torch.stack([var_exp.sum(), kl])
+
     def elbo_terms(self, data):
         """(sum_b var_exp_b over the given rows, KL) as a 2-element device tensor -- the two pieces
         svgp.py:172-174 combines; the first is what gets all-reduced when the minibatch is sharded."""
@@ -197,6 +245,10 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         shared = self._unwhitened_shared_factor_config()
         if shared is not None:
             return self._elbo_terms_unwhitened(X, Y, *shared)
+        if not self.whiten:
+            members = self._separate_stationary_members()
+            if members is not None:
+                return self._elbo_terms_unwhitened_separate(X, Y, *members)
         kl = self.prior_kl()
         f_mean, f_var = self.predict_f(X, full_cov=False, full_output_cov=False)
         var_exp = self.likelihood.variational_expectations(X, f_mean, f_var, Y)

@@ -530,6 +530,30 @@ def test_unwhitened_elbo_on_one_factorisation_matches_the_two_factorisation_path
     np.testing.assert_allclose(float(m.elbo((X, Y))), ref, rtol=1e-9)
 
 
+def test_unwhitened_separate_kernels_on_one_batched_factorisation(gp):
+    """whiten=False with SeparateIndependent kernels: ONE batched trapezoid [Kuu_p ; Kfu_p ; q_mu_p^T ; tril(q_sqrt_p)^T] against
+    the reference's structure (prior_kl with its own batched factorisation + the per-latent conditionals with a second
+    triangular solve) and against the oracle's map_fn loop; shared and separate inducing points."""
+    rng = np.random.default_rng(29)
+    X, Y, Z, q_mu, q_sqrt = _svgp_data(rng, 220, 2, 3, 130)
+    variances, lss = [1.0, 0.7, 1.4], [0.9, 1.3, 1.7]
+    kern = gp.kernels.SeparateIndependent([gp.kernels.RBF(variance=v, lengthscales=l) for v, l in zip(variances, lss)])
+    ivs = [(gp.inducing_variables.SharedIndependentInducingVariables(gp.inducing_variables.InducingPoints(Z)), [Z] * 3),
+           (gp.inducing_variables.SeparateIndependentInducingVariables(
+               [gp.inducing_variables.InducingPoints(Z + 0.01 * i) for i in range(3)]), [Z + 0.01 * i for i in range(3)])]
+    for iv, Zs in ivs:
+        m = gp.models.SVGP(kern, gp.likelihoods.Gaussian(0.1), iv, q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=3, whiten=False,
+                           num_data=1000)
+        assert m._separate_stationary_members() is not None and m._fused_separate_config() is None
+        one = float(m.elbo((X, Y)))
+        m._separate_stationary_members = lambda: None
+        two = float(m.elbo((X, Y)))
+        ref = orc.svgp_elbo_separate(X, Y, Zs, q_mu, q_sqrt, variances=variances, lengthscales_list=lss, noise_variance=0.1,
+                                     whiten=False, num_data=1000)
+        np.testing.assert_allclose(one, two, rtol=1e-10)
+        np.testing.assert_allclose(one, ref, rtol=1e-9)
+
+
 def test_golden_vectors(gp):
     """The committed golden fixtures (tests/golden/*.npz, generated from the oracle on the reference's
     own test fixtures) reproduce on the device."""
