@@ -270,6 +270,13 @@ def _product_worker(rank, world, port, q, backend):
         ref_s = orc.svgp_elbo_separate(X, Y, [Z] * P, q_mu, q_sqrt, variances=vs, lengthscales_list=lss, noise_variance=0.2,
                                        whiten=True, num_data=7000)
         np.testing.assert_allclose(elbo_s, ref_s, rtol=1e-9)
+        # and un-whitened (gpk_svgp_elbo_shard(whiten = 0): the KL is replicated, the data term all-reduced, as above)
+        mu = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=ls), gpflow.likelihoods.Gaussian(0.2), Z,
+                                q_mu=q_mu, q_sqrt=q_sqrt, num_data=7000, whiten=False)
+        assert mu._fused_config() is not None
+        elbo_u = float(distributed.svgp_elbo_data_parallel(mu, (ops.to_device(X), ops.to_device(Y))))
+        ref_u = orc.svgp_elbo(X, Y, Z, q_mu, q_sqrt, variance=1.1, lengthscales=ls, noise_variance=0.2, num_data=7000, whiten=False)
+        np.testing.assert_allclose(elbo_u, ref_u, rtol=1e-9)
         q.put((rank, elbo, ref))
     finally:
         dist.destroy_process_group()
