@@ -96,7 +96,10 @@ int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline
 int gpk_prof_begin(hipStream_t s, double flops, int kind);   // same facility for other kernels; returns a record index or -1
 void gpk_prof_end(int idx, hipStream_t s);
 
-// ---- single-launch SVGP step (mega.hip) ---------------------------------------------------------------------------
+// ---- single-launch SVGP step (mega.hip): A/B build only (`make exp`, GPK_MEGA=1).  Round 5 applied the stop rule of the
+// round-4 review: 2.7 - 3.0 ms at Cm against 2.0 - 2.1 ms for the multi-launch route, so the kernel, its workspace regions and
+// its entry points are compiled into libgpk_exp.so only and the product library carries no trace of them.
+#ifdef GPK_EXPERIMENTAL
 #ifndef GPK_MEGA_DEFAULT
 #define GPK_MEGA_DEFAULT 0
 #endif
@@ -106,6 +109,7 @@ int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, 
                          long ldl, double* Cacc, const double* q_mu, int P, const double* Y, long ldy, double* s0, double* fmean,
                          double* ssq, double* partial, int* flags, int* info, double* out, double variance, double noise,
                          double mean_const, int min_wgs);
+#endif
 
 // ---- leaf (leaf.hip): NB x NB Cholesky + inverse of the diagonal block --------------------------
 // A: pointer to the diagonal block (row-major, lda); nb <= NB valid rows/cols.

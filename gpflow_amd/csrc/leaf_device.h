@@ -56,51 +56,122 @@ __device__ __forceinline__ void diag_panel(d4& d, d4& x, int c, int g, int lane,
     const double s00 = pick(0, 0), s10 = pick(1, 0), s20 = pick(2, 0), s30 = pick(3, 0);
     const double s11 = pick(1, 1), s21 = pick(2, 1), s31 = pick(3, 1);
     const double s22 = pick(2, 2), s32 = pick(3, 2), s33 = pick(3, 3);
-    double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3;
-    if constexpr (FACTORED) {
-      l10 = s10; l20 = s20; l30 = s30; l21 = s21; l31 = s31; l32 = s32;
-      r0 = 1.0 / s00; r1 = 1.0 / s11; r2 = 1.0 / s22; r3 = 1.0 / s33;
+    double yop;
+    const int slot = (c < 4 && g <= c) ? c * 4 + g : -1;  // lane (m = c, k = g) holds Y[m][k] of the A-operand
+#ifdef GPK_LEAF_FRACTION_FREE
+    constexpr bool kRecurrence = FACTORED;   // (A/B only, `make ffleaf`: the fraction-free pivot block below)
+#else
+    constexpr bool kRecurrence = true;
+#endif
+    if constexpr (kRecurrence) {
+      double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3;
+      if constexpr (FACTORED) {
+        l10 = s10; l20 = s20; l30 = s30; l21 = s21; l31 = s31; l32 = s32;
+        r0 = 1.0 / s00; r1 = 1.0 / s11; r2 = 1.0 / s22; r3 = 1.0 / s33;
+      } else {
+        r0 = rsqrt_nr(s00);
+        l10 = s10 * r0; l20 = s20 * r0; l30 = s30 * r0;
+        const double p1 = fma(-l10, l10, s11);
+        r1 = rsqrt_nr(p1);
+        l21 = fma(-l20, l10, s21) * r1;
+        l31 = fma(-l30, l10, s31) * r1;
+        const double p2 = fma(-l21, l21, fma(-l20, l20, s22));
+        r2 = rsqrt_nr(p2);
+        l32 = fma(-l31, l21, fma(-l30, l20, s32)) * r2;
+        const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
+        r3 = rsqrt_nr(p3);
+        int idx = -1;
+        idx = !(p3 > 0.0) ? 3 : idx;
+        idx = !(p2 > 0.0) ? 2 : idx;
+        idx = !(p1 > 0.0) ? 1 : idx;
+        idx = !(s00 > 0.0) ? 0 : idx;
+        bad_col = (bad_col < 0 && idx >= 0) ? col0 + 4 * P + idx : bad_col;
+      }
+      // Y = inv(L4), lower triangular
+      const double y10 = -r1 * (l10 * r0);
+      const double y21 = -r2 * (l21 * r1);
+      const double y32 = -r3 * (l32 * r2);
+      const double y20 = -r2 * fma(l21, y10, l20 * r0);
+      const double y31 = -r3 * fma(l32, y21, l31 * r1);
+      const double y30 = -r3 * fma(l32, y20, fma(l31, y10, l30 * r0));
+      // flat select chain on the per-lane slot index (no divergent control flow: every Y value is wave-uniform)
+      yop = 0.0;
+      yop = (slot == 0) ? r0 : yop;
+      yop = (slot == 4) ? y10 : yop;
+      yop = (slot == 5) ? r1 : yop;
+      yop = (slot == 8) ? y20 : yop;
+      yop = (slot == 9) ? y21 : yop;
+      yop = (slot == 10) ? r2 : yop;
+      yop = (slot == 12) ? y30 : yop;
+      yop = (slot == 13) ? y31 : yop;
+      yop = (slot == 14) ? y32 : yop;
+      yop = (slot == 15) ? r3 : yop;
     } else {
-      r0 = rsqrt_nr(s00);
-      l10 = s10 * r0; l20 = s20 * r0; l30 = s30 * r0;
-      const double p1 = fma(-l10, l10, s11);
-      r1 = rsqrt_nr(p1);
-      l21 = fma(-l20, l10, s21) * r1;
-      l31 = fma(-l30, l10, s31) * r1;
-      const double p2 = fma(-l21, l21, fma(-l20, l20, s22));
-      r2 = rsqrt_nr(p2);
-      l32 = fma(-l31, l21, fma(-l30, l20, s32)) * r2;
-      const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
-      r3 = rsqrt_nr(p3);
-      // first non-positive pivot of this panel, branch-free (all values are wave-uniform)
+      // ROUND-5 EXPERIMENT, NOT THE PRODUCT PATH (compiled only with -DGPK_LEAF_FRACTION_FREE): Y = inv(chol(S4)) without a
+      // square root or a division on the dependent path.  The recurrence above (pivot -> rsqrt -> scale the column -> next
+      // pivot) is ~36 DEPENDENT fp64 ops per 4-column panel; the form below needs 15 levels.  Measured on the chip it is 0.5 - 1.5 %
+      // SLOWER at step level (profiles/r05_ab_leaf_fraction_free.log: factor phase 23 - 25 us either way): wave 0 is bound by the
+      // ISSUE of ~100 wave-uniform VALU instructions per panel (7 - 9 cycles each), not by their dependent latency, and this form
+      // issues ~15 more of them.  Kept as the record of that finding.  Fraction-free elimination:
+      //   t_ij = s00 s_ij - s_i0 s_j0,   u_ij = t11 t_ij - t_i1 t_j1,   w33 = u22 u33 - u32^2
+      // are the Schur complements scaled by the previous pivots (s00 = p0, t11 = p0 p1, u22 = p0^2 p1 p2, w33 = p0^4 p1^2 p2 p3),
+      // the same row operations applied to the identity give the rows N_k of the unit-lower inverse times those scales, and
+      //   Y[k][:] = (q0 q1 ... qk) N_k   with  q0 = rsqrt(s00), q1 = rsqrt(t11), q2 = rsqrt(u22), q3 = rsqrt(w33):
+      // six dependent ops to the last scaled pivot, the four rsqrt refinements run beside each other, 15 levels in all.
+      // Same backward error as the recurrence (tools/leaf_ff_check.py: |Y S Y^T - I| equal to within a factor 1.5 for
+      // condition numbers 1e1 ... 1e12).  Range: intermediate magnitudes reach pivot^8, so entries beyond ~1e+-35 over/underflow
+      // -- and are then REPORTED as a non-positive pivot, never silently accepted (NaN / 0 fail the `> 0` tests below).
+      const double t11 = fma(s00, s11, -(s10 * s10));
+      const double t21 = fma(s00, s21, -(s20 * s10));
+      const double t31 = fma(s00, s31, -(s30 * s10));
+      const double t22 = fma(s00, s22, -(s20 * s20));
+      const double t32 = fma(s00, s32, -(s30 * s20));
+      const double t33 = fma(s00, s33, -(s30 * s30));
+      const double u22 = fma(t11, t22, -(t21 * t21));
+      const double u32 = fma(t11, t32, -(t31 * t21));
+      const double u33 = fma(t11, t33, -(t31 * t31));
+      const double w33 = fma(u22, u33, -(u32 * u32));
+      // the four rsqrt refinements (rsqrt_nr, written out) level by level, so that the in-order issue of the wave sees four
+      // independent ops per level instead of four serial six-op chains; the rows of the scaled unit-lower inverse fill the slots
+      const double y0 = __builtin_amdgcn_rsq(s00), y1 = __builtin_amdgcn_rsq(t11), y2 = __builtin_amdgcn_rsq(u22),
+                   y3 = __builtin_amdgcn_rsq(w33);
+      const double a = t11 * s00;
+      const double f0 = s00 * y0, f1 = t11 * y1, f2 = u22 * y2, f3 = w33 * y3;
+      const double n20 = fma(t21, s10, -(t11 * s20)), n21 = -(t21 * s00);
+      const double e0 = fma(-f0, y0, 1.0), e1 = fma(-f1, y1, 1.0), e2 = fma(-f2, y2, 1.0), e3 = fma(-f3, y3, 1.0);
+      const double m30 = fma(t31, s10, -(t11 * s30)), m31 = -(t31 * s00);
+      const double g0 = fma(0.375, e0, 0.5), g1 = fma(0.375, e1, 0.5), g2 = fma(0.375, e2, 0.5), g3 = fma(0.375, e3, 0.5);
+      const double h0 = y0 * e0, h1 = y1 * e1, h2 = y2 * e2, h3 = y3 * e3;
+      const double n30 = fma(u22, m30, -(u32 * n20)), n31 = fma(u22, m31, -(u32 * n21)), n32 = -(u32 * a), n33 = u22 * a;
+      const double q0 = fma(h0, g0, y0), q1 = fma(h1, g1, y1), q2 = fma(h2, g2, y2), q3 = fma(h3, g3, y3);
+      // first non-positive pivot of this panel, branch-free (all values are wave-uniform); the scaled pivots have the sign
+      // of the true ones as long as every earlier pivot is positive, which is all the "first failure" needs
       int idx = -1;
-      idx = !(p3 > 0.0) ? 3 : idx;
-      idx = !(p2 > 0.0) ? 2 : idx;
-      idx = !(p1 > 0.0) ? 1 : idx;
+      idx = !(w33 > 0.0) ? 3 : idx;
+      idx = !(u22 > 0.0) ? 2 : idx;
+      idx = !(t11 > 0.0) ? 1 : idx;
       idx = !(s00 > 0.0) ? 0 : idx;
       bad_col = (bad_col < 0 && idx >= 0) ? col0 + 4 * P + idx : bad_col;
+      // per-lane operand  Y[m][k] = N[m][k] * rho_m:  the N entries are ready early (select chain off the critical path), the
+      // cumulative products rho_m = q0 ... qm last -- ONE select and one multiply behind q3
+      double nsel = 0.0;
+      nsel = (slot == 0) ? 1.0 : nsel;
+      nsel = (slot == 4) ? -s10 : nsel;
+      nsel = (slot == 5) ? s00 : nsel;
+      nsel = (slot == 8) ? n20 : nsel;
+      nsel = (slot == 9) ? n21 : nsel;
+      nsel = (slot == 10) ? a : nsel;
+      nsel = (slot == 12) ? n30 : nsel;
+      nsel = (slot == 13) ? n31 : nsel;
+      nsel = (slot == 14) ? n32 : nsel;
+      nsel = (slot == 15) ? n33 : nsel;
+      const double rho1 = q0 * q1, q23 = q2 * q3, rho2 = rho1 * q2, rho3 = rho1 * q23;
+      double rsel = q0;
+      rsel = (c == 1) ? rho1 : rsel;
+      rsel = (c == 2) ? rho2 : rsel;
+      rsel = (c == 3) ? rho3 : rsel;
+      yop = nsel * rsel;
     }
-    // Y = inv(L4), lower triangular
-    const double y10 = -r1 * (l10 * r0);
-    const double y21 = -r2 * (l21 * r1);
-    const double y32 = -r3 * (l32 * r2);
-    const double y20 = -r2 * fma(l21, y10, l20 * r0);
-    const double y31 = -r3 * fma(l32, y21, l31 * r1);
-    const double y30 = -r3 * fma(l32, y20, fma(l31, y10, l30 * r0));
-    // A-operand  Yop[m][k] = Y[m][k] (m < 4), lane (m = c, k = g): flat select chain on a per-lane slot index
-    // (no divergent control flow: every Y value is wave-uniform and already computed)
-    const int slot = (c < 4 && g <= c) ? c * 4 + g : -1;
-    double yop = 0.0;
-    yop = (slot == 0) ? r0 : yop;
-    yop = (slot == 4) ? y10 : yop;
-    yop = (slot == 5) ? r1 : yop;
-    yop = (slot == 8) ? y20 : yop;
-    yop = (slot == 9) ? y21 : yop;
-    yop = (slot == 10) ? r2 : yop;
-    yop = (slot == 12) ? y30 : yop;
-    yop = (slot == 13) ? y31 : yop;
-    yop = (slot == 14) ? y32 : yop;
-    yop = (slot == 15) ? r3 : yop;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     // panel of L:  D[m][n] = sum_k Y[m][k] S[n][4P+k]  ->  reg 0 of lane (n, g) = L[n][4P+g]
     double lp;

@@ -768,10 +768,16 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part2 = o; o += gpk_align_up((size_t)(GPK_REDUCE_MAXPART + 64) * sizeof(double), 256);
   l.off_V = o; o += gpk_align_up((size_t)m * P * sizeof(double), 256);
-  // single-launch step kernel (mega.hip): projection accumulator [P, rows, ld] and its flag words
-  l.off_C = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)P * rows_pad * l.ld * sizeof(double), 256) : 0;
-  l.off_flags = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up(gpk_mega_flag_ints(m) * sizeof(int), 256) : 0;
-  l.off_Lfin = o; o += (!q_diag && gpk_mega_supported(m, rows, P, 1 << 20)) ? gpk_align_up((size_t)m * l.ld * sizeof(double), 256) : 0;
+  // single-launch step kernel (mega.hip; A/B build only, GPK_MEGA=1): projection accumulator [P, rows, ld], flag words and the
+  // write-once copy of the factor.  The product library reserves nothing for it (round 4 did: +134 MB at Cm).
+  l.off_C = l.off_flags = l.off_Lfin = o;
+#ifdef GPK_EXPERIMENTAL
+  if (!q_diag && GPK_TUNE(MEGA, GPK_MEGA_DEFAULT) && gpk_mega_supported(m, rows, P, 1 << 20)) {
+    l.off_C = o; o += gpk_align_up((size_t)P * rows_pad * l.ld * sizeof(double), 256);
+    l.off_flags = o; o += gpk_align_up(gpk_mega_flag_ints(m) * sizeof(int), 256);
+    l.off_Lfin = o; o += gpk_align_up((size_t)m * l.ld * sizeof(double), 256);
+  }
+#endif
   l.total = o;
   return l;
 }
@@ -893,6 +899,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   // and the panel chain starts right after the much smaller Kuu build.  Work that depends on neither factorisation
   // nor minibatch solve -- tril(q_sqrt)^T for the projection and the whole KL term -- goes to that stream too, which
   // idles until the first 512 columns of Lm exist; gpk_potrf joins it.
+#ifdef GPK_EXPERIMENTAL
   // ---- single-launch route (mega.hip): builds + KL on the caller's stream, then ONE persistent kernel for everything
   // that depends on the factorisation.  Taken when the shapes fit one row block per compute unit.
   if (!q_diag && GPK_TUNE(MEGA, GPK_MEGA_DEFAULT) && rows > 0) {
@@ -919,6 +926,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
                                   mean_const, GPK_TUNE(MEGA_MIN_WGS, 96));
     }
   }
+#endif
   const bool side = m > GPK_NB && m < 4096 && rows > 256;
   // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only: the chain's first leaf waits for
   // nothing else, so it is the first thing enqueued
