@@ -10,7 +10,7 @@ fp64 torch tensors on the HIP device.  There is no CPU fallback.
 from . import config  # noqa: F401,E402
 from .base import Module, Parameter, set_trainable  # noqa: F401
 from .config import default_float, default_int, default_jitter  # noqa: F401
-from . import (conditionals, covariances, inducing_variables, kernels, kullback_leiblers,  # noqa: F401
+from . import (conditionals, covariances, functions, inducing_variables, kernels, kullback_leiblers,  # noqa: F401
                likelihoods, logdensities, mean_functions, models, optimizers, posteriors, priors, training, utilities)
 
 __version__ = "0.1.0"

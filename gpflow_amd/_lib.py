@@ -31,6 +31,7 @@ _SIGS = {
                                            C.POINTER(c_double), c_int, c_double, _dp, c_long, _dp, c_long]),
     "gpk_kernel_matrix_combine": (c_int, [c_void_p, c_int, c_int, _dp, c_int, c_long, _dp, c_int, c_long, c_int,
                                           C.POINTER(c_double), c_int, c_double, c_double, _dp, c_long, _dp, c_long]),
+    "gpk_diag_add": (c_int, [c_void_p, _dp, c_int, c_long, _dp]),
     "gpk_invd_elems": (c_size_t, [c_int, c_int]),
     "gpk_potrf": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_int, c_long, _dp, c_int, _dp]),
     "gpk_combine_parts": (c_int, [c_void_p, _dp, c_int, c_long, c_int, c_int, c_long, c_double, c_int, c_double, _dp, c_long]),
@@ -53,22 +54,22 @@ _SIGS = {
     "gpk_project_batched": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_long, _dp, c_long, c_int, _dp, _dp, c_size_t]),
     "gpk_reduce_workspace_bytes": (c_size_t, [c_int]),
     "gpk_gaussian_varexp_sum": (c_int, [c_void_p, _dp, c_long, _dp, c_int, c_int, _dp, c_int, _dp,
-                                        C.POINTER(c_double), c_int, c_double, c_double, _dp, _dp, _dp,
+                                        C.POINTER(c_double), c_int, c_double, _dp, c_double, _dp, _dp, _dp,
                                         c_size_t]),
     "gpk_gauss_kl_white": (c_int, [c_void_p, _dp, _dp, c_int, c_int, c_int, _dp, _dp, c_size_t]),
     "gpk_sum_log_diag": (c_int, [c_void_p, _dp, c_int, c_long, c_int, c_long, _dp]),
     "gpk_sumsq": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_int, _dp, _dp, c_size_t]),
     "gpk_gpr_lml_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gpk_gpr_lml": (c_int, [c_void_p, c_int, _dp, c_int, c_int, c_long, _dp, c_int, c_long,
-                            C.POINTER(c_double), c_int, c_double, c_double, c_double, _dp, _dp, _dp,
+                            C.POINTER(c_double), c_int, c_double, c_double, _dp, c_double, _dp, _dp, _dp,
                             c_size_t]),
-    "gpk_svgp_elbo_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "gpk_svgp_elbo_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "gpk_svgp_elbo_shard": (c_int, [c_void_p, c_int, _dp, c_int, c_long, _dp, _dp, c_int, c_long, c_long,
-                                    c_int, c_int, C.POINTER(c_double), c_int, c_double, c_double,
+                                    c_int, c_int, C.POINTER(c_double), c_int, c_double, c_double, _dp,
                                     c_double, c_double, _dp, _dp, c_int, c_int, _dp, _dp, _dp, c_size_t]),
     "gpk_svgp_elbo_sep_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gpk_svgp_elbo_shard_sep": (c_int, [c_void_p, C.POINTER(c_int), _dp, c_int, c_long, c_long, _dp, _dp, c_int, c_long, c_long,
-                                        c_int, c_int, C.POINTER(c_double), c_int, C.POINTER(c_double), c_double, c_double,
+                                        c_int, c_int, C.POINTER(c_double), c_int, C.POINTER(c_double), c_double, _dp, c_double,
                                         c_double, _dp, _dp, _dp, _dp, _dp, c_size_t]),
     "gpk_publish_host": (c_int, [c_void_p, _dp, c_int, _dp, c_void_p, c_int]),
     "gpk_profile_gemm_enable": (None, [c_int]),

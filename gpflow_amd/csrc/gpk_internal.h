@@ -132,9 +132,12 @@ int gpk_launch_sumsq_stage1(hipStream_t s, const double* A, int rows, int cols, 
 int gpk_launch_varexp_stage1(hipStream_t s, const double* Y, long ldy, const double* fmean, int rows,
                              int P, const double* s0, int s0_per_latent, const double* ssq,
                              const double* knn_host, int knn_per_latent, double noise,
-                             double mean_const, double* fvar_out, double* part, int* count);
+                             double mean_const, double* fvar_out, double* part, int* count,
+                             const double* noise_rows = nullptr);   // per-row noise variances [rows] or nullptr (constant `noise`)
 int gpk_launch_kl_white_stage1(hipStream_t s, const double* q_mu, const double* q_sqrt, int m, int P,
                                int q_diag, double* part, int* count);
+int gpk_launch_kl_unwhite_diag_stage1(hipStream_t s, const double* LinvT, long ldl, int m, const double* W, int P, double* part,
+                                      int* count);
 int gpk_launch_sum_log_diag_sq(hipStream_t s, const double* L, int n, long ldl, int batch, long strideL, double* out);
 int gpk_launch_row_stats_sep(hipStream_t s, const double* At, long strideAt, int rows, int m, long ldat, const double* V, int P,
                              double* sumsq, double* mv);

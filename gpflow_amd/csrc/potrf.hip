@@ -705,8 +705,8 @@ extern "C" size_t gpk_gpr_lml_workspace_bytes(int n, int d, int P) {
 
 extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int d, long ldx,
                            const double* Y, int P, long ldy, const double* ls_host, int ard,
-                           double variance, double noise_variance, double mean_const, double* out,
-                           int* info, void* ws, size_t ws_bytes) {
+                           double variance, double noise_variance, const double* noise_rows, double mean_const,
+                           double* out, int* info, void* ws, size_t ws_bytes) {
   if (!X || !Y || !out || !info || n <= 0 || P <= 0) return GPK_E_ARG;
   const LmlLayout l = lml_layout(n, P);
   if (!ws || ws_bytes < l.total) return GPK_E_WORKSPACE;
@@ -717,10 +717,15 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
   double* part = (double*)(w + l.off_part);
   double* logdet = (double*)(w + l.off_logdet);
   int rc;
-  // K(X,X) + noise I, lower tiles only (gpr.py:100-101)
+  // K(X,X) + noise I, lower tiles only (gpr.py:100-101); a heteroskedastic likelihood (noise_rows: one variance per data
+  // row, likelihoods/scalar_continuous.py:92-111) adds its vector to the diagonal instead (model_utils.py:46-50)
   rc = gpk_kernel_matrix(stream, family, X, n, ldx, nullptr, 0, 0, d, ls_host, ard, variance,
-                         noise_variance, 1, T, l.ld);
+                         noise_rows ? 0.0 : noise_variance, 1, T, l.ld);
   if (rc) return rc;
+  if (noise_rows) {
+    rc = gpk_diag_add(stream, T, n, l.ld, noise_rows);
+    if (rc) return rc;
+  }
   // (Y - m)^T as P extra rows (gpr.py:103, logdensities.py:149)
   rc = gpk_launch_transpose_shift(s, Y, n, P, ldy, T + (long)n * l.ld, l.ld, -mean_const);
   if (rc) return rc;
@@ -747,7 +752,7 @@ struct ElboLayout {
   size_t off_T, off_invd, off_LqT, off_s0, off_fmean, off_ssq, off_proj, off_part0, off_part1, off_part2, off_V, off_C, off_flags, off_Lfin, total;
 };
 
-ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
+ElboLayout elbo_layout(int m, int rows, int P, int q_diag, int whiten) {
   ElboLayout l{};
   l.ld = (long)gpk_align_up((size_t)m, 8);
   l.nt = 2 * gpk_gemm_tiles_n(m);
@@ -758,12 +763,16 @@ ElboLayout elbo_layout(int m, int rows, int P, int q_diag) {
   // T [m + rows_pad rows], then -- directly behind it, so that the un-whitened form can use ONE trapezoid [Kuu ; Kfu ; q_mu^T ;
   // tril(q_sqrt_p)^T] with the minibatch rows unpadded -- room for P + P m more rows; the whitened form keeps its LqT there
   l.off_T = o; o += (size_t)(m + rows_pad) * l.ld * sizeof(double);
-  l.off_LqT = o; o = gpk_align_up(o + (q_diag ? 0 : (size_t)(P + (size_t)P * m + 32) * l.ld * sizeof(double)), 256);
+  // (un-whitened with a diagonal q_sqrt: the trapezoid is [Kuu ; Kfu ; q_mu^T ; I] -- P + m more rows)
+  const size_t tail_rows = q_diag ? (whiten ? 0 : (size_t)P + m + 32) : (size_t)P + (size_t)P * m + 32;
+  l.off_LqT = o; o = gpk_align_up(o + tail_rows * l.ld * sizeof(double), 256);
   l.off_invd = o; o += gpk_align_up(gpk_invd_elems(m, 1) * sizeof(double), 256);
   l.off_s0 = o; o += gpk_align_up((size_t)rows * sizeof(double), 256);
   l.off_fmean = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
   l.off_ssq = o; o += gpk_align_up((size_t)rows * P * sizeof(double), 256);
-  l.off_proj = o; o += q_diag ? 0 : gpk_align_up(gpk_project_workspace_bytes(rows, m, P), 256);
+  // projection partials (full q_sqrt), or -- un-whitened with a diagonal q_sqrt -- the second solve A^T Lm^-1 [rows, ld]
+  l.off_proj = o; o += q_diag ? (whiten ? 0 : gpk_align_up((size_t)rows * l.ld * sizeof(double), 256))
+                              : gpk_align_up(gpk_project_workspace_bytes(rows, m, P), 256);
   l.off_part0 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part1 = o; o += gpk_align_up((size_t)GPK_REDUCE_MAXPART * sizeof(double), 256);
   l.off_part2 = o; o += gpk_align_up((size_t)(GPK_REDUCE_MAXPART + 64) * sizeof(double), 256);
@@ -800,30 +809,89 @@ int device_cus(int* ncu) {
 #ifdef GPK_EXPERIMENTAL
 // (A/B build only) byte offset of the step kernel's flag words / leaf time stamps inside the fused driver's workspace
 extern "C" __attribute__((visibility("default"))) long gpk_exp_svgp_flags_offset(int m, int rows, int P) {
-  return (long)elbo_layout(m, rows, P, 0).off_flags;
+  return (long)elbo_layout(m, rows, P, 0, 1).off_flags;
 }
 #endif
 
-extern "C" size_t gpk_svgp_elbo_workspace_bytes(int m, int rows, int d, int P, int q_diag) {
+extern "C" size_t gpk_svgp_elbo_workspace_bytes(int m, int rows, int d, int P, int q_diag, int whiten) {
   (void)d;
-  return elbo_layout(m, rows, P, q_diag).total;
+  return elbo_layout(m, rows, P, q_diag, whiten).total;
 }
 
 extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long ldz,
                                    const double* Xb, const double* Yb, int rows, long ldxb,
                                    long ldyb, int d, int P, const double* ls_host, int ard,
-                                   double variance, double noise_variance, double jitter,
+                                   double variance, double noise_variance, const double* noise_rows, double jitter,
                                    double mean_const, const double* q_mu, const double* q_sqrt,
                                    int q_diag, int whiten, double* out, int* info, void* ws,
                                    size_t ws_bytes) {
   if (!Z || !Xb || !Yb || !q_mu || !q_sqrt || !out || !info || m <= 0 || rows < 0 || P <= 0 || P > 16)
     return GPK_E_ARG;
-  if (!whiten && q_diag) return GPK_E_UNSUPPORTED;  // composed from the primitives by the Python host
-  const ElboLayout l = elbo_layout(m, rows, P, q_diag);
+  const ElboLayout l = elbo_layout(m, rows, P, q_diag, whiten);
   if (!ws || ws_bytes < l.total) return GPK_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   char* w = (char*)ws;
   double* T = (double*)(w + l.off_T);
+  if (!whiten && q_diag) {
+    // ---- whiten = 0 with a DIAGONAL q_sqrt [m, P] (kullback_leiblers.py:128-165: diag branch with K; conditionals/util.py:139-149)
+    // on ONE trapezoid [Kuu + jitter I ; Kfu ; q_mu^T ; I]: the identity rows come back as Lm^-T (written and solved by the
+    // factorisation at m^3 / 3, gpk_potrf_inv's row skipping), which gives everything the reference takes from its two
+    // factorisations and three triangular solves:
+    //     A^T = Kfu Lm^-T (fvar's Knn - sum A^2),  a^T = (Lm^-1 q_mu)^T (Mahalanobis term),  (Kuu^-1)_ii = |row i of Lm^-T|^2 (trace term),
+    //     A2^T = A^T Lm^-1 as one triangular-K GEMM (util.py:139's second solve of the minibatch columns) -> fmean = A2^T q_mu,
+    //     ssq = sum_i (A2_ib q_sqrt_ip)^2 (util.py:149).
+    double* invd_d = (double*)(w + l.off_invd);
+    double* s0_d = (double*)(w + l.off_s0);
+    double* fmean_d = (double*)(w + l.off_fmean);
+    double* ssq_d = (double*)(w + l.off_ssq);
+    double* pa = (double*)(w + l.off_part0);
+    double* pb = (double*)(w + l.off_part1);
+    double* pc = (double*)(w + l.off_part2);          // [MAXPART] trace / log det q partials, then [1] log det Lm
+    double* Kfu_d = T + (long)m * l.ld;
+    double* arow = Kfu_d + (long)rows * l.ld;          // [P, m]
+    double* LinvT = arow + (long)P * l.ld;             // [m, ld]: Lm^-T (upper triangular)
+    double* A2 = (double*)(w + l.off_proj);            // [rows, ld]
+    int rcd = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter, 1, T, l.ld);
+    if (rcd) return rcd;
+    const std::function<int(hipStream_t)> prod = [&](hipStream_t xs) -> int {
+      int r = gpk_kernel_matrix((void*)xs, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0, Kfu_d, l.ld);
+      if (r) return r;
+      return gpk_transpose((void*)xs, q_mu, m, P, P, arow, l.ld, 0, 1, 0, 0);
+    };
+    rcd = potrf_core(s, T, m, rows + P + m, l.ld, 1, 0, invd_d, 0, info, &prod, m);
+    if (rcd) return rcd;
+    if (rows > 0) {
+      GemmArgs g = gemm_base(rows, m, m, 1.0, Kfu_d, l.ld, LinvT, l.ld, 0.0, A2, l.ld, 1, 0, 0, 0);
+      g.b_tri = 1;  // LinvT[j, k] = Lm^-1[k, j] vanishes for k < j
+      rcd = gpk_launch_gemm(s, g);
+      if (rcd) return rcd;
+      rcd = gpk_row_sumsq(stream, Kfu_d, rows, m, l.ld, 1.0, 0.0, s0_d);
+      if (rcd) return rcd;
+      rcd = gpk_row_stats(stream, A2, rows, m, l.ld, q_mu, q_sqrt, P, 1.0, 0.0, nullptr, fmean_d, ssq_d);
+      if (rcd) return rcd;
+    }
+    int ca = 0;
+    rcd = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean_d, rows, P, s0_d, 0, ssq_d, &variance, 0, noise_variance, mean_const, nullptr,
+                                   pa, &ca, noise_rows);
+    if (rcd) return rcd;
+    const double* q0[1] = {pa};
+    const double one_d = 1.0;
+    rcd = gpk_launch_final(s, 1, q0, &ca, &one_d, 0.0, out);
+    if (rcd) return rcd;
+    // KL = 0.5 ( |a|^2 + sum_i [(Kuu^-1)_ii sum_p w_ip^2 - sum_p log w_ip^2] - M P ) + P sum log diag(Lm)
+    int cm_ = 0, ct = 0;
+    rcd = gpk_launch_sumsq_stage1(s, arow, P, m, l.ld, 0, pb, &cm_);
+    if (rcd) return rcd;
+    rcd = gpk_launch_kl_unwhite_diag_stage1(s, LinvT, l.ld, m, q_sqrt, P, pc, &ct);
+    if (rcd) return rcd;
+    double* ldl = pc + GPK_REDUCE_MAXPART;
+    rcd = gpk_sum_log_diag(stream, T, m, l.ld, 1, 0, ldl);
+    if (rcd) return rcd;
+    const double* kp[3] = {pb, pc, ldl};
+    const int kc[3] = {cm_, ct, 1};
+    const double ks[3] = {0.5, 0.5, (double)P};
+    return gpk_launch_final(s, 3, kp, kc, ks, -0.5 * (double)m * (double)P, out + 1);
+  }
   if (!whiten) {
     // ---- whiten = 0 (kullback_leiblers.py:98-165 with K = Kuu, conditionals/util.py:128-167 with white = False) on ONE
     // trapezoid [Kuu + jitter I ; Kfu ; q_mu^T ; tril(q_sqrt_p)^T].  The reference factors Kuu twice (once for the KL, once for
@@ -862,7 +930,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     if (rcu) return rcu;
     int ca = 0;
     rcu = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean_u, rows, P, s0_u, 0, ssq_u, &variance, 0, noise_variance, mean_const, nullptr,
-                                   pa, &ca);
+                                   pa, &ca, noise_rows);
     if (rcu) return rcu;
     const double* q0[1] = {pa};
     const double one_u = 1.0;
@@ -902,7 +970,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
 #ifdef GPK_EXPERIMENTAL
   // ---- single-launch route (mega.hip): builds + KL on the caller's stream, then ONE persistent kernel for everything
   // that depends on the factorisation.  Taken when the shapes fit one row block per compute unit.
-  if (!q_diag && GPK_TUNE(MEGA, GPK_MEGA_DEFAULT) && rows > 0) {
+  if (!q_diag && !noise_rows && GPK_TUNE(MEGA, GPK_MEGA_DEFAULT) && rows > 0) {
     int ncu = 0;
     rc = device_cus(&ncu);
     if (rc) return rc;
@@ -970,7 +1038,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   // sum_b var_exp_b  (likelihoods/scalar_continuous.py:139-148, svgp.py:174,181)
   int c0 = 0;
   rc = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean, rows, P, s0, 0, ssq, &variance, 0, noise_variance,
-                                mean_const, nullptr, part0, &c0);
+                                mean_const, nullptr, part0, &c0, noise_rows);
   if (rc) return rc;
   const double* p0[1] = {part0};
   const double one = 1.0;
@@ -1024,7 +1092,8 @@ extern "C" size_t gpk_svgp_elbo_sep_workspace_bytes(int m, int rows, int d, int 
 extern "C" int gpk_svgp_elbo_shard_sep(void* stream, const int* family_host, const double* Z, int m, long ldz, long strideZ,
                                        const double* Xb, const double* Yb, int rows, long ldxb, long ldyb, int d, int P,
                                        const double* ls_host, int ard, const double* variance_host, double noise_variance,
-                                       double jitter, double mean_const, const double* q_mu, const double* q_sqrt, double* out,
+                                       const double* noise_rows, double jitter, double mean_const, const double* q_mu,
+                                       const double* q_sqrt, double* out,
                                        int* info, void* ws, size_t ws_bytes) {
   if (!family_host || !Z || !Xb || !Yb || !q_mu || !q_sqrt || !ls_host || !variance_host || !out || !info || m <= 0 || rows < 0 ||
       P <= 0 || P > 16 || d <= 0 || strideZ < 0)
@@ -1083,7 +1152,7 @@ extern "C" int gpk_svgp_elbo_shard_sep(void* stream, const int* family_host, con
   if (rc) return rc;
   int c0 = 0;
   rc = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean, rows, P, s0, 1, ssq, variance_host, 1, noise_variance, mean_const, nullptr, part0,
-                                &c0);
+                                &c0, noise_rows);
   if (rc) return rc;
   const double* p0[1] = {part0};
   const double one = 1.0;

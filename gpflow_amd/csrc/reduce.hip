@@ -247,6 +247,7 @@ struct VarexpArgs {
   const double* s0; int s0_per_latent; const double* ssq;
   double knn[16]; int knn_per_latent;
   double noise, mean_const; double* fvar_out; double* part;
+  const double* noise_rows;   // per-row noise variances [rows] (heteroskedastic Gaussian, scalar_continuous.py:92-111) or nullptr
 };
 __global__ __launch_bounds__(RB) void varexp_kernel(VarexpArgs a) {
   __shared__ double sh[4];
@@ -262,7 +263,12 @@ __global__ __launch_bounds__(RB) void varexp_kernel(VarexpArgs a) {
     const double mu = a.fmean[e] + a.mean_const;
     const double dy = a.Y[(long)b * a.ldy + p] - mu;
     if (a.fvar_out) a.fvar_out[e] = fv;
-    acc += c0 - 0.5 * (dy * dy + fv) / a.noise;
+    if (a.noise_rows) {   // (workgroup-uniform branch)
+      const double nv = a.noise_rows[b];
+      acc += (-0.5 * log2pi - 0.5 * log(nv)) - 0.5 * (dy * dy + fv) / nv;
+    } else {
+      acc += c0 - 0.5 * (dy * dy + fv) / a.noise;
+    }
   }
   const double r = block_sum(acc, sh);
   if (threadIdx.x == 0) a.part[blockIdx.x] = r;
@@ -364,6 +370,18 @@ int gpk_launch_noop(hipStream_t s) {
   return 0;
 }
 
+// A[i,i] += v[i]:  add_noise_cov with a per-row likelihood variance (utilities/model_utils.py:33-38, 46-50)
+__global__ __launch_bounds__(256) void diag_add_kernel(double* __restrict__ A, int n, long lda, const double* __restrict__ v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) A[(long)i * lda + i] += v[i];
+}
+extern "C" int gpk_diag_add(void* stream, double* A, int n, long lda, const double* v) {
+  if (!A || !v || n < 0 || lda < n) return GPK_E_ARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(diag_add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, n, lda, v);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
 int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda, int batch, long strideA) {
   if (n <= 0) return 0;
   dim3 grid((unsigned)gpk_cdiv(n, 256), (unsigned)n, (unsigned)(batch > 0 ? batch : 1));
@@ -478,8 +496,8 @@ extern "C" int gpk_combine_parts(void* stream, const double* parts, int nparts, 
 extern "C" int gpk_gaussian_varexp_sum(void* stream, const double* Y, long ldy, const double* fmean,
                                        int rows, int P, const double* s0, int s0_per_latent,
                                        const double* ssq, const double* knn_host,
-                                       int knn_per_latent, double noise_variance, double mean_const,
-                                       double* fvar_out, double* out, void* ws, size_t ws_bytes) {
+                                       int knn_per_latent, double noise_variance, const double* noise_rows,
+                                       double mean_const, double* fvar_out, double* out, void* ws, size_t ws_bytes) {
   if (!Y || !fmean || !knn_host || !out || P <= 0 || P > 16 || rows < 0) return GPK_E_ARG;
   if (!ws || ws_bytes < gpk_reduce_workspace_bytes(rows)) return GPK_E_WORKSPACE;
   VarexpArgs a{};
@@ -487,7 +505,7 @@ extern "C" int gpk_gaussian_varexp_sum(void* stream, const double* Y, long ldy, 
   a.s0 = s0; a.s0_per_latent = s0_per_latent; a.ssq = ssq;
   for (int i = 0; i < (knn_per_latent ? P : 1); ++i) a.knn[i] = knn_host[i];
   a.knn_per_latent = knn_per_latent; a.noise = noise_variance; a.mean_const = mean_const;
-  a.fvar_out = fvar_out; a.part = (double*)ws;
+  a.fvar_out = fvar_out; a.part = (double*)ws; a.noise_rows = noise_rows;
   const int nb = nblocks_for((long)rows * P);
   hipLaunchKernelGGL(varexp_kernel, dim3(nb), dim3(RB), 0, (hipStream_t)stream, a);
   GPK_LAUNCH_CHECK();
@@ -518,6 +536,41 @@ extern "C" int gpk_sum_log_diag(void* stream, const double* L, int n, long ldl, 
   hipLaunchKernelGGL(sum_log_diag_kernel, dim3((unsigned)(batch > 0 ? batch : 1)), dim3(RB), 0,
                      (hipStream_t)stream, L, n, ldl, strideL, out);
   GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+// Un-whitened KL with a diagonal q_sqrt (kullback_leiblers.py:128-165, q_diag and K given): per inducing point i
+//   part += (K^-1)_ii * sum_p w_ip^2 - sum_p log(w_ip^2),   (K^-1)_ii = |row i of L^-T|^2  (rows of LinvT, upper triangular)
+__global__ __launch_bounds__(RB) void kl_unwhite_diag_kernel(const double* __restrict__ LinvT, long ldl, int m,
+                                                            const double* __restrict__ W, int P, double* __restrict__ part) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = blockIdx.x; i < m; i += gridDim.x) {
+    double ss = 0.0;
+    for (int k = i + threadIdx.x; k < m; k += RB) {
+      const double v = LinvT[(long)i * ldl + k];
+      ss += v * v;
+    }
+    const double kinv = block_sum(ss, sh);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double w2 = 0.0, lg = 0.0;
+      for (int p = 0; p < P; ++p) {
+        const double w = W[(long)i * P + p];
+        w2 += w * w;
+        lg += log(w * w);
+      }
+      acc += kinv * w2 - lg;
+    }
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+int gpk_launch_kl_unwhite_diag_stage1(hipStream_t s, const double* LinvT, long ldl, int m, const double* W, int P, double* part,
+                                      int* count) {
+  const int nb = m < GPK_REDUCE_MAXPART ? m : GPK_REDUCE_MAXPART;
+  hipLaunchKernelGGL(kl_unwhite_diag_kernel, dim3(nb), dim3(RB), 0, s, LinvT, ldl, m, W, P, part);
+  GPK_LAUNCH_CHECK();
+  *count = nb;
   return 0;
 }
 
@@ -566,13 +619,13 @@ int gpk_launch_sumsq_stage1(hipStream_t s, const double* A, int rows, int cols, 
 int gpk_launch_varexp_stage1(hipStream_t s, const double* Y, long ldy, const double* fmean, int rows,
                              int P, const double* s0, int s0_per_latent, const double* ssq,
                              const double* knn_host, int knn_per_latent, double noise,
-                             double mean_const, double* fvar_out, double* part, int* count) {
+                             double mean_const, double* fvar_out, double* part, int* count, const double* noise_rows) {
   VarexpArgs a{};
   a.Y = Y; a.ldy = ldy; a.fmean = fmean; a.rows = rows; a.P = P;
   a.s0 = s0; a.s0_per_latent = s0_per_latent; a.ssq = ssq;
   for (int i = 0; i < (knn_per_latent ? P : 1); ++i) a.knn[i] = knn_host[i];
   a.knn_per_latent = knn_per_latent; a.noise = noise; a.mean_const = mean_const;
-  a.fvar_out = fvar_out; a.part = part;
+  a.fvar_out = fvar_out; a.part = part; a.noise_rows = noise_rows;
   const int nb = nblocks_for((long)rows * P);
   hipLaunchKernelGGL(varexp_kernel, dim3(nb), dim3(RB), 0, s, a);
   GPK_LAUNCH_CHECK();

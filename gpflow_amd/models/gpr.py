@@ -44,14 +44,17 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
             Xs, _ = self.kernel.slice(X, None)
             family, var, ls = self.kernel.hyper()
             out, info = ops.gpr_lml(Xs, Y, variance=var, lengthscales=ls,
-                                    noise_variance=self.likelihood.noise_variance(), mean_const=c,
+                                    noise_variance=self.likelihood.noise_for(X), mean_const=c,
                                     family=family, ws=self._ws)
             ops.check_info(info)
             return out[0]
         K = self.kernel(X)
         n = K.shape[0]
-        idx = torch.arange(n, device=K.device)
-        K[idx, idx] += self.likelihood.noise_variance()  # add_noise_cov, model_utils.py:33-38
+        if self.likelihood.is_heteroskedastic:   # add_likelihood_noise_cov, model_utils.py:46-50
+            ops.diag_add_(K, self.likelihood.noise_for(X))
+        else:
+            idx = torch.arange(n, device=K.device)
+            K[idx, idx] += self.likelihood.noise_variance()  # add_noise_cov, model_utils.py:33-38
         _, info = ops.potrf_(K, n, zero_upper=True)
         ops.check_info(info)
         m = self.mean_function(X)
@@ -69,7 +72,10 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
         c = mf.constant_value()
         from ..kernels.base import gradient_spec
         combo = gradient_spec(k)            # Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315)
-        if combo is None and not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES) or c is None or lik.variance is None:
+        if lik.is_heteroskedastic:
+            raise NotImplementedError("gradients: the reverse pass takes a constant noise variance (a heteroskedastic Gaussian "
+                                      "likelihood is forward-only: log_marginal_likelihood, predict_*)")
+        if combo is None and not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES) or c is None or not lik.has_variance_parameter:
             raise NotImplementedError("gradients: SquaredExponential / Matern kernel (or a Sum / Product of them), constant mean, "
                                       "Gaussian likelihood with a variance parameter")
         X, Y = self.data
@@ -92,7 +98,7 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
             ops.check_info(info)
             host = {n: t.cpu().numpy() for n, t in g.items()}
             pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (lik.variance, host["noise_variance"])]
-        if isinstance(mf, Constant):
+        if isinstance(mf, Constant) and hasattr(mf, "c"):   # (Zero is a Constant without a parameter, functions.py:195-204)
             pairs.append((mf.c, host["mean_const"]))
         out = {}
         for par, gc in pairs:

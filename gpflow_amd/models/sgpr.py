@@ -127,7 +127,7 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         k, iv, lik = self.kernel, self.inducing_variable, self.likelihood
         c = self.mean_function.constant_value()
         if not (isinstance(k, Stationary) and isinstance(iv, InducingPoints) and isinstance(lik, Gaussian)
-                and lik.variance is not None and c is not None):
+                and lik.has_variance_parameter and c is not None):
             raise NotImplementedError("SGPR here: stationary kernel, InducingPoints, constant noise variance, constant mean")
         family, var, ls = k.hyper()
         X, Z = k.slice(self.data[0], iv.Z.device_value())
@@ -178,7 +178,7 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
         pairs = [(self.kernel.variance, host["variance"]), (self.kernel.lengthscales, host["lengthscales"]),
                  (self.likelihood.variance, host["noise_variance"]), (self.inducing_variable.Z, host["Z"])]
-        if isinstance(self.mean_function, Constant):
+        if isinstance(self.mean_function, Constant) and hasattr(self.mean_function, "c"):
             pairs.append((self.mean_function.c, host["mean_const"]))
         out = {}
         for par, gc in pairs:

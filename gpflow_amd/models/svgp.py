@@ -64,11 +64,8 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
     def _fused_config(self):
         """(stationary kernel, Z tensor, mean constant) when the whole ELBO shard is one C-ABI call:
         Gaussian likelihood, constant mean, and one stationary kernel shared by all latents (plain kernel +
-        InducingPoints, or SharedIndependent + SharedIndependentInducingVariables); whitened, or un-whitened with a
-        full q_sqrt."""
+        InducingPoints, or SharedIndependent + SharedIndependentInducingVariables); whitened or not, full or diagonal q_sqrt."""
         if not isinstance(self.likelihood, Gaussian):
-            return None
-        if not self.whiten and self.q_sqrt.device_value().dim() != 3:
             return None
         c = self.mean_function.constant_value()
         if c is None:
@@ -214,11 +211,11 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             family, var, ls = k.hyper()
             m, rows, d, P = Zs.shape[0], Xs.shape[0], Zs.shape[1], self.q_mu.shape[1]
             q_sqrt = self.q_sqrt.device_value()
-            key = (m, rows, d, P, q_sqrt.dim() == 2)
+            key = (m, rows, d, P, q_sqrt.dim() == 2, bool(self.whiten))
             if self._ws is None or self._ws[0] != key:
-                self._ws = (key, ops.svgp_elbo_workspace(m, rows, d, P, q_sqrt.dim() == 2))
+                self._ws = (key, ops.svgp_elbo_workspace(m, rows, d, P, q_sqrt.dim() == 2, self.whiten))
             out, info = ops.svgp_elbo_shard(Zs, Xs, Y, self.q_mu.device_value(), q_sqrt, variance=var,
-                                            lengthscales=ls, noise_variance=self.likelihood.noise_variance(),
+                                            lengthscales=ls, noise_variance=self.likelihood.noise_for(X),
                                             jitter=config.default_jitter(), mean_const=c, family=family,
                                             ws=self._ws[1], whiten=self.whiten)
             ops.check_info(info)
@@ -238,7 +235,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                 self._ws = (key, ops.svgp_elbo_sep_workspace(m, rows, d, P))
             out, info = ops.svgp_elbo_shard_sep(Zs, X.contiguous(), Y, self.q_mu.device_value(), self.q_sqrt.device_value(),
                                                 variances=[h[1] for h in hyp], lengthscales=ls, families=[h[0] for h in hyp],
-                                                noise_variance=self.likelihood.noise_variance(),
+                                                noise_variance=self.likelihood.noise_for(X),
                                                 jitter=config.default_jitter(), mean_const=c, ws=self._ws[1])
             ops.check_info(info)
             return out
@@ -276,7 +273,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         if isinstance(k, SharedIndependent) and isinstance(iv, SharedIndependentInducingVariables):
             k, iv = k.kernel, iv.inducing_variable
         c = self.mean_function.constant_value()
-        if not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES and isinstance(lik, Gaussian) and lik.variance is not None
+        if not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES and isinstance(lik, Gaussian) and lik.has_variance_parameter
                 and isinstance(iv, InducingPoints) and c is not None
                 and (self.q_sqrt.numpy().ndim == 3 or (allow_q_diag and self.q_sqrt.numpy().ndim == 2))
                 and (allow_active_dims or k.has_default_active_dims)):
@@ -302,7 +299,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             return None
         c = self.mean_function.constant_value()
         if not (all(isinstance(kk, IsotropicStationary) and kk.family in ops.KERNEL_FAMILIES for kk in k.kernels) and all(isinstance(v, InducingPoints) for v in ivs)
-                and isinstance(lik, Gaussian) and lik.variance is not None and c is not None and self.q_sqrt.numpy().ndim == 3
+                and isinstance(lik, Gaussian) and lik.has_variance_parameter and c is not None and self.q_sqrt.numpy().ndim == 3
                 and len(ivs) == len(k.kernels)):
             raise NotImplementedError("gradients: SeparateIndependent needs SquaredExponential / Matern members over InducingPoints, a "
                                       "Gaussian likelihood, full q_sqrt and a constant mean")
@@ -382,7 +379,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                 g_qs[p_:p_ + 1] = host["q_sqrt"]
             pairs += list(zgrads.values())
         pairs += [(lik.variance, g_noise), (self.q_mu, g_qmu), (self.q_sqrt, g_qs)]
-        if isinstance(mf, Constant):
+        if isinstance(mf, Constant) and hasattr(mf, "c"):   # (Zero is a Constant without a parameter, functions.py:195-204)
             pairs.append((mf.c, g_mean))
         out = {}
         for par, gc in pairs:
@@ -405,7 +402,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         spec, members = combo
         lik, mf, iv = self.likelihood, self.mean_function, self.inducing_variable
         c = mf.constant_value()
-        if not (self.whiten and isinstance(lik, Gaussian) and lik.variance is not None and isinstance(iv, InducingPoints)
+        if not (self.whiten and isinstance(lik, Gaussian) and lik.has_variance_parameter and isinstance(iv, InducingPoints)
                 and c is not None and self.q_sqrt.numpy().ndim == 3):
             raise NotImplementedError("gradients with a kernel combination: whitened SVGP, Gaussian likelihood, InducingPoints, "
                                       "full q_sqrt, constant mean")
@@ -421,7 +418,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             pairs += [(pv, gv[i]), (pl, g["lengthscales"][i].cpu().numpy())]
         pairs += [(iv.Z, g["Z"].cpu().numpy()), (lik.variance, g["noise_variance"].cpu().numpy()),
                   (self.q_mu, g["q_mu"].cpu().numpy()), (self.q_sqrt, g["q_sqrt"].cpu().numpy())]
-        if isinstance(mf, Constant):
+        if isinstance(mf, Constant) and hasattr(mf, "c"):   # (Zero is a Constant without a parameter, functions.py:195-204)
             pairs.append((mf.c, g["mean_const"].cpu().numpy()))
         out = {}
         for par, gc in pairs:

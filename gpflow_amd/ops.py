@@ -72,6 +72,18 @@ def _ls_host(lengthscales, d: int):
     return _lib.host_doubles(ls.tolist()), int(ard)
 
 
+def _noise_args(noise_variance, rows: int):
+    """(scalar, device pointer | None, keep-alive) for the (noise_variance, noise_rows) pair of the C-ABI: a float is the constant
+    noise of a homoskedastic Gaussian likelihood; a tensor / array with `rows` entries is one variance per data row
+    (Gaussian(variance=Function | scale=Function), likelihoods/scalar_continuous.py:92-111)."""
+    if isinstance(noise_variance, (torch.Tensor, np.ndarray)) and int(np.prod(tuple(noise_variance.shape))) != 1:
+        nv = to_device(noise_variance).reshape(-1).contiguous()
+        if nv.numel() != rows:
+            raise ValueError(f"per-row noise variances: expected {rows} entries, got {nv.numel()}")
+        return 1.0, nv.data_ptr(), nv
+    return float(noise_variance), None, None
+
+
 # ------------------------------------------------------------------------------------------------
 def kernel_matrix(X1: torch.Tensor, X2: Optional[torch.Tensor], *, variance: float, lengthscales,
                   family: str = "SquaredExponential", diag_add: float = 0.0, lower_only: bool = False,
@@ -159,6 +171,18 @@ def kernel_matrix_combine(X1: torch.Tensor, X2: Optional[torch.Tensor], G: torch
                                        _rowmajor(out, "out"))
     _lib.check(rc, "gpk_kernel_matrix_combine")
     return out
+
+
+def diag_add_(A: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """A[i,i] += v[i] in place (add_noise_cov with a per-row variance, utilities/model_utils.py:33-38) -- gpk_diag_add."""
+    lib = _lib.load()
+    _chk(A, "A", 2)
+    v = to_device(v).reshape(-1).contiguous()
+    n = min(A.shape[0], A.shape[1])
+    if v.numel() != n:
+        raise ValueError("diag_add_: one value per diagonal entry")
+    _lib.check(lib.gpk_diag_add(_stream(), A.data_ptr(), n, _rowmajor(A, "A"), v.data_ptr()), "gpk_diag_add")
+    return A
 
 
 def invd_alloc(n: int, batch: int = 1) -> torch.Tensor:
@@ -362,9 +386,10 @@ def project(At: torch.Tensor, LqT: torch.Tensor) -> torch.Tensor:
 
 
 def gaussian_varexp_sum(Y: torch.Tensor, fmean: torch.Tensor, *, s0: Optional[torch.Tensor],
-                        ssq: Optional[torch.Tensor], knn: Sequence[float], noise_variance: float,
+                        ssq: Optional[torch.Tensor], knn: Sequence[float], noise_variance,
                         mean_const: float = 0.0, s0_per_latent: bool = False, want_fvar: bool = False):
-    """Sum over rows/outputs of the Gaussian variational expectations; returns (scalar tensor, fvar|None)."""
+    """Sum over rows/outputs of the Gaussian variational expectations; returns (scalar tensor, fvar|None).
+    noise_variance: a float, or one variance per row [rows] (heteroskedastic likelihood)."""
     lib = _lib.load()
     _chk(Y, "Y", 2)
     _chk(fmean, "fmean", 2)
@@ -376,10 +401,11 @@ def gaussian_varexp_sum(Y: torch.Tensor, fmean: torch.Tensor, *, s0: Optional[to
     ws = _ws(int(lib.gpk_reduce_workspace_bytes(rows)))
     knn = list(np.atleast_1d(np.asarray(knn, dtype=np.float64)))
     per = int(len(knn) > 1)
+    nv, nv_rows, _keep = _noise_args(noise_variance, rows)
     rc = lib.gpk_gaussian_varexp_sum(_stream(), Y.data_ptr(), _rowmajor(Y, "Y"), fmean.data_ptr(), rows, P,
                                      s0.data_ptr() if s0 is not None else None, int(s0_per_latent),
                                      ssq.data_ptr() if ssq is not None else None,
-                                     _lib.host_doubles(knn), per, float(noise_variance), float(mean_const),
+                                     _lib.host_doubles(knn), per, nv, nv_rows, float(mean_const),
                                      fvar.data_ptr() if fvar is not None else None, out.data_ptr(),
                                      ws.data_ptr(), ws.numel() * 8)
     _lib.check(rc, "gpk_gaussian_varexp_sum")
@@ -450,10 +476,10 @@ def sumsq(A: torch.Tensor, *, upper_only: bool = False) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ fused
-def gpr_lml(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
+def gpr_lml(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, noise_variance,
             mean_const: float = 0.0, family: str = "SquaredExponential",
             ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(LML scalar tensor, info) -- gpk_gpr_lml."""
+    """(LML scalar tensor, info) -- gpk_gpr_lml.  noise_variance: a float, or one variance per data row [n]."""
     lib = _lib.load()
     _chk(X, "X", 2)
     _chk(Y, "Y", 2)
@@ -467,9 +493,10 @@ def gpr_lml(X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, 
     out = torch.empty(1, dtype=torch.float64, device=X.device)
     info = torch.zeros(1, dtype=torch.int32, device=X.device)
     ls, ard = _ls_host(lengthscales, d)
+    nv, nv_rows, _keep = _noise_args(noise_variance, n)
     rc = lib.gpk_gpr_lml(_stream(), KERNEL_FAMILIES[family], X.data_ptr(), n, d, _rowmajor(X, "X"),
                          Y.data_ptr(), P, _rowmajor(Y, "Y"), ls, ard, float(variance),
-                         float(noise_variance), float(mean_const), out.data_ptr(), info.data_ptr(),
+                         nv, nv_rows, float(mean_const), out.data_ptr(), info.data_ptr(),
                          ws.data_ptr(), ws.numel() * 8)
     _lib.check(rc, "gpk_gpr_lml")
     return out, info
@@ -527,7 +554,7 @@ def svgp_elbo_sep_workspace(m: int, rows: int, d: int, P: int) -> torch.Tensor:
 
 
 def svgp_elbo_shard_sep(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor, q_sqrt: torch.Tensor, *,
-                        variances, lengthscales, families, noise_variance: float, jitter: float, mean_const: float = 0.0,
+                        variances, lengthscales, families, noise_variance, jitter: float, mean_const: float = 0.0,
                         ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                         info: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Whitened shard with one kernel PER latent (SeparateIndependent): Z [m, d] (shared) or [P, m, d]; variances [P],
@@ -560,27 +587,28 @@ def svgp_elbo_shard_sep(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_m
     if info is None:
         info = torch.zeros(P, dtype=torch.int32, device=Xb.device)
     fam = (_lib.C.c_int * P)(*[KERNEL_FAMILIES[f] for f in families])
+    nv, nv_rows, _keep = _noise_args(noise_variance, rows)
     rc = lib.gpk_svgp_elbo_shard_sep(_stream(), fam, Z.data_ptr(), m, d, 0 if shared else m * d, Xb.data_ptr(), Yb.data_ptr(), rows,
                                      _rowmajor(Xb, "Xb"), _rowmajor(Yb, "Yb"), d, P, _lib.host_doubles(ls.reshape(-1).tolist()), ard,
-                                     _lib.host_doubles(var.tolist()), float(noise_variance), float(jitter), float(mean_const),
+                                     _lib.host_doubles(var.tolist()), nv, nv_rows, float(jitter), float(mean_const),
                                      q_mu.data_ptr(), q_sqrt.data_ptr(), out.data_ptr(), info.data_ptr(), ws.data_ptr(),
                                      ws.numel() * 8)
     _lib.check(rc, "gpk_svgp_elbo_shard_sep")
     return out, info
 
 
-def svgp_elbo_workspace(m: int, rows: int, d: int, P: int, q_diag: bool) -> torch.Tensor:
+def svgp_elbo_workspace(m: int, rows: int, d: int, P: int, q_diag: bool, whiten: bool = True) -> torch.Tensor:
     lib = _lib.load()
-    return _ws(int(lib.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, int(q_diag))))
+    return _ws(int(lib.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, int(q_diag), int(bool(whiten)))))
 
 
 def svgp_elbo_shard(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor,
-                    q_sqrt: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
+                    q_sqrt: torch.Tensor, *, variance: float, lengthscales, noise_variance,
                     jitter: float, mean_const: float = 0.0, family: str = "SquaredExponential",
                     ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                     info: Optional[torch.Tensor] = None, whiten: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """One shard of SVGP.elbo: out[0] = sum_b var_exp_b over this shard, out[1] = KL.  Returns (out, info).
-    whiten=False (full q_sqrt only): KL against N(0, Kuu) and the un-whitened conditional, on one factorisation."""
+    whiten=False: KL against N(0, Kuu) and the un-whitened conditional, on one factorisation (full or diagonal q_sqrt)."""
     lib = _lib.load()
     for name, t in (("Z", Z), ("Xb", Xb), ("Yb", Yb), ("q_mu", q_mu)):
         _chk(t, name, 2)
@@ -593,7 +621,7 @@ def svgp_elbo_shard(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: t
         raise ValueError("inconsistent shapes")
     if not (q_mu.is_contiguous() and q_sqrt.is_contiguous()):
         raise ValueError("q_mu / q_sqrt must be contiguous")
-    nbytes = int(lib.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, int(q_diag)))
+    nbytes = int(lib.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, int(q_diag), int(bool(whiten))))
     if ws is None or ws.numel() * 8 < nbytes:
         ws = _ws(nbytes)
     if out is None:
@@ -601,10 +629,11 @@ def svgp_elbo_shard(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: t
     if info is None:
         info = torch.zeros(1, dtype=torch.int32, device=Z.device)
     ls, ard = _ls_host(lengthscales, d)
+    nv, nv_rows, _keep = _noise_args(noise_variance, rows)
     rc = lib.gpk_svgp_elbo_shard(_stream(), KERNEL_FAMILIES[family], Z.data_ptr(), m, _rowmajor(Z, "Z"),
                                  Xb.data_ptr(), Yb.data_ptr(), rows, _rowmajor(Xb, "Xb"),
                                  _rowmajor(Yb, "Yb"), d, P, ls, ard, float(variance),
-                                 float(noise_variance), float(jitter), float(mean_const),
+                                 nv, nv_rows, float(jitter), float(mean_const),
                                  q_mu.data_ptr(), q_sqrt.data_ptr(), int(q_diag), int(bool(whiten)), out.data_ptr(),
                                  info.data_ptr(), ws.data_ptr(), ws.numel() * 8)
     _lib.check(rc, "gpk_svgp_elbo_shard")

@@ -151,6 +151,16 @@ class GPRPosterior(AbstractPosterior):
     def _err(self):
         return self.Y_data - self.mean_function(self.X_data)
 
+    def _K_plus_noise_into(self, Xsliced, out):
+        """K(X, X) + likelihood noise on the diagonal (add_likelihood_noise_cov, utilities/model_utils.py:46-50): the constant rides
+        inside the covariance build; a heteroskedastic likelihood adds its per-row variances at the (unsliced) data inputs."""
+        if self.likelihood.is_heteroskedastic:
+            self.kernel.K_into(Xsliced, None, out, lower_only=True)
+            ops.diag_add_(out, self.likelihood.noise_for(self.X_data))
+        else:
+            self.kernel.K_into(Xsliced, None, out, diag_add=self.likelihood.noise_variance(), lower_only=True)
+        return out
+
     def _precompute(self):
         """cache = (err, Lm) (posteriors.py:415-432); the block inverses and alpha = Lm^-1 err (which rides through
         the factorisation as P extra rows, logdensities.py:150 style) stay alongside Lm."""
@@ -159,7 +169,7 @@ class GPRPosterior(AbstractPosterior):
         err = self._err()
         P = err.shape[1]
         T = torch.empty((n + P, n), dtype=torch.float64, device=X.device)
-        self.kernel.K_into(X, None, T[:n], diag_add=self.likelihood.noise_variance(), lower_only=True)
+        self._K_plus_noise_into(X, T[:n])
         T[n:] = err.t()
         invd, info = ops.potrf_(T, n, zero_upper=True)
         ops.check_info(info)
@@ -195,7 +205,7 @@ class GPRPosterior(AbstractPosterior):
         P = err.shape[1]
         # one trapezoid [K + noise I ; Kxs ; err^T]: the factorisation returns A^T = Kxs Lm^-T and alpha^T = (Lm^-1 err)^T
         T = torch.empty((n + t + P, n), dtype=torch.float64, device=Xd.device)
-        self.kernel.K_into(Xd, None, T[:n], diag_add=self.likelihood.noise_variance(), lower_only=True)
+        self._K_plus_noise_into(Xd, T[:n])
         self.kernel.K_into(Xs, Xd, T[n:n + t])
         T[n + t:] = err.t()
         invd, info = ops.potrf_(T, n, zero_upper=True)

@@ -81,7 +81,7 @@ class SVGPTrainer:
         self.host = {"variance": k.variance, "lengthscales": k.lengthscales, "noise_variance": lik.variance}
         from .mean_functions import Constant
         mf = model.mean_function
-        if isinstance(mf, Constant):
+        if isinstance(mf, Constant) and hasattr(mf, "c"):   # (Zero is a Constant without a parameter, functions.py:195-204)
             # Constant.c is a trainable Parameter like any other (gpflow/functions.py:173-192): it joins the host set
             if np.size(mf.c.numpy()) != 1:
                 raise NotImplementedError("the reverse pass covers a scalar Constant mean")

@@ -75,6 +75,10 @@ int gpk_kernel_matrix(void* stream, int family, const double* X1, int n1, long l
                       const double* X2, int n2, long ldx2, int d, const double* ls_host, int ard,
                       double variance, double diag_add, int lower_only, double* K, long ldk);
 
+/* A[i,i] += v[i], i < n (v: DEVICE pointer):  add_noise_cov / add_likelihood_noise_cov with a per-row likelihood variance
+ * (utilities/model_utils.py:33-38, 46-50) -- the heteroskedastic counterpart of gpk_kernel_matrix's scalar diag_add. */
+int gpk_diag_add(void* stream, double* A, int n, long lda, const double* v);
+
 /* out = G .* k(X1, X2) (op 1), G + k(X1, X2) (op 2) or G .* (-2 dk/dr2)(X1, X2) (op 3), k recomputed from the inputs (one read of G, one write; G may
  * alias out).  Replaces the tf.multiply / tf.add_n reductions of Product / Sum kernels (kernels/base.py:216-220,
  * 283-329): the second factor / term is folded into the first matrix in place instead of being materialised.
@@ -190,12 +194,16 @@ int gpk_project_batched(void* stream, const double* At, int rows, int m, long ld
  *   fvar[b,p] = knn - s0[b | p,b] + ssq[p,b]
  *   out[0] = sum_b sum_p -0.5 log 2pi - 0.5 log nv - 0.5 ((Y[b,p] - fmean[b,p] - mean_const)^2 + fvar) / nv
  * s0 [rows] or [P,rows] (s0_per_latent), may be NULL; ssq [P,rows] may be NULL; fvar_out [rows,P]
- * optional.  knn: HOST pointer, P values if knn_per_latent else 1. */
+ * optional.  knn: HOST pointer, P values if knn_per_latent else 1.
+ * noise_rows: DEVICE pointer to one noise variance PER ROW [rows] -- a heteroskedastic Gaussian likelihood,
+ * Gaussian(variance=Function | scale=Function) evaluated at the rows (scalar_continuous.py:92-111, 139-148: nv becomes
+ * nv[b]) -- or NULL for the constant `noise_variance`.  The same pair (noise_variance, noise_rows) appears in the fused
+ * drivers below with the same meaning. */
 size_t gpk_reduce_workspace_bytes(int n);
 int gpk_gaussian_varexp_sum(void* stream, const double* Y, long ldy, const double* fmean, int rows,
                             int P, const double* s0, int s0_per_latent, const double* ssq,
                             const double* knn_host, int knn_per_latent, double noise_variance,
-                            double mean_const, double* fvar_out, double* out, void* ws,
+                            const double* noise_rows, double mean_const, double* fvar_out, double* out, void* ws,
                             size_t ws_bytes);
 
 /* whitened KL (kullback_leiblers.py:98-165 with K None):
@@ -222,12 +230,14 @@ int gpk_combine_parts(void* stream, const double* parts, int nparts, long stride
 /* ---- fused drivers -----------------------------------------------------------------------------------
  * GPR.log_marginal_likelihood (gpr.py:91-107), stationary kernel, Gaussian noise, constant mean:
  * builds K(X,X)+noise*I (lower) with (Y-mean)^T as extra rows into ws, factors, reduces.
- *   out[0] = LML (summed over the P columns of Y); info: device int. */
+ *   out[0] = LML (summed over the P columns of Y); info: device int.
+ * noise_rows (device, [n]) != NULL: K(X,X) + diag(noise_rows) instead -- add_likelihood_noise_cov with
+ * likelihood.variance_at(X) (utilities/model_utils.py:46-50, gpr.py:100-101). */
 size_t gpk_gpr_lml_workspace_bytes(int n, int d, int P);
 int gpk_gpr_lml(void* stream, int family, const double* X, int n, int d, long ldx, const double* Y,
                 int P, long ldy, const double* ls_host, int ard, double variance,
-                double noise_variance, double mean_const, double* out, int* info, void* ws,
-                size_t ws_bytes);
+                double noise_variance, const double* noise_rows, double mean_const, double* out, int* info,
+                void* ws, size_t ws_bytes);
 
 /* One shard of SVGP.elbo (svgp.py:166-181), whitened, one kernel shared by all P latents
  * (IndependentPosteriorSingleOutput posteriors.py:828-841 and the SharedIndependent branch :849-861):
@@ -236,13 +246,15 @@ int gpk_gpr_lml(void* stream, int family, const double* X, int n, int d, long ld
  * q_diag: q_sqrt is [m,P] instead of [P,m,m].
  * whiten = 0 (full q_sqrt): KL against N(0, Kuu) (kullback_leiblers.py:98-165 with K) and the un-whitened conditional
  * (conditionals/util.py:128-167, white = False) on ONE factorisation -- [Kuu ; Kfu ; q_mu^T ; tril(q_sqrt_p)^T] as one
- * trapezoid; the reference factors Kuu twice and solves the minibatch columns twice.  whiten = 0 with q_diag returns
- * GPK_E_UNSUPPORTED (the host composes that case from the primitives above). */
-size_t gpk_svgp_elbo_workspace_bytes(int m, int rows, int d, int P, int q_diag);
+ * trapezoid; the reference factors Kuu twice and solves the minibatch columns twice.  whiten = 0 with q_diag (round 5;
+ * kullback_leiblers.py:128-165 diag branch, util.py:139-149): the trapezoid is [Kuu ; Kfu ; q_mu^T ; I], the identity rows
+ * return Lm^-T, whose row norms are diag(Kuu^-1) (trace term) and which turns the second solve of the minibatch columns
+ * into one triangular-K GEMM.  The workspace query takes the same (q_diag, whiten) pair as the call. */
+size_t gpk_svgp_elbo_workspace_bytes(int m, int rows, int d, int P, int q_diag, int whiten);
 int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, int m, long ldz, const double* Xb,
                         const double* Yb, int rows, long ldxb, long ldyb, int d, int P,
                         const double* ls_host, int ard, double variance, double noise_variance,
-                        double jitter, double mean_const, const double* q_mu,
+                        const double* noise_rows, double jitter, double mean_const, const double* q_mu,
                         const double* q_sqrt, int q_diag, int whiten, double* out, int* info,
                         void* ws, size_t ws_bytes);
 
@@ -255,8 +267,8 @@ size_t gpk_svgp_elbo_sep_workspace_bytes(int m, int rows, int d, int P);
 int gpk_svgp_elbo_shard_sep(void* stream, const int* family_host, const double* Z, int m, long ldz, long strideZ,
                             const double* Xb, const double* Yb, int rows, long ldxb, long ldyb, int d, int P,
                             const double* ls_host, int ard, const double* variance_host, double noise_variance,
-                            double jitter, double mean_const, const double* q_mu, const double* q_sqrt, double* out,
-                            int* info, void* ws, size_t ws_bytes);
+                            const double* noise_rows, double jitter, double mean_const, const double* q_mu,
+                            const double* q_sqrt, double* out, int* info, void* ws, size_t ws_bytes);
 
 /* ---- result mailbox in mapped host memory ------------------------------------------------------------------------
  * Copies n doubles from device memory `src` (and one int from `info`, may be NULL) into `host_dst`, a buffer of PINNED,

@@ -264,8 +264,33 @@ def prior_kl(Z, q_mu, q_sqrt, *, variance, lengthscales, whiten=False, kernel="S
 
 
 # ----------------------------------------------------------------------------- L3: likelihood
+def _noise_column(noise_variance):
+    """A constant, or one variance per data row [N] -> [N, 1] (Gaussian._variance for a Function-valued variance / scale:
+    likelihoods/scalar_continuous.py:92-105 returns [N, 1], which then broadcasts against [N, P])."""
+    nv = np.asarray(noise_variance, dtype=np.float64)
+    return nv[:, None] if nv.ndim == 1 else nv
+
+
+def gaussian_variance_at(X, *, variance=None, scale=None, lower_bound=1e-6):
+    """Gaussian._variance (likelihoods/scalar_continuous.py:92-105) for a heteroskedastic likelihood: `variance` / `scale` is a
+    callable of X returning [N, 1]; its value is clipped from below at the lower bound (of the variance, or its square root for
+    a scale) when evaluated (utilities/parameter_or_function.py:45-58).  Returns one variance per row [N]."""
+    if variance is not None:
+        v = np.maximum(np.asarray(variance(X), dtype=np.float64), lower_bound)
+    else:
+        v = np.maximum(np.asarray(scale(X), dtype=np.float64), np.sqrt(lower_bound)) ** 2
+    return np.broadcast_to(v, (np.asarray(X).shape[0], 1))[:, 0].copy()
+
+
+def linear_function(A, b):
+    """gpflow/functions.py:96-126: X -> X A + b"""
+    A, b = np.atleast_2d(np.asarray(A, dtype=np.float64)), np.atleast_1d(np.asarray(b, dtype=np.float64))
+    return lambda X: np.tensordot(np.asarray(X, dtype=np.float64), A, axes=([-1], [0])) + b
+
+
 def gaussian_variational_expectations(Fmu, Fvar, Y, noise_variance):
-    """gpflow/likelihoods/scalar_continuous.py:139-148"""
+    """gpflow/likelihoods/scalar_continuous.py:139-148 (noise_variance: a constant or one value per row [N])"""
+    noise_variance = _noise_column(noise_variance)
     return np.sum(
         -0.5 * LOG2PI - 0.5 * np.log(noise_variance) - 0.5 * ((Y - Fmu) ** 2 + Fvar) / noise_variance,
         axis=-1,
@@ -274,18 +299,19 @@ def gaussian_variational_expectations(Fmu, Fvar, Y, noise_variance):
 
 def gaussian_predict_mean_and_var(Fmu, Fvar, noise_variance):
     """scalar_continuous.py:127-130"""
-    return Fmu.copy(), Fvar + noise_variance
+    return Fmu.copy(), Fvar + _noise_column(noise_variance)
 
 
 def gaussian_predict_log_density(Fmu, Fvar, Y, noise_variance):
     """scalar_continuous.py:132-136"""
-    return np.sum(gaussian_logdensity(Y, Fmu, Fvar + noise_variance), axis=-1)
+    return np.sum(gaussian_logdensity(Y, Fmu, Fvar + _noise_column(noise_variance)), axis=-1)
 
 
 # ----------------------------------------------------------------------------- L4: GPR
 def gpr_log_marginal_likelihood(X, Y, *, variance, lengthscales, noise_variance, mean=0.0,
                                 kernel="SquaredExponential"):
-    """gpflow/models/gpr.py:91-107"""
+    """gpflow/models/gpr.py:91-107 (noise_variance: a constant, or likelihood.variance_at(X) squeezed to [N] -- add_likelihood_noise_cov,
+    utilities/model_utils.py:46-50)"""
     K = stationary_K(kernel, X, None, variance=variance, lengthscales=lengthscales)
     ks = add_noise_cov(K, noise_variance)
     L = np.linalg.cholesky(ks)

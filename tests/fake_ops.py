@@ -254,6 +254,25 @@ def row_stats(At, *, V=None, W=None, want_sumsq=True):
     return sumsq, mv, wsq
 
 
+def _noise(noise_variance, rows):
+    """The (noise_variance, noise_rows) pair of the C-ABI: a constant, or one variance per row -> [rows, 1]."""
+    if isinstance(noise_variance, (torch.Tensor, np.ndarray)) and int(np.prod(tuple(noise_variance.shape))) != 1:
+        nv = _np(noise_variance).reshape(-1)
+        assert nv.size == rows, (nv.size, rows)
+        return nv[:, None]
+    return float(noise_variance)
+
+
+def diag_add_(A, v):
+    """gpk_diag_add: A[i,i] += v[i] in place"""
+    v = to_device(v).reshape(-1)
+    n = min(A.shape[0], A.shape[1])
+    assert v.numel() == n
+    idx = torch.arange(n)
+    A[idx, idx] += v
+    return A
+
+
 def gaussian_varexp_sum(Y, fmean, *, s0, ssq, knn, noise_variance, mean_const=0.0, s0_per_latent=False,
                         want_fvar=False):
     P = fmean.shape[1]
@@ -263,8 +282,9 @@ def gaussian_varexp_sum(Y, fmean, *, s0, ssq, knn, noise_variance, mean_const=0.
         fv = fv - (_np(s0).T if s0_per_latent else _np(s0)[:, None])
     if ssq is not None:
         fv = fv + _np(ssq).T
-    ve = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(noise_variance) \
-        - 0.5 * ((_np(Y) - _np(fmean) - mean_const) ** 2 + fv) / noise_variance
+    nv = _noise(noise_variance, fmean.shape[0])
+    ve = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(nv) \
+        - 0.5 * ((_np(Y) - _np(fmean) - mean_const) ** 2 + fv) / nv
     return torch.tensor([ve.sum()], dtype=torch.float64), (torch.from_numpy(fv) if want_fvar else None)
 
 
@@ -321,8 +341,11 @@ def gpr_lml(X, Y, *, variance, lengthscales, noise_variance, mean_const=0.0, fam
     """The fused driver, emulated by the same chain of primitives it runs (potrf.hip: gpk_gpr_lml)."""
     n, P = Y.shape
     T = torch.empty((n + P, n), dtype=torch.float64)
-    kernel_matrix(X, None, variance=variance, lengthscales=lengthscales, family=family, diag_add=noise_variance,
+    nv = _noise(noise_variance, n)
+    kernel_matrix(X, None, variance=variance, lengthscales=lengthscales, family=family, diag_add=0.0 if isinstance(nv, np.ndarray) else nv,
                   lower_only=True, out=T[:n])
+    if isinstance(nv, np.ndarray):
+        diag_add_(T[:n], torch.from_numpy(nv[:, 0].copy()))
     T[n:] = (Y - mean_const).t()
     _, info = potrf_(T, n)
     if int(info[0]):
@@ -364,7 +387,7 @@ def svgp_elbo_shard_sep(Z, Xb, Yb, q_mu, q_sqrt, *, variances, lengthscales, fam
     return res, inf
 
 
-def svgp_elbo_workspace(m, rows, d, P, q_diag):
+def svgp_elbo_workspace(m, rows, d, P, q_diag, whiten=True):
     return torch.empty(1, dtype=torch.float64)
 
 
@@ -373,9 +396,33 @@ def svgp_elbo_shard(Z, Xb, Yb, q_mu, q_sqrt, *, variance, lengthscales, noise_va
     """gpk_svgp_elbo_shard emulated by its own chain of primitives (shared kernel; whitened, or un-whitened on one trapezoid)."""
     M, rows, P = Z.shape[0], Xb.shape[0], q_mu.shape[1]
     kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+    if not whiten and q_sqrt.dim() == 2:
+        # un-whitened, diagonal q_sqrt: [Kuu ; Kfu ; q_mu^T ; I] -> A^T, (Lm^-1 q_mu)^T, Lm^-T (potrf.hip, round 5)
+        T = torch.empty((M + rows + P + M, M), dtype=torch.float64)
+        kernel_matrix(Z, None, diag_add=jitter, lower_only=True, out=T[:M], **kw)
+        if rows:
+            kernel_matrix(Xb, Z, out=T[M:M + rows], **kw)
+        T[M + rows:M + rows + P] = q_mu.t()
+        _, inf = potrf_(T, M, identity_rows=True)
+        res = torch.zeros(2, dtype=torch.float64)
+        if int(inf[0]) == 0:
+            At = T[M:M + rows].contiguous()
+            LinvT = T[M + rows + P:].contiguous()
+            A2 = gemm_nt(At, LinvT, b_tri=1) if rows else At
+            s0 = row_stats(At)[0] if rows else torch.zeros(0, dtype=torch.float64)
+            _, fmean, ssq = row_stats(A2, V=q_mu, W=q_sqrt, want_sumsq=False) if rows else (None, torch.zeros((0, P), dtype=torch.float64), torch.zeros((P, 0), dtype=torch.float64))
+            ve, _ = gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
+                                        mean_const=mean_const)
+            res[0] = ve[0]
+            kinv = (np.triu(_np(LinvT)) ** 2).sum(1)
+            w = _np(q_sqrt)
+            res[1] = 0.5 * float((_np(T[M + rows:M + rows + P]) ** 2).sum()) + 0.5 * float((kinv[:, None] * w ** 2).sum()) \
+                - 0.5 * float(np.log(w ** 2).sum()) - 0.5 * M * P + P * float(np.log(np.diagonal(_np(T[:M]))).sum())
+        if out is not None:
+            out.copy_(res)
+            res = out
+        return res, inf
     if not whiten:
-        if q_sqrt.dim() != 3:
-            raise RuntimeError("gpk_svgp_elbo_shard: unsupported (rc -4)")
         T = torch.empty((M + rows + P + P * M, M), dtype=torch.float64)
         kernel_matrix(Z, None, diag_add=jitter, lower_only=True, out=T[:M], **kw)
         if rows:

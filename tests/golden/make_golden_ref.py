@@ -330,6 +330,36 @@ def build():  # noqa: C901
     mu, var = sg.predict_f(Xs); qmu, qcov = sg.compute_qu()
     out.update(sgpr_X=X, sgpr_Y=Y, sgpr_Z=Z, sgpr_Xnew=Xs, sgpr_elbo=float(sg.elbo()), sgpr_upper=float(sg.upper_bound()),
                sgpr_mu=_n(mu), sgpr_var=_n(var), sgpr_qu_mu=_n(qmu), sgpr_qu_cov=_n(qcov))
+
+    # ---- heteroskedastic Gaussian likelihood (likelihoods/scalar_continuous.py:52-148, utilities/model_utils.py:46-50): the noise
+    # scale / variance is a Function of the inputs -- the reference's own recipe of tests/integration/test_linear_noise.py:59
+    # (Gaussian(scale=Linear())) with fixed coefficients, and a variance given as a polynomial that dips below the lower bound
+    rng = np.random.default_rng(61)
+    X = rng.uniform(size=(40, 2)); Y = np.sin(5 * X[:, :1]) + (0.7 - 0.5 * X[:, :1]) * rng.normal(size=(40, 1)); Xs = rng.uniform(size=(6, 2))
+    hA, hb = np.array([[-0.5], [0.2]]), np.array([0.7])
+    lik = gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=hA, b=hb))
+    hk = lambda: gpflow.kernels.SquaredExponential(variance=1.3, lengthscales=[0.3, 0.6])  # noqa: E731
+    hg = gpflow.models.GPR((X, Y), hk(), likelihood=lik)
+    ymu, yvar = hg.predict_y(Xs); fmu, fvar = hg.predict_f(Xs)
+    out.update(het_X=X, het_Y=Y, het_Xnew=Xs, het_A=hA, het_b=hb, het_variance_at=_n(lik.variance_at(X)),
+               het_gpr_lml=float(hg.log_marginal_likelihood()), het_gpr_fmu=_n(fmu), het_gpr_fvar=_n(fvar), het_gpr_ymu=_n(ymu),
+               het_gpr_yvar=_n(yvar), het_gpr_logdens=_n(hg.predict_log_density((Xs, np.cos(Xs[:, :1])))))
+    pmu, pvar = hg.posterior().predict_f(Xs)
+    out.update(het_gpr_cached_mu=_n(pmu), het_gpr_cached_var=_n(pvar))
+    Zh = X[:7].copy(); hq_mu = 0.3 * rng.normal(size=(7, 1)); hq_sqrt = (np.tril(0.1 * rng.normal(size=(7, 7))) + 0.6 * np.eye(7))[None]
+    for wh in (True, False):
+        hs = gpflow.models.SVGP(hk(), gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=hA, b=hb)), Zh, q_mu=hq_mu, q_sqrt=hq_sqrt,
+                                whiten=wh, num_data=400)
+        out[f"het_svgp_elbo_{'white' if wh else 'unwhite'}"] = float(hs.elbo((X, Y)))
+    out.update(het_Z=Zh, het_q_mu=hq_mu, het_q_sqrt=hq_sqrt)
+    # variance as a Function, clipped at the lower bound where the polynomial goes negative (parameter_or_function.py:52-56)
+    pw = np.array([[0.02, 0.3, -0.4, 0.0, 0.0, 0.0]])
+    likp = gpflow.likelihoods.Gaussian(variance=gpflow.functions.Polynomial(2, input_dim=2, w=pw), variance_lower_bound=1e-3)
+    hp = gpflow.models.GPR((X, Y), hk(), likelihood=likp)
+    hsq = gpflow.models.SVGP(hk(), gpflow.likelihoods.Gaussian(variance=gpflow.functions.Polynomial(2, input_dim=2, w=pw), variance_lower_bound=1e-3),
+                             Zh, q_mu=hq_mu, q_sqrt=np.abs(0.4 + 0.1 * rng.normal(size=(7, 1))), q_diag=True, num_data=400)
+    out.update(het_poly_w=pw, het_poly_variance_at=_n(likp.variance_at(X)), het_poly_gpr_lml=float(hp.log_marginal_likelihood()),
+               het_poly_q_sqrt_diag=_n(hsq.q_sqrt), het_poly_svgp_elbo_qdiag=float(hsq.elbo((X, Y))))
     return out
 
 

@@ -266,6 +266,77 @@ def test_fused_svgp_elbo_shard(gpu, m, rows, d, P, q_diag):
     np.testing.assert_allclose(o[1], kl_ref, rtol=1e-12)
 
 
+@pytest.mark.parametrize("m,rows,d,P", [(20, 50, 1, 2), (130, 257, 3, 2), (640, 1500, 8, 1), (1152, 300, 4, 3)])
+def test_fused_svgp_elbo_shard_unwhitened_q_diag(gpu, m, rows, d, P):
+    """gpk_svgp_elbo_shard(whiten = 0, q_diag = 1): [Kuu ; Kfu ; q_mu^T ; I] on one factorisation (the identity rows return Lm^-T)
+    against the oracle's literal form -- gauss_kl's diag branch with K (kullback_leiblers.py:128-165) and the un-whitened
+    conditional with a diagonal q_sqrt (conditionals/util.py:139-149).  With and without per-row noise variances."""
+    from gpflow_amd import ops
+    rng = np.random.default_rng(19)
+    X = rng.normal(size=(rows, d))
+    Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(rows, P))
+    Z = X[:m] + 0.05 * rng.normal(size=(m, d)) if m <= rows else rng.normal(size=(m, d))
+    q_mu = 0.1 * rng.normal(size=(m, P))
+    q_sqrt = rng.uniform(0.3, 0.8, size=(m, P))
+    kw = dict(variance=1.1, lengthscales=np.sqrt(d) * (0.8 + 0.05 * np.arange(d)) if d > 1 else 0.7)
+    for noise in (0.1, rng.uniform(0.05, 0.4, size=rows)):
+        out, info = ops.svgp_elbo_shard(_t(Z), _t(X), _t(Y), _t(q_mu), _t(q_sqrt), jitter=1e-6, whiten=False,
+                                        noise_variance=noise if np.isscalar(noise) else _t(noise), **kw)
+        ops.check_info(info)
+        s_ref, kl_ref = orc.svgp_elbo_terms(X, Y, Z, q_mu, q_sqrt, whiten=False, noise_variance=noise, **kw)
+        o = out.cpu().numpy()
+        # (kappa(Kuu) ~ 1e6 with the 1e-6 jitter: Kuu^-1-like terms carry kappa * eps)
+        np.testing.assert_allclose(o[0], s_ref, rtol=1e-8)
+        np.testing.assert_allclose(o[1], kl_ref, rtol=1e-8)
+
+
+def test_per_row_noise_variances(gpu):
+    """The (noise_variance, noise_rows) pair of the C-ABI: gpk_gaussian_varexp_sum, gpk_diag_add, gpk_gpr_lml and both fused ELBO
+    drivers with one variance per data row (a heteroskedastic Gaussian likelihood, scalar_continuous.py:92-148)."""
+    from gpflow_amd import ops
+    rng = np.random.default_rng(23)
+    rows, m, P, d = 333, 96, 3, 4
+    Y = rng.normal(size=(rows, P)); fmean = rng.normal(size=(rows, P))
+    s0 = rng.uniform(0, 0.5, size=rows); ssq = rng.uniform(0, 0.3, size=(P, rows))
+    nv = rng.uniform(0.05, 2.0, size=rows)
+    out, fvar = ops.gaussian_varexp_sum(_t(Y), _t(fmean), s0=_t(s0), ssq=_t(ssq), knn=[1.3], noise_variance=_t(nv), mean_const=0.1,
+                                        want_fvar=True)
+    fv = 1.3 - s0[:, None] + ssq.T
+    np.testing.assert_allclose(out.cpu().numpy()[0], orc.gaussian_variational_expectations(fmean + 0.1, fv, Y, nv).sum(), rtol=1e-13)
+    # a constant passed as a vector gives the scalar path's value (different rounding of log(nv): 1e-14)
+    o1, _ = ops.gaussian_varexp_sum(_t(Y), _t(fmean), s0=_t(s0), ssq=_t(ssq), knn=[1.3], noise_variance=0.2)
+    o2, _ = ops.gaussian_varexp_sum(_t(Y), _t(fmean), s0=_t(s0), ssq=_t(ssq), knn=[1.3], noise_variance=_t(np.full(rows, 0.2)))
+    np.testing.assert_allclose(o2.cpu().numpy(), o1.cpu().numpy(), rtol=1e-13)
+    with pytest.raises(ValueError):
+        ops.gaussian_varexp_sum(_t(Y), _t(fmean), s0=None, ssq=None, knn=[1.3], noise_variance=_t(nv[:5]))
+    A = rng.normal(size=(m, m + 3))
+    A2 = ops.diag_add_(_t(A)[:, :m], _t(nv[:m])).cpu().numpy()
+    np.testing.assert_array_equal(A2, A[:, :m] + np.diag(nv[:m]))
+    # fused GPR LML and both fused ELBO drivers
+    n = 520
+    X = rng.normal(size=(n, d)); Yg = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(n, 2))
+    nvn = rng.uniform(0.05, 0.5, size=n)
+    kw = dict(variance=1.2, lengthscales=0.8 + 0.1 * np.arange(d))
+    out, info = ops.gpr_lml(_t(X), _t(Yg), mean_const=0.05, noise_variance=_t(nvn), **kw)
+    ops.check_info(info)
+    np.testing.assert_allclose(out.cpu().numpy()[0], orc.gpr_log_marginal_likelihood(X, Yg, mean=0.05, noise_variance=nvn, **kw),
+                               rtol=1e-10)
+    Z = X[:m] + 0.05 * rng.normal(size=(m, d))
+    q_mu = 0.1 * rng.normal(size=(m, 2))
+    q_sqrt = np.stack([np.tril(0.05 * rng.normal(size=(m, m))) + 0.5 * np.eye(m) for _ in range(2)])
+    for wh in (True, False):
+        o, info = ops.svgp_elbo_shard(_t(Z), _t(X), _t(Yg), _t(q_mu), _t(q_sqrt), jitter=1e-6, whiten=wh, noise_variance=_t(nvn), **kw)
+        ops.check_info(info)
+        s_ref, kl_ref = orc.svgp_elbo_terms(X, Yg, Z, q_mu, q_sqrt, whiten=wh, noise_variance=nvn, **kw)
+        np.testing.assert_allclose(o.cpu().numpy(), [s_ref, kl_ref], rtol=1e-8)
+    o, info = ops.svgp_elbo_shard_sep(_t(Z), _t(X), _t(Yg), _t(q_mu), _t(q_sqrt), variances=[1.2, 0.9], lengthscales=[0.8, 1.1],
+                                      families=["SquaredExponential", "SquaredExponential"], noise_variance=_t(nvn), jitter=1e-6)
+    ops.check_info(info)
+    ref = orc.svgp_elbo_separate(X, Yg, [Z, Z], q_mu, q_sqrt, variances=[1.2, 0.9], lengthscales_list=[0.8, 1.1], noise_variance=nvn)
+    o = o.cpu().numpy()
+    np.testing.assert_allclose(o[0] - o[1], ref, rtol=1e-8)
+
+
 @pytest.mark.parametrize("m,rows,d,P", [(256, 300, 3, 1), (640, 1000, 8, 2), (1024, 2500, 8, 1), (1152, 777, 4, 3)])
 def test_svgp_elbo_shard_column_groups(gpu, m, rows, d, P):
     """The fused shard over the column-group shapes of the extra-row solve / q_sqrt projection, against the oracle: one

@@ -54,6 +54,46 @@ def test_ref_kernels(gp):
     close((k_ad + k_sl)(X, full_cov=False), G["k_sum_diag"], 1e-14)
 
 
+def test_ref_heteroskedastic_gaussian(gp):
+    """Gaussian(scale=Linear(A, b)) and Gaussian(variance=Polynomial) (likelihoods/scalar_continuous.py:52-148): per-row noise variances
+    through gpk_gpr_lml / gpk_diag_add (add_likelihood_noise_cov, utilities/model_utils.py:46-50) and the per-row variational
+    expectations inside gpk_svgp_elbo_shard (whitened, un-whitened, q_diag), against the values of the reference's own source."""
+    X, Y, Xs = G["het_X"], G["het_Y"], G["het_Xnew"]
+    mk_lik = lambda: gp.likelihoods.Gaussian(scale=gp.functions.Linear(A=G["het_A"], b=G["het_b"]))  # noqa: E731
+    mk_k = lambda: gp.kernels.SquaredExponential(variance=1.3, lengthscales=[0.3, 0.6])  # noqa: E731
+    lik = mk_lik()
+    assert lik.is_heteroskedastic
+    close(lik.variance_at(X), G["het_variance_at"], 1e-14)
+    m = gp.models.GPR((X, Y), mk_k(), likelihood=lik)
+    np.testing.assert_allclose(float(m.log_marginal_likelihood()), float(G["het_gpr_lml"]), rtol=1e-10)
+    mu, var = m.predict_f(Xs)
+    close(mu, G["het_gpr_fmu"]); close(var, G["het_gpr_fvar"])
+    ymu, yvar = m.predict_y(Xs)
+    close(ymu, G["het_gpr_ymu"]); close(yvar, G["het_gpr_yvar"])
+    close(m.predict_log_density((Xs, np.cos(Xs[:, :1]))), G["het_gpr_logdens"])
+    pmu, pvar = m.posterior().predict_f(Xs)
+    close(pmu, G["het_gpr_cached_mu"], 1e-7); close(pvar, G["het_gpr_cached_var"], 1e-7)
+    # a non-stationary route to the same LML: the composed path (K + diag(noise) by gpk_diag_add, then the primitives)
+    ksum = mk_k() + gp.kernels.SquaredExponential(variance=1e-12, lengthscales=1.0)
+    np.testing.assert_allclose(float(gp.models.GPR((X, Y), ksum, likelihood=mk_lik()).log_marginal_likelihood()),
+                               float(G["het_gpr_lml"]), rtol=1e-8)
+    for wh, name in ((True, "white"), (False, "unwhite")):
+        s = gp.models.SVGP(mk_k(), mk_lik(), G["het_Z"], q_mu=G["het_q_mu"], q_sqrt=G["het_q_sqrt"], whiten=wh, num_data=400)
+        np.testing.assert_allclose(float(s.elbo((X, Y))), float(G[f"het_svgp_elbo_{name}"]), rtol=1e-9)
+    likp = lambda: gp.likelihoods.Gaussian(variance=gp.functions.Polynomial(2, input_dim=2, w=G["het_poly_w"]),  # noqa: E731
+                                           variance_lower_bound=1e-3)
+    close(likp().variance_at(X), G["het_poly_variance_at"], 1e-14)
+    np.testing.assert_allclose(float(gp.models.GPR((X, Y), mk_k(), likelihood=likp()).log_marginal_likelihood()),
+                               float(G["het_poly_gpr_lml"]), rtol=1e-9)
+    sq = gp.models.SVGP(mk_k(), likp(), G["het_Z"], q_mu=G["het_q_mu"], q_sqrt=G["het_poly_q_sqrt_diag"], q_diag=True, num_data=400)
+    np.testing.assert_allclose(float(sq.elbo((X, Y))), float(G["het_poly_svgp_elbo_qdiag"]), rtol=1e-9)
+    # the reverse pass is for a constant noise variance: refused, not silently wrong
+    with pytest.raises(NotImplementedError):
+        m.log_marginal_likelihood_and_grad()
+    with pytest.raises(NotImplementedError):
+        s.elbo_and_grad((X, Y))
+
+
 def test_ref_gpr(gp):
     m = gp.models.GPR((G["gpr_X"], G["gpr_Y"]), gp.kernels.SquaredExponential(variance=1.0, lengthscales=2.0), noise_variance=1.0)
     Xn = G["gpr_Xnew"]

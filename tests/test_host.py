@@ -31,13 +31,18 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert set(_lib.EXPORTED_SYMBOLS) == declared
     assert built_lib.gpk_version().decode().startswith("gpk")
     assert built_lib.gpk_invd_elems(300, 2) == 2 * 3 * 128 * 128
-    assert built_lib.gpk_svgp_elbo_workspace_bytes(2048, 8192, 8, 1, 0) > (2048 + 8192) * 2048 * 8
+    assert built_lib.gpk_svgp_elbo_workspace_bytes(2048, 8192, 8, 1, 0, 1) > (2048 + 8192) * 2048 * 8
     # the separate-kernel driver keeps one trapezoid PER latent (config C5: 4 x (1024 + 8192) x 1024 doubles) + its tails
     sep = built_lib.gpk_svgp_elbo_sep_workspace_bytes(1024, 8192, 8, 4)
     assert 4 * (1024 + 8192) * 1024 * 8 < sep < 2 * 4 * (1024 + 8192) * 1024 * 8
     # argument errors are reported before anything touches a device (GPK_E_ARG = -1)
-    assert built_lib.gpk_svgp_elbo_shard_sep(None, None, None, 1024, 8, 0, None, None, 8192, 8, 4, 8, 4, None, 1, None, 0.1, 1e-6, 0.0,
-                                             None, None, None, None, None, 0) == -1
+    assert built_lib.gpk_svgp_elbo_shard_sep(None, None, None, 1024, 8, 0, None, None, 8192, 8, 4, 8, 4, None, 1, None, 0.1, None, 1e-6,
+                                             0.0, None, None, None, None, None, 0) == -1
+    # an un-whitened diagonal q_sqrt keeps P + m more trapezoid rows and the second-solve buffer; the whitened one neither
+    assert built_lib.gpk_svgp_elbo_workspace_bytes(2048, 8192, 8, 1, 1, 0) > built_lib.gpk_svgp_elbo_workspace_bytes(2048, 8192, 8, 1, 1, 1) \
+        + 8192 * 2048 * 8
+    # the single-launch step kernel of round 4 reserves nothing in the product library (its regions doubled this figure)
+    assert built_lib.gpk_svgp_elbo_workspace_bytes(2048, 8192, 8, 1, 0, 1) < 1.45 * (2048 + 8192 + 2048) * 2048 * 8
 
 
 def test_header_is_plain_c_and_a_c_client_links(built_lib, tmp_path):

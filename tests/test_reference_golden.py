@@ -78,6 +78,37 @@ def test_gpr():
     close(mu, G["c1_mu"]); close(var, G["c1_var"])
 
 
+def test_heteroskedastic_gaussian():
+    """Gaussian(scale=Linear(A, b)) / Gaussian(variance=Polynomial) of the reference (likelihoods/scalar_continuous.py:52-148,
+    utilities/model_utils.py:46-50) behind GPR (LML, predict_f / predict_y / predict_log_density) and SVGP.elbo (both whitenings,
+    q_diag): the oracle with one noise variance per row."""
+    X, Y, Xs = G["het_X"], G["het_Y"], G["het_Xnew"]
+    lin = orc.linear_function(G["het_A"], G["het_b"])
+    nv = orc.gaussian_variance_at(X, scale=lin)
+    close(nv[:, None], G["het_variance_at"], 1e-15)
+    kw = dict(variance=1.3, lengthscales=np.array([0.3, 0.6]))
+    close(orc.gpr_log_marginal_likelihood(X, Y, noise_variance=nv, **kw), G["het_gpr_lml"])
+    mu, var = orc.gpr_predict_f(X, Y, Xs, noise_variance=nv, **kw)
+    close(mu, G["het_gpr_fmu"]); close(var, G["het_gpr_fvar"])
+    close(mu, G["het_gpr_cached_mu"]); close(var, G["het_gpr_cached_var"], 1e-11)
+    nvs = orc.gaussian_variance_at(Xs, scale=lin)
+    ymu, yvar = orc.gaussian_predict_mean_and_var(mu, var, nvs)
+    close(ymu, G["het_gpr_ymu"]); close(yvar, G["het_gpr_yvar"])
+    close(orc.gaussian_predict_log_density(mu, var, np.cos(Xs[:, :1]), nvs), G["het_gpr_logdens"])
+    for wh, name in ((True, "white"), (False, "unwhite")):
+        close(orc.svgp_elbo(X, Y, G["het_Z"], G["het_q_mu"], G["het_q_sqrt"], noise_variance=nv, whiten=wh, num_data=400, **kw),
+              G[f"het_svgp_elbo_{name}"])
+    # variance as a polynomial that dips below the lower bound: clipped at 1e-3 when evaluated (parameter_or_function.py:52-56)
+    w = G["het_poly_w"]
+    poly = lambda X_: w[0, 0] + w[0, 1] * X_[:, 1:2] + w[0, 2] * X_[:, 1:2] ** 2   # noqa: E731  (powers (0,0), (0,1), (0,2))
+    nvp = orc.gaussian_variance_at(X, variance=poly, lower_bound=1e-3)
+    close(nvp[:, None], G["het_poly_variance_at"], 1e-15)
+    assert (nvp == 1e-3).sum() == 13
+    close(orc.gpr_log_marginal_likelihood(X, Y, noise_variance=nvp, **kw), G["het_poly_gpr_lml"])
+    close(orc.svgp_elbo(X, Y, G["het_Z"], G["het_q_mu"], G["het_poly_q_sqrt_diag"], noise_variance=nvp, whiten=True, num_data=400,
+                        **kw), G["het_poly_svgp_elbo_qdiag"])
+
+
 def test_gauss_kl():
     mu, sq, K, Kb = G["kl_mu"], G["kl_sqrt"], G["kl_K"], G["kl_Kb"]
     close(orc.gauss_kl(mu, sq), G["kl_white"]); close(orc.gauss_kl(mu, sq, K), G["kl_K_val"])

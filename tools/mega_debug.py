@@ -64,8 +64,8 @@ def main():
         q_sqrt = ops.to_device(np.tril(0.05 * rng.standard_normal((P, m, m))) + 0.5 * np.eye(m))
         Z, X, Y = ops.to_device(Zh), ops.to_device(Xh[m:]), ops.to_device(Yh[m:])
         ls = np.sqrt(d) * (0.8 + 0.05 * np.arange(d))
-        nbytes = int(prod.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, 0))
-        assert nbytes == int(exp.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, 0))
+        nbytes = int(prod.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, 0, 1))
+        assert nbytes == int(exp.gpk_svgp_elbo_workspace_bytes(m, rows, d, P, 0, 1))
         res = {}
         for name, lib in (("prod", prod), ("mega", exp)):
             ws = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=dev)
