@@ -1075,18 +1075,28 @@ extern "C" int gpk_profile_gemm_collect(double* total_ms, long* launches, double
 static int launch_select(hipStream_t s, const GemmArgs& a);
 
 // the same per-launch timing for kernels outside this file (kind 7: the single-launch SVGP step kernel, mega.hip)
+// grow the record table of the profiling facility.  The table pointer is published right after realloc (the old block may
+// have moved) and the capacity only ever covers records whose two events exist: a failed hipEventCreate leaves a shorter,
+// consistent table instead of a dangling pointer (advisor, round 4).
+static int prof_grow() {
+  const int cap = g_prof_cap ? 2 * g_prof_cap : 1024;
+  ProfRec* p = (ProfRec*)realloc(g_prof, sizeof(ProfRec) * cap);
+  if (!p) return GPK_E_ARG;
+  g_prof = p;
+  for (int i = g_prof_cap; i < cap; ++i) {
+    if (hipEventCreate(&p[i].e0) != hipSuccess) return i > g_prof_n ? 0 : GPK_E_ARG;
+    if (hipEventCreate(&p[i].e1) != hipSuccess) {
+      (void)hipEventDestroy(p[i].e0);
+      return i > g_prof_n ? 0 : GPK_E_ARG;
+    }
+    g_prof_cap = i + 1;
+  }
+  return 0;
+}
+
 int gpk_prof_begin(hipStream_t s, double flops, int kind) {
   if (!g_prof_on) return -1;
-  if (g_prof_n == g_prof_cap) {
-    const int cap = g_prof_cap ? 2 * g_prof_cap : 1024;
-    ProfRec* p = (ProfRec*)realloc(g_prof, sizeof(ProfRec) * cap);
-    if (!p) return -1;
-    for (int i = g_prof_cap; i < cap; ++i) {
-      if (hipEventCreate(&p[i].e0) != hipSuccess || hipEventCreate(&p[i].e1) != hipSuccess) return -1;
-    }
-    g_prof = p;
-    g_prof_cap = cap;
-  }
+  if (g_prof_n == g_prof_cap && (prof_grow() != 0 || g_prof_n == g_prof_cap)) return -1;
   ProfRec& r = g_prof[g_prof_n];
   r.flops = flops;
   r.kind = kind;
@@ -1101,15 +1111,9 @@ int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
   if (a.m <= 0 || a.n <= 0) return 0;
   if (!g_prof_on) return launch_select(s, a);
   if (g_prof_n == g_prof_cap) {
-    const int cap = g_prof_cap ? 2 * g_prof_cap : 1024;
-    ProfRec* p = (ProfRec*)realloc(g_prof, sizeof(ProfRec) * cap);
-    if (!p) return GPK_E_ARG;
-    for (int i = g_prof_cap; i < cap; ++i) {
-      GPK_HIP(hipEventCreate(&p[i].e0));
-      GPK_HIP(hipEventCreate(&p[i].e1));
-    }
-    g_prof = p;
-    g_prof_cap = cap;
+    const int rcg = prof_grow();
+    if (rcg) return rcg;
+    if (g_prof_n == g_prof_cap) return GPK_E_ARG;
   }
   ProfRec& r = g_prof[g_prof_n++];
   r.flops = algorithmic_flops(a);

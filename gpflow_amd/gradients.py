@@ -174,11 +174,19 @@ class KernelSpec:
       adjoint  member i sees  Kbar (Sum)  or  Kbar .* prod_{j != i} k_j  (Product: formed by the same in-place combine pass)
                and goes through `stationary_kernel_adjoint`; the input gradients of the members add up."""
 
-    def __init__(self, members, op=None):
+    def __init__(self, members, op=None, cols=None):
+        """members: [(family, variance, lengthscales)]; cols[i]: the input columns member i sees (its `active_dims` as an index
+        list, kernels/base.py:90-109) or None for all of them.  Members that see different columns are built and differentiated on
+        their own column slices; their input gradients are scattered back into the full columns and add up."""
         self.members = [(f, float(v), np.asarray(ls, dtype=np.float64)) for f, v, ls in members]
         self.op = op if len(self.members) > 1 else None
         if len(self.members) > 1 and op not in ("add", "mul"):
             raise ValueError("a kernel combination needs op 'add' or 'mul'")
+        cols = [None] * len(self.members) if cols is None else list(cols)
+        if len(cols) != len(self.members):
+            raise ValueError("one column selection per member")
+        self.cols = [None if c is None else np.asarray(c, dtype=np.int64).reshape(-1) for c in cols]
+        self._idx = {}
 
     @staticmethod
     def single(variance, lengthscales, family="SquaredExponential"):
@@ -188,13 +196,22 @@ class KernelSpec:
     def n(self) -> int:
         return len(self.members)
 
-    def build(self, X1, X2, out, diag_add: float = 0.0):
+    def _sl(self, i: int, X):
+        """member i's view of the inputs: the columns of its active_dims as a contiguous copy (None stays None)"""
+        if X is None or self.cols[i] is None:
+            return X
+        key = (i, str(X.device))
+        if key not in self._idx:
+            self._idx[key] = torch.as_tensor(self.cols[i], device=X.device)
+        return X.index_select(1, self._idx[key]).contiguous()
+
+    def build(self, X1, X2, out=None, diag_add: float = 0.0):
         last = self.n - 1
         f, v, ls = self.members[0]
-        ops.kernel_matrix(X1, X2, variance=v, lengthscales=ls, family=f, diag_add=diag_add if last == 0 else 0.0,
-                          lower_only=False, out=out)
+        out = ops.kernel_matrix(self._sl(0, X1), self._sl(0, X2), variance=v, lengthscales=ls, family=f,
+                                diag_add=diag_add if last == 0 else 0.0, lower_only=False, out=out)
         for i, (f, v, ls) in enumerate(self.members[1:], start=1):
-            ops.kernel_matrix_combine(X1, X2, out, op=self.op, variance=v, lengthscales=ls, family=f,
+            ops.kernel_matrix_combine(self._sl(i, X1), self._sl(i, X2), out, op=self.op, variance=v, lengthscales=ls, family=f,
                                       diag_add=diag_add if i == last else 0.0, out=out)
         return out
 
@@ -210,26 +227,37 @@ class KernelSpec:
 
     def warm(self, device, D: int) -> "KernelSpec":
         """device copies of the members' lengthscales, made now (see `ls_device`)"""
-        for _, _, ls in self.members:
-            ls_device(ls, D, device)
+        for i, (_, _, ls) in enumerate(self.members):
+            ls_device(ls, D if self.cols[i] is None else len(self.cols[i]), device)
         return self
 
     def adjoint(self, A, Bm, Kbar, symmetric: bool):
         dvs, dls, Abar = [], [], None
+        full = all(c is None for c in self.cols)
         for i, (f, v, ls) in enumerate(self.members):
             Kb = Kbar
             if self.op == "mul":
                 Kb = Kbar.clone()
                 for j, (fj, vj, lj) in enumerate(self.members):
                     if j != i:
-                        ops.kernel_matrix_combine(A, None if symmetric else Bm, Kb, op="mul", variance=vj, lengthscales=lj,
-                                                  family=fj, out=Kb)
-            dv, dl, Ab = stationary_kernel_adjoint(A, Bm, Kb, symmetric=symmetric, variance=v, lengthscales=ls, family=f)
+                        ops.kernel_matrix_combine(self._sl(j, A), None if symmetric else self._sl(j, Bm), Kb, op="mul", variance=vj,
+                                                  lengthscales=lj, family=fj, out=Kb)
+            Ai = self._sl(i, A)
+            Bi = Ai if (symmetric and Bm is A) else self._sl(i, Bm)
+            dv, dl, Ab = stationary_kernel_adjoint(Ai, Bi, Kb, symmetric=symmetric, variance=v, lengthscales=ls, family=f)
             if np.ndim(ls) == 0 or np.size(ls) == 1:
                 dl = dl.sum().reshape(1)
             dvs.append(dv.reshape(1))
             dls.append(dl)
-            Abar = Ab if Abar is None else Abar + Ab
+            if full:
+                Abar = Ab if Abar is None else Abar + Ab
+            else:   # scatter the member's input gradient back into the columns it read
+                if Abar is None:
+                    Abar = torch.zeros_like(A)
+                if self.cols[i] is None:
+                    Abar += Ab
+                else:
+                    Abar.index_add_(1, self._idx[(i, str(A.device))], Ab)
         return dvs, dls, Abar
 
     def pack(self, dvs, dls):
@@ -381,10 +409,10 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float = None
     return lml.reshape(1), grads, info
 
 
-def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales,
+def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, variance: float = None, lengthscales=None,
                        noise_variance: float, jitter: float, mean_const: float = 0.0,
                        family: str = "SquaredExponential", group=None, sharded: bool = False,
-                       num_data: Optional[int] = None
+                       num_data: Optional[int] = None, kernel_spec: "KernelSpec" = None
                        ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """SGPR.elbo (sgpr.py:181-290) and its gradient w.r.t. {variance, lengthscales, noise_variance, Z, mean_const}.
     With At = Kfu Lm^-T, S = At^T At, a = At^T err, q = |At|^2, e2 = |err|^2, B = I + S / s2, w = B^-1 a / s2:
@@ -406,8 +434,12 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     N = int(num_data) if num_data is not None else n
     if not sharded and N != n:
         raise ValueError("num_data differs from the number of rows of a model that is not sharded")
-    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
-    ls_device(lengthscales, D, Z.device)   # (before the first kernel is enqueued: see ls_device)
+    # (kernel_spec: a Sum / Product of stationary kernels, members possibly over different input columns -- round 5)
+    spec = kernel_spec if kernel_spec is not None else KernelSpec.single(variance, lengthscales, family)
+    spec.warm(dev, D)   # (device copies of the lengthscales BEFORE the first kernel is enqueued: see ls_device)
+    kdiag = spec.kdiag()
+    nmem = spec.n
+    nlsm = [int(np.size(ls)) for _, _, ls in spec.members]     # lengthscale entries per member (1 = isotropic)
 
     def all_reduce(t):
         if sharded:
@@ -417,9 +449,9 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
 
     eye = torch.eye(M, dtype=torch.float64, device=dev)
     T = torch.empty((M + n + M, M), dtype=torch.float64, device=dev)
-    ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
+    spec.build(Z, None, T[:M], diag_add=jitter)
     if n:
-        ops.kernel_matrix(X, Z, out=T[M:M + n], **kw)
+        spec.build(X, Z, T[M:M + n])
     _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
     L, At, LinvT = T[:M], T[M:M + n], T[M + n:]
     err = (Y - mean_const).contiguous()
@@ -440,7 +472,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     _, info2 = ops.potrf_(T2, M, zero_upper=True, identity_rows=True)
     LB, ct, LBinvT = T2[:M], T2[M:M + P], T2[M + P:]
     half_logdet_b = ops.sum_log_diag(LB)[0]
-    F = (-0.5 * N * P * LOG2PI - P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * (N * variance - q) / s2)
+    F = (-0.5 * N * P * LOG2PI - P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * (N * kdiag - q) / s2)
          - 0.5 * (e2 / s2 - ops.sumsq(ct)[0]))
     # ---- backward: the M x M tail (replicated)
     Binv = ops.gemm_nt(LBinvT, LBinvT, b_tri=1, a_tri=1)                                # B^-1 = LB^-T LB^-1
@@ -451,43 +483,44 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     Ssym = (2.0 / s2) * Bbar + (P / s2) * eye                                           # 2 S_bar + 2 q_bar I
     abar = w / s2
     # ---- this shard's rows
-    nls = D if np.size(lengthscales) > 1 else 1
-    part = torch.zeros(M * M + 1 + D + M * D + 1, dtype=torch.float64, device=dev)      # [Lm_bar part, dvar, dls, Z_bar, dmean]
+    # packed per-shard sums: [Lm_bar part (M x M), d/dvariance per member, d/dlengthscales per member, Z_bar (M x D), d/dmean]
+    nl_tot = sum(nlsm)
+    part = torch.zeros(M * M + nmem + nl_tot + M * D + 1, dtype=torch.float64, device=dev)
+    o = M * M
     if n:
         Atb = ops.gemm_nt(err, abar)                                                    # err a_bar^T  [n, M]
         ops.gemm_nt(At, Ssym, alpha=1.0, beta=1.0, C=Atb)                               # + At (2 S_bar + 2 q_bar I)
         Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)
         Kuf_bar = ops.transpose(Kfu_bar)
         part[:M * M] = torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)).reshape(-1)
-        dv1, dl1, Zb1 = stationary_kernel_adjoint(Z, X, Kuf_bar, symmetric=False, **kw)
-        o = M * M
-        part[o] = dv1
-        part[o + 1:o + 1 + D] = dl1
-        part[o + 1 + D:o + 1 + D + M * D] = Zb1.reshape(-1)
+        dv1, dl1, Zb1 = spec.adjoint(Z, X, Kuf_bar, symmetric=False)
+        part[o:o + nmem] = torch.cat(dv1)
+        part[o + nmem:o + nmem + nl_tot] = torch.cat([d.reshape(-1) for d in dl1])
+        part[o + nmem + nl_tot:o + nmem + nl_tot + M * D] = Zb1.reshape(-1)
         part[-1] = (err / s2 - ops.gemm_nt(At, abar.t().contiguous())).sum()
     all_reduce(part)                                                                    # ---- exchange 2: the shards' sums
-    o = M * M
     Lbar = part[:o].reshape(M, M)
-    dv1, dl1, Zb1, g_mean = part[o], part[o + 1:o + 1 + D], part[o + 1 + D:o + 1 + D + M * D].reshape(M, D), part[-1]
+    dv1 = [part[o + i].reshape(1) for i in range(nmem)]
+    offs = np.concatenate([[0], np.cumsum(nlsm)])
+    dl1 = [part[o + nmem + offs[i]:o + nmem + offs[i + 1]] for i in range(nmem)]
+    Zb1, g_mean = part[o + nmem + nl_tot:o + nmem + nl_tot + M * D].reshape(M, D), part[-1]
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
-    dv2, dl2, Zb2 = stationary_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
-    g_var = dv1 + dv2 - 0.5 * P * N / s2
-    g_ls = dl1 + dl2
-    if nls == 1:
-        g_ls = g_ls.sum().reshape(1)
+    dv2, dl2, Zb2 = spec.adjoint(Z, Z, Kuu_bar, symmetric=True)
+    g_var, g_ls = spec.pack([a + b - 0.5 * P * N / s2 * dk for a, b, dk in zip(dv1, dv2, spec.dkdiag())],
+                            [a + b for a, b in zip(dl1, dl2)])
     wa, ww = (w * a).sum(), (w * w).sum()
-    g_noise = (-P * (-0.5 * (M - torch.diagonal(Binv).sum()) / s2 + 0.5 * N / s2 - 0.5 * (N * variance - q) / s2 ** 2)
+    g_noise = (-P * (-0.5 * (M - torch.diagonal(Binv).sum()) / s2 + 0.5 * N / s2 - 0.5 * (N * kdiag - q) / s2 ** 2)
                + 0.5 * e2 / s2 ** 2 - 0.5 * wa / s2 ** 2 - 0.5 * ww / s2)
     status = torch.maximum(info, info2)
-    grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1), "Z": Zb1 + Zb2,
+    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise.reshape(1), "Z": Zb1 + Zb2,
              "mean_const": g_mean.reshape(1)}
     return F.reshape(1), grads, status
 
 
 def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu: torch.Tensor,
-                                  q_sqrt: torch.Tensor, *, variance: float, lengthscales, noise_variance: float,
+                                  q_sqrt: torch.Tensor, *, variance: float = None, lengthscales=None, noise_variance: float,
                                   jitter: float, scale: float = 1.0, mean_const: float = 0.0, kl_weight: float = 1.0,
-                                  family: str = "SquaredExponential"
+                                  family: str = "SquaredExponential", kernel_spec: "KernelSpec" = None
                        ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """The `whiten=False` SVGP: q(u) = N(q_mu, Lq Lq^T) on u itself (conditionals/util.py:137-139, kullback_leiblers.py:
     98-165 with K = Kuu).  With Linv = Lm^-1 (from the identity rows of the trapezoid):
@@ -510,12 +543,13 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     if tuple(q_sqrt.shape) not in ((P, M, M), (M, P)):
         raise ValueError("svgp_elbo_and_grad_unwhitened needs q_sqrt [P, M, M] or, for q_diag, [M, P]")
     dev = Z.device
-    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
-    ls_device(lengthscales, D, Z.device)   # (before the first kernel is enqueued: see ls_device)
+    # (kernel_spec: a Sum / Product of stationary kernels, members possibly over different input columns -- round 5)
+    spec = kernel_spec if kernel_spec is not None else KernelSpec.single(variance, lengthscales, family)
+    spec.warm(dev, D)   # (device copies of the lengthscales BEFORE the first kernel is enqueued: see ls_device)
     k = float(kl_weight)
     T = torch.empty((M + B + M, M), dtype=torch.float64, device=dev)
-    ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)
-    ops.kernel_matrix(Xb, Z, out=T[M:M + B], **kw)
+    spec.build(Z, None, T[:M], diag_add=jitter)
+    spec.build(Xb, Z, T[M:M + B])
     _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
     L, At, LinvT = T[:M], T[M:M + B], T[M + B:]
     Linv = ops.transpose(LinvT)                                                         # lower
@@ -540,7 +574,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
             V = V.unsqueeze(0)
         kl = 0.5 * (ops.sumsq(alphat)[0] - M * P - torch.log(Lq.diagonal(dim1=1, dim2=2) ** 2).sum()
                     + sum(ops.sumsq(V[p])[0] for p in range(P))) + P * ops.sum_log_diag(L)[0]
-    ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[variance], noise_variance=noise_variance,
+    ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[spec.kdiag()], noise_variance=noise_variance,
                                     mean_const=mean_const)
     F = scale * ve - k * kl
     # ---- backward
@@ -580,15 +614,13 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0) - torch.tril(X2)
     Lbar.diagonal().sub_(k * P / L.diagonal())
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
-    dv1, dl1, Zb1 = stationary_kernel_adjoint(Z, Xb, Kuf_bar, symmetric=False, **kw)
-    dv2, dl2, Zb2 = stationary_kernel_adjoint(Z, Z, Kuu_bar, symmetric=True, **kw)
-    g_var = dv1 + dv2 + c * B * P
-    g_ls = dl1 + dl2
-    if np.ndim(lengthscales) == 0 or np.size(lengthscales) == 1:
-        g_ls = g_ls.sum().reshape(1)
+    dv1, dl1, Zb1 = spec.adjoint(Z, Xb, Kuf_bar, symmetric=False)
+    dv2, dl2, Zb2 = spec.adjoint(Z, Z, Kuu_bar, symmetric=True)
+    g_var, g_ls = spec.pack([a + b + c * B * P * dk for a, b, dk in zip(dv1, dv2, spec.dkdiag())],
+                            [a + b for a, b in zip(dl1, dl2)])
     k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
     Q = 2.0 * noise_variance * (B * P * k0 - ve)
     g_noise = scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)
-    grads = {"variance": g_var.reshape(1), "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
+    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
              "Z": Zb1 + Zb2, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
     return F, grads, info

@@ -163,20 +163,31 @@ class Combination(Kernel):
         return self.K_diag(X) if not full_cov else self.K(X, X2)
 
 
-def gradient_spec(kernel):
+def gradient_spec(kernel, input_dim=None):
     """gradients.KernelSpec + [(variance Parameter, lengthscales Parameter)] for the kernels the reverse pass covers beyond a
-    single stationary one: a flat Sum / Product of isotropic-stationary members that all see every input column (members
-    with their own `active_dims` are refused: their input gradients would have to be scattered member by member).  None if
-    `kernel` is not such a combination."""
+    single stationary one: a flat Sum / Product of isotropic-stationary members (kernels/base.py:216-220, 305-315).  Members may
+    carry their own `active_dims` (kernels/base.py:90-109): the spec then builds and differentiates each member on its own columns
+    and scatters its input gradient back (round 5) -- `input_dim`, the number of input columns, resolves slices.  None if `kernel`
+    is not such a combination."""
     from .stationaries import IsotropicStationary
     from .. import gradients
     if not isinstance(kernel, Combination):
         return None
     ks = list(kernel.kernels)
-    if not all(isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES and k.has_default_active_dims for k in ks):
-        raise NotImplementedError("gradients of a kernel combination: Sum / Product of SquaredExponential / Matern members over all "
-                                  "input columns (kernels/base.py:216-220, 305-315)")
-    spec = gradients.KernelSpec([k.hyper() for k in ks], kernel._op)
+    if not all(isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES for k in ks):
+        raise NotImplementedError("gradients of a kernel combination: a flat Sum / Product of SquaredExponential / Matern members "
+                                  "(kernels/base.py:216-220, 305-315)")
+    cols = []
+    for k in ks:
+        if k.has_default_active_dims:
+            cols.append(None)
+        elif isinstance(k.active_dims, slice):
+            if input_dim is None:
+                raise NotImplementedError("gradients of a kernel combination with sliced active_dims need the input dimension")
+            cols.append(np.arange(int(input_dim))[k.active_dims])
+        else:
+            cols.append(np.asarray(k.active_dims, dtype=np.int64))
+    spec = gradients.KernelSpec([k.hyper() for k in ks], kernel._op, cols=cols)
     return spec, [(k.variance, k.lengthscales) for k in ks]
 
 

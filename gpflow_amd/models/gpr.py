@@ -71,7 +71,7 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
         k, lik, mf = self.kernel, self.likelihood, self.mean_function
         c = mf.constant_value()
         from ..kernels.base import gradient_spec
-        combo = gradient_spec(k)            # Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315)
+        combo = gradient_spec(k, self.data[0].shape[1])   # Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315)
         if lik.is_heteroskedastic:
             raise NotImplementedError("gradients: the reverse pass takes a constant noise variance (a heteroskedastic Gaussian "
                                       "likelihood is forward-only: log_marginal_likelihood, predict_*)")
@@ -104,7 +104,8 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
         for par, gc in pairs:
             if par.trainable:
                 u = par.unconstrained_variable
-                out[par] = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+                gu = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+                out[par] = out[par] + gu if par in out else gu   # (a Parameter shared by several members: k + k, tied lengthscales)
         # with parameter priors this is the log POSTERIOR density and its gradient: -training_loss (model.py:56-76)
         return self._add_log_prior(float(lml.cpu()[0]), out)
 

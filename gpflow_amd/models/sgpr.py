@@ -32,15 +32,17 @@ from .training_mixins import InternalDataTrainingLossMixin
 LOG2PI = float(np.log(2.0 * np.pi))
 
 
-def shard_statistics(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, variance: float, lengthscales, family: str,
-                     jitter: float, mean_const: float):
-    """(L [M,M] lower with zero upper, invd, packed statistics [M*M + M*P + 2]) of one row shard (see module doc)."""
+def shard_statistics(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, spec: "gradients.KernelSpec" = None, jitter: float,
+                     mean_const: float, variance: float = None, lengthscales=None, family: str = "SquaredExponential"):
+    """(L [M,M] lower with zero upper, invd, packed statistics [M*M + M*P + 2]) of one row shard (see module doc).
+    spec: the covariance function (one stationary kernel, or a Sum / Product of them -- gradients.KernelSpec)."""
     M, n, P = Z.shape[0], X.shape[0], Y.shape[1]
-    kw = dict(variance=variance, lengthscales=lengthscales, family=family)
+    if spec is None:
+        spec = gradients.KernelSpec.single(variance, lengthscales, family)
     T = torch.empty((M + n, M), dtype=torch.float64, device=Z.device)
-    ops.kernel_matrix(Z, None, diag_add=jitter, lower_only=False, out=T[:M], **kw)      # Kuu + jitter I  (sgpr.py:200)
+    spec.build(Z, None, T[:M], diag_add=jitter)                                         # Kuu + jitter I  (sgpr.py:200)
     if n:
-        ops.kernel_matrix(X, Z, out=T[M:], **kw)                                       # Kfu             (:199)
+        spec.build(X, Z, T[M:])                                                         # Kfu             (:199)
     invd, info = ops.potrf_(T, M, zero_upper=True)                                      # L (:201); At = Kfu L^-T (:204)
     ops.check_info(info)
     L, At = T[:M], T[M:]
@@ -126,16 +128,27 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
     def _config(self):
         k, iv, lik = self.kernel, self.inducing_variable, self.likelihood
         c = self.mean_function.constant_value()
-        if not (isinstance(k, Stationary) and isinstance(iv, InducingPoints) and isinstance(lik, Gaussian)
+        from ..kernels.base import Combination, gradient_spec
+        if not (isinstance(k, (Stationary, Combination)) and isinstance(iv, InducingPoints) and isinstance(lik, Gaussian)
                 and lik.has_variance_parameter and c is not None):
-            raise NotImplementedError("SGPR here: stationary kernel, InducingPoints, constant noise variance, constant mean")
+            raise NotImplementedError("SGPR here: stationary kernel (or a Sum / Product of them), InducingPoints, constant noise "
+                                      "variance, constant mean")
+        if isinstance(k, Combination):
+            # members slice for themselves (kernels/base.py:283-293): the spec works on the full columns
+            spec, _ = gradient_spec(k, self.data[0].shape[1])
+            return spec, self.data[0].contiguous(), iv.Z.device_value().contiguous(), float(c), lik.noise_variance()
         family, var, ls = k.hyper()
         X, Z = k.slice(self.data[0], iv.Z.device_value())
-        return dict(variance=var, lengthscales=ls, family=family), X, Z, float(c), lik.noise_variance()
+        return gradients.KernelSpec.single(var, ls, family), X, Z, float(c), lik.noise_variance()
+
+    def _slice_new(self, Xn):
+        """new inputs as the covariance spec expects them: sliced by a single kernel's active_dims, untouched for a combination"""
+        from ..kernels.base import Combination
+        return Xn.contiguous() if isinstance(self.kernel, Combination) else self.kernel.slice(Xn, None)[0]
 
     def _statistics(self):
         kw, X, Z, c, s2 = self._config()
-        L, invd, packed = shard_statistics(Z, X, self.data[1], jitter=config.default_jitter(), mean_const=c, **kw)
+        L, invd, packed = shard_statistics(Z, X, self.data[1], jitter=config.default_jitter(), mean_const=c, spec=kw)
         if self.sharded:
             import torch.distributed as dist
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
@@ -148,7 +161,7 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
     def elbo(self) -> torch.Tensor:
         """sgpr.py:279-290"""
         kw, Z, c, s2, L, invd, packed = self._statistics()
-        return elbo_from_statistics(packed, Z.shape[0], self.data[1].shape[1], self.num_data, variance=kw["variance"],
+        return elbo_from_statistics(packed, Z.shape[0], self.data[1].shape[1], self.num_data, variance=kw.kdiag(),
                                     noise_variance=s2)
 
     def upper_bound(self) -> torch.Tensor:
@@ -156,7 +169,7 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         if self.data[1].shape[1] != 1:
             raise NotImplementedError("upper_bound is written for a single output column in the reference (sgpr.py:126)")
         kw, Z, c, s2, L, invd, packed = self._statistics()
-        return upper_bound_from_statistics(packed, Z.shape[0], self.num_data, variance=kw["variance"], noise_variance=s2)
+        return upper_bound_from_statistics(packed, Z.shape[0], self.num_data, variance=kw.kdiag(), noise_variance=s2)
 
     def objective_and_grad(self):
         """(ELBO as a float, {Parameter: dELBO/d(unconstrained value)}) for the trainable parameters among kernel variance,
@@ -167,24 +180,41 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         from ..kernels.stationaries import IsotropicStationary
         from ..mean_functions import Constant
         from .svgp import SVGP
-        kw, _, _, c, s2 = self._config()
-        if not (isinstance(self.kernel, IsotropicStationary) and kw["family"] in ops.KERNEL_FAMILIES):
-            raise NotImplementedError("gradients: SquaredExponential / Matern kernel")
-        Z, X, scatter = SVGP._sliced(self.kernel, self.inducing_variable.Z.device_value(), self.data[0])
-        F, g, info = gradients.sgpr_elbo_and_grad(Z, X, self.data[1], noise_variance=s2, jitter=config.default_jitter(),
-                                                  mean_const=c, sharded=self.sharded, group=self.group,
-                                                  num_data=self.num_data, **kw)
-        ops.check_info(info)
-        host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
-        pairs = [(self.kernel.variance, host["variance"]), (self.kernel.lengthscales, host["lengthscales"]),
-                 (self.likelihood.variance, host["noise_variance"]), (self.inducing_variable.Z, host["Z"])]
+        from ..kernels.base import Combination, gradient_spec
+        kw, Xc, Zc, c, s2 = self._config()
+        if isinstance(self.kernel, Combination):
+            # a Sum / Product of stationary kernels (members possibly over different active_dims): the members' adjoints one by one
+            spec, members = gradient_spec(self.kernel, self.data[0].shape[1])
+            F, g, info = gradients.sgpr_elbo_and_grad(Zc, Xc, self.data[1], noise_variance=s2, jitter=config.default_jitter(),
+                                                      mean_const=c, sharded=self.sharded, group=self.group,
+                                                      num_data=self.num_data, kernel_spec=spec)
+            ops.check_info(info)
+            gv = g["variance"].cpu().numpy()
+            host = {n: t.cpu().numpy() for n, t in g.items() if n not in ("variance", "lengthscales")}
+            pairs = []
+            for i, (pv, pl) in enumerate(members):
+                pairs += [(pv, gv[i]), (pl, g["lengthscales"][i].cpu().numpy())]
+            pairs += [(self.likelihood.variance, host["noise_variance"]), (self.inducing_variable.Z, host["Z"])]
+        else:
+            if not (isinstance(self.kernel, IsotropicStationary) and self.kernel.family in ops.KERNEL_FAMILIES):
+                raise NotImplementedError("gradients: SquaredExponential / Matern kernel")
+            family, var, ls = self.kernel.hyper()
+            Z, X, scatter = SVGP._sliced(self.kernel, self.inducing_variable.Z.device_value(), self.data[0])
+            F, g, info = gradients.sgpr_elbo_and_grad(Z, X, self.data[1], noise_variance=s2, jitter=config.default_jitter(),
+                                                      mean_const=c, sharded=self.sharded, group=self.group,
+                                                      num_data=self.num_data, variance=var, lengthscales=ls, family=family)
+            ops.check_info(info)
+            host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
+            pairs = [(self.kernel.variance, host["variance"]), (self.kernel.lengthscales, host["lengthscales"]),
+                     (self.likelihood.variance, host["noise_variance"]), (self.inducing_variable.Z, host["Z"])]
         if isinstance(self.mean_function, Constant) and hasattr(self.mean_function, "c"):
             pairs.append((self.mean_function.c, host["mean_const"]))
         out = {}
         for par, gc in pairs:
             if par.trainable:
                 u = par.unconstrained_variable
-                out[par] = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+                gu = np.asarray(gc, dtype=np.float64).reshape(u.shape) * par.transform.forward_grad(u)
+                out[par] = out[par] + gu if par in out else gu
         return self._add_log_prior(float(F.cpu()[0]), out)   # (+ log prior density: -training_loss, model.py:56-76)
 
     # ---- prediction ------------------------------------------------------------------------------
@@ -198,19 +228,19 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         # tmp2 free of sigma, so mean = tmp2^T ct  exactly as below
         Xn = ops.to_device(Xnew)
         lead = Xn.shape[:-1]
-        Xn2, _ = self.kernel.slice(Xn.reshape(-1, Xn.shape[-1]), None)
-        t1 = ops.kernel_matrix(Xn2, Z, **kw)                                            # Kus^T [T, M]
+        Xn2 = self._slice_new(Xn.reshape(-1, Xn.shape[-1]))
+        t1 = kw.build(Xn2, Z)                                                           # Kus^T [T, M]
         ops.trsm_(t1, L, invd, trans=0)                                                 # tmp1^T = Kus^T L^-T
         t2 = t1.clone()
         ops.trsm_(t2, LB, invdB, trans=0)                                               # tmp2^T
         mean = ops.gemm_nt(t2, ct.contiguous()) + c                                     # [T, P]
         if full_cov:
-            var = ops.kernel_matrix(Xn2, None, **kw)
+            var = kw.build(Xn2, None)
             ops.gemm_nt(t2, t2, alpha=1.0, beta=1.0, C=var)
             ops.gemm_nt(t1, t1, alpha=-1.0, beta=1.0, C=var)
             var = var[None].expand(self.num_latent_gps, -1, -1).contiguous()
             return mean.reshape(lead + (P,)), var
-        v = kw["variance"] + ops.row_stats(t2)[0] - ops.row_stats(t1)[0]
+        v = kw.kdiag() + ops.row_stats(t2)[0] - ops.row_stats(t1)[0]
         var = v[:, None].expand(-1, self.num_latent_gps).contiguous()
         return mean.reshape(lead + (P,)), var.reshape(lead + (self.num_latent_gps,))
 
@@ -220,11 +250,11 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
             raise NotImplementedError("compute_qu on a sharded model")
         kw, X, Z, c, s2 = self._config()
         M, P = Z.shape[0], self.data[1].shape[1]
-        Kfu = ops.kernel_matrix(X, Z, **kw)
+        Kfu = kw.build(X, Z)
         Kuf = ops.transpose(Kfu)                                                        # [M, N]
         err = (self.data[1] - c).contiguous()
         T = torch.empty((M + M + P, M), dtype=torch.float64, device=Z.device)
-        kuu = ops.kernel_matrix(Z, None, diag_add=config.default_jitter(), **kw)
+        kuu = kw.build(Z, None, diag_add=config.default_jitter())
         T[:M] = kuu + gradients.splitk_gemm_nt(Kuf, Kuf, c_lower=True) / s2   # sig (lower triangle is read)
         T[M:2 * M] = kuu                                                                # rows -> kuu sig_sqrt^-T
         T[2 * M:] = gradients.splitk_gemm_nt(Kuf, err.t().contiguous()).t() / s2         # (scaled_kuf scaled_err)^T

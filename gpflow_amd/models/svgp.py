@@ -334,7 +334,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         # scope checks first: a model outside the reverse pass is refused before anything touches the device
         sep = self._separate_gradient_config()
         from ..kernels.base import gradient_spec
-        combo = gradient_spec(self.kernel) if sep is None else None   # Sum / Product of stationary kernels
+        combo = gradient_spec(self.kernel, int(tuple(data[0].shape)[-1])) if sep is None else None   # Sum / Product of stationary kernels
         if combo is not None:
             return self._elbo_and_grad_combination(data, combo)
         single = self.gradient_config(allow_active_dims=True, allow_q_diag=True) if sep is None else None
@@ -394,23 +394,25 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         return self._add_log_prior(Fv, out)   # (+ log prior density of the trainable parameters: model.py:56-76)
 
     def _elbo_and_grad_combination(self, data, combo):
-        """elbo_and_grad for a Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315): the whitened reverse
-        pass with the members' adjoints taken one by one (gradients.KernelSpec)."""
+        """elbo_and_grad for a Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315), members possibly over
+        different `active_dims`: the whitened or un-whitened reverse pass with the members' adjoints taken one by one
+        (gradients.KernelSpec)."""
         from .. import gradients
         from ..base import FillTriangular
         from ..mean_functions import Constant
         spec, members = combo
         lik, mf, iv = self.likelihood, self.mean_function, self.inducing_variable
         c = mf.constant_value()
-        if not (self.whiten and isinstance(lik, Gaussian) and lik.has_variance_parameter and isinstance(iv, InducingPoints)
+        if not (isinstance(lik, Gaussian) and lik.has_variance_parameter and isinstance(iv, InducingPoints)
                 and c is not None and self.q_sqrt.numpy().ndim == 3):
-            raise NotImplementedError("gradients with a kernel combination: whitened SVGP, Gaussian likelihood, InducingPoints, "
-                                      "full q_sqrt, constant mean")
+            raise NotImplementedError("gradients with a kernel combination: Gaussian likelihood, InducingPoints, full q_sqrt, "
+                                      "constant mean")
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
-        F, g, info = gradients.svgp_elbo_and_grad(iv.Z.device_value(), X, Y, self.q_mu.device_value(), self.q_sqrt.device_value(),
-                                                  noise_variance=lik.noise_variance(), jitter=config.default_jitter(), scale=scale,
-                                                  mean_const=float(c), kernel_spec=spec)
+        fn = gradients.svgp_elbo_and_grad if self.whiten else gradients.svgp_elbo_and_grad_unwhitened
+        F, g, info = fn(iv.Z.device_value(), X.contiguous(), Y, self.q_mu.device_value(), self.q_sqrt.device_value(),
+                        noise_variance=lik.noise_variance(), jitter=config.default_jitter(), scale=scale,
+                        mean_const=float(c), kernel_spec=spec)
         ops.check_info(info)
         gv = g["variance"].cpu().numpy()
         pairs = []

@@ -7,11 +7,17 @@ differentiates it.  Here a prior is any object with `log_prob(x) -> ndarray` (el
 from __future__ import annotations
 
 import numpy as np
+import torch
 from scipy.special import gammaln
 
 
 def _a(x):
     return np.asarray(x, dtype=np.float64)
+
+
+def _t(v, like):
+    """a prior's (host) parameter as a tensor beside `like`"""
+    return torch.as_tensor(np.asarray(v, dtype=np.float64), dtype=like.dtype, device=like.device)
 
 
 class Normal:
@@ -27,6 +33,15 @@ class Normal:
     def grad_log_prob(self, x):
         return -(_a(x) - self.loc) / (self.scale * self.scale)
 
+    def log_prob_torch(self, x):
+        loc, scale = _t(self.loc, x), _t(self.scale, x)
+        z = (x - loc) / scale
+        return -0.5 * z * z - torch.log(scale) - 0.5 * float(np.log(2.0 * np.pi))
+
+    def grad_log_prob_torch(self, x):
+        loc, scale = _t(self.loc, x), _t(self.scale, x)
+        return -(x - loc) / (scale * scale)
+
 
 class Gamma:
     """tfp.distributions.Gamma(concentration, rate): density x^(a-1) exp(-b x) b^a / Gamma(a)"""
@@ -41,6 +56,13 @@ class Gamma:
 
     def grad_log_prob(self, x):
         return (self.concentration - 1.0) / _a(x) - self.rate
+
+    def log_prob_torch(self, x):
+        a, b = _t(self.concentration, x), _t(self.rate, x)
+        return (a - 1.0) * torch.log(x) - b * x + a * torch.log(b) - torch.lgamma(a)
+
+    def grad_log_prob_torch(self, x):
+        return (_t(self.concentration, x) - 1.0) / x - _t(self.rate, x)
 
 
 class LogNormal:
@@ -58,6 +80,15 @@ class LogNormal:
         x = _a(x)
         return -(np.log(x) - self.loc) / (self.scale * self.scale * x) - 1.0 / x
 
+    def log_prob_torch(self, x):
+        loc, scale = _t(self.loc, x), _t(self.scale, x)
+        z = (torch.log(x) - loc) / scale
+        return -0.5 * z * z - torch.log(scale * x) - 0.5 * float(np.log(2.0 * np.pi))
+
+    def grad_log_prob_torch(self, x):
+        loc, scale = _t(self.loc, x), _t(self.scale, x)
+        return -(torch.log(x) - loc) / (scale * scale * x) - 1.0 / x
+
 
 class HalfNormal:
     """tfp.distributions.HalfNormal(scale)"""
@@ -72,6 +103,15 @@ class HalfNormal:
 
     def grad_log_prob(self, x):
         return -_a(x) / (self.scale * self.scale)
+
+    def log_prob_torch(self, x):
+        scale = _t(self.scale, x)
+        lp = -0.5 * (x / scale) ** 2 + 0.5 * float(np.log(2.0 / np.pi)) - torch.log(scale)
+        return torch.where(x >= 0.0, lp, torch.full_like(lp, -float("inf")))
+
+    def grad_log_prob_torch(self, x):
+        scale = _t(self.scale, x)
+        return -x / (scale * scale)
 
 
 def grad_log_prob(prior, x) -> np.ndarray:
@@ -92,3 +132,19 @@ def grad_log_prob(prior, x) -> np.ndarray:
             d.append((f(xp) - f(xm)) / (2.0 * hh))
         g[idx] = (4.0 * d[1] - d[0]) / 3.0
     return g
+
+
+# ---- priors on DEVICE-resident variables (training.SVGPTrainer keeps Z, q_mu, q_sqrt and their Adam moments in HBM) --------------
+def log_prob_device(prior, x: "torch.Tensor") -> "torch.Tensor":
+    """sum(prior.log_prob(x)) as a 0-d tensor on x's device: the closed forms above run there (elementwise torch glue); any other
+    prior object goes through the host once per call (it is user code over NumPy)."""
+    if hasattr(prior, "log_prob_torch"):
+        return prior.log_prob_torch(x).sum()
+    return torch.as_tensor(float(np.sum(prior.log_prob(x.detach().cpu().numpy()))), dtype=x.dtype, device=x.device)
+
+
+def grad_log_prob_device(prior, x: "torch.Tensor") -> "torch.Tensor":
+    """d sum(prior.log_prob(x)) / dx, shape of x, on x's device (see log_prob_device)."""
+    if hasattr(prior, "grad_log_prob_torch"):
+        return prior.grad_log_prob_torch(x)
+    return torch.as_tensor(grad_log_prob(prior, x.detach().cpu().numpy()), dtype=x.dtype, device=x.device)

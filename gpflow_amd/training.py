@@ -67,11 +67,9 @@ class SVGPTrainer:
         self.q_diag = model.q_sqrt.numpy().ndim == 2
         if self.q_diag and natgrad_gamma is not None:
             raise NotImplementedError("natural gradients need the full q_sqrt [P, M, M] (optimizers/natgrad.py:280-368)")
-        # priors (MAP, model.py:56-76): on the host-side hyper-parameters their gradient is added on the host every step; the
-        # device-resident variables (Z, q_mu, q_sqrt) would need it on the device
-        for p in (iv.Z, model.q_mu, model.q_sqrt):
-            if p.prior is not None:
-                raise NotImplementedError("the trainer supports priors on kernel / likelihood / mean parameters, not on Z, q_mu, q_sqrt")
+        # priors (MAP, model.py:47-76: the loss is -(ELBO + sum of the log prior densities of ALL trainable parameters)): on the
+        # host-side hyper-parameters their gradient is added on the host every step; on the device-resident variables (Z, q_mu,
+        # q_sqrt) it is evaluated and added on the device (`_device_prior`, round 5)
         self.model, self.group = model, group
         self.natgrad_gamma = None if natgrad_gamma is None else float(natgrad_gamma)
         self.mean_const = float(c)
@@ -109,9 +107,38 @@ class SVGPTrainer:
     def constrained(self, name: str) -> np.ndarray:
         return np.asarray(self.host[name].transform.forward(self.u[name]), dtype=np.float64)
 
+    def _device_prior(self, name: str):
+        """(log prior density as a 0-d device tensor, its gradient w.r.t. the device variable) of a device-resident variable
+        carrying a prior -- gpflow/base.py:201-224 evaluated where the variable lives.  Z and q_mu have identity transforms; a full
+        q_sqrt is its own constrained value (fill-triangular: a permutation, unit Jacobian; only the lower triangle is a variable);
+        a diagonal q_sqrt is kept unconstrained on the device, q = softplus(u) + lower."""
+        from .base import PriorOn
+        from .priors import grad_log_prob_device, log_prob_device
+        p = self.dev_params[name]
+        x = self.dev[name]
+        if name == "q_sqrt" and self.q_diag:
+            sig = torch.sigmoid(x)
+            if p.prior_on == PriorOn.CONSTRAINED:
+                q = torch.nn.functional.softplus(x) + self.q_lower
+                return log_prob_device(p.prior, q), grad_log_prob_device(p.prior, q) * sig
+            # prior on the unconstrained value, density reported in the constrained space: - log |dq/du| = - log sigmoid(u)
+            return log_prob_device(p.prior, x) - torch.log(sig).sum(), grad_log_prob_device(p.prior, x) - (1.0 - sig)
+        if name == "q_sqrt":
+            low = torch.tril(x)
+            if p.prior_on == PriorOn.CONSTRAINED:      # the constrained value is the whole [P, M, M] array, zeros included
+                return log_prob_device(p.prior, low), torch.tril(grad_log_prob_device(p.prior, low))
+            mask = torch.tril(torch.ones_like(x[0], dtype=torch.bool))
+            vec = low[:, mask]                          # the unconstrained vector: the lower-triangular entries
+            g = torch.zeros_like(x)
+            g[:, mask] = grad_log_prob_device(p.prior, vec)
+            return log_prob_device(p.prior, vec), g
+        return log_prob_device(p.prior, x), grad_log_prob_device(p.prior, x)
+
     def step(self, data, *, global_batch: Optional[int] = None) -> torch.Tensor:
-        """One Adam step on the minibatch (or this rank's shard of it); returns the ELBO estimate BEFORE the update as
-        a device tensor [1] (no host synchronisation beyond the scalar-gradient read-back)."""
+        """One Adam step on the minibatch (or this rank's shard of it); returns the objective BEFORE the update -- the ELBO
+        estimate plus the log prior density of every trainable parameter that carries a prior, i.e. -training_loss
+        (models/model.py:56-76), the same quantity `SVGP.elbo_and_grad` reports -- as a device tensor [1] (no host
+        synchronisation beyond the scalar-gradient read-back)."""
         import torch.distributed as dist
         Xb, Yb = ops.to_device(data[0]), ops.to_device(data[1])
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -158,6 +185,15 @@ class SVGPTrainer:
             from . import natgrad
             adam_names = ("Z",)
             nat = natgrad.natgrad_update(self.dev["q_mu"], self.dev["q_sqrt"], -g["q_mu"], -g["q_sqrt"], self.natgrad_gamma)
+        # MAP (model.py:47-76): the priors of the device-resident variables, evaluated BEFORE anything is updated
+        log_prior = 0.0
+        for name, par in self.dev_params.items():
+            if par.prior is not None and par.trainable:
+                if name != "Z" and nat is not None:
+                    raise NotImplementedError("a prior on q_mu / q_sqrt together with natural-gradient steps on q(u)")
+                lp, gp = self._device_prior(name)
+                g[name] = g[name] + gp
+                log_prior = log_prior + lp
         self.opt.t += 1
         if nat is not None:
             self.dev["q_mu"].copy_(nat[0])
@@ -174,8 +210,9 @@ class SVGPTrainer:
             if p.prior is not None:   # loss = -(ELBO + log prior): the prior's part, evaluated at the trainer's current value
                 p.assign_unconstrained(self.u[name])
                 gu = gu - p.log_prior_density_grad()
+                log_prior = log_prior + p.log_prior_density()
             self.u[name] = self.opt.update_host(name, self.u[name], gu)
-        return F
+        return F + log_prior
 
     def sync_to_model(self) -> None:
         for name, p in self.host.items():

@@ -41,11 +41,15 @@ def _rbf(X, X2, variance, ls, family="SquaredExponential"):
     raise KeyError(family)
 
 
-def combination_kernel(members, op):
+def combination_kernel(members, op, cols=None):
     """(k(A, B), k_diag) of a flat Sum ("add") / Product ("mul") of stationary members [(family, variance, lengthscales)] on
-    torch tensors: kernels/base.py:216-220 (tf.add_n of the member matrices), :305-315 (their elementwise product)."""
+    torch tensors: kernels/base.py:216-220 (tf.add_n of the member matrices), :305-315 (their elementwise product).  cols[i]: the
+    input columns member i sees (its active_dims, kernels/base.py:90-109; each member slices for itself, :283-293), None = all."""
+    cols = [None] * len(members) if cols is None else cols
+
     def kfun(A, Bm):
-        mats = [_rbf(A, Bm, v, ls, f) for f, v, ls in members]
+        sl = lambda T_, c: T_ if c is None else T_[:, list(c)]  # noqa: E731
+        mats = [_rbf(sl(A, c), sl(Bm, c), v, ls, f) for (f, v, ls), c in zip(members, cols)]
         out = mats[0]
         for m_ in mats[1:]:
             out = out + m_ if op == "add" else out * m_
@@ -143,26 +147,32 @@ def gpr_lml_value_and_grads(X, Y, *, variance, lengthscales, noise_variance, mea
 
 
 def combination_value_and_grads(model, X, Y, members, op, *, noise_variance, Z=None, q_mu=None, q_sqrt=None, num_data=None,
-                                jitter=1e-6, mean=0.0):
-    """Value and gradients of GPR.log_marginal_likelihood ("gpr") or the whitened SVGP.elbo ("svgp") under a Sum / Product of
-    stationary kernels, by autograd: {"variance": [n], "lengthscales": [per member], "noise_variance", "Z", "q_mu", "q_sqrt"}."""
+                                jitter=1e-6, mean=0.0, cols=None):
+    """Value and gradients of GPR.log_marginal_likelihood ("gpr"), SVGP.elbo whitened ("svgp") / un-whitened ("svgp_unwhitened") or
+    SGPR.elbo ("sgpr") under a Sum / Product of stationary kernels (members over the columns `cols`), by autograd:
+    {"variance": [n], "lengthscales": [per member], "noise_variance", "Z", "q_mu", "q_sqrt"}."""
     t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
     vs = [t(v, True) for _, v, _ in members]
     lss = [t(np.atleast_1d(ls), True) for _, _, ls in members]
-    kfun, kd = combination_kernel([(f, v, ls) for (f, _, _), v, ls in zip(members, vs, lss)], op)
+    kfun, kd = combination_kernel([(f, v, ls) for (f, _, _), v, ls in zip(members, vs, lss)], op, cols)
     nv = t(noise_variance, True)
     out = {}
     if model == "gpr":
         F = gpr_lml_torch(t(X), t(Y), None, None, nv, t(mean), kfun=kfun)
+    elif model == "sgpr":
+        Zt = t(Z, True)
+        F = sgpr_elbo_torch(t(X), t(Y), Zt, None, None, nv, jitter=jitter, mean=t(mean), kfun=kfun, kdiag=kd)
     else:
         Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
-        F = svgp_elbo_torch(t(X), t(Y), Zt, qm, qs, None, None, nv, num_data=num_data, jitter=jitter, mean=t(mean), whiten=True,
-                            kfun=kfun, kdiag=kd)
+        F = svgp_elbo_torch(t(X), t(Y), Zt, qm, qs, None, None, nv, num_data=num_data, jitter=jitter, mean=t(mean),
+                            whiten=(model == "svgp"), kfun=kfun, kdiag=kd)
     F.backward()
     out.update(variance=np.array([float(v.grad) for v in vs]), lengthscales=[ls.grad.numpy().copy() for ls in lss],
                noise_variance=float(nv.grad))
     if model != "gpr":
-        out.update(Z=Zt.grad.numpy().copy(), q_mu=qm.grad.numpy().copy(), q_sqrt=qs.grad.numpy().copy())
+        out.update(Z=Zt.grad.numpy().copy())
+    if model in ("svgp", "svgp_unwhitened"):
+        out.update(q_mu=qm.grad.numpy().copy(), q_sqrt=qs.grad.numpy().copy())
     return float(F.detach()), out
 
 
@@ -227,13 +237,18 @@ def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma, xi_transform="XiNat"):
 
 # ----------------------------------------------------------------------------- SGPR gradients (SURVEY 8f rows 1 + 3)
 def sgpr_elbo_torch(X, Y, Z, variance, lengthscales, noise_variance, *, jitter=1e-6, mean=0.0,
-                    family="SquaredExponential"):
-    """SGPR.elbo (gpflow/models/sgpr.py:181-290) on torch fp64 tensors, constant noise variance."""
+                    family="SquaredExponential", kfun=None, kdiag=None):
+    """SGPR.elbo (gpflow/models/sgpr.py:181-290) on torch fp64 tensors, constant noise variance.  kfun / kdiag: a kernel
+    combination (combination_kernel) instead of the single stationary kernel."""
     N, P = Y.shape
     M = Z.shape[0]
     sigma = torch.sqrt(noise_variance)
-    kuf = _rbf(Z, X, variance, lengthscales, family)
-    kuu = _rbf(Z, Z, variance, lengthscales, family) + jitter * torch.eye(M, dtype=torch.float64)
+    if kfun is None:
+        kfun = lambda A_, B_: _rbf(A_, B_, variance, lengthscales, family)  # noqa: E731
+    else:
+        variance = kdiag
+    kuf = kfun(Z, X)
+    kuu = kfun(Z, Z) + jitter * torch.eye(M, dtype=torch.float64)
     L = torch.linalg.cholesky(kuu)
     A = torch.linalg.solve_triangular(L, kuf / sigma, upper=False)
     AAT = A @ A.T

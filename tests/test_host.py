@@ -237,13 +237,17 @@ def test_gradient_entry_points_refuse_unsupported_models_before_touching_the_dev
         with pytest.raises(NotImplementedError):
             gpflow.optimizers.NaturalGradient(1.0).minimize(m, data)
     # (round 3: SVGP.elbo_and_grad itself covers q_diag, active_dims and the Matern families; round 4: Sum / Product of
-    #  stationary kernels over all input columns, whitened -- tests/test_gpu_gradients.py.  Still out: combinations whose
-    #  members have their own active_dims, and un-whitened combinations)
-    mixed = gpflow.models.SVGP(gpflow.kernels.Matern32(active_dims=[0]) + gpflow.kernels.SquaredExponential(), lik, Z)
-    unwhite = gpflow.models.SVGP(gpflow.kernels.Matern32() * gpflow.kernels.SquaredExponential(), lik, Z, whiten=False)
-    for m in (mixed, unwhite):
+    #  stationary kernels; round 5: members with their own active_dims, combinations under the un-whitened SVGP and SGPR --
+    #  tests/test_gpu_gradients.py.  Still out: nested combinations, a diagonal q_sqrt under a combination, and a
+    #  heteroskedastic likelihood -- the reverse pass differentiates a constant noise variance)
+    nested = gpflow.models.SVGP((gpflow.kernels.Matern32() + gpflow.kernels.SquaredExponential()) * gpflow.kernels.SquaredExponential(), lik, Z)
+    comb_qdiag = gpflow.models.SVGP(gpflow.kernels.Matern32() * gpflow.kernels.SquaredExponential(), lik, Z, q_diag=True)
+    hetero = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear()), Z)
+    for m in (nested, comb_qdiag, hetero):
         with pytest.raises(NotImplementedError):
             m.elbo_and_grad(data)
+    with pytest.raises(NotImplementedError):
+        training.SVGPTrainer(hetero)
     with pytest.raises(NotImplementedError):
         gpflow.optimizers.Scipy().minimize(object())
 
