@@ -717,6 +717,19 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk)
   const int r = lane & 15, g = lane >> 4;
   const int col = n0 + wave * 16 + r;
   double* __restrict__ C = p.C + (long)bz * p.strideC;
+  // stream hand-offs without queue packets (GemmArgs::sig_ptr / wait_ptr)
+  if (p.sig_ptr && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    __hip_atomic_store(p.sig_ptr, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (p.wait_ptr) {
+    if (tid == 0) {
+      const long long t0 = wall_clock64();   // (100 MHz; bounded: a lost hand-off must never hang the device -- 0.5 s, then on)
+      while ((int)(__hip_atomic_load(p.wait_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.wait_val) < 0 &&
+             wall_clock64() - t0 < 50000000LL)
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's tiles were released by ITS kernel end; drop stale lines
+  }
   // gridDim.y < number of 16-row blocks: the workgroup walks the row blocks with stride gridDim.y and keeps its B tile
   // (used when the chain is confined to the reserved compute units: ONE round of workgroups, B staged once per CU)
   const int nmb = (p.m + SM_BM - 1) / SM_BM;
@@ -965,6 +978,7 @@ int launch_cfg(hipStream_t s, const GemmArgs& a) {
 }  // namespace
 
 int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
+bool gpk_gemm_takes_latency_kernel(const GemmArgs& a) { return a.m > 0 && a.n > 0 && !a.no_small && small_ok(a); }
 
 int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
                            const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX) {

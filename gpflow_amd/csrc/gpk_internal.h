@@ -82,8 +82,18 @@ struct GemmArgs {
                     // then walk the row blocks with their B tile staged once (the in-group updates of the extra rows)
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
   int pair_k_align; // set by the launcher for paired triangular-K launches: time-aligned K traversal (gemm_nt_fast)
+  // In-kernel stream hand-offs of the factorisation's latency chain (one-shot latency kernel only; potrf.hip, round 5).  An
+  // event record / wait between two kernels of one stream costs 4.6 / 6.3 us on MI355X, back-to-back kernels 0.3 us:
+  //   sig_ptr:  workgroup (0,0,0) stores sig_val there on entry -- "everything queued before this kernel on its stream has
+  //             completed" (in-order queue: the previous kernel's end-of-kernel release is done), read by
+  //             hipStreamWaitValue32 on other streams;
+  //   wait_ptr: every workgroup spins (bounded) until (int)(*wait_ptr - wait_val) >= 0, then acquires at agent scope: the
+  //             word is written by hipStreamWriteValue32 behind the producing kernel on ITS stream.
+  int* sig_ptr; int sig_val;
+  const int* wait_ptr; int wait_val;
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
+bool gpk_gemm_takes_latency_kernel(const GemmArgs& a);   // the launch would run on the one-shot latency kernel (sig / wait honoured)
 
 // fused in-group solve of `rows` right-hand-side rows against nb <= 4 leaf blocks of the factor (gemm.hip); E / Eo point at
 // the group's first column, Lgg at L[c0, c0], X at the group's first block inverse

@@ -85,7 +85,12 @@ struct Aux {
   double check_us[3] = {0, 0, 0}, check_first_us[3] = {0, 0, 0};
   int recreated = 0;
   hipStream_t shift = nullptr;   // (kept alive: the extra stream that moved the re-created set onto other hardware queues)
+  // packet-free hand-offs of the latency chain (potrf_core, "chain flags"): one word per panel for "panel solved" (F) and for
+  // "rest-update done" (R), written with the epoch of the factorisation that owns them (monotonic per device)
+  int* flags = nullptr;
+  int epoch = 0;
 };
+constexpr int kMaxFlagPanels = 512;
 Aux g_aux[16];
 
 int masked_stream(hipStream_t* out, int ncu, int first, int last) {  // CUs [first, last)
@@ -231,6 +236,10 @@ int aux_get(int dev, int need, Aux** out) {
               a.check_us[0], a.check_us[1], a.check_us[2], pm, a.check_first_us[0], a.check_first_us[1], a.check_first_us[2], a.recreated, cu[0], cu[1], cu[2]);
     }
     a.ready = true;
+  }
+  if (!a.flags) {
+    GPK_HIP(hipMalloc((void**)&a.flags, sizeof(int) * 2 * kMaxFlagPanels));
+    GPK_HIP(hipMemset(a.flags, 0, sizeof(int) * 2 * kMaxFlagPanels));
   }
   if (a.nev < need) {
     hipEvent_t* n = (hipEvent_t*)realloc(a.ev, sizeof(hipEvent_t) * need);
@@ -468,6 +477,12 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   if (useX && X != B) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
+  const bool use_flags = GPK_TUNE(CHAIN_FLAGS, 1) && batch == 1 && aux->flags != nullptr;
+  int* flagF = aux->flags;
+  int* flagR = aux->flags + kMaxFlagPanels;
+  const int epoch = ++aux->epoch;
+  bool rest_flagged = false;   // the most recent rest-update was followed by a write of R[last_rest]
+  std::vector<char> panel_flagged(npanels, 0);
   int xg0 = 0;         // first column of the current extra-row group
   // (512 columns for M = 2048: 256 / 384 measured slower there.  For M <= 1024 the extra-row stream would start after half of
   // the chain: 256 columns for a batch of problems -- C5 separate 2.036 -> 1.977 ms -- and 128 for a single one -- C3 0.834 ->
@@ -481,17 +496,53 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // ---- P: the critical path.  Panel p, then the strip = columns of panel p+1 (look-ahead) -----------
     rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info);
     if (rc) return rc;
-    GPK_HIP(hipEventRecord(evF[p], P));
     const double* Pn = A + (long)c1 * lda + c0;  // rows c1.. of the solved panel
+    GemmArgs strip{};
+    if (c1 < n) {
+      strip = gemm_base(R - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0, A + (long)c1 * lda + c1, lda, batch, strideA,
+                        strideA, strideA);
+      strip.c_lower = 1;
+    }
+    // Chain flags (round 5).  Between two kernels of the panel stream an event record costs 4.6 us and an event wait 6.3 us of
+    // queue-packet processing (rocprofv3 timelines, profiles/r05_timeline_chain_flags_*.txt); two kernels back to back start
+    // 0.3 us apart.  Single-leaf panels (the SVGP sizes and the narrow tail of a large factorisation: leaf -> solve -> strip,
+    // 16 - 32 times per factorisation) therefore hand over WITHOUT packets on this stream:
+    //   "panel p solved"     the strip kernel stores the epoch into F[p] on entry (its predecessor, the solve, has completed
+    //                        and released); the rest-update and extra-row streams wait for it with hipStreamWaitValue32;
+    //   "rest-update done"   hipStreamWriteValue32(R[p]) behind the rest-update on ITS stream; the next strip's workgroups
+    //                        spin on it in-kernel (normally already there: the rest-update has a leaf's time of slack).
+    // (stream memory operations only on the plain streams: on the CU-masked bulk stream of large factorisations a
+    // hipStreamWriteValue32 was observed to overtake the kernel queued before it -- wrong factor at n = 5000 -- so a panel whose
+    // extra-row group waits on that stream keeps its event, and so does a strip whose rest-update ran there)
+    const bool x_waits_here = useX && (c1 == n || ((c1 - xg0) >= xgroup || (large && c1 - xg0 >= nbo)) ||
+                                       (!large && (nbo == NB) && (n >= 8 * NB) && (c1 == n - 2 * NB || c1 == n - NB)));
+    const bool flagged = use_flags && p < kMaxFlagPanels && c1 < n && (c1 - c0) <= NB && gpk_gemm_takes_latency_kernel(strip) &&
+                         !(x_waits_here && X == aux->B);
+    panel_flagged[p] = flagged ? 1 : 0;
+    if (!flagged) GPK_HIP(hipEventRecord(evF[p], P));
     if (c1 < n) {
       // columns c1:c2 also received the most recent rest-update (on a bulk stream): order the two
-      if (last_rest >= 0) GPK_HIP(hipStreamWaitEvent(P, evR[last_rest], 0));
-      GemmArgs u = gemm_base(R - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0,
-                             A + (long)c1 * lda + c1, lda, batch, strideA, strideA, strideA);
-      u.c_lower = 1;
-      rc = gpk_launch_gemm(P, u);
+      if (last_rest >= 0) {
+        if (flagged && rest_flagged) {
+          strip.wait_ptr = flagR + last_rest;
+          strip.wait_val = epoch;
+        } else {
+          GPK_HIP(hipStreamWaitEvent(P, evR[last_rest], 0));
+        }
+      }
+      if (flagged) {
+        strip.sig_ptr = flagF + p;
+        strip.sig_val = epoch;
+      }
+      rc = gpk_launch_gemm(P, strip);
       if (rc) return rc;
     }
+    // (what the other streams wait for: the flag word of a flagged panel, else the event)
+    auto wait_panel = [&](hipStream_t st) -> int {
+      if (panel_flagged[p]) GPK_HIP(hipStreamWaitValue32(st, flagF + p, (uint32_t)epoch, hipStreamWaitValueGte, 0xffffffffu));
+      else GPK_HIP(hipStreamWaitEvent(st, evF[p], 0));
+      return 0;
+    };
     // ---- B: rest of the outer trailing update  A[c2:, c2:] -= P[c2:] P[c2:]^T, lower tiles only --------
     // While the trailing matrix is large the factorisation is bound by these GEMMs (masked stream B); they start as soon
     // as panel p is solved.
@@ -501,10 +552,12 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
         // the unmasked stream of the SVGP-size scheme.  (A stream masked to half the CUs would keep CUs free for the leaf,
         // but its hand-offs to P took ~55 us instead of ~5: 190 us per panel instead of 56, GPR N = 16384 36.6 vs 32.0 ms.)
         Bp = aux->Bs;
-        GPK_HIP(hipStreamWaitEvent(Bp, evF[p], 0));
+        rc = wait_panel(Bp);
+        if (rc) return rc;
         if (last_rest >= 0 && last_bulk != Bp) GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
       } else {
-        GPK_HIP(hipStreamWaitEvent(B, evF[p], 0));
+        rc = wait_panel(B);
+        if (rc) return rc;
       }
       const double* P2 = A + (long)c2 * lda + c0;
       GemmArgs u = gemm_base(R - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
@@ -518,6 +571,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       rc = gpk_launch_gemm(Bp, u);
       if (rc) return rc;
       GPK_HIP(hipEventRecord(evR[p], Bp));
+      rest_flagged = use_flags && p < kMaxFlagPanels && Bp != aux->B;
+      if (rest_flagged) GPK_HIP(hipStreamWriteValue32(Bp, flagR + p, (uint32_t)epoch, 0));
       last_bulk = Bp;
       last_rest = p;
     }
@@ -534,7 +589,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     if (useX && (c1 == n || full_group || tail_group)) {
       const int g0 = xg0;
       xg0 = c1;
-      GPK_HIP(hipStreamWaitEvent(X, evF[p], 0));
+      rc = wait_panel(X);
+      if (rc) return rc;
       // (columns [g0, c1) may span several 512-groups when the outer panel is wider than a group)
       for (int h0 = g0; h0 < c1; h0 += NBO) {
         const int h1 = std::min(h0 + NBO, c1);
