@@ -391,7 +391,7 @@ int solve_group_bwd(hipStream_t s, double* Bm, long ldb, int rows, const double*
 // build, transposes, KL).  It is enqueued after the first panel's chain kernels: every host call issued before the first
 // leaf delays the whole step, and nothing on the bulk stream is needed for ~4 panels.
 int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
-               int* info, const std::function<int(hipStream_t)>* x_prologue = nullptr, int tri = 0) {
+               int* info, const std::function<int(hipStream_t)>* x_prologue = nullptr, int tri = 0, bool tri_prefilled = false) {
   if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
   if (tri && (tri != n || extra < n || batch > 1)) return GPK_E_ARG;
   if (batch <= 0) batch = 1;
@@ -399,7 +399,9 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   if (n == 0) return 0;
   // tri = n: the LAST n extra rows are the identity (written here) and come back as L^-T.  Row j of that block stays
   // zero left of column j, so column group [c0, c1) only has to process its first c1 rows: n^3 / 3 flop instead of n^3.
-  if (tri) {
+  // tri_prefilled: the caller (or its x_prologue) puts an UPPER-TRIANGULAR block there itself -- tril(q_sqrt)^T of the
+  // un-whitened ELBO: the same rows-stay-zero argument holds for any block that is zero left of its diagonal.
+  if (tri && !tri_prefilled) {
     const int rci = gpk_launch_set_identity(S, A + (long)(n + extra - tri) * lda, n, lda);
     if (rci) return rci;
   }
@@ -462,7 +464,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // cap on the persistent workgroups of the big extra-row updates, so that some CUs stay free for the panel stream's
   // one-shot kernels (A/B on the SVGP step, round 1: cap 320 -> 448 steps/s, no cap 435, cap 224 -> 431; round 3: 256 ->
   // 419, 320 -> 441, 384 -> 447)
-  if (!large) bulk.cap = GPK_TUNE(EXTRA_MAX_WGS, 320);
+  // (round 5, with the packet-free chain: 224 -- one workgroup on 224 compute units, 32 left to the chain's one-shot kernels --
+  //  is level with 320 on the whitened step and 2 - 5 % faster on the un-whitened one, whose extra-row stream is a quarter
+  //  longer; a batch of problems keeps 320: C5 separate 2.04 against 2.02 ms; 240 / 248 lose 5 %, profiles/r05_ab_caps.log)
+  if (!large) bulk.cap = batch > 1 ? GPK_TUNE(EXTRA_MAX_WGS_BATCHED, 320) : GPK_TUNE(EXTRA_MAX_WGS, 224);
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
   hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
   hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1], evJoinB = aux->ev[2 * npanels + 2],
@@ -477,7 +482,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   if (useX && X != B) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
-  const bool use_flags = GPK_TUNE(CHAIN_FLAGS, 1) && batch == 1 && aux->flags != nullptr;
+  const bool use_flags = GPK_TUNE(CHAIN_FLAGS, 1) && (batch == 1 || GPK_TUNE(CHAIN_FLAGS_BATCHED, 1)) && aux->flags != nullptr;
   int* flagF = aux->flags;
   int* flagR = aux->flags + kMaxFlagPanels;
   const int epoch = ++aux->epoch;
@@ -976,7 +981,9 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
       if (r) return r;
       return gpk_transpose((void*)xs, q_sqrt, m, m, m, GT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
     };
-    rcu = potrf_core(s, T, m, rows + P + P * m, l.ld, 1, 0, invd_u, 0, info, &pro);
+    // (P = 1: the m rows of tril(q_sqrt)^T are the LAST rows of the trapezoid and upper triangular -- row j stays zero left of
+    //  column j until its column group is reached, so the row solve skips them there: 3/8 of their work, round 5)
+    rcu = potrf_core(s, T, m, rows + P + P * m, l.ld, 1, 0, invd_u, 0, info, &pro, P == 1 ? m : 0, true);
     if (rcu) return rcu;
     rcu = gpk_transpose(stream, arow, P, m, l.ld, V, P, 0, 1, 0, 0);           // a = Lm^-1 q_mu as [m, P]
     if (rcu) return rcu;
