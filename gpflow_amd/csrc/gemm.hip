@@ -16,6 +16,7 @@
 // (b) tiles are swept in 8-wide column groups (A/B panel reuse out of the 4 MiB L2).
 #include "gpk_internal.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -839,7 +840,10 @@ __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
   const int r = lane & 15, g = lane >> 4;
   double* As = smem;               // [16][LDK]
   double* Bs = smem + 16 * LDK;    // [128][LDK]
-  const int m0 = blockIdx.x * 16;
+  // (gridDim.x < number of 16-row slivers: the workgroup walks the slivers with stride gridDim.x -- a cap on the resident
+  //  workgroups keeps compute units free for the factorisation's chain, GROUP_SOLVE_MAX_WGS in potrf.hip)
+  for (int m0 = blockIdx.x * 16; m0 < p.rows; m0 += gridDim.x * 16) {
+  if (m0 != (int)blockIdx.x * 16) __syncthreads();   // the previous sliver's last operand tile is no longer read
   int rowi[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -913,10 +917,11 @@ __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
       for (int e = 0; e < 4; ++e) c[jp][e] = -1.0 * (u0[e] + u1[e]);
     }
   }
+  }  // sliver loop
 }
 
 int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
-                       const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX) {
+                       const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX, int max_wgs) {
   if (rows <= 0) return 0;
   if (batch < 1) batch = 1;
   if (!E || !Eo || !Lgg || !X || nb < 1 || nb > 4) return GPK_E_ARG;
@@ -929,7 +934,9 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   GroupSolveArgs a{};
   a.E = E; a.lde = lde; a.Eo = Eo; a.ldeo = ldeo; a.L = Lgg; a.ldl = ldl; a.X = X; a.rows = rows; a.nb = nb;
   a.strideE = strideE; a.strideEo = strideEo; a.strideL = strideL; a.strideX = strideX;
-  hipLaunchKernelGGL(group_solve_kernel, dim3((unsigned)gpk_cdiv(rows, 16), (unsigned)batch), dim3(512), LDS, s, a);
+  unsigned gx = (unsigned)gpk_cdiv(rows, 16);
+  if (max_wgs > 0 && gx * (unsigned)batch > (unsigned)max_wgs) gx = (unsigned)std::max(1, max_wgs / batch);
+  hipLaunchKernelGGL(group_solve_kernel, dim3(gx, (unsigned)batch), dim3(512), LDS, s, a);
   GPK_LAUNCH_CHECK();
   return 0;
 }
@@ -981,8 +988,8 @@ int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
 bool gpk_gemm_takes_latency_kernel(const GemmArgs& a) { return a.m > 0 && a.n > 0 && !a.no_small && small_ok(a); }
 
 int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
-                           const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX) {
-  return launch_group_solve(s, E, lde, Eo, ldeo, rows, Lgg, ldl, X, nb, batch, strideE, strideEo, strideL, strideX);
+                           const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX, int max_wgs) {
+  return launch_group_solve(s, E, lde, Eo, ldeo, rows, Lgg, ldl, X, nb, batch, strideE, strideEo, strideL, strideX, max_wgs);
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events around every GEMM launch, on the

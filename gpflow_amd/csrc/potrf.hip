@@ -36,6 +36,7 @@ inline GemmArgs gemm_base(int m, int n, int k, double alpha, const double* A, lo
 // how a bulk GEMM beside the latency chain is launched
 struct Bulk {
   int cap = 0;    // cap on the persistent workgroups of the big (K >= 256) updates, 0 = one workgroup per tile
+  int group_cap = 0;   // cap on the workgroups of the fused in-group solve, 0 = one per 16-row sliver
   void apply(GemmArgs& g) const {
     if (cap > 0 && g.k >= 256) g.max_wgs = cap;
   }
@@ -267,7 +268,7 @@ int current_device(int* dev) {
 
 // factor the outer panel [c0,c1) of the square part (rows up to `rows`) on stream s
 int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, int batch, long strideA,
-                 double* invd, long strideInv, int* info) {
+                 double* invd, long strideInv, int* info, int chain_wgs = 0) {
   int rc;
   for (int j0 = c0; j0 < c1; j0 += NB) {
     const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
@@ -283,6 +284,7 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
     GemmArgs g = gemm_base(below, nb, nb, 1.0, panel, lda, invb, NB, 0.0, panel, lda, batch, strideA,
                            strideInv, strideA);
     g.b_tri = 2;
+    g.max_wgs = chain_wgs;
     rc = gpk_launch_gemm(s, g);
     if (rc) return rc;
     const int ncols = c1 - j1;
@@ -318,7 +320,7 @@ int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, double
     // (the fused kernel stages its operand tiles by 16-byte LDS-DMA: an 8-byte-aligned factor takes the per-block loop below)
     // the whole in-group phase (nbk solves + nbk - 1 updates of the latency kernel) as ONE launch with the same arithmetic
     rc = gpk_launch_group_solve(s, E + c0, lde, Eo + c0, ldeo, rows, L + (long)c0 * ldl + c0, ldl, invd + (long)(c0 / NB) * NB * NB,
-                                nbk, batch, strideE, strideEo, strideL, strideInv);
+                                nbk, batch, strideE, strideEo, strideL, strideInv, bulk.group_cap);
     if (rc) return rc;
   } else {
     for (int j0 = c0; j0 < c1; j0 += NB) {
@@ -468,6 +470,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   //  is level with 320 on the whitened step and 2 - 5 % faster on the un-whitened one, whose extra-row stream is a quarter
   //  longer; a batch of problems keeps 320: C5 separate 2.04 against 2.02 ms; 240 / 248 lose 5 %, profiles/r05_ab_caps.log)
   if (!large) bulk.cap = batch > 1 ? GPK_TUNE(EXTRA_MAX_WGS_BATCHED, 320) : GPK_TUNE(EXTRA_MAX_WGS, 224);
+  if (!large) bulk.group_cap = GPK_TUNE(GROUP_SOLVE_MAX_WGS, 0);
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
   hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
   hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1], evJoinB = aux->ev[2 * npanels + 2],
@@ -499,7 +502,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     const int c2 = (p + 2 <= npanels) ? cuts[p + 2] : n;
     const bool narrow = large && (c1 - c0 <= NB) && nbo > NB;  // single-leaf panel in the chain-bound end of a large factorisation
     // ---- P: the critical path.  Panel p, then the strip = columns of panel p+1 (look-ahead) -----------
-    rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info);
+    const int chain_wgs = (!large && batch == 1) ? GPK_TUNE(CHAIN_MAX_WGS, 0) : 0;
+    rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info, chain_wgs);
     if (rc) return rc;
     const double* Pn = A + (long)c1 * lda + c0;  // rows c1.. of the solved panel
     GemmArgs strip{};
@@ -507,6 +511,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       strip = gemm_base(R - c1, c2 - c1, c1 - c0, -1.0, Pn, lda, Pn, lda, 1.0, A + (long)c1 * lda + c1, lda, batch, strideA,
                         strideA, strideA);
       strip.c_lower = 1;
+      strip.max_wgs = chain_wgs;
     }
     // Chain flags (round 5).  Between two kernels of the panel stream an event record costs 4.6 us and an event wait 6.3 us of
     // queue-packet processing (rocprofv3 timelines, profiles/r05_timeline_chain_flags_*.txt); two kernels back to back start
