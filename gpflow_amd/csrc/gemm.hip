@@ -41,14 +41,8 @@ struct TileCfg {
 // Tiles are numbered group-of-8-columns major, row-major inside a group; each XCD takes a
 // contiguous 1/8 of that sequence.  With c_lower (and square tiles) only the tiles on or below
 // the diagonal are numbered, so every XCD gets the same amount of work.
-__device__ __forceinline__ void tile_order(int lin, int b_tri, int gx, int gy, int total, int compact, int& tile_m,
-                                           int& tile_n) {
-  const int xcd = lin & 7, local = lin >> 3;
-  const int q = total >> 3, r = total & 7;
-  int nl = xcd * q + (xcd < r ? xcd : r) + local;
-  // triangular-K work (b_tri = 1, many column tiles) is heaviest in the first column groups:
-  // keep plain round-robin there so all XCDs walk the groups together, heaviest first
-  if (b_tri == 1 && gx > GROUP_N) nl = lin;
+// position nl of the tile sequence -> (tile_m, tile_n)
+__device__ __forceinline__ void tile_decode(int nl, int gx, int gy, int compact, int& tile_m, int& tile_n) {
   tile_m = 0; tile_n = 0;
   if (compact) {
     int g = 0;
@@ -84,6 +78,17 @@ __device__ __forceinline__ void tile_order(int lin, int b_tri, int gx, int gy, i
   }
 }
 
+__device__ __forceinline__ void tile_order(int lin, int b_tri, int gx, int gy, int total, int compact, int& tile_m,
+                                           int& tile_n) {
+  const int xcd = lin & 7, local = lin >> 3;
+  const int q = total >> 3, r = total & 7;
+  int nl = xcd * q + (xcd < r ? xcd : r) + local;
+  // triangular-K work (b_tri = 1, many column tiles) is heaviest in the first column groups:
+  // keep plain round-robin there so all XCDs walk the groups together, heaviest first
+  if (b_tri == 1 && gx > GROUP_N) nl = lin;
+  tile_decode(nl, gx, gy, compact, tile_m, tile_n);
+}
+
 __device__ __forceinline__ d2 load2(const double* __restrict__ base, long ld, int row, int nrows,
                                     int k, int ke, bool vec_ok) {
   d2 v = {0.0, 0.0};
@@ -111,9 +116,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
   const int bz = blockIdx.y;
 
   int tile_m, tile_n;
-  tile_order(blockIdx.x, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+  if (BM == 64 && BN == 64 && p.tail_first1 > 0) {
+    // the last, partial round of a lower-only launch of the 128 x 128 fast tile (launch_fast, "tail split"): positions
+    // tail_first + blockIdx.x / 4 of ITS tile sequence (gx, gy in 128-tiles), each as four 64 x 64 quarters
+    int tm, tn;
+    tile_decode(p.tail_first1 - 1 + ((int)blockIdx.x >> 2), gx, gy, 1, tm, tn);
+    tile_m = 2 * tm + (((int)blockIdx.x >> 1) & 1);
+    tile_n = 2 * tn + ((int)blockIdx.x & 1);
+  } else {
+    tile_order(blockIdx.x, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (p.c_lower && n0 > m0 + BM - 1) return;
+  if (m0 >= p.m || n0 >= p.n) return;
 
   const double* __restrict__ A = p.A + (long)bz * p.strideA;
   const double* __restrict__ B = p.B + (long)bz * p.strideB;
@@ -652,6 +667,21 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
       return 0;
     }
   }
+  // Tail split (round 5 EXPERIMENT, off: measured no gain).  The N = 16384 trailing updates take 146 us + 0.414 us per tile
+  // (7139 tiles: 3102 us ... 1224 tiles: 653 us), i.e. ~0.7 of a 205-us tile round of ramp and drain per launch, 9 % of the
+  // 25 ms those launches sum to.  If that were the partly filled LAST round, running the remainder as 64 x 64 quarters on the
+  // generic kernel (four times the workgroups, a quarter of the tile time) would recover most of it; built and measured
+  // (profiles/r05_ab_gpr_tail_split.log): 31.4 - 31.6 against 31.25 ms -- the overhead does not depend on the remainder
+  // (5459 tiles = 11.006 rounds take 11.45 round times, 4949 = 9.98 rounds 10.3): workgroups drift apart over fifteen rounds
+  // and the drain is the same ~0.7 round whatever the tile count.
+  int tail_tiles = 0;
+  if (EPI == 0 && a.c_lower && a.max_wgs == 0 && nb == 1 && !a.b_tri && !a.a_tri && GPK_TUNE(TAIL_SPLIT, 0)) {
+    const int slots = 2 * (a.stagger_first > 0 ? a.stagger_first : 256);
+    const int r = total % slots;
+    if (total >= 2 * slots && r > 0 && r * 100 <= slots * GPK_TUNE(TAIL_SPLIT_PCT, 50)) tail_tiles = r;
+  }
+  const int total_all = total;
+  total -= tail_tiles;
   unsigned nwg = (unsigned)total;
   if (a.max_wgs > 0 && (unsigned)a.max_wgs < nwg) nwg = (unsigned)a.max_wgs;
   GemmArgs b = a;
@@ -668,6 +698,17 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, nb, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total,
                      compact);
   GPK_LAUNCH_CHECK();
+  if (tail_tiles > 0) {
+    using Cfg = TileCfg<64, 64, 4, 1>;
+    static const hipError_t attrt = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<64, 64, 4, 1>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    GPK_HIP(attrt);
+    GemmArgs t = a;
+    t.tail_first1 = total_all - tail_tiles + 1;
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 1>), dim3((unsigned)(4 * tail_tiles), 1, 1), dim3(256), Cfg::LDS_BYTES, s, t, gx,
+                       gy, 4 * tail_tiles, 1);
+    GPK_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -91,6 +91,7 @@ struct GemmArgs {
   //             word is written by hipStreamWriteValue32 behind the producing kernel on ITS stream.
   int* sig_ptr; int sig_val;
   const int* wait_ptr; int wait_val;
+  int tail_first1;  // set by the launcher only (generic 64 x 64 kernel; launch_fast, "tail split"): 1 + first position, 0 = off
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);
 bool gpk_gemm_takes_latency_kernel(const GemmArgs& a);   // the launch would run on the one-shot latency kernel (sig / wait honoured)
