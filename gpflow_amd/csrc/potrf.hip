@@ -389,11 +389,15 @@ int solve_group_bwd(hipStream_t s, double* Bm, long ldb, int rows, const double*
   return 0;
 }
 
+// b_prologue (large factorisations): work of the CALLER that everything EXCEPT the first panel's columns waits for -- the GPR
+// driver builds only those columns before the call and the rest of K(X, X) here, on the bulk stream, beside the first panel's
+// chain, which nothing else would overlap (first_panel_columns below tells it how many columns that is).
 // x_prologue: work of the CALLER that belongs on the bulk stream before the first extra-row group (the SVGP driver's Kfu
 // build, transposes, KL).  It is enqueued after the first panel's chain kernels: every host call issued before the first
 // leaf delays the whole step, and nothing on the bulk stream is needed for ~4 panels.
 int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
-               int* info, const std::function<int(hipStream_t)>* x_prologue = nullptr, int tri = 0, bool tri_prefilled = false) {
+               int* info, const std::function<int(hipStream_t)>* x_prologue = nullptr, int tri = 0, bool tri_prefilled = false,
+               const std::function<int(hipStream_t)>* b_prologue = nullptr) {
   if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
   if (tri && (tri != n || extra < n || batch > 1)) return GPK_E_ARG;
   if (batch <= 0) batch = 1;
@@ -452,7 +456,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> lock(g_aux[dev].mu);
   Aux* aux = nullptr;
-  rc = aux_get(dev, 2 * npanels + 8, &aux);
+  rc = aux_get(dev, 2 * npanels + 8, &aux);   // (+ fork, three joins, the b_prologue event)
   if (rc) return rc;
   const bool large = n >= 4096;
   hipStream_t P = aux->P, B = large ? aux->B : aux->Bs;
@@ -485,6 +489,18 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   if (useX && X != B) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
+  hipEvent_t evBpro = aux->ev[2 * npanels + 4];
+  bool bpro_pending = false;
+  if (b_prologue) {
+    rc = (*b_prologue)(B);
+    if (rc) return rc;
+    if (B != S) {
+      GPK_HIP(hipEventRecord(evBpro, B));
+      bpro_pending = true;
+      if (useX && X != B) GPK_HIP(hipStreamWaitEvent(X, evBpro, 0));
+      if (aux->Bs != B) GPK_HIP(hipStreamWaitEvent(aux->Bs, evBpro, 0));
+    }
+  }
   const bool use_flags = GPK_TUNE(CHAIN_FLAGS, 1) && (batch == 1 || GPK_TUNE(CHAIN_FLAGS_BATCHED, 1)) && aux->flags != nullptr;
   int* flagF = aux->flags;
   int* flagR = aux->flags + kMaxFlagPanels;
@@ -531,6 +547,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     panel_flagged[p] = flagged ? 1 : 0;
     if (!flagged) GPK_HIP(hipEventRecord(evF[p], P));
     if (c1 < n) {
+      if (bpro_pending) {   // the strip is the first kernel of the chain that leaves the first panel's columns
+        GPK_HIP(hipStreamWaitEvent(P, evBpro, 0));
+        bpro_pending = false;
+      }
       // columns c1:c2 also received the most recent rest-update (on a bulk stream): order the two
       if (last_rest >= 0) {
         if (flagged && rest_flagged) {
@@ -624,6 +644,17 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   }
   if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, batch, strideA);
   return 0;
+}
+}  // namespace
+
+namespace {
+// number of leading columns the FIRST outer panel of a factorisation of size n covers (same rule as potrf_core's cuts)
+int first_panel_columns(int n) {
+  const int nbo_large = (GPK_TUNE(NBO, 640) / NB) * NB;
+  const int nbo = (n >= 4096) ? (nbo_large >= NB ? nbo_large : NBO) : NB;
+  const int narrow_tail = (nbo > NB) ? (GPK_TUNE(NARROW_TAIL, 4096) / NB) * NB : 0;
+  const int w = (nbo > NB && n > narrow_tail) ? nbo : NB;
+  return w < n ? w : n;
 }
 }  // namespace
 
@@ -784,19 +815,43 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
   double* logdet = (double*)(w + l.off_logdet);
   int rc;
   // K(X,X) + noise I, lower tiles only (gpr.py:100-101); a heteroskedastic likelihood (noise_rows: one variance per data
-  // row, likelihoods/scalar_continuous.py:92-111) adds its vector to the diagonal instead (model_utils.py:46-50)
-  rc = gpk_kernel_matrix(stream, family, X, n, ldx, nullptr, 0, 0, d, ls_host, ard, variance,
-                         noise_rows ? 0.0 : noise_variance, 1, T, l.ld);
-  if (rc) return rc;
-  if (noise_rows) {
-    rc = gpk_diag_add(stream, T, n, l.ld, noise_rows);
+  // row, likelihoods/scalar_continuous.py:92-111) adds its vector to the diagonal instead (model_utils.py:46-50).
+  // Large n (round 5 EXPERIMENT, off): the first outer panel's chain (5 leaves and their in-panel solves, ~0.5 ms) has nothing
+  // to overlap with -- so only ITS columns are built before the factorisation starts and the remaining (n - w)^2 block is
+  // built on the factorisation's bulk stream beside that chain (b_prologue).  Same formula per element: bit-identical
+  // (tests at n = 4224 / 5000).  Measured at N = 16384: 31.13 - 31.21 against 31.17 - 31.23 ms (profiles/r05_ab_gpr_split_build.log):
+  // the build's 65536 workgroups take every compute unit and the chain's one-workgroup leaves queue behind them, so the 0.4 ms
+  // of build overlap ~0.05 ms of chain.  Kept behind GPK_GPR_SPLIT_BUILD in the A/B build.
+  const int w0 = first_panel_columns(n);
+  const bool split_build = n >= 4096 && w0 < n && GPK_TUNE(GPR_SPLIT_BUILD, 0);
+  std::function<int(hipStream_t)> bpro;
+  if (!split_build) {
+    rc = gpk_kernel_matrix(stream, family, X, n, ldx, nullptr, 0, 0, d, ls_host, ard, variance,
+                           noise_rows ? 0.0 : noise_variance, 1, T, l.ld);
     if (rc) return rc;
+    if (noise_rows) {
+      rc = gpk_diag_add(stream, T, n, l.ld, noise_rows);
+      if (rc) return rc;
+    }
+  } else {
+    // columns [0, w0): all rows (the w0 x w0 top block gets its upper triangle too; the factorisation never reads it)
+    rc = gpk_kernel_matrix(stream, family, X, n, ldx, X, w0, ldx, d, ls_host, ard, variance, 0.0, 0, T, l.ld);
+    if (rc) return rc;
+    rc = noise_rows ? gpk_diag_add(stream, T, w0, l.ld, noise_rows) : gpk_launch_diag_add_scalar(s, T, w0, l.ld, noise_variance);
+    if (rc) return rc;
+    bpro = [&, w0](hipStream_t bs) -> int {
+      double* Kb = T + (long)w0 * l.ld + w0;
+      int r = gpk_kernel_matrix((void*)bs, family, X + (long)w0 * ldx, n - w0, ldx, nullptr, 0, 0, d, ls_host, ard, variance,
+                                noise_rows ? 0.0 : noise_variance, 1, Kb, l.ld);
+      if (r) return r;
+      return noise_rows ? gpk_diag_add((void*)bs, Kb, n - w0, l.ld, noise_rows + w0) : 0;
+    };
   }
   // (Y - m)^T as P extra rows (gpr.py:103, logdensities.py:149)
   rc = gpk_launch_transpose_shift(s, Y, n, P, ldy, T + (long)n * l.ld, l.ld, -mean_const);
   if (rc) return rc;
   // L = chol(K); extra rows -> alpha^T = (L^-1 (Y-m))^T  (gpr.py:102, logdensities.py:150)
-  rc = gpk_potrf(stream, T, n, P, l.ld, 1, 0, invd, 0, info);
+  rc = potrf_core(s, T, n, P, l.ld, 1, 0, invd, 0, info, nullptr, 0, false, split_build ? &bpro : nullptr);
   if (rc) return rc;
   // p = -0.5 sum alpha^2 - 0.5 N log 2pi - sum log diag L, summed over the P columns
   rc = gpk_sum_log_diag(stream, T, n, l.ld, 1, 0, logdet);

@@ -375,6 +375,16 @@ __global__ __launch_bounds__(256) void diag_add_kernel(double* __restrict__ A, i
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) A[(long)i * lda + i] += v[i];
 }
+__global__ __launch_bounds__(256) void diag_add_scalar_kernel(double* __restrict__ A, int n, long lda, double v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) A[(long)i * lda + i] += v;
+}
+int gpk_launch_diag_add_scalar(hipStream_t s, double* A, int n, long lda, double v) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(diag_add_scalar_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, n, lda, v);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int gpk_diag_add(void* stream, double* A, int n, long lda, const double* v) {
   if (!A || !v || n < 0 || lda < n) return GPK_E_ARG;
   if (n == 0) return 0;

@@ -232,7 +232,7 @@ def test_row_stats_project_reductions(gpu):
     np.testing.assert_allclose(ops.sumsq(_t(At)).cpu().numpy()[0], (At ** 2).sum(), rtol=1e-13)
 
 
-@pytest.mark.parametrize("n,d,P", [(50, 1, 1), (512, 2, 1), (700, 8, 3)])
+@pytest.mark.parametrize("n,d,P", [(50, 1, 1), (512, 2, 1), (700, 8, 3), (4224, 3, 2), (5000, 4, 1)])
 def test_fused_gpr_lml(gpu, n, d, P):
     from gpflow_amd import ops
     rng = np.random.default_rng(8)
@@ -243,6 +243,16 @@ def test_fused_gpr_lml(gpu, n, d, P):
     ops.check_info(info)
     ref = orc.gpr_log_marginal_likelihood(X, Y, mean=0.05, **kw)
     np.testing.assert_allclose(out.cpu().numpy()[0], ref, rtol=1e-10)
+    if n >= 4096:
+        # large n: only the first outer panel's columns are built before the factorisation starts, the rest beside its chain
+        # on the bulk stream (potrf.hip, gpk_gpr_lml) -- repeated calls and per-row noise through the same split
+        out2, _ = ops.gpr_lml(_t(X), _t(Y), mean_const=0.05, **kw)
+        assert float(out2.cpu()[0]) == float(out.cpu()[0])
+        nv = rng.uniform(0.05, 0.3, size=n)
+        kw["noise_variance"] = nv
+        outh, info = ops.gpr_lml(_t(X), _t(Y), mean_const=0.05, **{**kw, "noise_variance": _t(nv)})
+        ops.check_info(info)
+        np.testing.assert_allclose(outh.cpu().numpy()[0], orc.gpr_log_marginal_likelihood(X, Y, mean=0.05, **kw), rtol=1e-10)
 
 
 @pytest.mark.parametrize("m,rows,d,P,q_diag", [(20, 50, 1, 2, False), (200, 300, 8, 1, False), (300, 1000, 8, 4, False), (130, 257, 3, 2, True)])
