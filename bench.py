@@ -331,8 +331,11 @@ def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
             pj = json.load(f)
         kb_traffic = float(pj["rbf_kernel<0> full 16384^2"]["hbm_bytes_per_launch"])
         traffic = float(pj["gemm_nt_fast<0,false> trailing update"]["hbm_bytes_per_launch"])
+        predict_traffic = float(pj["GPR predict_f fused, whole call"]["hbm_bytes_per_call"]) \
+            if "GPR predict_f fused, whole call" in pj else None
     except Exception:
         kb_traffic = None
+        predict_traffic = None
     trailing = {"bound": "mfma", "kernel": "gemm_nt_fast<0,false>, lower tiles, K = 640 (outer trailing updates)",
                 "achieved": tu_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tu_tf / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
@@ -370,7 +373,11 @@ def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
                "ms_total": t_pred * 1e3, "algorithmic_gflop": pred_flops / 1e9,
                "roofline": {"bound": "mfma", "achieved": pred_flops / t_pred / 1e12, "peak": FP64_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": pred_flops / t_pred / 1e12 / FP64_PEAK_TFLOPS,
-                            "kernel": "whole call (gemm_nt_fast launches carry > 97 % of the flops)", "traffic": None},
+                            "kernel": "whole call (gemm_nt_fast launches carry > 97 % of the flops)", "traffic": predict_traffic,
+                            "traffic_note": "FETCH_SIZE x2 + WRITE_SIZE summed over EVERY kernel of one fused call (PMC passes on "
+                                            "tools/predict_pmc_probe.py, profiles/pmc_traffic.json); algorithmic bytes of the call: "
+                                            "the N^2/2 lower triangle written and read once + the T x N test rows = "
+                                            f"{(n * n / 2 * 8 * 2 + T * n * 8 * 2) / 1e9:.2f} GB"},
                "cached_posterior_ms": t_cached * 1e3, "cached_posterior_gflop": float(n) * n * T / 1e9,
                "cached_posterior_tflops": float(n) * n * T / t_cached / 1e12,
                "routes_max_abs_diff": {"mean": float((pred["mu"] - cached["mu"]).abs().max()),

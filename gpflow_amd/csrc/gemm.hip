@@ -765,9 +765,13 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk)
   if (p.wait_ptr) {
     if (tid == 0) {
       const long long t0 = wall_clock64();   // (100 MHz; bounded: a lost hand-off must never hang the device -- 0.5 s, then on)
-      while ((int)(__hip_atomic_load(p.wait_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.wait_val) < 0 &&
-             wall_clock64() - t0 < 50000000LL)
+      bool timed_out = false;
+      while ((int)(__hip_atomic_load(p.wait_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.wait_val) < 0) {
+        if (wall_clock64() - t0 >= 50000000LL) { timed_out = true; break; }
         __builtin_amdgcn_s_sleep(2);
+      }
+      // a hand-off that never arrived is an internal error: the factorisation status becomes INT_MAX (gpk.h, "info")
+      if (timed_out && p.wait_info) atomicMax(p.wait_info, 0x7fffffff);
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's tiles were released by ITS kernel end; drop stale lines

@@ -37,17 +37,18 @@ inline GemmArgs gemm_base(int m, int n, int k, double alpha, const double* A, lo
 struct Bulk {
   int cap = 0;    // cap on the persistent workgroups of the big (K >= 256) updates, 0 = one workgroup per tile
   int group_cap = 0;   // cap on the workgroups of the fused in-group solve, 0 = one per 16-row sliver
+  int kmin = 256;      // updates with K below this are not capped
   void apply(GemmArgs& g) const {
-    if (cap > 0 && g.k >= 256) g.max_wgs = cap;
+    if (cap > 0 && g.k >= kmin) g.max_wgs = cap;
   }
 };
 }  // namespace
 
 extern "C" const char* gpk_version(void) {
 #ifdef GPK_EXPERIMENTAL
-  return "gpk 0.3 (gfx950, fp64 MFMA) [A/B build: environment tunables enabled]";
+  return "gpk 0.4 (gfx950, fp64 MFMA) [A/B build: environment tunables enabled]";
 #else
-  return "gpk 0.3 (gfx950, fp64 MFMA)";
+  return "gpk 0.4 (gfx950, fp64 MFMA)";
 #endif
 }
 
@@ -475,6 +476,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   //  longer; a batch of problems keeps 320: C5 separate 2.04 against 2.02 ms; 240 / 248 lose 5 %, profiles/r05_ab_caps.log)
   if (!large) bulk.cap = batch > 1 ? GPK_TUNE(EXTRA_MAX_WGS_BATCHED, 320) : GPK_TUNE(EXTRA_MAX_WGS, 224);
   if (!large) bulk.group_cap = GPK_TUNE(GROUP_SOLVE_MAX_WGS, 0);
+  if (!large) bulk.kmin = GPK_TUNE(EXTRA_CAP_KMIN, 256);
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
   hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
   hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1], evJoinB = aux->ev[2 * npanels + 2],
@@ -556,6 +558,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
         if (flagged && rest_flagged) {
           strip.wait_ptr = flagR + last_rest;
           strip.wait_val = epoch;
+          strip.wait_info = info;
         } else {
           GPK_HIP(hipStreamWaitEvent(P, evR[last_rest], 0));
         }

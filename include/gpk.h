@@ -15,12 +15,17 @@
  *   - numerical failure (non-positive pivot) is reported LAPACK-style through a device int
  *     `info` (0 = ok, j+1 = first bad pivot column) that the caller reads when it next syncs
  *     (TF raises InvalidArgumentError "Cholesky decomposition was not successful" at the same spot);
+ *     INT_MAX = an internal stream hand-off of the factorisation timed out (0.5 s; never observed -- the bounded wait exists so
+ *     that a lost hand-off cannot hang the device);
  *
  * Internal state and threading (the complete list; nothing else in the library is mutable)
  *   - gpk_potrf with n > 128 (and the two fused drivers, which call it) uses per-device state created lazily on the
  *     first such call: five internal HIP streams (P panel, high priority / X side / one placeholder that fixes the
  *     stream-to-hardware-queue layout / Bs bulk-small / B bulk, CU-masked) and a pool of timing-disabled events that grows
- *     to 2 * panels + 8.  That first call also runs a ~1 ms self-check of the stream layout (a few hundred empty kernels;
+ *     to 2 * panels + 8, and 4 KB of device memory for hand-off words: single-leaf panels of the latency chain are handed
+ *     over between these streams with hipStreamWaitValue32 / hipStreamWriteValue32 and an in-kernel poll instead of event
+ *     packets (an event record / wait between two kernels of one stream costs 4.6 / 6.3 us on MI355X; the poll is bounded:
+ *     after 0.5 s a waiting kernel proceeds rather than hang the device).  That first call also runs a ~1 ms self-check of the stream layout (a few hundred empty kernels;
  *     the ONLY place the library synchronises) and creates the streams again if a pair of them hands kernels over slowly
  *     (gpk_stream_selfcheck).  Afterwards no device memory is allocated and nothing synchronises: work is forked from and
  *     joined to the caller's stream with events only.  (The streams are created in an order that keeps the panel and bulk
