@@ -410,8 +410,12 @@ def stream_selfcheck(lib):
     now, first, rec = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), ctypes.c_int()
     if lib.gpk_stream_selfcheck(now, first, ctypes.byref(rec)) != 0:
         return None
+    mode = int(lib.gpk_chain_handoff_mode())
     return {"handoff_us_P_X_Bs_pairs": [round(v, 1) for v in now], "first_layout_us": [round(v, 1) for v in first],
-            "streams_recreated": bool(rec.value), "limit_us": 30}
+            "streams_recreated": bool(rec.value), "limit_us": 30,
+            "chain_handoff": {1: "stream memory operations + in-kernel polls (no event packets on the chain)",
+                              0: "events (kernels of two streams were NOT seen running concurrently: a serialising tool is attached)"
+                              }.get(mode, "not initialised")}
 
 
 def spawn_ranks(n: int, dry: bool) -> int:

@@ -36,6 +36,7 @@ _SIGS = {
     "gpk_potrf": (c_int, [c_void_p, _dp, c_int, c_int, c_long, c_int, c_long, _dp, c_int, _dp]),
     "gpk_combine_parts": (c_int, [c_void_p, _dp, c_int, c_long, c_int, c_int, c_long, c_double, c_int, c_double, _dp, c_long]),
     "gpk_stream_selfcheck": (c_int, [C.POINTER(c_double), C.POINTER(c_double), C.POINTER(c_int)]),
+    "gpk_chain_handoff_mode": (c_int, []),
     "gpk_potrf_inv": (c_int, [c_void_p, _dp, c_int, c_int, c_long, _dp, c_int, _dp]),
     "gpk_trtri_blocks": (c_int, [c_void_p, _dp, c_int, c_long, c_int, c_long, _dp]),
     "gpk_trsm": (c_int, [c_void_p, c_int, _dp, c_long, _dp, c_int, _dp, c_int, c_long, c_int, c_long,

@@ -135,6 +135,7 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
 int gpk_launch_zero_upper(hipStream_t s, double* A, int n, long lda, int batch, long strideA);
 int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda, int batch = 1, long strideA = 0);
 int gpk_launch_diag_add_scalar(hipStream_t s, double* A, int n, long lda, double v);   // A[i,i] += v
+int gpk_probe_concurrent_kernels(hipStream_t a, hipStream_t b, int* scratch, int* concurrent);   // init-time probe (reduce.hip)
 int gpk_launch_noop(hipStream_t s);  // empty kernel (stream hand-off probe)
 int gpk_launch_sum_parts(hipStream_t s, const double* part, int nt, int rows, long stridePart, int P,
                          double* ssq);

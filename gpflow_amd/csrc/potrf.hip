@@ -91,6 +91,7 @@ struct Aux {
   // "rest-update done" (R), written with the epoch of the factorisation that owns them (monotonic per device)
   int* flags = nullptr;
   int epoch = 0;
+  int concurrent = -1;   // 1: kernels of two streams were seen running at the same time (init-time probe); 0: serialised by a tool
 };
 constexpr int kMaxFlagPanels = 512;
 Aux g_aux[16];
@@ -242,6 +243,11 @@ int aux_get(int dev, int need, Aux** out) {
   if (!a.flags) {
     GPK_HIP(hipMalloc((void**)&a.flags, sizeof(int) * 2 * kMaxFlagPanels));
     GPK_HIP(hipMemset(a.flags, 0, sizeof(int) * 2 * kMaxFlagPanels));
+    // in-kernel hand-offs need kernels of two streams to RUN concurrently: under rocprofv3 --pmc (or any tool that serialises
+    // kernels) they would deadlock, so the chain then keeps its events (gpk_probe_concurrent_kernels: <= 2 ms, once per device)
+    int conc = 0;
+    const int rcp = gpk_probe_concurrent_kernels(a.X, a.P, a.flags, &conc);
+    a.concurrent = (rcp == 0 && conc) ? 1 : 0;
   }
   if (a.nev < need) {
     hipEvent_t* n = (hipEvent_t*)realloc(a.ev, sizeof(hipEvent_t) * need);
@@ -503,7 +509,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       if (aux->Bs != B) GPK_HIP(hipStreamWaitEvent(aux->Bs, evBpro, 0));
     }
   }
-  const bool use_flags = GPK_TUNE(CHAIN_FLAGS, 1) && (batch == 1 || GPK_TUNE(CHAIN_FLAGS_BATCHED, 1)) && aux->flags != nullptr;
+  const bool use_flags = GPK_TUNE(CHAIN_FLAGS, 1) && (batch == 1 || GPK_TUNE(CHAIN_FLAGS_BATCHED, 1)) && aux->flags != nullptr &&
+                         aux->concurrent == 1;
   int* flagF = aux->flags;
   int* flagR = aux->flags + kMaxFlagPanels;
   const int epoch = ++aux->epoch;
@@ -674,6 +681,15 @@ extern "C" int gpk_stream_selfcheck(double* us_now, double* us_first, int* recre
   }
   if (recreated) *recreated = a.recreated;
   return 0;
+}
+
+extern "C" int gpk_chain_handoff_mode(void) {
+  int dev = 0;
+  if (current_device(&dev)) return -1;
+  std::lock_guard<std::recursive_mutex> lock(g_aux[dev].mu);
+  const Aux& a = g_aux[dev];
+  if (!a.ready || a.concurrent < 0) return -1;
+  return (GPK_TUNE(CHAIN_FLAGS, 1) && a.concurrent == 1) ? 1 : 0;
 }
 
 extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch,

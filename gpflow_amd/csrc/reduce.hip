@@ -370,6 +370,35 @@ int gpk_launch_noop(hipStream_t s) {
   return 0;
 }
 
+// ---- can two kernels of this process run at the same time? -----------------------------------------------------------------
+// The chain flags of potrf.hip let a kernel wait in-kernel for a word that a kernel (or stream write) on ANOTHER stream sets.
+// Under a tool that serialises kernel execution (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL) the producer would never start while the
+// consumer spins: a deadlock inside the runtime's own stream-wait kernel, which has no timeout.  So the first factorisation of a
+// device asks: a kernel that waits at most 2 ms for a word, and one on a second stream that sets it.
+__global__ void probe_wait_kernel(const int* flag, int* result) {
+  const long long t0 = wall_clock64();   // 100 MHz
+  int seen = 0;
+  while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) && wall_clock64() - t0 < 200000LL)
+    __builtin_amdgcn_s_sleep(8);
+  *result = seen ? 1 : 0;
+}
+__global__ void probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+int gpk_probe_concurrent_kernels(hipStream_t a, hipStream_t b, int* scratch /* 2 device ints */, int* concurrent) {
+  GPK_HIP(hipMemsetAsync(scratch, 0, 2 * sizeof(int), a));
+  GPK_HIP(hipStreamSynchronize(a));
+  hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, a, scratch, scratch + 1);
+  GPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, b, scratch);
+  GPK_LAUNCH_CHECK();
+  GPK_HIP(hipStreamSynchronize(a));
+  GPK_HIP(hipStreamSynchronize(b));
+  int h[2] = {0, 0};
+  GPK_HIP(hipMemcpy(h, scratch, sizeof(h), hipMemcpyDeviceToHost));
+  *concurrent = h[1];
+  GPK_HIP(hipMemset(scratch, 0, 2 * sizeof(int)));
+  return 0;
+}
+
 // A[i,i] += v[i]:  add_noise_cov with a per-row likelihood variance (utilities/model_utils.py:33-38, 46-50)
 __global__ __launch_bounds__(256) void diag_add_kernel(double* __restrict__ A, int n, long lda, const double* __restrict__ v) {
   const int i = blockIdx.x * 256 + threadIdx.x;

@@ -124,6 +124,11 @@ int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch, lo
  * stream set (us_first[3]); *recreated = 1 if the first set was slow (> 30 us: two active hardware queues on one
  * microengine pipe) and the streams were created again.  GPK_E_UNSUPPORTED before the first factorisation with n > 128. */
 int gpk_stream_selfcheck(double* us_now, double* us_first, int* recreated);
+/* How the factorisation's latency chain hands over between the internal streams on the current device: 1 = stream memory
+ * operations + in-kernel polls (no event packets between the chain's kernels), 0 = events -- chosen by the first factorisation,
+ * which checks that kernels of two streams really run at the same time (a tool that serialises kernels, e.g. rocprofv3 --pmc,
+ * would deadlock the polls) -- , -1 = no factorisation with n > 128 has been issued on this device yet. */
+int gpk_chain_handoff_mode(void);
 
 /* gpk_potrf for callers that also need the explicit inverse factor (the reverse pass: gradients.py; the reference
  * gets the same quantities from the triangular solves inside TF's Cholesky gradient).  A is [n + extra + n, lda]:

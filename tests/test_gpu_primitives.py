@@ -2,6 +2,8 @@
 
 Tolerances are stated per test; fp64 throughout.  Inputs are asymmetric on purpose (transpose-detecting).
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.linalg as sla
@@ -533,3 +535,37 @@ def test_host_mailbox(gpu):
     box.post(torch.ones(3, dtype=torch.float64, device=dev))
     vals, status = box.wait()
     assert status == 0 and np.all(vals == 1.0)
+
+
+def test_chain_handoff_mode_and_serialised_kernels(gpu):
+    """The factorisation's chain hands over with stream memory operations + in-kernel polls (gpk_chain_handoff_mode() == 1) when
+    kernels of two streams really run concurrently, and falls back to events when a tool serialises kernels -- there the polls
+    would deadlock inside the runtime's stream-wait kernel (seen with rocprofv3 --pmc).  AMD_SERIALIZE_KERNEL=3 makes the HIP
+    runtime wait around every launch: a child process under it must finish, report mode 0 and the same factor."""
+    import subprocess
+    import sys
+    from gpflow_amd import _lib, ops
+    rng = np.random.default_rng(5)
+    _, K = _spd(rng, 1100)
+    T = _t(np.vstack([K, rng.normal(size=(300, 1100))]))
+    _, info = ops.potrf_(T, 1100, zero_upper=True)
+    ops.check_info(info)
+    assert _lib.load().gpk_chain_handoff_mode() == 1
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_gpu_primitives as tp\n"
+        "from gpflow_amd import _lib, ops\n"
+        "rng = np.random.default_rng(5)\n"
+        "_, K = tp._spd(rng, 1100)\n"
+        "T = tp._t(np.vstack([K, rng.normal(size=(300, 1100))]))\n"
+        "_, info = ops.potrf_(T, 1100, zero_upper=True)\n"
+        "ops.check_info(info)\n"
+        "L = T.cpu().numpy()[:1100]\n"
+        "print('MODE', _lib.load().gpk_chain_handoff_mode(), 'ERR', float(np.abs(L @ L.T - K).max()))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMD_SERIALIZE_KERNEL="3")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("MODE")][0].split()
+    assert int(line[1]) == 0 and float(line[3]) < 5e-12, line
