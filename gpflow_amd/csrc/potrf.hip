@@ -539,7 +539,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       strip.max_wgs = chain_wgs;
     }
     // Chain flags (round 5).  Between two kernels of the panel stream an event record costs 4.6 us and an event wait 6.3 us of
-    // queue-packet processing (rocprofv3 timelines, profiles/r05_timeline_chain_flags_*.txt); two kernels back to back start
+    // queue-packet processing (rocprofv3 timelines, profiles/r05_rows1024_events_timeline.txt, r05_ab_chain_flags.log); two kernels back to back start
     // 0.3 us apart.  Single-leaf panels (the SVGP sizes and the narrow tail of a large factorisation: leaf -> solve -> strip,
     // 16 - 32 times per factorisation) therefore hand over WITHOUT packets on this stream:
     //   "panel p solved"     the strip kernel stores the epoch into F[p] on entry (its predecessor, the solve, has completed

@@ -6,9 +6,9 @@ tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/${tag}_bench -o bench -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other > $root/gpurun_out/${tag}_bench_under_rocprof.json 2> $root/gpurun_out/${tag}_bench.err
-timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $root/gpurun_out/${tag}_pmc_fetch -o pmc -- python $root/tools/prof_run.py both > $root/gpurun_out/${tag}_pmc_fetch.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $root/gpurun_out/${tag}_pmc_write -o pmc -- python $root/tools/prof_run.py both > $root/gpurun_out/${tag}_pmc_write.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $root/gpurun_out/${tag}_pmc_mfma -o pmc -- python $root/tools/prof_run.py both > $root/gpurun_out/${tag}_pmc_mfma.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $root/gpurun_out/${tag}_pmc_fetch -o pmc -- python $root/tools/prof_run.py both > $root/gpurun_out/${tag}_pmc_fetch.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $root/gpurun_out/${tag}_pmc_write -o pmc -- python $root/tools/prof_run.py both > $root/gpurun_out/${tag}_pmc_write.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $root/gpurun_out/${tag}_pmc_mfma -o pmc -- python $root/tools/prof_run.py both > $root/gpurun_out/${tag}_pmc_mfma.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $root/gpurun_out/${tag}_pmc_kb_write -o pmc -- python $root/tools/kb_probe.py > $root/gpurun_out/${tag}_pmc_kb_write.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $root/gpurun_out/${tag}_pmc_kb_fetch -o pmc -- python $root/tools/kb_probe.py > $root/gpurun_out/${tag}_pmc_kb_fetch.log 2>&1
 cd $root

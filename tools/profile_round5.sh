@@ -4,7 +4,7 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}; cd $root
 bash tools/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --pmc $c -d $root/gpurun_out/r05_pred_$c -o pmc -- python $root/tools/predict_pmc_probe.py > $root/gpurun_out/r05_pred_$c.log 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && timeout 150 rocprofv3 --kernel-trace --pmc $c -d $root/gpurun_out/r05_pred_$c -o pmc -- python $root/tools/predict_pmc_probe.py > $root/gpurun_out/r05_pred_$c.log 2>&1 )
   python tools/pmc_total.py $(find gpurun_out/r05_pred_$c -name "*.db" | head -1) 3 > gpurun_out/r05_pmc_predict_$c.txt 2>&1
   rm -rf gpurun_out/r05_pred_$c
 done
