@@ -33,9 +33,13 @@ LOG2PI = float(np.log(2.0 * np.pi))
 
 
 def shard_statistics(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, spec: "gradients.KernelSpec" = None, jitter: float,
-                     mean_const: float, variance: float = None, lengthscales=None, family: str = "SquaredExponential"):
+                     mean_const: float, variance: float = None, lengthscales=None, family: str = "SquaredExponential",
+                     noise_rows: Optional[torch.Tensor] = None):
     """(L [M,M] lower with zero upper, invd, packed statistics [M*M + M*P + 2]) of one row shard (see module doc).
-    spec: the covariance function (one stationary kernel, or a Sum / Product of them -- gradients.KernelSpec)."""
+    spec: the covariance function (one stationary kernel, or a Sum / Product of them -- gradients.KernelSpec).
+    noise_rows [n]: one noise variance per data row (a heteroskedastic Gaussian likelihood, sgpr.py:207-211: A = L^-1 Kuf / sigma,
+    err / sigma) -- the rows of At and err are scaled by 1 / sigma_n, so every statistic is the reference's with sigma^2 = 1, and two
+    more scalars ride behind them: sum_n log sigma_n^2 and sum_n 1 / sigma_n^2 (the trace_k and log_sigma_sq terms, :236-247)."""
     M, n, P = Z.shape[0], X.shape[0], Y.shape[1]
     if spec is None:
         spec = gradients.KernelSpec.single(variance, lengthscales, family)
@@ -46,15 +50,25 @@ def shard_statistics(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, spec:
     invd, info = ops.potrf_(T, M, zero_upper=True)                                      # L (:201); At = Kfu L^-T (:204)
     ops.check_info(info)
     L, At = T[:M], T[M:]
-    packed = torch.zeros(M * M + M * P + 2, dtype=torch.float64, device=Z.device)
+    het = noise_rows is not None
+    packed = torch.zeros(M * M + M * P + (4 if het else 2), dtype=torch.float64, device=Z.device)
     if n:
         err = (Y - mean_const).contiguous()
+        if het:
+            w = 1.0 / noise_rows.reshape(-1)
+            sw = torch.sqrt(w)
+            At = At * sw[:, None]                                                       # rows of A^T / sigma_n (elementwise glue)
+            err = err * sw[:, None]
         A = ops.transpose(At)                                                           # [M, n]
         S = gradients.splitk_gemm_nt(A, A, c_lower=True)                                # At^T At, lower tiles (:205)
         packed[:M * M] = torch.tril(S).reshape(-1)
         packed[M * M:M * M + M * P] = gradients.splitk_gemm_nt(A, err.t().contiguous()).reshape(-1)   # At^T err (:268)
-        packed[-2] = ops.sumsq(err)[0]
-        packed[-1] = ops.sumsq(At)[0]
+        o = M * M + M * P
+        packed[o] = ops.sumsq(err)[0]
+        packed[o + 1] = ops.sumsq(At)[0]
+        if het:
+            packed[o + 2] = -torch.log(w).sum()
+            packed[o + 3] = w.sum()
     return L, invd, packed
 
 
@@ -71,15 +85,24 @@ def tail_factor(packed: torch.Tensor, M: int, P: int, scale: float):
     return T2[:M], invdB, T2[M:]
 
 
-def elbo_from_statistics(packed: torch.Tensor, M: int, P: int, N: int, *, variance: float, noise_variance: float):
-    """sgpr.py:214-290 from the (all-reduced) statistics; the reference's A carries 1/sigma, here it is explicit."""
+def elbo_from_statistics(packed: torch.Tensor, M: int, P: int, N: int, *, variance: float, noise_variance):
+    """sgpr.py:214-290 from the (all-reduced) statistics; the reference's A carries 1/sigma, here it is explicit.
+    noise_variance None: heteroskedastic statistics (rows already scaled by 1 / sigma_n; shard_statistics(noise_rows=...))."""
+    o = M * M + M * P
+    if noise_variance is None:
+        LB, _, ct = tail_factor(packed, M, P, 1.0)
+        half_logdet_b = ops.sum_log_diag(LB)[0]
+        trace = variance * packed[o + 3] - packed[o + 1]                                # sum kdiag / sigma^2 - tr(A A^T)   :236-242
+        logdet = -P * (half_logdet_b + 0.5 * packed[o + 2] + 0.5 * trace)               # :248-251 with sum log sigma_n^2
+        quad = -0.5 * (packed[o] - ops.sumsq(ct)[0])
+        return -0.5 * N * P * LOG2PI + logdet + quad
     s2 = noise_variance
     LB, _, ct = tail_factor(packed, M, P, 1.0 / s2)
     half_logdet_b = ops.sum_log_diag(LB)[0]                                             # :245
-    trace = N * variance / s2 - packed[-1] / s2                                         # :236-242
+    trace = N * variance / s2 - packed[o + 1] / s2                                      # :236-242
     logdet = -P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * trace)           # :248-251
     # the reference's c = LB^-1 A err with A = At^T / sigma and err / sigma: both sigma factors sit in a / s2, so ct IS c^T
-    quad = -0.5 * (packed[-2] / s2 - ops.sumsq(ct)[0])                                   # :272-276
+    quad = -0.5 * (packed[o] / s2 - ops.sumsq(ct)[0])                                    # :272-276
     return -0.5 * N * P * LOG2PI + logdet + quad                                        # :287-290
 
 
@@ -87,12 +110,12 @@ def upper_bound_from_statistics(packed: torch.Tensor, M: int, N: int, *, varianc
     """sgpr.py:85-148 (single-output form, as written in the reference)."""
     s2 = noise_variance
     LB, _, _ = tail_factor(packed, M, 1, 1.0 / s2)
-    c_tr = N * variance - packed[-1]                                                    # :121
+    c_tr = N * variance - packed[M * M + M + 1]                                         # :121
     cn_var = float(s2 + c_tr)                                                           # :124 (host scalar: one read-back)
     _, _, vt = tail_factor(packed, M, 1, 1.0 / cn_var)                                  # LC, v (:130-137)
     const = -0.5 * N * float(np.log(2 * np.pi * s2))
     logdet = -ops.sum_log_diag(LB)[0]
-    quad = -0.5 * packed[-2] / cn_var + 0.5 * ops.sumsq(vt)[0]
+    quad = -0.5 * packed[M * M + M] / cn_var + 0.5 * ops.sumsq(vt)[0]
     return const + logdet + quad
 
 
@@ -130,16 +153,22 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         c = self.mean_function.constant_value()
         from ..kernels.base import Combination, gradient_spec
         if not (isinstance(k, (Stationary, Combination)) and isinstance(iv, InducingPoints) and isinstance(lik, Gaussian)
-                and lik.has_variance_parameter and c is not None):
-            raise NotImplementedError("SGPR here: stationary kernel (or a Sum / Product of them), InducingPoints, constant noise "
-                                      "variance, constant mean")
+                and c is not None):
+            raise NotImplementedError("SGPR here: stationary kernel (or a Sum / Product of them), InducingPoints, Gaussian "
+                                      "likelihood, constant mean")
+        # s2: the constant noise variance, or None for a heteroskedastic likelihood (variance / scale a Function of the inputs,
+        # likelihoods/scalar_continuous.py:52-111): then `self._noise_rows()` is sigma_n^2 at the data inputs (sgpr.py:207)
+        s2 = None if lik.is_heteroskedastic else lik.noise_variance()
         if isinstance(k, Combination):
             # members slice for themselves (kernels/base.py:283-293): the spec works on the full columns
             spec, _ = gradient_spec(k, self.data[0].shape[1])
-            return spec, self.data[0].contiguous(), iv.Z.device_value().contiguous(), float(c), lik.noise_variance()
+            return spec, self.data[0].contiguous(), iv.Z.device_value().contiguous(), float(c), s2
         family, var, ls = k.hyper()
         X, Z = k.slice(self.data[0], iv.Z.device_value())
-        return gradients.KernelSpec.single(var, ls, family), X, Z, float(c), lik.noise_variance()
+        return gradients.KernelSpec.single(var, ls, family), X, Z, float(c), s2
+
+    def _noise_rows(self):
+        return self.likelihood.noise_for(self.data[0]) if self.likelihood.is_heteroskedastic else None
 
     def _slice_new(self, Xn):
         """new inputs as the covariance spec expects them: sliced by a single kernel's active_dims, untouched for a combination"""
@@ -148,7 +177,8 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
 
     def _statistics(self):
         kw, X, Z, c, s2 = self._config()
-        L, invd, packed = shard_statistics(Z, X, self.data[1], jitter=config.default_jitter(), mean_const=c, spec=kw)
+        L, invd, packed = shard_statistics(Z, X, self.data[1], jitter=config.default_jitter(), mean_const=c, spec=kw,
+                                           noise_rows=self._noise_rows())
         if self.sharded:
             import torch.distributed as dist
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
@@ -169,6 +199,9 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         if self.data[1].shape[1] != 1:
             raise NotImplementedError("upper_bound is written for a single output column in the reference (sgpr.py:126)")
         kw, Z, c, s2, L, invd, packed = self._statistics()
+        if s2 is None:
+            raise NotImplementedError("upper_bound with a heteroskedastic likelihood (sgpr.py:124-131 rescales every row by its own "
+                                      "sigma_n^2 + c: a second pass over the rows that the packed statistics do not keep)")
         return upper_bound_from_statistics(packed, Z.shape[0], self.num_data, variance=kw.kdiag(), noise_variance=s2)
 
     def objective_and_grad(self):
@@ -182,6 +215,8 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         from .svgp import SVGP
         from ..kernels.base import Combination, gradient_spec
         kw, Xc, Zc, c, s2 = self._config()
+        if s2 is None or not self.likelihood.has_variance_parameter:
+            raise NotImplementedError("gradients: the reverse pass takes a constant noise variance held as a `variance` Parameter")
         if isinstance(self.kernel, Combination):
             # a Sum / Product of stationary kernels (members possibly over different active_dims): the members' adjoints one by one
             spec, members = gradient_spec(self.kernel, self.data[0].shape[1])
@@ -223,7 +258,7 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         assert_params_false(self.predict_f, full_output_cov=full_output_cov)
         kw, Z, c, s2, L, invd, packed = self._statistics()
         M, P = Z.shape[0], self.data[1].shape[1]
-        LB, invdB, ct = tail_factor(packed, M, P, 1.0 / s2)
+        LB, invdB, ct = tail_factor(packed, M, P, 1.0 if s2 is None else 1.0 / s2)   # (heteroskedastic: rows already scaled)
         # the reference's c carries one factor sigma more than ct (A = At^T / sigma, err / sigma): mean = tmp2^T c with
         # tmp2 free of sigma, so mean = tmp2^T ct  exactly as below
         Xn = ops.to_device(Xnew)
@@ -251,8 +286,13 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         kw, X, Z, c, s2 = self._config()
         M, P = Z.shape[0], self.data[1].shape[1]
         Kfu = kw.build(X, Z)
-        Kuf = ops.transpose(Kfu)                                                        # [M, N]
         err = (self.data[1] - c).contiguous()
+        if s2 is None:   # scaled_kuf = kuf / std, scaled_err = err / std per data row (sgpr.py:366-377)
+            sw = torch.rsqrt(self._noise_rows())
+            Kfu = Kfu * sw[:, None]
+            err = err * sw[:, None]
+            s2 = 1.0
+        Kuf = ops.transpose(Kfu)                                                        # [M, N]
         T = torch.empty((M + M + P, M), dtype=torch.float64, device=Z.device)
         kuu = kw.build(Z, None, diag_add=config.default_jitter())
         T[:M] = kuu + gradients.splitk_gemm_nt(Kuf, Kuf, c_lower=True) / s2   # sig (lower triangle is read)

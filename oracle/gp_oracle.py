@@ -388,9 +388,14 @@ def svgp_elbo_separate(X, Y, Zs, q_mu, q_sqrt, *, variances, lengthscales_list, 
 
 
 # ----------------------------------------------------------------------------- SGPR
+def _noise_rows(noise_variance, N):
+    """sigma_n^2 per data row [N]: a constant broadcast, or likelihood.variance_at(X) squeezed (sgpr.py:207)"""
+    return np.broadcast_to(np.asarray(noise_variance, dtype=np.float64).reshape(-1), (N,)).copy()
+
+
 def sgpr_common(X, Z, *, variance, lengthscales, noise_variance, jitter=DEFAULT_JITTER):
-    """gpflow/models/sgpr.py:181-213 (_common_calculation), constant noise variance."""
-    sigma = np.sqrt(noise_variance)
+    """gpflow/models/sgpr.py:181-213 (_common_calculation); noise_variance a constant or one value per data row [N]."""
+    sigma = np.sqrt(_noise_rows(noise_variance, np.asarray(X).shape[0]))
     kuf = Kuf(Z, X, variance=variance, lengthscales=lengthscales)
     kuu = Kuu(Z, variance=variance, lengthscales=lengthscales, jitter=jitter)
     L = np.linalg.cholesky(kuu)
@@ -406,11 +411,12 @@ def sgpr_elbo(X, Y, Z, *, variance, lengthscales, noise_variance, mean=0.0, jitt
     N, P = Y.shape
     A, AAT, LB, _ = sgpr_common(X, Z, variance=variance, lengthscales=lengthscales, noise_variance=noise_variance,
                                 jitter=jitter)
-    trace_k = N * variance / noise_variance                      # :236-238  (K_diag = variance)
+    nv = _noise_rows(noise_variance, N)
+    trace_k = np.sum(variance / nv)                              # :236-238  (K_diag = variance)
     trace_q = np.trace(AAT)                                      # :240
     half_logdet_b = np.sum(np.log(np.diag(LB)))                  # :245
-    logdet = -P * (half_logdet_b + 0.5 * N * np.log(noise_variance) + 0.5 * (trace_k - trace_q))   # :248-251
-    err = (Y - mean) / np.sqrt(noise_variance)                   # :266
+    logdet = -P * (half_logdet_b + 0.5 * np.sum(np.log(nv)) + 0.5 * (trace_k - trace_q))   # :248-251
+    err = (Y - mean) / np.sqrt(nv)[:, None]                      # :266
     c = sla.solve_triangular(LB, A @ err, lower=True)            # :268-269
     quad = -0.5 * (np.sum(err * err) - np.sum(c * c))            # :272-276
     const = -0.5 * N * P * LOG2PI                                # :287
@@ -420,7 +426,7 @@ def sgpr_elbo(X, Y, Z, *, variance, lengthscales, noise_variance, mean=0.0, jitt
 def sgpr_predict_f(X, Y, Z, Xnew, *, variance, lengthscales, noise_variance, mean=0.0, full_cov=False,
                    jitter=DEFAULT_JITTER):
     """gpflow/models/sgpr.py:292-345"""
-    sigma = np.sqrt(noise_variance)
+    sigma = np.sqrt(_noise_rows(noise_variance, np.asarray(X).shape[0]))[:, None]
     A, _, LB, L = sgpr_common(X, Z, variance=variance, lengthscales=lengthscales, noise_variance=noise_variance,
                               jitter=jitter)
     Kus = Kuf(Z, Xnew, variance=variance, lengthscales=lengthscales)
@@ -438,14 +444,14 @@ def sgpr_predict_f(X, Y, Z, Xnew, *, variance, lengthscales, noise_variance, mea
 
 def sgpr_compute_qu(X, Y, Z, *, variance, lengthscales, noise_variance, mean=0.0, jitter=DEFAULT_JITTER):
     """gpflow/models/sgpr.py:351-384: q(u) = N(mu, cov)."""
-    std = np.sqrt(noise_variance)
+    std = np.sqrt(_noise_rows(noise_variance, np.asarray(X).shape[0]))
     kuf = Kuf(Z, X, variance=variance, lengthscales=lengthscales)
     kuu = Kuu(Z, variance=variance, lengthscales=lengthscales, jitter=jitter)
     skuf = kuf / std
     sig_sqrt = np.linalg.cholesky(kuu + skuf @ skuf.T)
     sig_sqrt_kuu = sla.solve_triangular(sig_sqrt, kuu, lower=True)
     cov = sig_sqrt_kuu.T @ sig_sqrt_kuu
-    mu = sig_sqrt_kuu.T @ sla.solve_triangular(sig_sqrt, skuf @ ((Y - mean) / std), lower=True)
+    mu = sig_sqrt_kuu.T @ sla.solve_triangular(sig_sqrt, skuf @ ((Y - mean) / std[:, None]), lower=True)
     return mu, cov
 
 

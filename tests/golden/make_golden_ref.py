@@ -360,6 +360,10 @@ def build():  # noqa: C901
                              Zh, q_mu=hq_mu, q_sqrt=np.abs(0.4 + 0.1 * rng.normal(size=(7, 1))), q_diag=True, num_data=400)
     out.update(het_poly_w=pw, het_poly_variance_at=_n(likp.variance_at(X)), het_poly_gpr_lml=float(hp.log_marginal_likelihood()),
                het_poly_q_sqrt_diag=_n(hsq.q_sqrt), het_poly_svgp_elbo_qdiag=float(hsq.elbo((X, Y))))
+    # SGPR under the same likelihood (the reference's tests/integration/test_linear_noise.py recipe, sgpr.py:181-384 with sigma_n per row)
+    hsg = gpflow.models.SGPR((X, Y), hk(), Zh, likelihood=gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=hA, b=hb)))
+    smu, svar = hsg.predict_f(Xs); squ, sqc = hsg.compute_qu()
+    out.update(het_sgpr_elbo=float(hsg.elbo()), het_sgpr_mu=_n(smu), het_sgpr_var=_n(svar), het_sgpr_qu_mu=_n(squ), het_sgpr_qu_cov=_n(sqc))
     return out
 
 

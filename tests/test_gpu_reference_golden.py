@@ -87,6 +87,17 @@ def test_ref_heteroskedastic_gaussian(gp):
                                float(G["het_poly_gpr_lml"]), rtol=1e-9)
     sq = gp.models.SVGP(mk_k(), likp(), G["het_Z"], q_mu=G["het_q_mu"], q_sqrt=G["het_poly_q_sqrt_diag"], q_diag=True, num_data=400)
     np.testing.assert_allclose(float(sq.elbo((X, Y))), float(G["het_poly_svgp_elbo_qdiag"]), rtol=1e-9)
+    # SGPR under the same likelihood: rows of A^T and err scaled by 1 / sigma_n (sgpr.py:207-211), two more scalars in the statistics
+    sg = gp.models.SGPR((X, Y), mk_k(), G["het_Z"], likelihood=mk_lik())
+    np.testing.assert_allclose(float(sg.elbo()), float(G["het_sgpr_elbo"]), rtol=1e-9)
+    smu, svar = sg.predict_f(Xs)
+    close(smu, G["het_sgpr_mu"], 1e-8); close(svar, G["het_sgpr_var"], 1e-8)
+    qmu, qcov = sg.compute_qu()
+    close(qmu, G["het_sgpr_qu_mu"], 1e-7); close(qcov, G["het_sgpr_qu_cov"], 1e-7)
+    with pytest.raises(NotImplementedError):
+        sg.upper_bound()
+    with pytest.raises(NotImplementedError):
+        sg.objective_and_grad()
     # the reverse pass is for a constant noise variance: refused, not silently wrong
     with pytest.raises(NotImplementedError):
         m.log_marginal_likelihood_and_grad()

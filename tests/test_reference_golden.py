@@ -107,6 +107,13 @@ def test_heteroskedastic_gaussian():
     close(orc.gpr_log_marginal_likelihood(X, Y, noise_variance=nvp, **kw), G["het_poly_gpr_lml"])
     close(orc.svgp_elbo(X, Y, G["het_Z"], G["het_q_mu"], G["het_poly_q_sqrt_diag"], noise_variance=nvp, whiten=True, num_data=400,
                         **kw), G["het_poly_svgp_elbo_qdiag"])
+    # SGPR with one sigma_n per data row (sgpr.py:181-384)
+    skw = dict(noise_variance=nv, **kw)
+    close(orc.sgpr_elbo(X, Y, G["het_Z"], **skw), G["het_sgpr_elbo"])
+    smu, svar = orc.sgpr_predict_f(X, Y, G["het_Z"], Xs, **skw)
+    close(smu, G["het_sgpr_mu"]); close(svar, G["het_sgpr_var"], 1e-11)
+    qmu, qcov = orc.sgpr_compute_qu(X, Y, G["het_Z"], **skw)
+    close(qmu, G["het_sgpr_qu_mu"], 1e-10); close(qcov, G["het_sgpr_qu_cov"], 1e-10)
 
 
 def test_gauss_kl():
