@@ -30,6 +30,12 @@ class Function(Module):
         """Scalar c such that f(X) == c everywhere, or None (enables the fused device paths)."""
         return None
 
+    def backward(self, X, gbar):
+        """[(Parameter, dF/d(constrained value) as a device tensor)] given gbar = dF/d f(X) [N, Q]: the reverse pass of the function
+        (TF autodiff in the reference), written out for the classes here -- used for the parameters of a heteroskedastic noise
+        function (likelihoods.Gaussian.noise_param_grads)."""
+        raise NotImplementedError(f"reverse pass of {type(self).__name__}")
+
 
 class MeanFunction(Function):
     """functions.py:67-70"""
@@ -45,6 +51,9 @@ class Additive(MeanFunction):
     def __call__(self, X):
         return self.add_1(X) + self.add_2(X)
 
+    def backward(self, X, gbar):
+        return self.add_1.backward(X, gbar) + self.add_2.backward(X, gbar)
+
     def constant_value(self):
         a, b = self.add_1.constant_value(), self.add_2.constant_value()
         return None if a is None or b is None else a + b
@@ -59,6 +68,12 @@ class Product(MeanFunction):
 
     def __call__(self, X):
         return self.prod_1(X) * self.prod_2(X)
+
+    def backward(self, X, gbar):
+        f1, f2 = self.prod_1(X), self.prod_2(X)
+        q = gbar.shape[-1]
+        red = lambda g, f: g if f.shape[-1] == q else g.sum(-1, keepdim=True)  # noqa: E731  (a [N, 1] factor broadcast over Q)
+        return self.prod_1.backward(X, red(gbar * f2, f1)) + self.prod_2.backward(X, red(gbar * f1, f2))
 
     def constant_value(self):
         a, b = self.prod_1.constant_value(), self.prod_2.constant_value()
@@ -85,6 +100,19 @@ class Linear(MeanFunction):
         b = ops.to_device(np.atleast_1d(np.asarray(self.b.numpy(), dtype=np.float64)))
         return torch.tensordot(X, A, dims=([-1], [0])) + b
 
+    def backward(self, X, gbar):
+        X = ops.to_device(X)
+        gA = X.t() @ gbar                                       # [D, Q']: Q' = Q, or 1 when A broadcasts over the outputs
+        A_shape, b_shape = tuple(self.A.shape), tuple(np.atleast_1d(self.b.numpy()).shape)
+        if gA.shape[1] != A_shape[1]:
+            gA = gA.sum(1, keepdim=True)
+        if gA.shape[0] != A_shape[0]:
+            gA = gA.sum(0, keepdim=True)
+        gb = gbar.sum(0)
+        if gb.numel() != int(np.prod(b_shape)):
+            gb = gb.sum().reshape(1)
+        return [(self.A, gA), (self.b, gb.reshape(self.b.numpy().shape))]
+
 
 class Identity(Linear):
     """y_i = x_i (functions.py:129-170)"""
@@ -94,6 +122,9 @@ class Identity(Linear):
 
     def __call__(self, X):
         return ops.to_device(X)
+
+    def backward(self, X, gbar):
+        return []
 
     def _need_dim(self):
         if self.input_dim is None:
@@ -135,6 +166,11 @@ class Constant(MeanFunction):
         c = np.atleast_1d(self.c.numpy())
         return float(c[0]) if c.size == 1 else None
 
+    def backward(self, X, gbar):
+        g = gbar.sum(0)
+        n = int(np.size(self.c.numpy()))
+        return [(self.c, (g if g.numel() == n else g.sum().reshape(1)).reshape(self.c.numpy().shape))]
+
 
 class Zero(Constant):
     """functions.py:195-204"""
@@ -148,6 +184,9 @@ class Zero(Constant):
 
     def constant_value(self):
         return 0.0
+
+    def backward(self, X, gbar):
+        return []
 
 
 class Polynomial(MeanFunction):
@@ -172,3 +211,11 @@ class Polynomial(MeanFunction):
         raised = torch.pow(X[..., None, :], powers)            # [..., n_terms, input_dim]
         prod = torch.prod(raised, dim=-1)                      # [..., n_terms]
         return torch.einsum("...i,ji->...j", prod, ops.to_device(self.w.numpy()))
+
+    def backward(self, X, gbar):
+        X = ops.to_device(X)
+        prod = torch.prod(torch.pow(X[..., None, :], ops.to_device(self.powers)), dim=-1)      # [N, n_terms]
+        gw = gbar.t() @ prod                                                                    # [Q', n_terms]
+        if gw.shape[0] != self.w.shape[0]:
+            gw = gw.expand(self.w.shape[0], -1) if gw.shape[0] == 1 else gw.sum(0, keepdim=True)
+        return [(self.w, gw)]

@@ -314,11 +314,28 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     F = scale * ve - kl_weight * kl
 
     # ---------------------------------------------------------------- backward
-    c = -0.5 * scale / noise_variance                                                   # dF/dfvar (every b, p)
-    r = (scale / noise_variance) * (Yb - fmean - mean_const)                            # dF/dfmean [B, P]
+    # het: one noise variance per row (a heteroskedastic Gaussian likelihood, round 5): dF/dfvar is a per-row vector, applied as a
+    # row scaling of the factors it multiplied as a scalar (elementwise glue on [B, M] arrays); the scalar path is unchanged
+    het = torch.is_tensor(noise_variance) and noise_variance.numel() > 1
+    if het:
+        nv = noise_variance.reshape(-1)
+        cvec = (-0.5 * scale) / nv                                                      # dF/dfvar per row [B]
+        c = None
+        r = (scale / nv)[:, None] * (Yb - fmean - mean_const)                           # dF/dfmean [B, P]
+    else:
+        c = -0.5 * scale / noise_variance                                               # dF/dfvar (every b, p)
+        r = (scale / noise_variance) * (Yb - fmean - mean_const)                        # dF/dfmean [B, P]
     Atb = ops.gemm_nt(r, q_mu)                                                          # r q_mu^T  [B, M]
     if q_diag:                                                                          # + 2c At (sum_p q_p^2 - P) per column
-        Atb.addcmul_(At, (2.0 * c) * ((q_sqrt * q_sqrt).sum(1) - P)[None, :])
+        if het:
+            Atb.addcmul_(At * (2.0 * cvec)[:, None], ((q_sqrt * q_sqrt).sum(1) - P)[None, :])
+        else:
+            Atb.addcmul_(At, (2.0 * c) * ((q_sqrt * q_sqrt).sum(1) - P)[None, :])
+    elif het:
+        Wc = W * cvec[None, :, None]                                                    # rows of W_p scaled by c_b
+        for p in range(P):
+            ops.gemm_nt(Wc[p], Lq[p], alpha=2.0, beta=1.0, C=Atb, b_tri=2)
+        Atb.addcmul_(At, cvec[:, None], value=-2.0 * P)
     else:
         for p in range(P):                                                              # + 2c W_p Lq_p^T (Lq_p lower: b_tri 2)
             ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=Atb, b_tri=2)
@@ -330,11 +347,15 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     def branch_q():
         g_mu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                # At^T r - q_mu
         if q_diag:   # d/dq = 2c colsum(At^2) q - (q - 1/q)   (KL of a diagonal q: kullback_leiblers.py:131-133,146-148)
+            if het:
+                colsq2c = 2.0 * ((At * At) * cvec[:, None]).sum(0)                      # 2 sum_b c_b At[b, m]^2
+                return g_mu, colsq2c[:, None] * q_sqrt - kl_weight * (q_sqrt - 1.0 / q_sqrt)
             colsq = ops.row_stats(A)[0]
             return g_mu, (2.0 * c) * colsq[:, None] * q_sqrt - kl_weight * (q_sqrt - 1.0 / q_sqrt)
-        g = torch.stack([splitk_gemm_nt(A, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c)
+        Wg, ag = (Wc, 2.0) if het else (W, 2.0 * c)
+        g = torch.stack([splitk_gemm_nt(A, ops.transpose(Wg[p]), c_lower=True, alpha=ag)
                          for p in range(P)]) if P > 1 else \
-            splitk_gemm_nt(A, ops.transpose(W[0]), c_lower=True, alpha=2.0 * c).unsqueeze(0)
+            splitk_gemm_nt(A, ops.transpose(Wg[0]), c_lower=True, alpha=ag).unsqueeze(0)
         g.sub_(Lq, alpha=kl_weight)                                                     # 2c tril(At^T W_p) - Lq_p
         g.diagonal(dim1=1, dim2=2).add_(kl_weight / Lq.diagonal(dim1=1, dim2=2))
         return g_mu, g
@@ -362,12 +383,20 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     else:
         g_qmu, g_qs = branch_q()
     dkd = spec.dkdiag()                                                                 # Knn = kdiag in every fvar
-    g_var, g_ls = spec.pack([a + b + c * B * P * dk for a, b, dk in zip(dv1, dv2, dkd)], [a + b for a, b in zip(dl1, dl2)])
-    # sum_bp ((y - f)^2 + fvar) recovered from the forward value:  ve = B P k0 - Q / (2 s2)
-    k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
-    Q = 2.0 * noise_variance * (B * P * k0 - ve)
-    g_noise = scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)
-    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
+    csum = cvec.sum() * P if het else c * B * P
+    g_var, g_ls = spec.pack([a + b + csum * dk for a, b, dk in zip(dv1, dv2, dkd)], [a + b for a, b in zip(dl1, dl2)])
+    if het:
+        # dF/d sigma_n^2 = scale sum_p (-1 / (2 s2_n) + ((y - f)^2 + fvar) / (2 s2_n^2)): one entry per row (likelihood parameters
+        # are reached through Gaussian.noise_param_grads)
+        fvar = (spec.kdiag() - s0)[:, None] + ssq.t()
+        resid = Yb - fmean - mean_const
+        g_noise = scale * (-0.5 * P / nv + 0.5 * (resid * resid + fvar).sum(1) / (nv * nv))
+    else:
+        # sum_bp ((y - f)^2 + fvar) recovered from the forward value:  ve = B P k0 - Q / (2 s2)
+        k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
+        Q = 2.0 * noise_variance * (B * P * k0 - ve)
+        g_noise = (scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)).reshape(1)
+    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise,
              "Z": Zb1 + Zb2, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
     return F, grads, info
 
@@ -389,7 +418,12 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float = None
     spec = kernel_spec if kernel_spec is not None else KernelSpec.single(variance, lengthscales, family)
     spec.warm(dev, D)   # (device copies of the lengthscales BEFORE the first kernel is enqueued: see ls_device)
     T = torch.empty((N + P + N, N), dtype=torch.float64, device=dev)
-    spec.build(X, None, T[:N], diag_add=noise_variance)
+    het = torch.is_tensor(noise_variance) and noise_variance.numel() > 1   # one variance per data row (heteroskedastic likelihood)
+    if het:
+        spec.build(X, None, T[:N])
+        ops.diag_add_(T[:N], noise_variance)                                            # add_likelihood_noise_cov, model_utils.py:46-50
+    else:
+        spec.build(X, None, T[:N], diag_add=noise_variance)
     T[N:N + P] = (Y - mean_const).t()
     invd, info = ops.potrf_(T, N, zero_upper=True, identity_rows=True)                  # (the last N rows: I -> L^-T, N^3/3)
     L, alphat, LinvT = T[:N], T[N:N + P], T[N + P:]
@@ -404,7 +438,9 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float = None
     Kbar = low + torch.tril(low, -1).t()                                                # symmetric, full
     dvs, dlss, _ = spec.adjoint(X, X, Kbar, symmetric=True)
     dvar, dls = spec.pack(dvs, dlss)
-    grads = {"variance": dvar, "lengthscales": dls, "noise_variance": torch.diagonal(Kbar).sum().reshape(1),
+    # d LML / d sigma_n^2 = Kbar_nn: their sum for a constant noise variance, the vector for a heteroskedastic likelihood
+    grads = {"variance": dvar, "lengthscales": dls,
+             "noise_variance": torch.diagonal(Kbar).clone() if het else torch.diagonal(Kbar).sum().reshape(1),
              "mean_const": betat.sum().reshape(1)}
     return lml.reshape(1), grads, info
 

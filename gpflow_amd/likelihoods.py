@@ -84,6 +84,22 @@ class Gaussian(Likelihood):
             raise ValueError("noise_for expects X [N, D]")
         return self.variance_at(X)[:, 0].contiguous()
 
+    def noise_param_grads(self, X, g_noise):
+        """[(Parameter, dF/d(constrained value))] of the noise function's parameters, given g_noise [N] = dF/d sigma_n^2 at the rows of
+        X (what the per-row reverse passes return as "noise_variance") -- the chain rule through _variance (clip at the lower
+        bound: no gradient where the function sits below it; scale: d s^2 = 2 s ds) and the Function itself."""
+        X = ops.to_device(X)
+        fn = self.variance if self.variance is not None else self.scale
+        raw = fn(X)
+        g = g_noise.reshape(-1, 1)
+        if raw.shape[-1] != 1:
+            raise NotImplementedError("gradients of a heteroskedastic noise function with more than one output column")
+        if self.variance is not None:
+            gbar = g * (raw > self.variance_lower_bound)
+        else:
+            gbar = g * (2.0 * torch.clamp(raw, min=self.scale_lower_bound)) * (raw > self.scale_lower_bound)
+        return fn.backward(X, gbar)
+
     def variance_at(self, X) -> torch.Tensor:
         """scalar_continuous.py:107-111: [..., N, 1]"""
         X = ops.to_device(X)

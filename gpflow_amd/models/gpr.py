@@ -72,32 +72,35 @@ class GPR(GPModel, InternalDataTrainingLossMixin):
         c = mf.constant_value()
         from ..kernels.base import gradient_spec
         combo = gradient_spec(k, self.data[0].shape[1])   # Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315)
-        if lik.is_heteroskedastic:
-            raise NotImplementedError("gradients: the reverse pass takes a constant noise variance (a heteroskedastic Gaussian "
-                                      "likelihood is forward-only: log_marginal_likelihood, predict_*)")
-        if combo is None and not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES) or c is None or not lik.has_variance_parameter:
+        het = lik.is_heteroskedastic   # round 5: d LML / d sigma_n^2 per row, chained through the noise function's own reverse pass
+        if combo is None and not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES) or c is None \
+                or not (lik.has_variance_parameter or het):
             raise NotImplementedError("gradients: SquaredExponential / Matern kernel (or a Sum / Product of them), constant mean, "
                                       "Gaussian likelihood with a variance parameter")
         X, Y = self.data
         if combo is not None:
             spec, members = combo
-            lml, g, info = gradients.gpr_lml_and_grad(ops.to_device(X).contiguous(), Y, noise_variance=lik.noise_variance(),
+            lml, g, info = gradients.gpr_lml_and_grad(ops.to_device(X).contiguous(), Y, noise_variance=lik.noise_for(X),
                                                       mean_const=c, kernel_spec=spec)
             ops.check_info(info)
             gv = g["variance"].cpu().numpy()
             pairs = []
             for i, (pv, pl) in enumerate(members):
                 pairs += [(pv, gv[i]), (pl, g["lengthscales"][i].cpu().numpy())]
-            host = {"noise_variance": g["noise_variance"].cpu().numpy(), "mean_const": g["mean_const"].cpu().numpy()}
-            pairs.append((lik.variance, host["noise_variance"]))
+            host = {"mean_const": g["mean_const"].cpu().numpy()}
+            noise_pairs = [(lik.variance, g["noise_variance"].cpu().numpy())] if not het else \
+                [(par, gv.cpu().numpy()) for par, gv in lik.noise_param_grads(X, g["noise_variance"])]
+            pairs += noise_pairs
         else:
-            X, _ = k.slice(X, None)    # active_dims (kernels/base.py:90-109); nothing is differentiated w.r.t. X
+            Xs, _ = k.slice(X, None)    # active_dims (kernels/base.py:90-109); nothing is differentiated w.r.t. X
             family, var, ls = k.hyper()
-            lml, g, info = gradients.gpr_lml_and_grad(X.contiguous(), Y, variance=var, lengthscales=ls,
-                                                      noise_variance=lik.noise_variance(), mean_const=c, family=family)
+            lml, g, info = gradients.gpr_lml_and_grad(Xs.contiguous(), Y, variance=var, lengthscales=ls,
+                                                      noise_variance=lik.noise_for(X), mean_const=c, family=family)
             ops.check_info(info)
-            host = {n: t.cpu().numpy() for n, t in g.items()}
-            pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (lik.variance, host["noise_variance"])]
+            host = {n: t.cpu().numpy() for n, t in g.items() if n != "noise_variance"}
+            pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"])]
+            pairs += [(lik.variance, g["noise_variance"].cpu().numpy())] if not het else \
+                [(par, gv.cpu().numpy()) for par, gv in lik.noise_param_grads(X, g["noise_variance"])]
         if isinstance(mf, Constant) and hasattr(mf, "c"):   # (Zero is a Constant without a parameter, functions.py:195-204)
             pairs.append((mf.c, host["mean_const"]))
         out = {}

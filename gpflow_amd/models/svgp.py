@@ -261,7 +261,7 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             scale = 1.0
         return terms[0] * scale - terms[1]
 
-    def gradient_config(self, allow_active_dims: bool = False, allow_q_diag: bool = False):
+    def gradient_config(self, allow_active_dims: bool = False, allow_q_diag: bool = False, allow_heteroskedastic: bool = False):
         """(kernel, InducingPoints, mean constant) if the hand-written reverse pass covers this model: whitened or not,
         Gaussian likelihood with a variance parameter, full q_sqrt, constant mean, and ONE isotropic stationary kernel
         (SquaredExponential / Matern12 / 32 / 52; `active_dims` and `q_diag` only where the caller
@@ -273,7 +273,8 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         if isinstance(k, SharedIndependent) and isinstance(iv, SharedIndependentInducingVariables):
             k, iv = k.kernel, iv.inducing_variable
         c = self.mean_function.constant_value()
-        if not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES and isinstance(lik, Gaussian) and lik.has_variance_parameter
+        noise_ok = isinstance(lik, Gaussian) and (lik.has_variance_parameter or (allow_heteroskedastic and lik.is_heteroskedastic))
+        if not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES and noise_ok
                 and isinstance(iv, InducingPoints) and c is not None
                 and (self.q_sqrt.numpy().ndim == 3 or (allow_q_diag and self.q_sqrt.numpy().ndim == 2))
                 and (allow_active_dims or k.has_default_active_dims)):
@@ -337,11 +338,14 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         combo = gradient_spec(self.kernel, int(tuple(data[0].shape)[-1])) if sep is None else None   # Sum / Product of stationary kernels
         if combo is not None:
             return self._elbo_and_grad_combination(data, combo)
-        single = self.gradient_config(allow_active_dims=True, allow_q_diag=True) if sep is None else None
+        # (a heteroskedastic Gaussian likelihood -- per-row dF/d sigma_n^2 chained through the noise function -- in the whitened
+        #  single-kernel reverse pass, round 5)
+        single = self.gradient_config(allow_active_dims=True, allow_q_diag=True, allow_heteroskedastic=self.whiten) if sep is None else None
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
         fn = gradients.svgp_elbo_and_grad if self.whiten else gradients.svgp_elbo_and_grad_unwhitened
-        common = dict(noise_variance=lik.noise_variance(), jitter=config.default_jitter(), scale=scale)
+        het = lik.is_heteroskedastic
+        common = dict(noise_variance=lik.noise_for(X), jitter=config.default_jitter(), scale=scale)
         pairs = []
         if sep is None:
             k, iv, c = single
@@ -354,6 +358,8 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
             pairs = [(k.variance, host["variance"]), (k.lengthscales, host["lengthscales"]), (iv.Z, host["Z"])]
             g_noise, g_mean, g_qmu, g_qs = host["noise_variance"], host["mean_const"], host["q_mu"], host["q_sqrt"]
+            if het:
+                pairs += [(par, gv.cpu().numpy()) for par, gv in lik.noise_param_grads(X, g["noise_variance"])]
         else:
             # SeparateIndependent (conditionals/util.py:566-629): L independent single-output problems that share the
             # likelihood, the mean constant and the rows of the minibatch; ELBO and the shared gradients are their sums
@@ -378,7 +384,9 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                 g_qmu[:, p_:p_ + 1] = host["q_mu"]
                 g_qs[p_:p_ + 1] = host["q_sqrt"]
             pairs += list(zgrads.values())
-        pairs += [(lik.variance, g_noise), (self.q_mu, g_qmu), (self.q_sqrt, g_qs)]
+        if not het:
+            pairs.append((lik.variance, g_noise))
+        pairs += [(self.q_mu, g_qmu), (self.q_sqrt, g_qs)]
         if isinstance(mf, Constant) and hasattr(mf, "c"):   # (Zero is a Constant without a parameter, functions.py:195-204)
             pairs.append((mf.c, g_mean))
         out = {}

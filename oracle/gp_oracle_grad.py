@@ -61,12 +61,18 @@ def combination_kernel(members, op, cols=None):
     return kfun, kd
 
 
+def _nvcol(noise_variance):
+    """a constant, or one noise variance per row [B] -> [B, 1] (broadcasts against [B, P]; likelihoods/scalar_continuous.py:92-105)"""
+    return noise_variance[:, None] if (torch.is_tensor(noise_variance) and noise_variance.dim() == 1) else noise_variance
+
+
 def svgp_elbo_torch(X, Y, Z, q_mu, q_sqrt, variance, lengthscales, noise_variance, *, num_data=None, jitter=1e-6,
                     mean=0.0, whiten=True, family="SquaredExponential", kfun=None, kdiag=None):
     """SVGP.elbo (svgp.py:166-181) on torch fp64 tensors; q_sqrt [P, M, M]; whiten as in the reference.  kfun / kdiag: a
     kernel combination (combination_kernel) instead of the single stationary kernel."""
     M = Z.shape[0]
     B = X.shape[0]
+    noise_variance = _nvcol(noise_variance)
     if kfun is None:
         kfun = lambda A_, B_: _rbf(A_, B_, variance, lengthscales, family)  # noqa: E731
     else:
@@ -130,7 +136,8 @@ def gpr_lml_torch(X, Y, variance, lengthscales, noise_variance, mean=0.0, family
     """GPR.log_marginal_likelihood (gpr.py:91-107; logdensities.py:139-156) on torch fp64 tensors."""
     N = X.shape[0]
     Kxx = kfun(X, X) if kfun is not None else _rbf(X, X, variance, lengthscales, family)
-    K = Kxx + noise_variance * torch.eye(N, dtype=torch.float64)                                  # gpr.py:100-101
+    nvd = noise_variance if (torch.is_tensor(noise_variance) and noise_variance.dim() == 1) else noise_variance * torch.ones(N, dtype=torch.float64)
+    K = Kxx + torch.diag(nvd)                                                                    # gpr.py:100-101, model_utils.py:46-50
     L = torch.linalg.cholesky(K)                                                                 # :102
     alpha = torch.linalg.solve_triangular(L, Y - mean, upper=False)                              # logdensities.py:150
     P = Y.shape[1]
@@ -270,3 +277,26 @@ def sgpr_elbo_value_and_grads(X, Y, Z, *, variance, lengthscales, noise_variance
     F.backward()
     g = {"variance": var.grad, "lengthscales": ls.grad, "noise_variance": nv.grad, "Z": Zt.grad, "mean_const": mc.grad}
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}
+
+
+def heteroskedastic_value_and_grads(model, X, Y, *, A, b, variance, lengthscales, Z=None, q_mu=None, q_sqrt=None, num_data=None,
+                                    jitter=1e-6, mean=0.0, lower_bound=1e-6):
+    """GPR.log_marginal_likelihood ("gpr") or the whitened SVGP.elbo ("svgp") under Gaussian(scale=Linear(A, b))
+    (likelihoods/scalar_continuous.py:52-111: sigma_n^2 = max(x_n A + b, sqrt(lower bound))^2) and their gradients w.r.t. A, b and
+    the other parameters, by autograd."""
+    t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
+    At, bt = t(np.atleast_2d(A), True), t(np.atleast_1d(b), True)
+    var, ls = t(variance, True), t(np.atleast_1d(lengthscales), True)
+    Xt = t(X)
+    nv = torch.clamp(Xt @ At + bt, min=float(np.sqrt(lower_bound)))[:, 0] ** 2
+    out = {}
+    if model == "gpr":
+        F = gpr_lml_torch(Xt, t(Y), var, ls, nv, t(mean))
+    else:
+        Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
+        F = svgp_elbo_torch(Xt, t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=t(mean), whiten=True)
+    F.backward()
+    out.update(A=At.grad.numpy().copy(), b=bt.grad.numpy().copy(), variance=float(var.grad), lengthscales=ls.grad.numpy().copy())
+    if model != "gpr":
+        out.update(Z=Zt.grad.numpy().copy(), q_mu=qm.grad.numpy().copy(), q_sqrt=qs.grad.numpy().copy())
+    return float(F.detach()), out

@@ -815,3 +815,49 @@ def test_combinations_over_different_active_dims_and_under_sgpr_and_the_unwhiten
     _, gdup = m2.objective_and_grad()
     _, rg = orcg.combination_value_and_grads("gpr", X, Y[:, :1], [("SquaredExponential", 0.6, np.array(1.1))] * 2, op, noise_variance=0.2)
     chk(gdup[ksh.variance] / ksh.variance.transform.forward_grad(ksh.variance.unconstrained_variable), rg["variance"].sum())
+
+
+@pytest.mark.parametrize("q_diag", [False, True])
+def test_heteroskedastic_noise_in_the_reverse_pass(gpu, q_diag):
+    """Gaussian(scale=Linear(A, b)) (the reference's tests/integration/test_linear_noise.py recipe; likelihoods/scalar_continuous.py:
+    52-148): GPR.log_marginal_likelihood and the whitened SVGP.elbo with their gradients w.r.t. the NOISE FUNCTION's parameters (A, b)
+    and everything else -- dF/d sigma_n^2 per row from the device reverse pass, chained through the clip and the function's own
+    reverse pass -- against torch autograd over the restated likelihood; Scipy then fits the noise slope."""
+    import gpflow_amd as gpflow
+    rng = np.random.default_rng(20220630)
+    N, M, P = 240, 30, 1
+    X = rng.random((N, 2)); Xc = X[:, :1]
+    Y = np.sin(5 * Xc) + (0.7 - 0.6 * Xc) * rng.standard_normal((N, 1))
+    A0, b0 = np.array([[-0.3], [0.05]]), np.array([0.6])
+    Z = X[:M] + 0.01 * rng.normal(size=(M, 2)); q_mu = 0.2 * rng.normal(size=(M, P))
+    qs = 0.4 + np.abs(rng.normal(size=(M, P))) if q_diag else np.tril(0.1 * rng.normal(size=(P, M, M))) + 0.5 * np.eye(M)
+    mk_lik = lambda: gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=A0.copy(), b=b0.copy()))  # noqa: E731
+    mk_k = lambda: gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.25, 0.9])  # noqa: E731
+
+    def chk(got, ref, tol=1e-8):
+        got = np.asarray(got, dtype=np.float64).reshape(np.shape(ref))
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (np.abs(got - ref).max(), np.abs(ref).max())
+
+    def unc(m, par, g):   # d/d(constrained) from the model's d/d(unconstrained)
+        return np.asarray(g[par]) / par.transform.forward_grad(par.unconstrained_variable)
+    if not q_diag:
+        m = gpflow.models.GPR((X, Y), mk_k(), likelihood=mk_lik())
+        v, g = m.objective_and_grad()
+        rv, rg = orcg.heteroskedastic_value_and_grads("gpr", X, Y, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9])
+        assert abs(v - rv) <= 1e-9 * abs(rv) and abs(v - float(m.log_marginal_likelihood().cpu())) <= 1e-9 * abs(v)
+        chk(g[m.likelihood.scale.A], rg["A"]); chk(g[m.likelihood.scale.b], rg["b"])
+        chk(unc(m, m.kernel.variance, g), rg["variance"]); chk(unc(m, m.kernel.lengthscales, g), rg["lengthscales"])
+        before = v
+        res = gpflow.optimizers.Scipy().minimize(m, options=dict(maxiter=60))
+        assert -res.fun > before + 5.0
+        assert abs(float(np.ravel(m.likelihood.scale.A.numpy())[0]) + 0.6) < 0.25      # the slope the data were drawn with
+    s = gpflow.models.SVGP(mk_k(), mk_lik(), Z.copy(), q_mu=q_mu, q_sqrt=qs, q_diag=q_diag, num_data=5 * N)
+    v, g = s.elbo_and_grad((X, Y))
+    rv, rg = orcg.heteroskedastic_value_and_grads("svgp", X, Y, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9], Z=Z, q_mu=q_mu,
+                                                  q_sqrt=qs, num_data=5 * N)
+    assert abs(v - rv) <= 1e-9 * abs(rv) and abs(v - float(s.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+    chk(g[s.likelihood.scale.A], rg["A"]); chk(g[s.likelihood.scale.b], rg["b"])
+    chk(g[s.inducing_variable.Z], rg["Z"]); chk(g[s.q_mu], rg["q_mu"])
+    chk(unc(s, s.kernel.variance, g), rg["variance"]); chk(unc(s, s.kernel.lengthscales, g), rg["lengthscales"])
+    if q_diag:
+        chk(unc(s, s.q_sqrt, g), rg["q_sqrt"])
