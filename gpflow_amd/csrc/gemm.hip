@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
     // the last, partial round of a lower-only launch of the 128 x 128 fast tile (launch_fast, "tail split"): positions
     // tail_first + blockIdx.x / 4 of ITS tile sequence (gx, gy in 128-tiles), each as four 64 x 64 quarters
     int tm, tn;
-    tile_decode(p.tail_first1 - 1 + ((int)blockIdx.x >> 2), gx, gy, 1, tm, tn);
+    tile_decode(p.tail_first1 - 1 + ((int)blockIdx.x >> 2), gx, gy, compact, tm, tn);
     tile_m = 2 * tm + (((int)blockIdx.x >> 1) & 1);
     tile_n = 2 * tn + ((int)blockIdx.x & 1);
   } else {
@@ -629,7 +629,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   constexpr size_t LDS_BYTES = 2 * (size_t)256 * LDSS * sizeof(double);
   // (function-local statics: initialised once, thread-safe)
   static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  // (capped launches ask for more, below)
   static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<EPI, true>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
   GPK_HIP(attr0);
@@ -680,6 +680,15 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     const int r = total % slots;
     if (total >= 2 * slots && r > 0 && r * 100 <= slots * GPK_TUNE(TAIL_SPLIT_PCT, 50)) tail_tiles = r;
   }
+  // The same split DOES pay for the capped launches of the extra-row stream (round 5): 224 persistent workgroups walk 768 / 512 /
+  // 256 tiles in 4 / 3 / 2 rounds of ~78 us where 3.43 / 2.29 / 1.14 would do -- a few rounds, no drift, and that stream is the
+  // critical path of the SVGP step.  The whole rounds stay on the persistent workgroups; the remainder runs as 64 x 64 quarters
+  // on every compute unit, for about a third of a round.
+  if (EPI == 0 && !a.c_lower && a.max_wgs > 0 && a.max_wgs < total && nb == 1 && !a.b_tri && !a.a_tri &&
+      GPK_TUNE(TAIL_SPLIT_CAPPED, 1)) {
+    const int r = total % a.max_wgs;
+    if (r > 0 && r * 100 <= a.max_wgs * GPK_TUNE(TAIL_SPLIT_CAPPED_PCT, 60)) tail_tiles = r;
+  }
   const int total_all = total;
   total -= tail_tiles;
   unsigned nwg = (unsigned)total;
@@ -695,7 +704,17 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
                           ? (int)((a.k / 16) * 170 * stagger_on / 200)
                           : 0;
   }
-  hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, nb, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total,
+  // A CAPPED launch (persistent workgroups, fewer than compute units x 2) asks for more than half of a CU's LDS, so that no two
+  // of its workgroups can share a compute unit.  Without that the dispatcher doubles them up on whatever CUs are free at launch
+  // time -- the chain's strip holds 80 - 120 CUs for ~10 us -- and, the tile walk being static, the doubled-up pairs run at half
+  // speed for the WHOLE kernel: the first extra-row update of an SVGP step took 318 or 483 us depending on what it was launched
+  // beside (profiles/r05_step_timeline.txt, round 5).
+  size_t lds_bytes = LDS_BYTES;
+  if (EPI == 0 && a.max_wgs > 0 && nwg < (unsigned)total && nb == 1) {
+    const int kb = GPK_TUNE(CAP_EXCL_LDS_KB, 84);
+    if (kb > 0 && kb <= 160 && (size_t)kb * 1024 > LDS_BYTES) lds_bytes = (size_t)kb * 1024;
+  }
+  hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, nb, 1), dim3(256), lds_bytes, s, b, gx, gy, total,
                      compact);
   GPK_LAUNCH_CHECK();
   if (tail_tiles > 0) {
@@ -706,7 +725,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     GemmArgs t = a;
     t.tail_first1 = total_all - tail_tiles + 1;
     hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 4, 1>), dim3((unsigned)(4 * tail_tiles), 1, 1), dim3(256), Cfg::LDS_BYTES, s, t, gx,
-                       gy, 4 * tail_tiles, 1);
+                       gy, 4 * tail_tiles, compact);
     GPK_LAUNCH_CHECK();
   }
   return 0;
@@ -965,6 +984,165 @@ __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
   }  // sliver loop
 }
 
+
+// Round 5: the same in-group solve with 32 rows per workgroup and the operand tiles PIPELINED through LDS.
+// The kernel above stages each 128 x 128 operand tile whole (133 KB, nothing else fits) and waits for it: 10 exposed L2 round trips
+// per 16-row sliver, 512 workgroups at one per compute unit = two rounds, ~111 us per 8192 x 512 group on the extra-row stream --
+// which is the critical path of the SVGP step from the fourth panel on (profiles/r05_step_timeline.txt).  Here
+//   * a workgroup owns TWO 16-row tiles: every B fragment read from LDS feeds two MFMAs, 256 workgroups = one round at 8192 rows;
+//   * the operand tiles of all products of the group form ONE stream of K-quarters (128 rows x 32 K = 32 KB, up to 40 of them)
+//     that runs two quarters ahead of the MFMAs through a ring of three LDS buffers, across product boundaries -- their addresses
+//     do not depend on any result;
+//   * the quarters are unpadded; the 16-byte chunk c of tile row r sits in slot c ^ (r & 15) (the permutation is applied on the
+//     GLOBAL address of the LDS-DMA lane), so the 32 lanes of a ds_read_b64 group still hit 64 distinct banks.
+// Per element the arithmetic is unchanged (K ascending, two alternating accumulators, the update accumulated onto -C and negated).
+constexpr int GS2_LDK = 130;                     // A rows: 128 + 2 doubles
+constexpr int GS2_Q = 128 * 32;                  // doubles per operand quarter
+constexpr size_t GS2_LDS = (size_t)(32 * GS2_LDK + 3 * GS2_Q) * sizeof(double);
+
+__global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
+  constexpr int LDK = GS2_LDK, NBK = 128;
+  {
+    const long b = blockIdx.y;
+    p.E += b * p.strideE; p.Eo += b * p.strideEo; p.L += b * p.strideL; p.X += b * p.strideX;
+  }
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  double* As = smem;                 // [32][LDK]
+  double* Bq = smem + 32 * LDK;      // [3][128][32], chunk-swizzled
+  const int nb = p.nb;
+  const int nprod = nb + nb * (nb - 1) / 2;
+  const int nstages = 4 * nprod;
+  // operand tile of product k in issue order (j = 0: X_0, L_10, L_20, L_30; j = 1: X_1, L_21, L_31; ...)
+  auto tile_of = [&](int k, const double*& src, long& ld) {
+    int j = 0, left = k;
+    while (left >= nb - j) { left -= nb - j; ++j; }
+    if (left == 0) { src = p.X + (long)j * NBK * NBK; ld = NBK; }
+    else { src = p.L + (long)(j + left) * NBK * p.ldl + (long)j * NBK; ld = p.ldl; }
+  };
+  // LDS-DMA of one quarter: wave w fills row blocks 4w .. 4w+3 (4 rows x 16 chunks = 64 lanes x 16 bytes each)
+  const int drow = lane >> 4, dslot = lane & 15;
+  int issue = 0;
+  auto issue_stage = [&]() {
+    if (issue < nstages) {
+      const double* src; long ld;
+      tile_of(issue >> 2, src, ld);
+      const int q = issue & 3;
+      double* dst = Bq + (issue % 3) * GS2_Q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rb = wave * 4 + i;
+        const int row = rb * 4 + drow;
+        const double* gsrc = src + (long)row * ld + q * 32 + ((dslot ^ (row & 15)) << 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)(dst + rb * 128), 16, 0, 0);
+      }
+    }
+    ++issue;
+  };
+  // fragment addresses: B[row 16 w + r][k = 4 kk + g] of a quarter -> chunk 2 kk + (g >> 1), half g & 1
+  const int brow = (wave * 16 + r) * 32 + (g & 1);
+  const int bx0 = ((g >> 1) ^ (r & 1));  // low chunk bit after the swizzle
+  const int bxh = r & 14;                // high chunk bits are XORed with 2 kk
+  const double* ap = As + r * LDK + g;
+  for (int m0 = blockIdx.x * 32; m0 < p.rows; m0 += gridDim.x * 32) {
+    if (m0 != (int)blockIdx.x * 32) __syncthreads();   // the previous sliver's buffers are no longer read
+    issue = 0;
+    int cs = 0;
+    issue_stage();
+    issue_stage();
+    const int colw = wave * 16 + r;
+    int rowi[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int rr = m0 + 16 * t + g + 4 * e;
+        rowi[t][e] = rr < p.rows ? rr : p.rows - 1;
+      }
+    d4 c[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        if (jb < nb) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c[t][jb][e] = p.E[(long)rowi[t][e] * p.lde + jb * NBK + colw];
+        }
+      }
+    auto put_a = [&](const d4& v0, const d4& v1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        As[(g + 4 * e) * LDK + colw] = v0[e];
+        As[(16 + g + 4 * e) * LDK + colw] = v1[e];
+      }
+    };
+    // one K-quarter of the current product: acc[t][0] takes the even K groups of four, acc[t][1] the odd ones
+    auto stage = [&](int q, d4 (&acc)[2][2]) {
+      if (cs + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4): all but this wave's newest quarter have landed
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+      __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): this wave's A rows are in LDS
+      __builtin_amdgcn_s_barrier();
+      issue_stage();   // quarter cs + 2 replaces quarter cs - 1, which every wave has finished reading
+      const double* bq = Bq + (cs % 3) * GS2_Q + brow;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const double b = bq[(((2 * kk) ^ bxh) | bx0) << 1];
+        const double a0 = ap[q * 32 + kk * 4];
+        const double a1 = ap[16 * LDK + q * 32 + kk * 4];
+        acc[0][kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][kk & 1], 0, 0, 0);
+        acc[1][kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][kk & 1], 0, 0, 0);
+      }
+      ++cs;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j >= nb) break;
+      // ---- S_j = E_j X_j^T --------------------------------------------------------------------------------------------
+      if (j > 0) __syncthreads();   // every wave has finished reading the previous A rows
+      put_a(c[0][j], c[1][j]);
+      d4 acc[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { acc[t][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[t][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) stage(q, acc);
+      d4 sj[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sj[t][e] = 1.0 * (acc[t][0][e] + acc[t][1][e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int rr = m0 + 16 * t + g + 4 * e;
+          if (rr < p.rows) p.Eo[(long)rr * p.ldeo + j * NBK + colw] = sj[t][e];
+        }
+      }
+      if (j + 1 >= nb) break;
+      __syncthreads();   // everyone has read E_j
+      put_a(sj[0], sj[1]);
+      // ---- E_j' -= S_j L_j'j^T ----------------------------------------------------------------------------------------
+#pragma unroll
+      for (int jp = 1; jp < 4; ++jp) {
+        if (jp <= j || jp >= nb) continue;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][0][e] = -1.0 * c[t][jp][e];  // (beta / alpha) C with alpha = -1, beta = 1
+          acc[t][1] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage(q, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c[t][jp][e] = -1.0 * (acc[t][0][e] + acc[t][1][e]);
+      }
+    }
+  }  // sliver loop
+}
+
 int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
                        const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX, int max_wgs) {
   if (rows <= 0) return 0;
@@ -979,6 +1157,16 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   GroupSolveArgs a{};
   a.E = E; a.lde = lde; a.Eo = Eo; a.ldeo = ldeo; a.L = Lgg; a.ldl = ldl; a.X = X; a.rows = rows; a.nb = nb;
   a.strideE = strideE; a.strideEo = strideEo; a.strideL = strideL; a.strideX = strideX;
+  if (GPK_TUNE(GROUP_SOLVE_V2, 1)) {
+    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(group_solve2_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS2_LDS);
+    GPK_HIP(attr2);
+    unsigned gx2 = (unsigned)gpk_cdiv(rows, 32);
+    if (max_wgs > 0 && gx2 * (unsigned)batch > (unsigned)max_wgs) gx2 = (unsigned)std::max(1, max_wgs / batch);
+    hipLaunchKernelGGL(group_solve2_kernel, dim3(gx2, (unsigned)batch), dim3(512), GS2_LDS, s, a);
+    GPK_LAUNCH_CHECK();
+    return 0;
+  }
   unsigned gx = (unsigned)gpk_cdiv(rows, 16);
   if (max_wgs > 0 && gx * (unsigned)batch > (unsigned)max_wgs) gx = (unsigned)std::max(1, max_wgs / batch);
   hipLaunchKernelGGL(group_solve_kernel, dim3(gx, (unsigned)batch), dim3(512), LDS, s, a);

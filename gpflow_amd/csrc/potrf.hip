@@ -396,6 +396,9 @@ int solve_group_bwd(hipStream_t s, double* Bm, long ldb, int rows, const double*
   return 0;
 }
 
+// p_prologue: work of the CALLER that the first leaf waits for and nothing else does -- the fused drivers' Kuu build.  It is
+// enqueued ON the panel stream, so the first leaf follows it back to back (0.3 us) instead of behind an event record on the caller's
+// stream and a wait on the panel stream (~15 us per step, round 5).
 // b_prologue (large factorisations): work of the CALLER that everything EXCEPT the first panel's columns waits for -- the GPR
 // driver builds only those columns before the call and the rest of K(X, X) here, on the bulk stream, beside the first panel's
 // chain, which nothing else would overlap (first_panel_columns below tells it how many columns that is).
@@ -404,7 +407,8 @@ int solve_group_bwd(hipStream_t s, double* Bm, long ldb, int rows, const double*
 // leaf delays the whole step, and nothing on the bulk stream is needed for ~4 panels.
 int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
                int* info, const std::function<int(hipStream_t)>* x_prologue = nullptr, int tri = 0, bool tri_prefilled = false,
-               const std::function<int(hipStream_t)>* b_prologue = nullptr) {
+               const std::function<int(hipStream_t)>* b_prologue = nullptr,
+               const std::function<int(hipStream_t)>* p_prologue = nullptr) {
   if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
   if (tri && (tri != n || extra < n || batch > 1)) return GPK_E_ARG;
   if (batch <= 0) batch = 1;
@@ -446,6 +450,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   double* E = A + (long)n * lda;       // the extra rows
   int rc;
   if (n <= NB) {  // one leaf; nothing to overlap
+    if (p_prologue) {
+      rc = (*p_prologue)(S);
+      if (rc) return rc;
+    }
     if (x_prologue) {
       rc = (*x_prologue)(S);
       if (rc) return rc;
@@ -487,6 +495,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   hipEvent_t* evR = aux->ev + npanels;  // [npanels] rest of the trailing update of panel p done (on B)
   hipEvent_t evFork = aux->ev[2 * npanels], evJoinP = aux->ev[2 * npanels + 1], evJoinB = aux->ev[2 * npanels + 2],
              evJoinX = aux->ev[2 * npanels + 3];
+  const bool p_on_panel = p_prologue && GPK_TUNE(KUU_ON_PANEL, 1);
+  if (p_prologue && !p_on_panel) {
+    rc = (*p_prologue)(S);
+    if (rc) return rc;
+  }
   if (x_prologue && !useX) {  // the extra rows ride through the panel solves: they must exist before the first one
     rc = (*x_prologue)(S);
     if (rc) return rc;
@@ -495,6 +508,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   GPK_HIP(hipStreamWaitEvent(P, evFork, 0));
   if (B != S) GPK_HIP(hipStreamWaitEvent(B, evFork, 0));
   if (useX && X != B) GPK_HIP(hipStreamWaitEvent(X, evFork, 0));
+  if (p_on_panel) {
+    rc = (*p_prologue)(P);
+    if (rc) return rc;
+  }
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
   hipEvent_t evBpro = aux->ev[2 * npanels + 4];
@@ -991,14 +1008,16 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     double* arow = Kfu_d + (long)rows * l.ld;          // [P, m]
     double* LinvT = arow + (long)P * l.ld;             // [m, ld]: Lm^-T (upper triangular)
     double* A2 = (double*)(w + l.off_proj);            // [rows, ld]
-    int rcd = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter, 1, T, l.ld);
-    if (rcd) return rcd;
+    int rcd = 0;
+    const std::function<int(hipStream_t)> kuu_d = [&](hipStream_t ps) -> int {
+      return gpk_kernel_matrix((void*)ps, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter, 1, T, l.ld);
+    };
     const std::function<int(hipStream_t)> prod = [&](hipStream_t xs) -> int {
       int r = gpk_kernel_matrix((void*)xs, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0, Kfu_d, l.ld);
       if (r) return r;
       return gpk_transpose((void*)xs, q_mu, m, P, P, arow, l.ld, 0, 1, 0, 0);
     };
-    rcd = potrf_core(s, T, m, rows + P + m, l.ld, 1, 0, invd_d, 0, info, &prod, m);
+    rcd = potrf_core(s, T, m, rows + P + m, l.ld, 1, 0, invd_d, 0, info, &prod, m, false, nullptr, &kuu_d);
     if (rcd) return rcd;
     if (rows > 0) {
       GemmArgs g = gemm_base(rows, m, m, 1.0, Kfu_d, l.ld, LinvT, l.ld, 0.0, A2, l.ld, 1, 0, 0, 0);
@@ -1051,8 +1070,10 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     double* Kfu_u = T + (long)m * l.ld;
     double* arow = Kfu_u + (long)rows * l.ld;          // [P, m]
     double* GT = arow + (long)P * l.ld;                // [P][m][ld]
-    int rcu = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter, 1, T, l.ld);
-    if (rcu) return rcu;
+    int rcu = 0;
+    const std::function<int(hipStream_t)> kuu_u = [&](hipStream_t ps) -> int {
+      return gpk_kernel_matrix((void*)ps, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter, 1, T, l.ld);
+    };
     const std::function<int(hipStream_t)> pro = [&](hipStream_t xs) -> int {
       int r = gpk_kernel_matrix((void*)xs, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0, Kfu_u, l.ld);
       if (r) return r;
@@ -1062,7 +1083,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     };
     // (P = 1: the m rows of tril(q_sqrt)^T are the LAST rows of the trapezoid and upper triangular -- row j stays zero left of
     //  column j until its column group is reached, so the row solve skips them there: 3/8 of their work, round 5)
-    rcu = potrf_core(s, T, m, rows + P + P * m, l.ld, 1, 0, invd_u, 0, info, &pro, P == 1 ? m : 0, true);
+    rcu = potrf_core(s, T, m, rows + P + P * m, l.ld, 1, 0, invd_u, 0, info, &pro, P == 1 ? m : 0, true, nullptr, &kuu_u);
     if (rcu) return rcu;
     rcu = gpk_transpose(stream, arow, P, m, l.ld, V, P, 0, 1, 0, 0);           // a = Lm^-1 q_mu as [m, P]
     if (rcu) return rcu;
@@ -1139,10 +1160,10 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
 #endif
   const bool side = m > GPK_NB && m < 4096 && rows > 256;
   // Kuu + jitter I (posteriors.py:835, covariances/kuus.py:29-34), lower tiles only: the chain's first leaf waits for
-  // nothing else, so it is the first thing enqueued
-  rc = gpk_kernel_matrix(stream, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter,
-                         1, T, l.ld);
-  if (rc) return rc;
+  // nothing else, so the factorisation enqueues it on its panel stream, directly in front of that leaf
+  const std::function<int(hipStream_t)> kuu_build = [&](hipStream_t ps) -> int {
+    return gpk_kernel_matrix((void*)ps, family, Z, m, ldz, nullptr, 0, 0, d, ls_host, ard, variance, jitter, 1, T, l.ld);
+  };
   int c1 = 0;
   // everything else that precedes the minibatch solve, as one closure: enqueued by the factorisation on its bulk stream
   // (side) or here on the caller's stream
@@ -1161,7 +1182,7 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     return gpk_launch_final(xs, 1, p1s, &c1, &halfs, -0.5 * (double)m * (double)P, out + 1);
   };
   // Lm = chol(Kuu);  A^T = Kfu Lm^-T   (conditionals/util.py:67,125)
-  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, &prologue);
+  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, &prologue, 0, false, nullptr, &kuu_build);
   if (rc) return rc;
   // s0 = sum_k A^2 (util.py:133), fmean = A^T q_mu (util.py:144), q_diag: ssq = sum (A q_sqrt)^2 (:149)
   rc = gpk_row_stats(stream, Kfu, rows, m, l.ld, q_mu, q_diag ? q_sqrt : nullptr, P, 1.0, 0.0, s0, fmean,
@@ -1254,12 +1275,15 @@ extern "C" int gpk_svgp_elbo_shard_sep(void* stream, const int* family_host, con
   double* part1 = (double*)(w + l.off_part1);
   const int nls = ard ? d : 1;
   int rc;
-  // Kuu_p + jitter I (lower tiles): the chain's first (batched) leaf waits for nothing else
-  for (int p = 0; p < P; ++p) {
-    rc = gpk_kernel_matrix(stream, family_host[p], Z + (long)p * strideZ, m, ldz, nullptr, 0, 0, d, ls_host + (long)p * nls, ard,
-                           variance_host[p], jitter, 1, T + (long)p * l.strideT, l.ld);
-    if (rc) return rc;
-  }
+  // Kuu_p + jitter I (lower tiles): the chain's first (batched) leaf waits for nothing else -- enqueued on the panel stream
+  const std::function<int(hipStream_t)> kuu_build = [&](hipStream_t ps) -> int {
+    for (int p = 0; p < P; ++p) {
+      const int r = gpk_kernel_matrix((void*)ps, family_host[p], Z + (long)p * strideZ, m, ldz, nullptr, 0, 0, d, ls_host + (long)p * nls,
+                                      ard, variance_host[p], jitter, 1, T + (long)p * l.strideT, l.ld);
+      if (r) return r;
+    }
+    return 0;
+  };
   const bool side = m > GPK_NB && m < 4096 && rows > 256;
   int c1 = 0;
   auto kl_and_transpose = [&](hipStream_t xs) -> int {
@@ -1280,7 +1304,7 @@ extern "C" int gpk_svgp_elbo_shard_sep(void* stream, const int* family_host, con
     }
     return side ? kl_and_transpose(xs) : 0;
   };
-  rc = potrf_core(s, T, m, rows, l.ld, P, l.strideT, invd, 0, info, &prologue);
+  rc = potrf_core(s, T, m, rows, l.ld, P, l.strideT, invd, 0, info, &prologue, 0, false, nullptr, &kuu_build);
   if (rc) return rc;
   if (!side) {
     rc = kl_and_transpose(s);
