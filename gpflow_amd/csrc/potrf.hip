@@ -405,10 +405,24 @@ int solve_group_bwd(hipStream_t s, double* Bm, long ldb, int rows, const double*
 // x_prologue: work of the CALLER that belongs on the bulk stream before the first extra-row group (the SVGP driver's Kfu
 // build, transposes, KL).  It is enqueued after the first panel's chain kernels: every host call issued before the first
 // leaf delays the whole step, and nothing on the bulk stream is needed for ~4 panels.
+// late_work: work of the CALLER that nothing in the factorisation needs (the whitened driver's tril(q_sqrt)^T and KL term).  It is
+// enqueued on the rest-update stream after the sixth panel: the first four panels are HOST-bound -- ~7 enqueue calls of 5 - 8 us
+// per panel against ~55 us of kernels -- so every launch issued there delays the chain (round 5: the second leaf started 52 us
+// after the first strip had finished), and the rest-update stream has a leaf's time of slack per panel.
+typedef std::function<int(hipStream_t)> StreamWork;
+struct PotrfHooks {
+  const StreamWork* x_prologue = nullptr;
+  const StreamWork* b_prologue = nullptr;
+  const StreamWork* p_prologue = nullptr;
+  const StreamWork* late_work = nullptr;
+};
+
 int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
-               int* info, const std::function<int(hipStream_t)>* x_prologue = nullptr, int tri = 0, bool tri_prefilled = false,
-               const std::function<int(hipStream_t)>* b_prologue = nullptr,
-               const std::function<int(hipStream_t)>* p_prologue = nullptr) {
+               int* info, const PotrfHooks& hooks = PotrfHooks(), int tri = 0, bool tri_prefilled = false) {
+  const StreamWork* x_prologue = hooks.x_prologue;
+  const StreamWork* b_prologue = hooks.b_prologue;
+  const StreamWork* p_prologue = hooks.p_prologue;
+  const StreamWork* late_work = hooks.late_work;
   if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
   if (tri && (tri != n || extra < n || batch > 1)) return GPK_E_ARG;
   if (batch <= 0) batch = 1;
@@ -456,6 +470,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     }
     if (x_prologue) {
       rc = (*x_prologue)(S);
+      if (rc) return rc;
+    }
+    if (late_work) {
+      rc = (*late_work)(S);
       if (rc) return rc;
     }
     rc = factor_panel(S, A, R, 0, n, lda, batch, strideA, invd, strideInv, info);
@@ -539,6 +557,22 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // 0.803 ms, C5 shared 1.314 -> 1.30 ms, but C5 separate 1.97 -> 2.11; profiles/r04_ab_c5.log, r04_ab_xgroup_small.log)
   const int xgroup_small = batch > 1 ? GPK_TUNE(XGROUP_SMALL_BATCH, 256) : GPK_TUNE(XGROUP_SMALL, 128);
   const int xgroup = std::max(NB, ((n <= 1024 ? xgroup_small : GPK_TUNE(XGROUP, NBO)) / NB) * NB);
+  // (round 5 knobs: width of the FIRST extra-row group -- the extra-row stream idles until it is factored -- and the row count above
+  //  which the shrinking groups at the end are dropped: with many rows that stream, not the chain, finishes last)
+  const int xgroup_first = std::max(NB, (GPK_TUNE(XGROUP_FIRST, 0) > 0 ? (GPK_TUNE(XGROUP_FIRST, 0) / NB) * NB : xgroup));
+  // (A/B, profiles/r05_ab_extra_row_stream.log: M = 2048 x 8192 rows 1.97 - 1.99 -> 1.934 ms without the shrinking groups;
+  //  M = 1024, whose every panel is a group already, keeps them: 0.76 against 0.78 ms)
+  const int tail_zone_max_rows = n > 1024 ? GPK_TUNE(XTAIL_ZONE_MAX_ROWS, 4096) : (1 << 30);
+  const int late_panel = std::min(npanels - 1, GPK_TUNE(LATE_WORK_PANEL, 5));
+  // the event of the most recent rest-update, recorded when first needed: its stream is in order, so a record issued later covers it
+  bool evr_recorded = false;
+  auto need_evr = [&]() -> int {
+    if (!evr_recorded && last_rest >= 0) {
+      GPK_HIP(hipEventRecord(evR[last_rest], last_bulk));
+      evr_recorded = true;
+    }
+    return 0;
+  };
   for (int p = 0; p < npanels; ++p) {
     const int c0 = cuts[p], c1 = cuts[p + 1];
     const int c2 = (p + 2 <= npanels) ? cuts[p + 2] : n;
@@ -566,8 +600,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // (stream memory operations only on the plain streams: on the CU-masked bulk stream of large factorisations a
     // hipStreamWriteValue32 was observed to overtake the kernel queued before it -- wrong factor at n = 5000 -- so a panel whose
     // extra-row group waits on that stream keeps its event, and so does a strip whose rest-update ran there)
-    const bool x_waits_here = useX && (c1 == n || ((c1 - xg0) >= xgroup || (large && c1 - xg0 >= nbo)) ||
-                                       (!large && (nbo == NB) && (n >= 8 * NB) && (c1 == n - 2 * NB || c1 == n - NB)));
+    const bool tail_zone = !large && (nbo == NB) && (n >= 8 * NB) && (extra < tail_zone_max_rows);
+    const int xgroup_now = (xg0 == 0 && !large) ? xgroup_first : xgroup;
+    const bool x_waits_here = useX && (c1 == n || ((c1 - xg0) >= xgroup_now || (large && c1 - xg0 >= nbo)) ||
+                                       (tail_zone && (c1 == n - 2 * NB || c1 == n - NB)));
     const bool flagged = use_flags && p < kMaxFlagPanels && c1 < n && (c1 - c0) <= NB && gpk_gemm_takes_latency_kernel(strip) &&
                          !(x_waits_here && X == aux->B);
     panel_flagged[p] = flagged ? 1 : 0;
@@ -584,6 +620,8 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
           strip.wait_val = epoch;
           strip.wait_info = info;
         } else {
+          rc = need_evr();
+          if (rc) return rc;
           GPK_HIP(hipStreamWaitEvent(P, evR[last_rest], 0));
         }
       }
@@ -611,7 +649,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
         Bp = aux->Bs;
         rc = wait_panel(Bp);
         if (rc) return rc;
-        if (last_rest >= 0 && last_bulk != Bp) GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
+        if (last_rest >= 0 && last_bulk != Bp) {
+          rc = need_evr();
+          if (rc) return rc;
+          GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
+        }
       } else {
         rc = wait_panel(B);
         if (rc) return rc;
@@ -627,9 +669,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       }
       rc = gpk_launch_gemm(Bp, u);
       if (rc) return rc;
-      GPK_HIP(hipEventRecord(evR[p], Bp));
       rest_flagged = use_flags && p < kMaxFlagPanels && Bp != aux->B;
       if (rest_flagged) GPK_HIP(hipStreamWriteValue32(Bp, flagR + p, (uint32_t)epoch, 0));
+      else GPK_HIP(hipEventRecord(evR[p], Bp));
+      evr_recorded = !rest_flagged;   // (a flagged rest-update gets its event only if somebody asks for it: need_evr)
       last_bulk = Bp;
       last_rest = p;
     }
@@ -637,12 +680,16 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       rc = (*x_prologue)(X);
       if (rc) return rc;
     }
+    if (late_work && p == late_panel) {
+      // (on the stream of the most recent rest-update, whose last event the join below waits for)
+      rc = (*late_work)(last_bulk);
+      if (rc) return rc;
+    }
     // ---- X: the extra rows against the finished columns, in groups of up to 512 columns (so that the big
     // right-looking update is a K = 512 GEMM).  For the small sizes the groups shrink towards the end (.., n-256,
     // n-128, n): whatever is left of the extra-row work when the LAST leaf finishes is exposed latency.
-    const bool tail_zone = !large && (nbo == NB) && (n >= 8 * NB);
     const bool tail_group = tail_zone && (c1 == n - 2 * NB || c1 == n - NB);
-    const bool full_group = ((c1 - xg0) >= xgroup || (large && c1 - xg0 >= nbo)) && !(tail_zone && c1 > n - 2 * NB && c1 < n);
+    const bool full_group = ((c1 - xg0) >= xgroup_now || (large && c1 - xg0 >= nbo)) && !(tail_zone && c1 > n - 2 * NB && c1 < n);
     if (useX && (c1 == n || full_group || tail_group)) {
       const int g0 = xg0;
       xg0 = c1;
@@ -716,7 +763,7 @@ extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, in
 
 extern "C" int gpk_potrf_inv(void* stream, double* A, int n, int extra, long lda, double* invd, int zero_upper,
                              int* info) {
-  return potrf_core((hipStream_t)stream, A, n, extra + n, lda, 1, 0, invd, zero_upper, info, nullptr, n);
+  return potrf_core((hipStream_t)stream, A, n, extra + n, lda, 1, 0, invd, zero_upper, info, PotrfHooks(), n);
 }
 
 extern "C" int gpk_trtri_blocks(void* stream, const double* L, int n, long ldl, int batch,
@@ -887,7 +934,9 @@ extern "C" int gpk_gpr_lml(void* stream, int family, const double* X, int n, int
   rc = gpk_launch_transpose_shift(s, Y, n, P, ldy, T + (long)n * l.ld, l.ld, -mean_const);
   if (rc) return rc;
   // L = chol(K); extra rows -> alpha^T = (L^-1 (Y-m))^T  (gpr.py:102, logdensities.py:150)
-  rc = potrf_core(s, T, n, P, l.ld, 1, 0, invd, 0, info, nullptr, 0, false, split_build ? &bpro : nullptr);
+  PotrfHooks hk;
+  hk.b_prologue = split_build ? &bpro : nullptr;
+  rc = potrf_core(s, T, n, P, l.ld, 1, 0, invd, 0, info, hk);
   if (rc) return rc;
   // p = -0.5 sum alpha^2 - 0.5 N log 2pi - sum log diag L, summed over the P columns
   rc = gpk_sum_log_diag(stream, T, n, l.ld, 1, 0, logdet);
@@ -1017,7 +1066,10 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
       if (r) return r;
       return gpk_transpose((void*)xs, q_mu, m, P, P, arow, l.ld, 0, 1, 0, 0);
     };
-    rcd = potrf_core(s, T, m, rows + P + m, l.ld, 1, 0, invd_d, 0, info, &prod, m, false, nullptr, &kuu_d);
+    PotrfHooks hkd;
+    hkd.x_prologue = &prod;
+    hkd.p_prologue = &kuu_d;
+    rcd = potrf_core(s, T, m, rows + P + m, l.ld, 1, 0, invd_d, 0, info, hkd, m);
     if (rcd) return rcd;
     if (rows > 0) {
       GemmArgs g = gemm_base(rows, m, m, 1.0, Kfu_d, l.ld, LinvT, l.ld, 0.0, A2, l.ld, 1, 0, 0, 0);
@@ -1083,7 +1135,10 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     };
     // (P = 1: the m rows of tril(q_sqrt)^T are the LAST rows of the trapezoid and upper triangular -- row j stays zero left of
     //  column j until its column group is reached, so the row solve skips them there: 3/8 of their work, round 5)
-    rcu = potrf_core(s, T, m, rows + P + P * m, l.ld, 1, 0, invd_u, 0, info, &pro, P == 1 ? m : 0, true, nullptr, &kuu_u);
+    PotrfHooks hku;
+    hku.x_prologue = &pro;
+    hku.p_prologue = &kuu_u;
+    rcu = potrf_core(s, T, m, rows + P + P * m, l.ld, 1, 0, invd_u, 0, info, hku, P == 1 ? m : 0, true);
     if (rcu) return rcu;
     rcu = gpk_transpose(stream, arow, P, m, l.ld, V, P, 0, 1, 0, 0);           // a = Lm^-1 q_mu as [m, P]
     if (rcu) return rcu;
@@ -1168,9 +1223,11 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   // everything else that precedes the minibatch solve, as one closure: enqueued by the factorisation on its bulk stream
   // (side) or here on the caller's stream
   const std::function<int(hipStream_t)> prologue = [&](hipStream_t xs) -> int {
-    int r = gpk_kernel_matrix((void*)xs, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0, Kfu, l.ld);
-    if (r) return r;
-    if (!side) return 0;
+    return gpk_kernel_matrix((void*)xs, family, Xb, rows, ldxb, Z, m, ldz, d, ls_host, ard, variance, 0.0, 0, Kfu, l.ld);
+  };
+  // tril(q_sqrt)^T for the projection and the whole KL term depend on neither the factorisation nor the minibatch solve
+  const std::function<int(hipStream_t)> late = [&](hipStream_t xs) -> int {
+    int r = 0;
     if (!q_diag) {
       r = gpk_transpose((void*)xs, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
       if (r) return r;
@@ -1182,7 +1239,11 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
     return gpk_launch_final(xs, 1, p1s, &c1, &halfs, -0.5 * (double)m * (double)P, out + 1);
   };
   // Lm = chol(Kuu);  A^T = Kfu Lm^-T   (conditionals/util.py:67,125)
-  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, &prologue, 0, false, nullptr, &kuu_build);
+  PotrfHooks hk;
+  hk.x_prologue = &prologue;
+  hk.p_prologue = &kuu_build;
+  hk.late_work = side ? &late : nullptr;
+  rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, hk);
   if (rc) return rc;
   // s0 = sum_k A^2 (util.py:133), fmean = A^T q_mu (util.py:144), q_diag: ssq = sum (A q_sqrt)^2 (:149)
   rc = gpk_row_stats(stream, Kfu, rows, m, l.ld, q_mu, q_diag ? q_sqrt : nullptr, P, 1.0, 0.0, s0, fmean,
@@ -1302,9 +1363,14 @@ extern "C" int gpk_svgp_elbo_shard_sep(void* stream, const int* family_host, con
                                       l.ld);
       if (r) return r;
     }
-    return side ? kl_and_transpose(xs) : 0;
+    return 0;
   };
-  rc = potrf_core(s, T, m, rows, l.ld, P, l.strideT, invd, 0, info, &prologue, 0, false, nullptr, &kuu_build);
+  const std::function<int(hipStream_t)> late = [&](hipStream_t xs) -> int { return kl_and_transpose(xs); };
+  PotrfHooks hk;
+  hk.x_prologue = &prologue;
+  hk.p_prologue = &kuu_build;
+  hk.late_work = side ? &late : nullptr;
+  rc = potrf_core(s, T, m, rows, l.ld, P, l.strideT, invd, 0, info, hk);
   if (rc) return rc;
   if (!side) {
     rc = kl_and_transpose(s);
