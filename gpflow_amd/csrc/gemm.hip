@@ -1430,5 +1430,6 @@ extern "C" int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, cons
   g.a_tri = (m <= k) ? ((b_tri >> 4) & 3) : 0;  // (a hint: ignoring it is always correct)
   if ((b_tri & ~0x33) || g.b_tri == 3 || g.a_tri == 3) return GPK_E_ARG;
   g.epi = 0; g.batch = batch > 0 ? batch : 1;
+  if (kGpkExp) g.max_wgs = GPK_TUNE(GEMM_NT_MAX_WGS, 0);   // (A/B build only: tools/capped_gemm_probe.py)
   return gpk_launch_gemm((hipStream_t)stream, g);
 }
