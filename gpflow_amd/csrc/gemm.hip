@@ -997,11 +997,21 @@ __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
 //     GLOBAL address of the LDS-DMA lane), so the 32 lanes of a ds_read_b64 group still hit 64 distinct banks.
 // Per element the arithmetic is unchanged (K ascending, two alternating accumulators, the update accumulated onto -C and negated).
 constexpr int GS2_LDK = 130;                     // A rows: 128 + 2 doubles
-constexpr int GS2_Q = 128 * 32;                  // doubles per operand quarter
-constexpr size_t GS2_LDS = (size_t)(32 * GS2_LDK + 3 * GS2_Q) * sizeof(double);
+template <int QK>
+constexpr size_t gs2_lds() { return (size_t)(32 * GS2_LDK + 3 * 128 * QK) * sizeof(double); }
 
+// QK = K columns per pipeline stage.  32: 40 stages of 16 MFMAs per wave, 132 KB of LDS (a compute unit of its own).
+// 16: 80 stages of 8 MFMAs, 80.5 KB -- a workgroup then fits BESIDE one 73.7 KB workgroup of the tiled GEMM, so the in-group
+// solve no longer waits for the compute units that the chain's rest-update (launched at the same flag) has just taken.
+template <int QK>
 __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
   constexpr int LDK = GS2_LDK, NBK = 128;
+  constexpr int NQ = NBK / QK;            // stages per product
+  constexpr int QELEMS = 128 * QK;        // doubles per stage buffer
+  constexpr int CH = QK / 2;              // 16-byte chunks per row of a stage
+  constexpr int DROWS = 64 / CH;          // rows per LDS-DMA instruction
+  constexpr int DPW = (128 / DROWS) / 8;  // LDS-DMA instructions per wave and stage
+  static_assert(QK == 32 || QK == 16, "stage width");
   {
     const long b = blockIdx.y;
     p.E += b * p.strideE; p.Eo += b * p.strideEo; p.L += b * p.strideL; p.X += b * p.strideX;
@@ -1011,10 +1021,12 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   double* As = smem;                 // [32][LDK]
-  double* Bq = smem + 32 * LDK;      // [3][128][32], chunk-swizzled
+  double* Bq = smem + 32 * LDK;      // [3][128][QK], chunk-swizzled
   const int nb = p.nb;
   const int nprod = nb + nb * (nb - 1) / 2;
-  const int nstages = 4 * nprod;
+  const int nstages = NQ * nprod;
+  // swizzle of a tile row's chunks: QK = 32 -> row & 15 (16 chunks), QK = 16 -> (row >> 1) & 7 (8 chunks, two rows per 64 banks)
+  auto swz = [](int row) -> int { return QK == 32 ? (row & 15) : ((row >> 1) & 7); };
   // operand tile of product k in issue order (j = 0: X_0, L_10, L_20, L_30; j = 1: X_1, L_21, L_31; ...)
   auto tile_of = [&](int k, const double*& src, long& ld) {
     int j = 0, left = k;
@@ -1022,30 +1034,29 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
     if (left == 0) { src = p.X + (long)j * NBK * NBK; ld = NBK; }
     else { src = p.L + (long)(j + left) * NBK * p.ldl + (long)j * NBK; ld = p.ldl; }
   };
-  // LDS-DMA of one quarter: wave w fills row blocks 4w .. 4w+3 (4 rows x 16 chunks = 64 lanes x 16 bytes each)
-  const int drow = lane >> 4, dslot = lane & 15;
+  // LDS-DMA of one stage: 64 lanes x 16 bytes = DROWS rows x CH chunks per instruction
+  const int drow = lane / CH, dslot = lane % CH;
   int issue = 0;
   auto issue_stage = [&]() {
     if (issue < nstages) {
       const double* src; long ld;
-      tile_of(issue >> 2, src, ld);
-      const int q = issue & 3;
-      double* dst = Bq + (issue % 3) * GS2_Q;
+      tile_of(issue / NQ, src, ld);
+      const int q = issue % NQ;
+      double* dst = Bq + (issue % 3) * QELEMS;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rb = wave * 4 + i;
-        const int row = rb * 4 + drow;
-        const double* gsrc = src + (long)row * ld + q * 32 + ((dslot ^ (row & 15)) << 1);
+      for (int i = 0; i < DPW; ++i) {
+        const int rb = wave * DPW + i;
+        const int row = rb * DROWS + drow;
+        const double* gsrc = src + (long)row * ld + q * QK + ((dslot ^ swz(row)) << 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                          (__attribute__((address_space(3))) void*)(dst + rb * 128), 16, 0, 0);
       }
     }
     ++issue;
   };
-  // fragment addresses: B[row 16 w + r][k = 4 kk + g] of a quarter -> chunk 2 kk + (g >> 1), half g & 1
-  const int brow = (wave * 16 + r) * 32 + (g & 1);
-  const int bx0 = ((g >> 1) ^ (r & 1));  // low chunk bit after the swizzle
-  const int bxh = r & 14;                // high chunk bits are XORed with 2 kk
+  // fragment addresses: B[row 16 w + r][k = 4 kk + g] of a stage -> chunk 2 kk + (g >> 1), half g & 1
+  const int brow = (wave * 16 + r) * QK + (g & 1);
+  const int bsw = swz(r), bgh = g >> 1;
   const double* ap = As + r * LDK + g;
   for (int m0 = blockIdx.x * 32; m0 < p.rows; m0 += gridDim.x * 32) {
     if (m0 != (int)blockIdx.x * 32) __syncthreads();   // the previous sliver's buffers are no longer read
@@ -1079,19 +1090,20 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
         As[(16 + g + 4 * e) * LDK + colw] = v1[e];
       }
     };
-    // one K-quarter of the current product: acc[t][0] takes the even K groups of four, acc[t][1] the odd ones
+    // one stage of the current product: acc[t][0] takes the even K groups of four, acc[t][1] the odd ones
     auto stage = [&](int q, d4 (&acc)[2][2]) {
-      if (cs + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4): all but this wave's newest quarter have landed
-      else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+      // all but this wave's newest stage have landed (vmcnt(DPW)); the last stage has nothing behind it (vmcnt(0))
+      if (cs + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0F70 | DPW);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
       __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): this wave's A rows are in LDS
       __builtin_amdgcn_s_barrier();
-      issue_stage();   // quarter cs + 2 replaces quarter cs - 1, which every wave has finished reading
-      const double* bq = Bq + (cs % 3) * GS2_Q + brow;
+      issue_stage();   // stage cs + 2 replaces stage cs - 1, which every wave has finished reading
+      const double* bq = Bq + (cs % 3) * QELEMS + brow;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const double b = bq[(((2 * kk) ^ bxh) | bx0) << 1];
-        const double a0 = ap[q * 32 + kk * 4];
-        const double a1 = ap[16 * LDK + q * 32 + kk * 4];
+      for (int kk = 0; kk < QK / 4; ++kk) {
+        const double b = bq[((2 * kk + bgh) ^ bsw) << 1];
+        const double a0 = ap[q * QK + kk * 4];
+        const double a1 = ap[16 * LDK + q * QK + kk * 4];
         acc[0][kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][kk & 1], 0, 0, 0);
         acc[1][kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][kk & 1], 0, 0, 0);
       }
@@ -1107,7 +1119,7 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) { acc[t][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[t][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) stage(q, acc);
+      for (int q = 0; q < NQ; ++q) stage(q, acc);
       d4 sj[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -1133,7 +1145,7 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
           acc[t][1] = (d4){0.0, 0.0, 0.0, 0.0};
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) stage(q, acc);
+        for (int q = 0; q < NQ; ++q) stage(q, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1141,6 +1153,18 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
       }
     }
   }  // sliver loop
+}
+
+template <int QK>
+int launch_group_solve2(hipStream_t s, const GroupSolveArgs& a, int rows, int batch, int max_wgs) {
+  static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(group_solve2_kernel<QK>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds<QK>());
+  GPK_HIP(attr2);
+  unsigned gx2 = (unsigned)gpk_cdiv(rows, 32);
+  if (max_wgs > 0 && gx2 * (unsigned)batch > (unsigned)max_wgs) gx2 = (unsigned)std::max(1, max_wgs / batch);
+  hipLaunchKernelGGL(group_solve2_kernel<QK>, dim3(gx2, (unsigned)batch), dim3(512), gs2_lds<QK>(), s, a);
+  GPK_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
@@ -1158,14 +1182,10 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   a.E = E; a.lde = lde; a.Eo = Eo; a.ldeo = ldeo; a.L = Lgg; a.ldl = ldl; a.X = X; a.rows = rows; a.nb = nb;
   a.strideE = strideE; a.strideEo = strideEo; a.strideL = strideL; a.strideX = strideX;
   if (GPK_TUNE(GROUP_SOLVE_V2, 1)) {
-    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(group_solve2_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS2_LDS);
-    GPK_HIP(attr2);
-    unsigned gx2 = (unsigned)gpk_cdiv(rows, 32);
-    if (max_wgs > 0 && gx2 * (unsigned)batch > (unsigned)max_wgs) gx2 = (unsigned)std::max(1, max_wgs / batch);
-    hipLaunchKernelGGL(group_solve2_kernel, dim3(gx2, (unsigned)batch), dim3(512), GS2_LDS, s, a);
-    GPK_LAUNCH_CHECK();
-    return 0;
+    // (stage width 16 -- co-resident with a tiled-GEMM workgroup -- measured 3 % SLOWER on the SVGP step, same box: 2.14 - 2.16 against
+    //  2.02 - 2.10 ms, profiles/r05_ab_extra_row_stream.log: twice the barriers, and the wait for compute units was not the larger loss)
+    return GPK_TUNE(GROUP_SOLVE_QK, 32) == 16 ? launch_group_solve2<16>(s, a, rows, batch, max_wgs)
+                                             : launch_group_solve2<32>(s, a, rows, batch, max_wgs);
   }
   unsigned gx = (unsigned)gpk_cdiv(rows, 16);
   if (max_wgs > 0 && gx * (unsigned)batch > (unsigned)max_wgs) gx = (unsigned)std::max(1, max_wgs / batch);
