@@ -189,6 +189,59 @@ def test_trsm_both(gpu, n, m):
     np.testing.assert_allclose(X1, sla.solve_triangular(L.T, Bm.T, lower=False).T, rtol=0, atol=1e-10)
 
 
+@pytest.mark.parametrize("n,m,batch", [(512, 1024, 1), (384, 1039, 1), (256, 1040, 1), (640, 1100, 1), (512, 1025, 3)])
+def test_trsm_fused_group_solve(gpu, n, m, batch):
+    """Right-hand-side counts >= 1024 take the pipelined in-group solve (group_solve2_kernel: 32 rows per workgroup, operand quarters
+    through a ring of LDS buffers): 4 / 3 / 2 leaf blocks per group, a 4 + 1 split, row counts that are not multiples of 32 or 16,
+    and a batch of problems.  Oracle: scipy triangular solves per problem."""
+    import torch
+    from gpflow_amd import ops
+    rng = np.random.default_rng(61)
+    Ls, Bs = [], []
+    for _ in range(batch):
+        _, K = _spd(rng, n)
+        Ls.append(np.linalg.cholesky(K))
+        Bs.append(rng.normal(size=(m, n)))
+    if batch == 1:
+        Ld = _t(Ls[0])
+        invd = ops.trtri_blocks(Ld)
+        X0 = ops.trsm_(_t(Bs[0]), Ld, invd, trans=0).cpu().numpy()
+        np.testing.assert_allclose(X0, sla.solve_triangular(Ls[0], Bs[0].T, lower=True).T, rtol=0, atol=1e-11)
+        return
+    # batched: the trapezoid entry point with extra rows (batch of factorisations, extra rows solved group by group)
+    T = np.stack([np.vstack([L @ L.T, B]) for L, B in zip(Ls, Bs)])
+    Td = _t(T)
+    invd, info = ops.potrf_(Td, n, zero_upper=True)
+    ops.check_info(info)
+    out = Td.cpu().numpy()
+    for b in range(batch):
+        np.testing.assert_allclose(out[b, :n], Ls[b], rtol=0, atol=5e-12)
+        np.testing.assert_allclose(out[b, n:], sla.solve_triangular(Ls[b], Bs[b].T, lower=True).T, rtol=0, atol=1e-10)
+
+
+def test_potrf_many_extra_rows_capped_updates(gpu):
+    """n = 1536 with 8192 extra rows: the extra-row stream's K = 512 updates have 512 / 256 tiles, more than the 224 persistent
+    workgroups they are capped to, so the remainder of each launch runs as 64 x 64 quarters behind it (launch_fast, "remainder
+    round"); the in-group solves are the pipelined kernel at 4 blocks per group.  Oracle: LAPACK Cholesky + triangular solve."""
+    from gpflow_amd import ops
+    rng = np.random.default_rng(62)
+    n, extra = 1536, 8192
+    _, K = _spd(rng, n)
+    Bm = rng.normal(size=(extra, n))
+    Td = _t(np.vstack([K, Bm]))
+    invd, info = ops.potrf_(Td, n, zero_upper=True)
+    ops.check_info(info)
+    out = Td.cpu().numpy()
+    Lref = np.linalg.cholesky(K)
+    np.testing.assert_allclose(out[:n], Lref, rtol=0, atol=5e-12)
+    ref = sla.solve_triangular(Lref, Bm.T, lower=True).T
+    np.testing.assert_allclose(out[n:], ref, rtol=0, atol=1e-10)
+    # twice the same answer, bit for bit (persistent workgroups + remainder launch: no order depends on timing)
+    Td2 = _t(np.vstack([K, Bm]))
+    ops.potrf_(Td2, n, zero_upper=True)
+    np.testing.assert_array_equal(Td2.cpu().numpy(), out)
+
+
 def test_row_stats_project_reductions(gpu):
     from gpflow_amd import ops
     rng = np.random.default_rng(7)
