@@ -890,6 +890,7 @@ struct GroupSolveArgs {
   const double* X;               // block inverses of the group, consecutive [nb][128][128]
   int rows, nb;
   long strideE, strideEo, strideL, strideX;   // batched form (blockIdx.y = problem): element offsets between problems
+  int stage_barrier;                          // (A/B build) a workgroup barrier at EVERY pipeline stage of group_solve2_kernel
 };
 
 __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
@@ -1091,13 +1092,19 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
       }
     };
     // one stage of the current product: acc[t][0] takes the even K groups of four, acc[t][1] the odd ones
-    auto stage = [&](int q, d4 (&acc)[2][2]) {
+    // The B rows a wave reads (tile rows 16 w .. 16 w + 15 = its output columns) are the rows IT copies: the operand stream needs
+    // no workgroup barrier at all, only the wave's own vmcnt -- the eight waves drift apart and fill each other's LDS waits.  The
+    // A rows are shared: one barrier after each put_a (first stage of a product whose A operand changed).
+    auto stage = [&](int q, d4 (&acc)[2][2], bool a_changed) {
       // all but this wave's newest stage have landed (vmcnt(DPW)); the last stage has nothing behind it (vmcnt(0))
       if (cs + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0F70 | DPW);
       else __builtin_amdgcn_s_waitcnt(0x0F70);
-      __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): this wave's A rows are in LDS
-      __builtin_amdgcn_s_barrier();
-      issue_stage();   // stage cs + 2 replaces stage cs - 1, which every wave has finished reading
+      asm volatile("" ::: "memory");
+      if (a_changed || p.stage_barrier) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this wave's A rows are in LDS
+        __builtin_amdgcn_s_barrier();
+      }
+      issue_stage();   // stage cs + 2 replaces stage cs - 1 of this wave's rows, whose fragments it has consumed
       const double* bq = Bq + (cs % 3) * QELEMS + brow;
 #pragma unroll
       for (int kk = 0; kk < QK / 4; ++kk) {
@@ -1119,7 +1126,7 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) { acc[t][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[t][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) stage(q, acc);
+      for (int q = 0; q < NQ; ++q) stage(q, acc, q == 0);
       d4 sj[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -1145,7 +1152,7 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
           acc[t][1] = (d4){0.0, 0.0, 0.0, 0.0};
         }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) stage(q, acc);
+        for (int q = 0; q < NQ; ++q) stage(q, acc, q == 0 && jp == j + 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1181,6 +1188,7 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   GroupSolveArgs a{};
   a.E = E; a.lde = lde; a.Eo = Eo; a.ldeo = ldeo; a.L = Lgg; a.ldl = ldl; a.X = X; a.rows = rows; a.nb = nb;
   a.strideE = strideE; a.strideEo = strideEo; a.strideL = strideL; a.strideX = strideX;
+  a.stage_barrier = GPK_TUNE(GS2_STAGE_BARRIER, 0);
   if (GPK_TUNE(GROUP_SOLVE_V2, 1)) {
     // (stage width 16 -- co-resident with a tiled-GEMM workgroup -- measured 3 % SLOWER on the SVGP step, same box: 2.14 - 2.16 against
     //  2.02 - 2.10 ms, profiles/r05_ab_extra_row_stream.log: twice the barriers, and the wait for compute units was not the larger loss)
