@@ -891,6 +891,8 @@ struct GroupSolveArgs {
   int rows, nb;
   long strideE, strideEo, strideL, strideX;   // batched form (blockIdx.y = problem): element offsets between problems
   int stage_barrier;                          // (A/B build) a workgroup barrier at EVERY pipeline stage of group_solve2_kernel
+  int j0, j1;                                 // group_solve2_kernel: leaf blocks [j0, j1) are solved by THIS launch (the blocks before j0 by
+                                              // earlier ones); the updated, still unsolved blocks >= j1 go back to E (E == Eo then)
 };
 
 __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
@@ -1023,14 +1025,15 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
   const int r = lane & 15, g = lane >> 4;
   double* As = smem;                 // [32][LDK]
   double* Bq = smem + 32 * LDK;      // [3][128][QK], chunk-swizzled
-  const int nb = p.nb;
-  const int nprod = nb + nb * (nb - 1) / 2;
+  const int nb = p.nb, j0 = p.j0, j1 = p.j1;
+  int nprod = 0;
+  for (int j = j0; j < j1; ++j) nprod += nb - j;
   const int nstages = NQ * nprod;
   // swizzle of a tile row's chunks: QK = 32 -> row & 15 (16 chunks), QK = 16 -> (row >> 1) & 7 (8 chunks, two rows per 64 banks)
   auto swz = [](int row) -> int { return QK == 32 ? (row & 15) : ((row >> 1) & 7); };
   // operand tile of product k in issue order (j = 0: X_0, L_10, L_20, L_30; j = 1: X_1, L_21, L_31; ...)
   auto tile_of = [&](int k, const double*& src, long& ld) {
-    int j = 0, left = k;
+    int j = j0, left = k;
     while (left >= nb - j) { left -= nb - j; ++j; }
     if (left == 0) { src = p.X + (long)j * NBK * NBK; ld = NBK; }
     else { src = p.L + (long)(j + left) * NBK * p.ldl + (long)j * NBK; ld = p.ldl; }
@@ -1079,7 +1082,7 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb) {
-        if (jb < nb) {
+        if (jb >= j0 && jb < nb) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) c[t][jb][e] = p.E[(long)rowi[t][e] * p.lde + jb * NBK + colw];
         }
@@ -1118,9 +1121,10 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (j >= nb) break;
+      if (j < j0) continue;
+      if (j >= j1) break;
       // ---- S_j = E_j X_j^T --------------------------------------------------------------------------------------------
-      if (j > 0) __syncthreads();   // every wave has finished reading the previous A rows
+      if (j > j0) __syncthreads();   // every wave has finished reading the previous A rows
       put_a(c[0][j], c[1][j]);
       d4 acc[2][2];
 #pragma unroll
@@ -1159,6 +1163,18 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
           for (int e = 0; e < 4; ++e) c[t][jp][e] = -1.0 * (acc[t][0][e] + acc[t][1][e]);
       }
     }
+    // a partial launch hands the updated, unsolved blocks back (in place)
+#pragma unroll
+    for (int jp = 1; jp < 4; ++jp) {
+      if (jp < j1 || jp >= nb) continue;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int rr = m0 + 16 * t + g + 4 * e;
+          if (rr < p.rows) p.Eo[(long)rr * p.ldeo + jp * NBK + colw] = c[t][jp][e];
+        }
+    }
   }  // sliver loop
 }
 
@@ -1175,8 +1191,13 @@ int launch_group_solve2(hipStream_t s, const GroupSolveArgs& a, int rows, int ba
 }
 
 int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
-                       const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX, int max_wgs) {
+                       const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX, int max_wgs,
+                       int j0, int j1) {
   if (rows <= 0) return 0;
+  if (j1 < 0) j1 = nb;
+  if (j0 < 0 || j0 >= j1 || j1 > nb) return GPK_E_ARG;
+  const bool partial = j0 > 0 || j1 < nb;
+  if (partial && (E != Eo || lde != ldeo || strideE != strideEo || !GPK_TUNE(GROUP_SOLVE_V2, 1))) return GPK_E_UNSUPPORTED;
   if (batch < 1) batch = 1;
   if (!E || !Eo || !Lgg || !X || nb < 1 || nb > 4) return GPK_E_ARG;
   if ((ldl & 1) || (reinterpret_cast<uintptr_t>(Lgg) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return GPK_E_UNSUPPORTED;
@@ -1189,6 +1210,7 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   a.E = E; a.lde = lde; a.Eo = Eo; a.ldeo = ldeo; a.L = Lgg; a.ldl = ldl; a.X = X; a.rows = rows; a.nb = nb;
   a.strideE = strideE; a.strideEo = strideEo; a.strideL = strideL; a.strideX = strideX;
   a.stage_barrier = GPK_TUNE(GS2_STAGE_BARRIER, 0);
+  a.j0 = j0; a.j1 = j1;
   if (GPK_TUNE(GROUP_SOLVE_V2, 1)) {
     // (stage width 16 -- co-resident with a tiled-GEMM workgroup -- measured 3 % SLOWER on the SVGP step, same box: 2.14 - 2.16 against
     //  2.02 - 2.10 ms, profiles/r05_ab_extra_row_stream.log: twice the barriers, and the wait for compute units was not the larger loss)
@@ -1249,8 +1271,9 @@ int gpk_gemm_tiles_n(int n) { return gpk_cdiv(n, 128); }
 bool gpk_gemm_takes_latency_kernel(const GemmArgs& a) { return a.m > 0 && a.n > 0 && !a.no_small && small_ok(a); }
 
 int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
-                           const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX, int max_wgs) {
-  return launch_group_solve(s, E, lde, Eo, ldeo, rows, Lgg, ldl, X, nb, batch, strideE, strideEo, strideL, strideX, max_wgs);
+                           const double* X, int nb, int batch, long strideE, long strideEo, long strideL, long strideX, int max_wgs,
+                           int j0, int j1) {
+  return launch_group_solve(s, E, lde, Eo, ldeo, rows, Lgg, ldl, X, nb, batch, strideE, strideEo, strideL, strideX, max_wgs, j0, j1);
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events around every GEMM launch, on the

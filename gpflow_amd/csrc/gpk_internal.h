@@ -102,7 +102,7 @@ bool gpk_gemm_takes_latency_kernel(const GemmArgs& a);   // the launch would run
 // (batch > 1: blockIdx.y walks the problems, strides in elements)
 int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
                            const double* X, int nb, int batch = 1, long strideE = 0, long strideEo = 0, long strideL = 0,
-                           long strideX = 0, int max_wgs = 0);   // max_wgs > 0: at most that many workgroups, walking the 16-row slivers
+                           long strideX = 0, int max_wgs = 0, int j0 = 0, int j1 = -1);   // max_wgs > 0: at most that many workgroups, walking the 16-row slivers
 int gpk_gemm_tiles_n(int n);   // number of column tiles the launcher will use for n columns
 int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg)
 int gpk_prof_begin(hipStream_t s, double flops, int kind);   // same facility for other kernels; returns a record index or -1

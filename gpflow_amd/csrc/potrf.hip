@@ -314,16 +314,29 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
 // The solved columns S are written to Eo (ldeo) -- the same matrix as E for the in-place form, a separate one when the
 // caller wants A^T apart from the consumed input rows.  Used for the extra rows of the factorisation and, group after
 // group, by gpk_trsm(trans = 0).
+// part_j0 >= 0 (progressive form, first group of an SVGP-size factorisation): only leaf block part_j0 of the group is solved by
+// this call -- it has just been factored -- and the group's later blocks get its K = 128 update; the large GEMM follows the LAST block.
+bool group_solve_fused_ok(int nbk, int c0, int c1, int rows, const double* L, long ldl, const double* invd, int batch, long strideL,
+                          long strideInv) {
+  const bool batch_ok = batch <= 1 || (GPK_TUNE(GROUP_FUSED_BATCH, 1) && !(strideL & 1) && !(strideInv & 1));
+  return batch_ok && nbk >= 2 && nbk <= 4 && nbk * NB == c1 - c0 && (c0 % NB) == 0 && rows >= GPK_TUNE(GROUP_FUSED_MIN_ROWS, 1024) &&
+         !(ldl & 1) && !(reinterpret_cast<uintptr_t>(L + (long)c0 * ldl + c0) & 15) &&
+         !(reinterpret_cast<uintptr_t>(invd + (long)(c0 / NB) * NB * NB) & 15) && GPK_TUNE(GROUP_FUSED, 1);
+}
+
 int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, double* Eo, long ldeo, int rows, const double* L,
                     long ldl, const double* invd, long strideInv, int n, int c0, int c1, int batch, long strideE,
-                    long strideEo, long strideL) {
+                    long strideEo, long strideL, int part_j0 = -1, int part_cap = 0) {
   int rc;
   const int nbk = (c1 - c0) / NB;
+  if (part_j0 >= 0) {
+    rc = gpk_launch_group_solve(s, E + c0, lde, Eo + c0, ldeo, rows, L + (long)c0 * ldl + c0, ldl, invd + (long)(c0 / NB) * NB * NB,
+                                nbk, batch, strideE, strideEo, strideL, strideInv, part_cap, part_j0, part_j0 + 1);
+    if (rc) return rc;
+    if (part_j0 + 1 < nbk) return 0;
+  } else
   // (a batch of problems: blockIdx.y walks them; C5 with separate kernels 2.14 -> 2.07 ms against the tiled per-block launches)
-  const bool batch_ok = batch <= 1 || (GPK_TUNE(GROUP_FUSED_BATCH, 1) && !(strideL & 1) && !(strideInv & 1));
-  if (batch_ok && nbk >= 2 && nbk <= 4 && nbk * NB == c1 - c0 && (c0 % NB) == 0 && rows >= GPK_TUNE(GROUP_FUSED_MIN_ROWS, 1024) &&
-      !(ldl & 1) && !(reinterpret_cast<uintptr_t>(L + (long)c0 * ldl + c0) & 15) &&
-      !(reinterpret_cast<uintptr_t>(invd + (long)(c0 / NB) * NB * NB) & 15) && GPK_TUNE(GROUP_FUSED, 1)) {
+  if (group_solve_fused_ok(nbk, c0, c1, rows, L, ldl, invd, batch, strideL, strideInv)) {
     // (the fused kernel stages its operand tiles by 16-byte LDS-DMA: an 8-byte-aligned factor takes the per-block loop below)
     // the whole in-group phase (nbk solves + nbk - 1 updates of the latency kernel) as ONE launch with the same arithmetic
     rc = gpk_launch_group_solve(s, E + c0, lde, Eo + c0, ldeo, rows, L + (long)c0 * ldl + c0, ldl, invd + (long)(c0 / NB) * NB * NB,
@@ -563,6 +576,17 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // (A/B, profiles/r05_ab_extra_row_stream.log: M = 2048 x 8192 rows 1.97 - 1.99 -> 1.934 ms without the shrinking groups;
   //  M = 1024, whose every panel is a group already, keeps them: 0.76 against 0.78 ms)
   const int tail_zone_max_rows = n > 1024 ? GPK_TUNE(XTAIL_ZONE_MAX_ROWS, 4096) : (1 << 30);
+  // (A/B, profiles/r05_ab_extra_row_stream.log: latency kernel everywhere 1.903 1.907 | tiled from 150 workgroups 1.867 1.869 |
+  //  from 250: 1.886 1.896 | always: 1.883 1.897; caps of 16 / 32 / 64 walking workgroups on the latency kernel: 2.41 / 2.06 / 1.94)
+  const bool rest_tiled = useX && !large && batch == 1 && extra >= GPK_TUNE(REST_TILED_MIN_ROWS, 4096);
+  const int rest_tiled_min_wgs = GPK_TUNE(REST_TILED_MIN_WGS, 150);
+  const int rest_small_wgs = (useX && !large && batch == 1 && extra >= 4096) ? GPK_TUNE(REST_SMALL_WGS, 0) : 0;
+  const int prog_end = std::min(xgroup_first, n);
+  const int prog_cap = GPK_TUNE(XFIRST_PART_WGS, 128);
+  const bool progressive = useX && !large && nbo == NB && batch == 1 && GPK_TUNE(XFIRST_PROGRESSIVE, 1) && GPK_TUNE(GROUP_SOLVE_V2, 1) &&
+                           prog_end >= 2 * NB && extra >= GPK_TUNE(XFIRST_PROGRESSIVE_MIN_ROWS, 4096) &&
+                           group_solve_fused_ok(prog_end / NB, 0, prog_end, tri ? extra - tri + prog_end : extra, A, lda, invd, batch, strideA,
+                                                strideInv);
   const int late_panel = std::min(npanels - 1, GPK_TUNE(LATE_WORK_PANEL, 5));
   // the event of the most recent rest-update, recorded when first needed: its stream is in order, so a record issued later covers it
   bool evr_recorded = false;
@@ -662,6 +686,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       GemmArgs u = gemm_base(R - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
+      // (round 5) While the extra-row stream's capped updates hold 224 compute units, a rest-update on the one-shot latency kernel
+      // -- up to 512 workgroups of 150 KB each -- queues through the 32 free ones for ~140 us and the chain's strips queue behind
+      // it; the tiled kernel's 74-KB workgroups fit beside the capped ones.
+      if (rest_tiled && (long)gpk_cdiv(u.m, 16) * gpk_cdiv(u.n, 128) >= rest_tiled_min_wgs) u.no_small = 1;
+      else if (rest_small_wgs > 0) { u.small_loop = 1; u.max_wgs = rest_small_wgs; }
       if (Bp == aux->B && large) {
         u.stagger_first = aux->bulk_cus;
         // persistent workgroups (two per CU of the masked stream) that walk the tile list: no workgroup launch per tile
@@ -688,6 +717,21 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // ---- X: the extra rows against the finished columns, in groups of up to 512 columns (so that the big
     // right-looking update is a K = 512 GEMM).  For the small sizes the groups shrink towards the end (.., n-256,
     // n-128, n): whatever is left of the extra-row work when the LAST leaf finishes is exposed latency.
+    // Progressive first group (round 5).  The extra-row stream has nothing to do until the first group (four panels, ~245 us) is
+    // factored, and then spends ~100 us on that group's in-group solve before its first large update can start.  Instead, as soon
+    // as panel j of the first group is solved, ONE leaf block of the in-group solve runs (S_j = E_j X_j^T and the K = 128 update of
+    // the group's later blocks: 4 + 3 + 2 + 1 block products), on a capped number of workgroups so that the chain -- alone on the
+    // critical path there -- keeps its compute units.  When the fourth panel is done only one block product is left.
+    if (progressive && xg0 == 0 && c1 <= prog_end) {
+      rc = wait_panel(X);
+      if (rc) return rc;
+      const int xrows = tri ? extra - tri + prog_end : extra;
+      rc = solve_group_fwd(X, bulk, E, lda, E, lda, xrows, A, lda, invd, strideInv, n, 0, prog_end, batch, strideA, strideA, strideA,
+                           c0 / NB, prog_cap);
+      if (rc) return rc;
+      if (c1 == prog_end) xg0 = c1;
+      continue;
+    }
     const bool tail_group = tail_zone && (c1 == n - 2 * NB || c1 == n - NB);
     const bool full_group = ((c1 - xg0) >= xgroup_now || (large && c1 - xg0 >= nbo)) && !(tail_zone && c1 > n - 2 * NB && c1 < n);
     if (useX && (c1 == n || full_group || tail_group)) {
