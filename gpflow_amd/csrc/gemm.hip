@@ -708,7 +708,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   // of its workgroups can share a compute unit.  Without that the dispatcher doubles them up on whatever CUs are free at launch
   // time -- the chain's strip holds 80 - 120 CUs for ~10 us -- and, the tile walk being static, the doubled-up pairs run at half
   // speed for the WHOLE kernel: the first extra-row update of an SVGP step took 318 or 483 us depending on what it was launched
-  // beside (profiles/r05_step_timeline.txt, round 5).
+  // beside (profiles/r05_step_timeline_before_extra_row_work.txt, round 5).
   size_t lds_bytes = LDS_BYTES;
   if (EPI == 0 && a.max_wgs > 0 && nwg < (unsigned)total && nb == 1) {
     const int kb = GPK_TUNE(CAP_EXCL_LDS_KB, 84);
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
 // Round 5: the same in-group solve with 32 rows per workgroup and the operand tiles PIPELINED through LDS.
 // The kernel above stages each 128 x 128 operand tile whole (133 KB, nothing else fits) and waits for it: 10 exposed L2 round trips
 // per 16-row sliver, 512 workgroups at one per compute unit = two rounds, ~111 us per 8192 x 512 group on the extra-row stream --
-// which is the critical path of the SVGP step from the fourth panel on (profiles/r05_step_timeline.txt).  Here
+// which is the critical path of the SVGP step from the fourth panel on (profiles/r05_step_timeline_before_extra_row_work.txt).  Here
 //   * a workgroup owns TWO 16-row tiles: every B fragment read from LDS feeds two MFMAs, 256 workgroups = one round at 8192 rows;
 //   * the operand tiles of all products of the group form ONE stream of K-quarters (128 rows x 32 K = 32 KB, up to 40 of them)
 //     that runs two quarters ahead of the MFMAs through a ring of three LDS buffers, across product boundaries -- their addresses
@@ -1196,8 +1196,7 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   if (rows <= 0) return 0;
   if (j1 < 0) j1 = nb;
   if (j0 < 0 || j0 >= j1 || j1 > nb) return GPK_E_ARG;
-  const bool partial = j0 > 0 || j1 < nb;
-  if (partial && (E != Eo || lde != ldeo || strideE != strideEo || !GPK_TUNE(GROUP_SOLVE_V2, 1))) return GPK_E_UNSUPPORTED;
+  if ((j0 > 0 || j1 < nb) && (E != Eo || lde != ldeo || strideE != strideEo || !GPK_TUNE(GROUP_SOLVE_V2, 1))) return GPK_E_UNSUPPORTED;
   if (batch < 1) batch = 1;
   if (!E || !Eo || !Lgg || !X || nb < 1 || nb > 4) return GPK_E_ARG;
   if ((ldl & 1) || (reinterpret_cast<uintptr_t>(Lgg) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return GPK_E_UNSUPPORTED;
@@ -1211,7 +1210,14 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   a.strideE = strideE; a.strideEo = strideEo; a.strideL = strideL; a.strideX = strideX;
   a.stage_barrier = GPK_TUNE(GS2_STAGE_BARRIER, 0);
   a.j0 = j0; a.j1 = j1;
-  if (GPK_TUNE(GROUP_SOLVE_V2, 1)) {
+  // Which kernel: the pipelined one (32 rows per workgroup) runs its 10 block products in ~70 us whatever the row count; the
+  // staged one (16 rows) needs ~45 us per ROUND of 256 workgroups (one per CU).  tools/group_solve_probe.py, 512 columns, us:
+  //   rows 1024: 41 / 70   2048: 47 / 70   4096: 54 / 73   8192: 101 / 82   (staged / pipelined)
+  // so the pipelined kernel takes over where the staged one would need a second round.  (The first version of this switch sent
+  // everything to the pipelined kernel: the 1024- / 2048- / 4096-row rank shards of the strong-scaling workload lost 5 / 9 / 5 %.)
+  const bool partial = j0 > 0 || j1 < nb;
+  const long slivers16 = (long)gpk_cdiv(rows, 16) * batch;
+  if (GPK_TUNE(GROUP_SOLVE_V2, 1) && (partial || slivers16 > GPK_TUNE(GROUP_SOLVE_V2_MIN_SLIVERS, 256))) {
     // (stage width 16 -- co-resident with a tiled-GEMM workgroup -- measured 3 % SLOWER on the SVGP step, same box: 2.14 - 2.16 against
     //  2.02 - 2.10 ms, profiles/r05_ab_extra_row_stream.log: twice the barriers, and the wait for compute units was not the larger loss)
     return GPK_TUNE(GROUP_SOLVE_QK, 32) == 16 ? launch_group_solve2<16>(s, a, rows, batch, max_wgs)

@@ -575,16 +575,18 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   const int xgroup_first = std::max(NB, (GPK_TUNE(XGROUP_FIRST, 0) > 0 ? (GPK_TUNE(XGROUP_FIRST, 0) / NB) * NB : xgroup));
   // (A/B, profiles/r05_ab_extra_row_stream.log: M = 2048 x 8192 rows 1.97 - 1.99 -> 1.934 ms without the shrinking groups;
   //  M = 1024, whose every panel is a group already, keeps them: 0.76 against 0.78 ms)
-  const int tail_zone_max_rows = n > 1024 ? GPK_TUNE(XTAIL_ZONE_MAX_ROWS, 4096) : (1 << 30);
+  const int tail_zone_max_rows = n > 1024 ? GPK_TUNE(XTAIL_ZONE_MAX_ROWS, 6144) : (1 << 30);
   // (A/B, profiles/r05_ab_extra_row_stream.log: latency kernel everywhere 1.903 1.907 | tiled from 150 workgroups 1.867 1.869 |
   //  from 250: 1.886 1.896 | always: 1.883 1.897; caps of 16 / 32 / 64 walking workgroups on the latency kernel: 2.41 / 2.06 / 1.94)
-  const bool rest_tiled = useX && !large && batch == 1 && extra >= GPK_TUNE(REST_TILED_MIN_ROWS, 4096);
+  // (all three "many extra rows" switches -- this one, the progressive first group, no shrinking groups at the end -- were measured
+  //  at 8192 rows (gain) and 4096 rows (loss: 1.71 -> 1.82 ms for this one, tools/strong_scaling_emulation.py): threshold 6144)
+  const bool rest_tiled = useX && !large && batch == 1 && extra >= GPK_TUNE(REST_TILED_MIN_ROWS, 6144);
   const int rest_tiled_min_wgs = GPK_TUNE(REST_TILED_MIN_WGS, 150);
-  const int rest_small_wgs = (useX && !large && batch == 1 && extra >= 4096) ? GPK_TUNE(REST_SMALL_WGS, 0) : 0;
+  const int rest_small_wgs = (useX && !large && batch == 1 && extra >= 6144) ? GPK_TUNE(REST_SMALL_WGS, 0) : 0;
   const int prog_end = std::min(xgroup_first, n);
   const int prog_cap = GPK_TUNE(XFIRST_PART_WGS, 128);
   const bool progressive = useX && !large && nbo == NB && batch == 1 && GPK_TUNE(XFIRST_PROGRESSIVE, 1) && GPK_TUNE(GROUP_SOLVE_V2, 1) &&
-                           prog_end >= 2 * NB && extra >= GPK_TUNE(XFIRST_PROGRESSIVE_MIN_ROWS, 4096) &&
+                           prog_end >= 2 * NB && extra >= GPK_TUNE(XFIRST_PROGRESSIVE_MIN_ROWS, 6144) &&
                            group_solve_fused_ok(prog_end / NB, 0, prog_end, tri ? extra - tri + prog_end : extra, A, lda, invd, batch, strideA,
                                                 strideInv);
   const int late_panel = std::min(npanels - 1, GPK_TUNE(LATE_WORK_PANEL, 5));

@@ -189,11 +189,13 @@ def test_trsm_both(gpu, n, m):
     np.testing.assert_allclose(X1, sla.solve_triangular(L.T, Bm.T, lower=False).T, rtol=0, atol=1e-10)
 
 
-@pytest.mark.parametrize("n,m,batch", [(512, 1024, 1), (384, 1039, 1), (256, 1040, 1), (640, 1100, 1), (512, 1025, 3)])
+@pytest.mark.parametrize("n,m,batch", [(512, 1024, 1), (384, 1039, 1), (512, 4128, 1), (384, 4119, 1), (256, 4200, 1), (640, 4111, 1),
+                                       (512, 1400, 3), (512, 1025, 3)])
 def test_trsm_fused_group_solve(gpu, n, m, batch):
-    """Right-hand-side counts >= 1024 take the pipelined in-group solve (group_solve2_kernel: 32 rows per workgroup, operand quarters
-    through a ring of LDS buffers): 4 / 3 / 2 leaf blocks per group, a 4 + 1 split, row counts that are not multiples of 32 or 16,
-    and a batch of problems.  Oracle: scipy triangular solves per problem."""
+    """The fused in-group solve: up to 256 sixteen-row slivers (rows x batch) run on the staged kernel (group_solve_kernel), more on
+    the pipelined one (group_solve2_kernel: 32 rows per workgroup, operand quarters through a ring of LDS buffers).  4 / 3 / 2 leaf
+    blocks per group, a 4 + 1 split, row counts that are not multiples of 32 or 16, batches of problems on either side of the switch.
+    Oracle: scipy triangular solves per problem."""
     import torch
     from gpflow_amd import ops
     rng = np.random.default_rng(61)
