@@ -1000,15 +1000,33 @@ __global__ __launch_bounds__(512) void group_solve_kernel(GroupSolveArgs p) {
 //     GLOBAL address of the LDS-DMA lane), so the 32 lanes of a ds_read_b64 group still hit 64 distinct banks.
 // Per element the arithmetic is unchanged (K ascending, two alternating accumulators, the update accumulated onto -C and negated).
 constexpr int GS2_LDK = 130;                     // A rows: 128 + 2 doubles
-template <int QK>
-constexpr size_t gs2_lds() { return (size_t)(32 * GS2_LDK + 3 * 128 * QK) * sizeof(double); }
+template <int QK, int RING>
+constexpr size_t gs2_lds() { return (size_t)(32 * GS2_LDK + RING * 128 * QK) * sizeof(double); }
 
 // QK = K columns per pipeline stage.  32: 40 stages of 16 MFMAs per wave, 132 KB of LDS (a compute unit of its own).
 // 16: 80 stages of 8 MFMAs, 80.5 KB -- a workgroup then fits BESIDE one 73.7 KB workgroup of the tiled GEMM, so the in-group
 // solve no longer waits for the compute units that the chain's rest-update (launched at the same flag) has just taken.
-template <int QK>
+// s_waitcnt vmcnt(n * DPW) for a wave-uniform n in 0 .. NMAX (the instruction takes an immediate)
+template <int DPW, int NMAX>
+__device__ __forceinline__ void gs2_wait_vm(int n) {
+  if constexpr (NMAX > 0) {
+    if (n >= NMAX) {
+      constexpr int c = NMAX * DPW;
+      static_assert(c < 64, "vmcnt");
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (c & 15) | ((c >> 4) << 14));
+      return;
+    }
+    gs2_wait_vm<DPW, NMAX - 1>(n);
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+}
+
+// RING = stage buffers; the operand stream runs RING - 1 stages ahead of the MFMAs.
+template <int QK, int RING>
 __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
   constexpr int LDK = GS2_LDK, NBK = 128;
+  constexpr int AHEAD = RING - 1;
   constexpr int NQ = NBK / QK;            // stages per product
   constexpr int QELEMS = 128 * QK;        // doubles per stage buffer
   constexpr int CH = QK / 2;              // 16-byte chunks per row of a stage
@@ -1024,36 +1042,37 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   double* As = smem;                 // [32][LDK]
-  double* Bq = smem + 32 * LDK;      // [3][128][QK], chunk-swizzled
+  double* Bq = smem + 32 * LDK;      // [RING][128][QK], chunk-swizzled
   const int nb = p.nb, j0 = p.j0, j1 = p.j1;
   int nprod = 0;
   for (int j = j0; j < j1; ++j) nprod += nb - j;
   const int nstages = NQ * nprod;
   // swizzle of a tile row's chunks: QK = 32 -> row & 15 (16 chunks), QK = 16 -> (row >> 1) & 7 (8 chunks, two rows per 64 banks)
   auto swz = [](int row) -> int { return QK == 32 ? (row & 15) : ((row >> 1) & 7); };
-  // operand tile of product k in issue order (j = 0: X_0, L_10, L_20, L_30; j = 1: X_1, L_21, L_31; ...)
-  auto tile_of = [&](int k, const double*& src, long& ld) {
-    int j = j0, left = k;
-    while (left >= nb - j) { left -= nb - j; ++j; }
-    if (left == 0) { src = p.X + (long)j * NBK * NBK; ld = NBK; }
-    else { src = p.L + (long)(j + left) * NBK * p.ldl + (long)j * NBK; ld = p.ldl; }
-  };
-  // LDS-DMA of one stage: 64 lanes x 16 bytes = DROWS rows x CH chunks per instruction
+  // LDS-DMA of one stage: 64 lanes x 16 bytes = DROWS rows x CH chunks per instruction.  The operand tiles come in issue order
+  // (j = j0: X_j0, L_(j0+1)j0, ...; then j0 + 1: ...), tracked by (pj, pjp, pq): block column, block row (pjp == pj: the block
+  // inverse X_pj), stage inside the tile.  Per lane only a 32-bit element offset inside the tile, for either row stride.
   const int drow = lane / CH, dslot = lane % CH;
-  int issue = 0;
+  const int drow0 = wave * DPW * DROWS + drow;   // this lane's row in the wave's first copy; copy i adds i * DROWS
+  int issue = 0, pj = j0, pjp = j0, pq = 0;
   auto issue_stage = [&]() {
     if (issue < nstages) {
-      const double* src; long ld;
-      tile_of(issue / NQ, src, ld);
-      const int q = issue % NQ;
-      double* dst = Bq + (issue % 3) * QELEMS;
+      const bool isx = pjp == pj;
+      const double* src = (isx ? p.X + (long)pj * NBK * NBK : p.L + (long)pjp * NBK * p.ldl + (long)pj * NBK) + pq * QK;
+      const unsigned ld = isx ? (unsigned)NBK : (unsigned)p.ldl;   // (rows < 128, ld < 2^21: 32-bit element offsets)
+      double* dst = Bq + (issue % RING) * QELEMS;
 #pragma unroll
       for (int i = 0; i < DPW; ++i) {
         const int rb = wave * DPW + i;
-        const int row = rb * DROWS + drow;
-        const double* gsrc = src + (long)row * ld + q * QK + ((dslot ^ swz(row)) << 1);
+        const int row = drow0 + i * DROWS;
+        const double* gsrc = src + ((unsigned)row * ld + (unsigned)((dslot ^ swz(row)) << 1));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                          (__attribute__((address_space(3))) void*)(dst + rb * 128), 16, 0, 0);
+      }
+      if (++pq == NQ) {
+        pq = 0;
+        if (pjp + 1 < nb) ++pjp;
+        else { ++pj; pjp = pj; }
       }
     }
     ++issue;
@@ -1064,10 +1083,10 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
   const double* ap = As + r * LDK + g;
   for (int m0 = blockIdx.x * 32; m0 < p.rows; m0 += gridDim.x * 32) {
     if (m0 != (int)blockIdx.x * 32) __syncthreads();   // the previous sliver's buffers are no longer read
-    issue = 0;
+    issue = 0; pj = j0; pjp = j0; pq = 0;
     int cs = 0;
-    issue_stage();
-    issue_stage();
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) issue_stage();
     const int colw = wave * 16 + r;
     int rowi[2][4];
 #pragma unroll
@@ -1099,23 +1118,37 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
     // no workgroup barrier at all, only the wave's own vmcnt -- the eight waves drift apart and fill each other's LDS waits.  The
     // A rows are shared: one barrier after each put_a (first stage of a product whose A operand changed).
     auto stage = [&](int q, d4 (&acc)[2][2], bool a_changed) {
-      // all but this wave's newest stage have landed (vmcnt(DPW)); the last stage has nothing behind it (vmcnt(0))
-      if (cs + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0F70 | DPW);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      // stage cs has landed when at most the stages behind it are in flight: min(AHEAD - 1, stages left) x DPW of this wave's copies
+      {
+        const int behind = nstages - 1 - cs < AHEAD - 1 ? nstages - 1 - cs : AHEAD - 1;
+        gs2_wait_vm<DPW, AHEAD - 1>(behind);
+      }
       asm volatile("" ::: "memory");
       if (a_changed || p.stage_barrier) {
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this wave's A rows are in LDS
         __builtin_amdgcn_s_barrier();
       }
-      issue_stage();   // stage cs + 2 replaces stage cs - 1 of this wave's rows, whose fragments it has consumed
-      const double* bq = Bq + (cs % 3) * QELEMS + brow;
+      issue_stage();   // stage cs + AHEAD replaces stage cs - 1 of this wave's rows, whose fragments it has consumed
+      // fragments double-buffered in registers, the three LDS reads of step kk + 1 between the two MFMAs of step kk.  (Measured
+      // and not kept: the same pipeline hand-issued three steps deep with counted lgkmcnt waits -- 64.3 against 62.3 us per launch,
+      // and rings of 5 / 7 stage buffers -- 72 - 84 us: neither the LDS round trip nor the L2 one is what a sliver waits for; the
+      // seven barrier pairs around the changes of the shared A rows and the 20-odd us of launch, load and store are.)
+      const double* bq = Bq + (cs % RING) * QELEMS + brow;
+      double fb[2], fa0[2], fa1[2];
+      auto frag = [&](int kk, int f) {
+        fb[f] = bq[((2 * kk + bgh) ^ bsw) << 1];
+        fa0[f] = ap[q * QK + kk * 4];
+        fa1[f] = ap[16 * LDK + q * QK + kk * 4];
+      };
+      frag(0, 0);
 #pragma unroll
       for (int kk = 0; kk < QK / 4; ++kk) {
-        const double b = bq[((2 * kk + bgh) ^ bsw) << 1];
-        const double a0 = ap[q * QK + kk * 4];
-        const double a1 = ap[16 * LDK + q * QK + kk * 4];
-        acc[0][kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][kk & 1], 0, 0, 0);
-        acc[1][kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][kk & 1], 0, 0, 0);
+        if (kk + 1 < QK / 4) frag(kk + 1, (kk + 1) & 1);
+        acc[0][kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[kk & 1], fb[kk & 1], acc[0][kk & 1], 0, 0, 0);
+        acc[1][kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[kk & 1], fb[kk & 1], acc[1][kk & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // 1 MFMA
+        if (kk + 1 < QK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // 1 MFMA
       }
       ++cs;
     };
@@ -1178,14 +1211,15 @@ __global__ __launch_bounds__(512) void group_solve2_kernel(GroupSolveArgs p) {
   }  // sliver loop
 }
 
-template <int QK>
+template <int QK, int RING>
 int launch_group_solve2(hipStream_t s, const GroupSolveArgs& a, int rows, int batch, int max_wgs) {
-  static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(group_solve2_kernel<QK>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds<QK>());
+  static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(group_solve2_kernel<QK, RING>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs2_lds<QK, RING>());
   GPK_HIP(attr2);
   unsigned gx2 = (unsigned)gpk_cdiv(rows, 32);
   if (max_wgs > 0 && gx2 * (unsigned)batch > (unsigned)max_wgs) gx2 = (unsigned)std::max(1, max_wgs / batch);
-  hipLaunchKernelGGL(group_solve2_kernel<QK>, dim3(gx2, (unsigned)batch), dim3(512), gs2_lds<QK>(), s, a);
+  constexpr size_t lds = gs2_lds<QK, RING>();
+  hipLaunchKernelGGL((group_solve2_kernel<QK, RING>), dim3(gx2, (unsigned)batch), dim3(512), lds, s, a);
   GPK_LAUNCH_CHECK();
   return 0;
 }
@@ -1220,8 +1254,11 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   if (GPK_TUNE(GROUP_SOLVE_V2, 1) && (partial || slivers16 > GPK_TUNE(GROUP_SOLVE_V2_MIN_SLIVERS, 256))) {
     // (stage width 16 -- co-resident with a tiled-GEMM workgroup -- measured 3 % SLOWER on the SVGP step, same box: 2.14 - 2.16 against
     //  2.02 - 2.10 ms, profiles/r05_ab_extra_row_stream.log: twice the barriers, and the wait for compute units was not the larger loss)
-    return GPK_TUNE(GROUP_SOLVE_QK, 32) == 16 ? launch_group_solve2<16>(s, a, rows, batch, max_wgs)
-                                             : launch_group_solve2<32>(s, a, rows, batch, max_wgs);
+    switch (GPK_TUNE(GROUP_SOLVE_QK, 32) * 100 + GPK_TUNE(GROUP_SOLVE_RING, 3)) {
+      case 1603: return launch_group_solve2<16, 3>(s, a, rows, batch, max_wgs);
+      case 1605: return launch_group_solve2<16, 5>(s, a, rows, batch, max_wgs);
+      default: return launch_group_solve2<32, 3>(s, a, rows, batch, max_wgs);
+    }
   }
   unsigned gx = (unsigned)gpk_cdiv(rows, 16);
   if (max_wgs > 0 && gx * (unsigned)batch > (unsigned)max_wgs) gx = (unsigned)std::max(1, max_wgs / batch);
