@@ -39,7 +39,8 @@ def shard_statistics(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, spec:
     spec: the covariance function (one stationary kernel, or a Sum / Product of them -- gradients.KernelSpec).
     noise_rows [n]: one noise variance per data row (a heteroskedastic Gaussian likelihood, sgpr.py:207-211: A = L^-1 Kuf / sigma,
     err / sigma) -- the rows of At and err are scaled by 1 / sigma_n, so every statistic is the reference's with sigma^2 = 1, and two
-    more scalars ride behind them: sum_n log sigma_n^2 and sum_n 1 / sigma_n^2 (the trace_k and log_sigma_sq terms, :236-247)."""
+    more scalars ride behind them: sum_n log sigma_n^2 and sum_n 1 / sigma_n^2 (the trace_k and log_sigma_sq terms, :236-247), and a
+    third for the upper bound: |At|_F^2 of the UNSCALED rows (its c = sum Kdiag - sum A^2, :126)."""
     M, n, P = Z.shape[0], X.shape[0], Y.shape[1]
     if spec is None:
         spec = gradients.KernelSpec.single(variance, lengthscales, family)
@@ -51,10 +52,11 @@ def shard_statistics(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, spec:
     ops.check_info(info)
     L, At = T[:M], T[M:]
     het = noise_rows is not None
-    packed = torch.zeros(M * M + M * P + (4 if het else 2), dtype=torch.float64, device=Z.device)
+    packed = torch.zeros(M * M + M * P + (5 if het else 2), dtype=torch.float64, device=Z.device)
     if n:
         err = (Y - mean_const).contiguous()
         if het:
+            packed[M * M + M * P + 4] = ops.sumsq(At)[0]
             w = 1.0 / noise_rows.reshape(-1)
             sw = torch.sqrt(w)
             At = At * sw[:, None]                                                       # rows of A^T / sigma_n (elementwise glue)
@@ -116,6 +118,19 @@ def upper_bound_from_statistics(packed: torch.Tensor, M: int, N: int, *, varianc
     const = -0.5 * N * float(np.log(2 * np.pi * s2))
     logdet = -ops.sum_log_diag(LB)[0]
     quad = -0.5 * packed[M * M + M] / cn_var + 0.5 * ops.sumsq(vt)[0]
+    return const + logdet + quad
+
+
+def upper_bound_heteroskedastic(packed: torch.Tensor, packed_cn: torch.Tensor, M: int, N: int):
+    """sgpr.py:85-148 with one sigma_n^2 per data row.  `packed`: the statistics of shard_statistics(noise_rows = sigma_n^2) -- LB and
+    sum log sigma_n^2 come from them; `packed_cn`: a SECOND pass over the rows with noise_rows = sigma_n^2 + c (:129-131: A_cn, err / cn_std),
+    whose rows are scaled by 1 / cn_std, so LC, v and the quadratic term are the constant-noise ones with variance 1."""
+    o = M * M + M
+    LB, _, _ = tail_factor(packed, M, 1, 1.0)                                           # :121-123 (rows already carry 1 / sigma_n)
+    const = -0.5 * N * LOG2PI - 0.5 * packed[o + 2]                                     # :132  -0.5 sum log(2 pi sigma_n^2)
+    logdet = -ops.sum_log_diag(LB)[0]                                                   # :133
+    _, _, vt = tail_factor(packed_cn, M, 1, 1.0)                                        # LC, v (:139-142)
+    quad = -0.5 * packed_cn[o] + 0.5 * ops.sumsq(vt)[0]                                 # :143-145
     return const + logdet + quad
 
 
@@ -199,10 +214,19 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         if self.data[1].shape[1] != 1:
             raise NotImplementedError("upper_bound is written for a single output column in the reference (sgpr.py:126)")
         kw, Z, c, s2, L, invd, packed = self._statistics()
+        M = Z.shape[0]
         if s2 is None:
-            raise NotImplementedError("upper_bound with a heteroskedastic likelihood (sgpr.py:124-131 rescales every row by its own "
-                                      "sigma_n^2 + c: a second pass over the rows that the packed statistics do not keep)")
-        return upper_bound_from_statistics(packed, Z.shape[0], self.num_data, variance=kw.kdiag(), noise_variance=s2)
+            # sgpr.py:124-131 rescales every row by ITS sigma_n^2 + c, where c needs the statistics of ALL rows: a second pass
+            # (covariances, solve, statistics again -- the same cost as the first; one more all-reduce on a sharded model)
+            c_tr = self.num_data * kw.kdiag() - float(packed[M * M + M + 4].cpu())      # :126 (host scalar: one read-back)
+            _, X, _, _, _ = self._config()
+            _, _, packed_cn = shard_statistics(Z, X, self.data[1], jitter=config.default_jitter(), mean_const=c, spec=kw,
+                                               noise_rows=self._noise_rows() + c_tr)
+            if self.sharded:
+                import torch.distributed as dist
+                dist.all_reduce(packed_cn, op=dist.ReduceOp.SUM, group=self.group)
+            return upper_bound_heteroskedastic(packed, packed_cn, M, self.num_data)
+        return upper_bound_from_statistics(packed, M, self.num_data, variance=kw.kdiag(), noise_variance=s2)
 
     def objective_and_grad(self):
         """(ELBO as a float, {Parameter: dELBO/d(unconstrained value)}) for the trainable parameters among kernel variance,

@@ -411,10 +411,11 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         spec, members = combo
         lik, mf, iv = self.likelihood, self.mean_function, self.inducing_variable
         c = mf.constant_value()
-        if not (isinstance(lik, Gaussian) and lik.has_variance_parameter and isinstance(iv, InducingPoints)
-                and c is not None and self.q_sqrt.numpy().ndim == 3):
-            raise NotImplementedError("gradients with a kernel combination: Gaussian likelihood, InducingPoints, full q_sqrt, "
-                                      "constant mean")
+        # (a diagonal q_sqrt [M, P] goes through the same two reverse passes: the covariance spec and the q_diag branches of
+        #  gradients.svgp_elbo_and_grad / _unwhitened are independent of each other)
+        if not (isinstance(lik, Gaussian) and lik.has_variance_parameter and isinstance(iv, InducingPoints) and c is not None):
+            raise NotImplementedError("gradients with a kernel combination: Gaussian likelihood with a variance parameter, "
+                                      "InducingPoints, constant mean")
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
         fn = gradients.svgp_elbo_and_grad if self.whiten else gradients.svgp_elbo_and_grad_unwhitened

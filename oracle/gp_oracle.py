@@ -456,23 +456,26 @@ def sgpr_compute_qu(X, Y, Z, *, variance, lengthscales, noise_variance, mean=0.0
 
 
 def sgpr_upper_bound(X, Y, Z, *, variance, lengthscales, noise_variance, mean=0.0, jitter=DEFAULT_JITTER):
-    """gpflow/models/sgpr.py:85-148 (Titsias 2014 upper bound), constant noise variance, P = 1 semantics as written."""
+    """gpflow/models/sgpr.py:85-148 (Titsias 2014 upper bound), P = 1 semantics as written; noise_variance a constant or one
+    value per data row [N] (likelihood.variance_at(X), :108): every row is then rescaled by ITS sigma_n^2 + c (:124-131)."""
     N = X.shape[0]
+    sigma_sq = _noise_rows(noise_variance, N)                                   # :108
     kuu = Kuu(Z, variance=variance, lengthscales=lengthscales, jitter=jitter)
     kuf = Kuf(Z, X, variance=variance, lengthscales=lengthscales)
     L = np.linalg.cholesky(kuu)
-    A = sla.solve_triangular(L, kuf, lower=True)
-    A_sigma = A / np.sqrt(noise_variance)
-    LB = np.linalg.cholesky(np.eye(len(Z)) + A_sigma @ A_sigma.T)
-    c = N * variance - np.sum(A * A)
-    cn_var = noise_variance + c
-    const = -0.5 * N * np.log(2 * np.pi * noise_variance)
-    logdet = -np.sum(np.log(np.diag(LB)))
-    A_cn = A / np.sqrt(cn_var)
+    A = sla.solve_triangular(L, kuf, lower=True)                                # :118
+    A_sigma = sla.solve_triangular(L, kuf / np.sqrt(sigma_sq), lower=True)      # :120
+    LB = np.linalg.cholesky(np.eye(len(Z)) + A_sigma @ A_sigma.T)               # :121-123
+    c = N * variance - np.sum(A * A)                                            # :126  (K_diag = variance)
+    cn_var = sigma_sq + c                                                       # :129
+    cn_std = np.sqrt(cn_var)
+    const = -0.5 * np.sum(np.log(2 * np.pi * sigma_sq))                         # :132
+    logdet = -np.sum(np.log(np.diag(LB)))                                       # :133
+    A_cn = sla.solve_triangular(L, kuf / cn_std, lower=True)                    # :135
     err = Y - mean
-    LC = np.linalg.cholesky(np.eye(len(Z)) + A_cn @ A_cn.T)
-    v = sla.solve_triangular(LC, A_cn @ (err / np.sqrt(cn_var)), lower=True)
-    quad = -0.5 * np.sum((err / np.sqrt(cn_var)) ** 2) + 0.5 * np.sum(v * v)
+    LC = np.linalg.cholesky(np.eye(len(Z)) + A_cn @ A_cn.T)                     # :139
+    v = sla.solve_triangular(LC, A_cn @ (err / cn_std[:, None]), lower=True)    # :140-142
+    quad = -0.5 * np.sum((err / cn_std[:, None]) ** 2) + 0.5 * np.sum(v * v)    # :143-145
     return const + logdet + quad
 
 

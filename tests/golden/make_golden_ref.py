@@ -363,7 +363,8 @@ def build():  # noqa: C901
     # SGPR under the same likelihood (the reference's tests/integration/test_linear_noise.py recipe, sgpr.py:181-384 with sigma_n per row)
     hsg = gpflow.models.SGPR((X, Y), hk(), Zh, likelihood=gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=hA, b=hb)))
     smu, svar = hsg.predict_f(Xs); squ, sqc = hsg.compute_qu()
-    out.update(het_sgpr_elbo=float(hsg.elbo()), het_sgpr_mu=_n(smu), het_sgpr_var=_n(svar), het_sgpr_qu_mu=_n(squ), het_sgpr_qu_cov=_n(sqc))
+    out.update(het_sgpr_elbo=float(hsg.elbo()), het_sgpr_mu=_n(smu), het_sgpr_var=_n(svar), het_sgpr_qu_mu=_n(squ), het_sgpr_qu_cov=_n(sqc),
+               het_sgpr_upper=float(hsg.upper_bound()))   # sgpr.py:85-148 with sigma_n^2 + c per row (:124-131)
     return out
 
 

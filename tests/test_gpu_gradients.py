@@ -734,6 +734,31 @@ def test_sum_and_product_kernels_in_the_reverse_pass(gpu, op):
     sv = gpflow.models.SVGP(kc, gpflow.likelihoods.Gaussian(0.2), Z.copy(), q_mu=q_mu, q_sqrt=q_sqrt, num_latent_gps=P, num_data=5 * N)
     v2, g2 = sv.elbo_and_grad((X, Y))
     assert abs(v2 - float(sv.elbo((X, Y)).cpu())) <= 1e-9 * abs(v2) and ks[1].lengthscales in g2 and sv.inducing_variable.Z in g2
+    # a DIAGONAL q_sqrt under the combination (svgp.py:90-148 with q_diag = True; refused until round 5), whitened and not:
+    # the reverse pass against autograd over the restated model, then the model surface against central differences of its own ELBO
+    qd = 0.4 + 0.2 * np.abs(rng.normal(size=(M, P)))
+    for wh, name, fn in ((True, "svgp", gradients.svgp_elbo_and_grad), (False, "svgp_unwhitened", gradients.svgp_elbo_and_grad_unwhitened)):
+        F, g, info = fn(t(Z), t(X), t(Y), t(q_mu), t(qd), noise_variance=0.2, jitter=1e-6, scale=5.0, kernel_spec=spec)
+        rv, rg = orcg.combination_value_and_grads(name, X, Y, members, op, noise_variance=0.2, Z=Z, q_mu=q_mu, q_sqrt=qd, num_data=5 * N)
+        assert int(info.cpu()[0]) == 0 and abs(float(F.cpu()[0]) - rv) <= 1e-9 * abs(rv)
+        for k in ("variance", "noise_variance", "Z", "q_mu", "q_sqrt"):
+            chk(g[k], rg[k], 1e-7 if not wh else 1e-8)
+        for i in range(3):
+            chk(g["lengthscales"][i], rg["lengthscales"][i], 1e-7 if not wh else 1e-8)
+        sd = gpflow.models.SVGP(kc, gpflow.likelihoods.Gaussian(0.2), Z.copy(), q_mu=q_mu, q_sqrt=qd, q_diag=True, whiten=wh,
+                                num_latent_gps=P, num_data=5 * N)
+        v3, g3 = sd.elbo_and_grad((X, Y))
+        assert abs(v3 - float(sd.elbo((X, Y)).cpu())) <= 1e-9 * abs(v3) and sd.q_sqrt in g3 and ks[0].lengthscales in g3
+        par = sd.q_sqrt
+        u0 = np.array(par.unconstrained_variable, dtype=np.float64, copy=True)
+        vals = []
+        for dlt in (1e-5, -1e-5):
+            u = u0.copy(); u[3, 1] += dlt
+            par.assign_unconstrained(u)
+            vals.append(float(sd.elbo((X, Y)).cpu()))
+        par.assign_unconstrained(u0)
+        fd = (vals[0] - vals[1]) / 2e-5
+        assert abs(float(np.asarray(g3[par])[3, 1]) - fd) <= 2e-5 * max(1.0, abs(fd)), fd
 
 
 @pytest.mark.parametrize("op", ["add", "mul"])

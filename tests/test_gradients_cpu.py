@@ -239,6 +239,76 @@ def test_sgpr_statistics_composition_on_emulated_primitives(monkeypatch):
     assert abs(float(ub) - ref_ub) <= 1e-10 * abs(ref_ub)
 
 
+def test_sgpr_heteroskedastic_statistics_and_upper_bound_on_emulated_primitives(monkeypatch):
+    """One noise variance per data row (Gaussian(scale = Function), sgpr.py:207-211 and :108-145): statistics of two row shards summed
+    by hand, ELBO and upper bound against the oracle -- the bound needs a SECOND pass with noise_rows = sigma_n^2 + c, where c comes
+    from the summed first pass."""
+    import torch
+    import fake_ops
+    from gpflow_amd import gradients
+    from gpflow_amd.models import sgpr
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    monkeypatch.setattr(sgpr, "ops", fake_ops)
+    rng = np.random.default_rng(81)
+    N, M, D = 500, 60, 2
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, 1)); Z = rng.normal(size=(M, D))
+    nv = (0.2 + 0.1 * np.abs(X[:, 0]) + 0.05 * X[:, 1] ** 2)            # sigma_n^2 at the data inputs
+    ls = np.array([0.9, 1.2])
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    kw = dict(variance=1.1, lengthscales=ls, family="SquaredExponential", jitter=1e-6, mean_const=0.2)
+    shards = [(0, 263), (263, 500)]
+    packed = sum(sgpr.shard_statistics(t(Z), t(X[lo:hi]), t(Y[lo:hi]), noise_rows=t(nv[lo:hi]), **kw)[2] for lo, hi in shards)
+    okw = dict(variance=1.1, lengthscales=ls, noise_variance=nv, mean=0.2)
+    elbo = sgpr.elbo_from_statistics(packed, M, 1, N, variance=1.1, noise_variance=None)
+    ref = orc.sgpr_elbo(X, Y, Z, **okw)
+    assert abs(float(elbo) - ref) <= 1e-10 * abs(ref)
+    c_tr = N * 1.1 - float(packed[M * M + M + 4])
+    packed_cn = sum(sgpr.shard_statistics(t(Z), t(X[lo:hi]), t(Y[lo:hi]), noise_rows=t(nv[lo:hi] + c_tr), **kw)[2] for lo, hi in shards)
+    ub = sgpr.upper_bound_heteroskedastic(packed, packed_cn, M, N)
+    ref_ub = orc.sgpr_upper_bound(X, Y, Z, **okw)
+    assert abs(float(ub) - ref_ub) <= 1e-10 * abs(ref_ub)
+    assert ref < ref_ub
+    # a constant noise variance given per row reproduces the constant-noise bound
+    L, invd, pk1 = sgpr.shard_statistics(t(Z), t(X), t(Y), **kw)
+    ub_c = sgpr.upper_bound_from_statistics(pk1, M, N, variance=1.1, noise_variance=0.3)
+    pkh = sgpr.shard_statistics(t(Z), t(X), t(Y), noise_rows=t(np.full(N, 0.3)), **kw)[2]
+    c0 = N * 1.1 - float(pkh[M * M + M + 4])
+    pkc = sgpr.shard_statistics(t(Z), t(X), t(Y), noise_rows=t(np.full(N, 0.3 + c0)), **kw)[2]
+    assert abs(float(sgpr.upper_bound_heteroskedastic(pkh, pkc, M, N)) - float(ub_c)) <= 1e-10 * abs(float(ub_c))
+
+
+@pytest.mark.parametrize("op", ["add", "mul"])
+def test_kernel_combination_with_diagonal_q_sqrt_on_emulated_primitives(monkeypatch, op):
+    """Sum / Product of stationary kernels (kernels/base.py:216-220, 305-315) under an SVGP with q_diag = True (svgp.py:90-148),
+    whitened and un-whitened: value and every gradient of the hand-written reverse pass against autograd over the restated
+    model.  (The covariance spec and the q_diag branches of the reverse pass do not interact; this pins that.)"""
+    import torch
+    import fake_ops
+    from gpflow_amd import gradients
+    monkeypatch.setattr(gradients, "ops", fake_ops)
+    rng = np.random.default_rng(32)
+    N, D, M, P = 120, 3, 30, 2
+    X = rng.normal(size=(N, D)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P))
+    Z = X[:M] + 0.05 * rng.normal(size=(M, D))
+    q_mu = 0.2 * rng.normal(size=(M, P)); q_sqrt = 0.4 + 0.2 * np.abs(rng.normal(size=(M, P)))
+    members = [("SquaredExponential", 1.2, np.array([0.9, 1.1, 1.3])), ("Matern32", 0.7, np.array(0.8))]
+    cols = [[0, 1, 2], [1]] if op == "mul" else None      # (the Product: its second member over one input column)
+    mem = members if cols is None else [members[0], ("Matern32", 0.7, np.array(0.8))]
+    spec = gradients.KernelSpec(mem, op, cols) if cols is not None else gradients.KernelSpec(mem, op)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))  # noqa: E731
+    for name, fn in (("svgp", gradients.svgp_elbo_and_grad), ("svgp_unwhitened", gradients.svgp_elbo_and_grad_unwhitened)):
+        F, g, info = fn(t(Z), t(X), t(Y), t(q_mu), t(q_sqrt), noise_variance=0.2, jitter=1e-6, scale=5.0, kernel_spec=spec)
+        rv, rg = orcg.combination_value_and_grads(name, X, Y, mem, op, noise_variance=0.2, Z=Z, q_mu=q_mu, q_sqrt=q_sqrt,
+                                                  num_data=5 * N, cols=cols)
+        assert int(info[0]) == 0 and abs(float(F[0]) - rv) <= 1e-10 * abs(rv)
+        for k in ("variance", "noise_variance", "Z", "q_mu", "q_sqrt"):
+            ref = np.asarray(rg[k])
+            np.testing.assert_allclose(np.asarray(g[k]).reshape(ref.shape), ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=k)
+        for i in range(2):
+            ref = np.asarray(rg["lengthscales"][i])
+            np.testing.assert_allclose(g["lengthscales"][i].numpy().reshape(ref.shape), ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+
+
 def test_natgrad_update_on_emulated_primitives_and_svgp_vs_sgpr(monkeypatch):
     """(i) the written-out natural-gradient step == the literal restatement of natgrad.py with autograd through the
     parameter conversions; (ii) tests/gpflow/optimizers/test_natural_gradient.py:171 (test_svgp_vs_sgpr): with a Gaussian

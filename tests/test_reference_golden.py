@@ -114,6 +114,8 @@ def test_heteroskedastic_gaussian():
     close(smu, G["het_sgpr_mu"]); close(svar, G["het_sgpr_var"], 1e-11)
     qmu, qcov = orc.sgpr_compute_qu(X, Y, G["het_Z"], **skw)
     close(qmu, G["het_sgpr_qu_mu"], 1e-10); close(qcov, G["het_sgpr_qu_cov"], 1e-10)
+    close(orc.sgpr_upper_bound(X, Y, G["het_Z"], **skw), G["het_sgpr_upper"])   # every row rescaled by its own sigma_n^2 + c
+    assert float(G["het_sgpr_elbo"]) < float(G["het_gpr_lml"]) < float(G["het_sgpr_upper"])
 
 
 def test_gauss_kl():
