@@ -614,15 +614,36 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
                                     mean_const=mean_const)
     F = scale * ve - k * kl
     # ---- backward
-    c = -0.5 * scale / noise_variance
-    r = (scale / noise_variance) * (Yb - fmean - mean_const)
+    # het: one noise variance per row (a heteroskedastic Gaussian likelihood): dF/dfvar is a per-row vector c_b, applied as a row
+    # scaling of the factors the scalar multiplied (same treatment as the whitened pass); the scalar path is unchanged
+    het = torch.is_tensor(noise_variance) and noise_variance.numel() > 1
+    if het:
+        nv = noise_variance.reshape(-1)
+        cvec = (-0.5 * scale) / nv
+        c = None
+        r = (scale / nv)[:, None] * (Yb - fmean - mean_const)
+    else:
+        c = -0.5 * scale / noise_variance
+        r = (scale / noise_variance) * (Yb - fmean - mean_const)
     A2tb = ops.gemm_nt(r, q_mu)
+    Wc = None
     if q_diag:
-        A2tb.addcmul_(A2t, (2.0 * c) * s[None, :])
-    for p in range(0 if q_diag else P):
-        ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=A2tb, b_tri=2)
+        if het:
+            A2tb.addcmul_(A2t * (2.0 * cvec)[:, None], s[None, :])
+        else:
+            A2tb.addcmul_(A2t, (2.0 * c) * s[None, :])
+    elif het:
+        Wc = W * cvec[None, :, None]                                                    # rows of W_p scaled by c_b
+        for p in range(P):
+            ops.gemm_nt(Wc[p], Lq[p], alpha=2.0, beta=1.0, C=A2tb, b_tri=2)
+    else:
+        for p in range(P):
+            ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=A2tb, b_tri=2)
     Atb = ops.gemm_nt(A2tb, Linv, b_tri=2)                                              # A2t_bar Linv^T
-    Atb.add_(At, alpha=-2.0 * c * P)
+    if het:
+        Atb.addcmul_(At, cvec[:, None], value=-2.0 * P)
+    else:
+        Atb.add_(At, alpha=-2.0 * c * P)
     A = ops.transpose(At)
     A2 = ops.transpose(A2t)
     Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)
@@ -631,9 +652,11 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     Kinv_qmu_t = ops.gemm_nt(alphat, LinvT, b_tri=1)                                    # (Linv^T alpha)^T  [P, M]
     g_qmu = splitk_gemm_nt(A2, r.t().contiguous()) - k * Kinv_qmu_t.t()
     if q_diag:   # d/dq_mp = 2c colsum(A2t^2)_m q_mp - k ((Kuu^-1)_mm q_mp - 1 / q_mp)
-        g_qs = (2.0 * c) * ops.row_stats(A2)[0][:, None] * qd - k * (kinv_diag[:, None] * qd - 1.0 / qd)
+        colsq2c = 2.0 * ((A2t * A2t) * cvec[:, None]).sum(0) if het else (2.0 * c) * ops.row_stats(A2)[0]
+        g_qs = colsq2c[:, None] * qd - k * (kinv_diag[:, None] * qd - 1.0 / qd)
     else:
-        g_qs = torch.stack([splitk_gemm_nt(A2, ops.transpose(W[p]), c_lower=True, alpha=2.0 * c) for p in range(P)])
+        Wg, ag = (Wc, 2.0) if het else (W, 2.0 * c)
+        g_qs = torch.stack([splitk_gemm_nt(A2, ops.transpose(Wg[p]), c_lower=True, alpha=ag) for p in range(P)])
         for p in range(P):
             KinvLq = ops.gemm_nt(LinvT, ops.transpose(V[p], mode=1), b_tri=1, a_tri=1)  # Linv^T V_p = Kuu^-1 Lq_p (V_p lower)
             g_qs[p] -= k * torch.tril(KinvLq)
@@ -652,11 +675,17 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
     dv1, dl1, Zb1 = spec.adjoint(Z, Xb, Kuf_bar, symmetric=False)
     dv2, dl2, Zb2 = spec.adjoint(Z, Z, Kuu_bar, symmetric=True)
-    g_var, g_ls = spec.pack([a + b + c * B * P * dk for a, b, dk in zip(dv1, dv2, spec.dkdiag())],
+    csum = cvec.sum() * P if het else c * B * P
+    g_var, g_ls = spec.pack([a + b + csum * dk for a, b, dk in zip(dv1, dv2, spec.dkdiag())],
                             [a + b for a, b in zip(dl1, dl2)])
-    k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
-    Q = 2.0 * noise_variance * (B * P * k0 - ve)
-    g_noise = scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)
-    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise.reshape(1),
+    if het:   # dF/d sigma_n^2 per row (likelihood parameters are reached through Gaussian.noise_param_grads)
+        fvar = (spec.kdiag() - s0)[:, None] + ssq.t()
+        resid = Yb - fmean - mean_const
+        g_noise = scale * (-0.5 * P / nv + 0.5 * (resid * resid + fvar).sum(1) / (nv * nv))
+    else:
+        k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
+        Q = 2.0 * noise_variance * (B * P * k0 - ve)
+        g_noise = (scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)).reshape(1)
+    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise,
              "Z": Zb1 + Zb2, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
     return F, grads, info

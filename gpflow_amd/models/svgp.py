@@ -338,9 +338,9 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         combo = gradient_spec(self.kernel, int(tuple(data[0].shape)[-1])) if sep is None else None   # Sum / Product of stationary kernels
         if combo is not None:
             return self._elbo_and_grad_combination(data, combo)
-        # (a heteroskedastic Gaussian likelihood -- per-row dF/d sigma_n^2 chained through the noise function -- in the whitened
-        #  single-kernel reverse pass, round 5)
-        single = self.gradient_config(allow_active_dims=True, allow_q_diag=True, allow_heteroskedastic=self.whiten) if sep is None else None
+        # (a heteroskedastic Gaussian likelihood -- per-row dF/d sigma_n^2 chained through the noise function -- in the single-kernel
+        #  reverse passes, whitened and un-whitened: round 5)
+        single = self.gradient_config(allow_active_dims=True, allow_q_diag=True, allow_heteroskedastic=True) if sep is None else None
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
         fn = gradients.svgp_elbo_and_grad if self.whiten else gradients.svgp_elbo_and_grad_unwhitened

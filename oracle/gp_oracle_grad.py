@@ -281,7 +281,7 @@ def sgpr_elbo_value_and_grads(X, Y, Z, *, variance, lengthscales, noise_variance
 
 def heteroskedastic_value_and_grads(model, X, Y, *, A, b, variance, lengthscales, Z=None, q_mu=None, q_sqrt=None, num_data=None,
                                     jitter=1e-6, mean=0.0, lower_bound=1e-6):
-    """GPR.log_marginal_likelihood ("gpr") or the whitened SVGP.elbo ("svgp") under Gaussian(scale=Linear(A, b))
+    """GPR.log_marginal_likelihood ("gpr") or SVGP.elbo whitened ("svgp") / un-whitened ("svgp_unwhitened") under Gaussian(scale=Linear(A, b))
     (likelihoods/scalar_continuous.py:52-111: sigma_n^2 = max(x_n A + b, sqrt(lower bound))^2) and their gradients w.r.t. A, b and
     the other parameters, by autograd."""
     t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
@@ -294,7 +294,7 @@ def heteroskedastic_value_and_grads(model, X, Y, *, A, b, variance, lengthscales
         F = gpr_lml_torch(Xt, t(Y), var, ls, nv, t(mean))
     else:
         Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
-        F = svgp_elbo_torch(Xt, t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=t(mean), whiten=True)
+        F = svgp_elbo_torch(Xt, t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=t(mean), whiten=(model == "svgp"))
     F.backward()
     out.update(A=At.grad.numpy().copy(), b=bt.grad.numpy().copy(), variance=float(var.grad), lengthscales=ls.grad.numpy().copy())
     if model != "gpr":

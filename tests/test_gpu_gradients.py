@@ -886,3 +886,15 @@ def test_heteroskedastic_noise_in_the_reverse_pass(gpu, q_diag):
     chk(unc(s, s.kernel.variance, g), rg["variance"]); chk(unc(s, s.kernel.lengthscales, g), rg["lengthscales"])
     if q_diag:
         chk(unc(s, s.q_sqrt, g), rg["q_sqrt"])
+    # the un-whitened SVGP under the same likelihood (refused until the end of round 5): the same per-row dF/d sigma_n^2 through the
+    # A2t = At Lm^-1 chain; 1e-7 like every un-whitened gradient (one more kappa(Lm))
+    su = gpflow.models.SVGP(mk_k(), mk_lik(), Z.copy(), q_mu=q_mu, q_sqrt=qs, q_diag=q_diag, whiten=False, num_data=5 * N)
+    v, g = su.elbo_and_grad((X, Y))
+    rv, rg = orcg.heteroskedastic_value_and_grads("svgp_unwhitened", X, Y, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9], Z=Z,
+                                                  q_mu=q_mu, q_sqrt=qs, num_data=5 * N)
+    assert abs(v - rv) <= 1e-9 * abs(rv) and abs(v - float(su.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+    chk(g[su.likelihood.scale.A], rg["A"], 1e-7); chk(g[su.likelihood.scale.b], rg["b"], 1e-7)
+    chk(g[su.inducing_variable.Z], rg["Z"], 1e-7); chk(g[su.q_mu], rg["q_mu"], 1e-7)
+    chk(unc(su, su.kernel.variance, g), rg["variance"], 1e-7); chk(unc(su, su.kernel.lengthscales, g), rg["lengthscales"], 1e-7)
+    if q_diag:
+        chk(unc(su, su.q_sqrt, g), rg["q_sqrt"], 1e-7)

@@ -98,11 +98,12 @@ def test_ref_heteroskedastic_gaussian(gp):
     np.testing.assert_allclose(float(sg.upper_bound()), float(G["het_sgpr_upper"]), rtol=1e-9)
     with pytest.raises(NotImplementedError):
         sg.objective_and_grad()
-    # gradients through the noise function: GPR and the whitened SVGP have them (tests/test_gpu_gradients.py); the un-whitened
-    # reverse pass still differentiates a constant noise variance and says so
+    # gradients through the noise function: GPR and both SVGP parametrisations have them (tests/test_gpu_gradients.py); here the
+    # un-whitened model's value from the reverse pass agrees with the reference's ELBO
     assert m.likelihood.scale.A in m.log_marginal_likelihood_and_grad()[1]
-    with pytest.raises(NotImplementedError):
-        s.elbo_and_grad((X, Y))
+    vu, gu = s.elbo_and_grad((X, Y))
+    np.testing.assert_allclose(vu, float(G["het_svgp_elbo_unwhite"]), rtol=1e-9)
+    assert s.likelihood.scale.A in gu and s.likelihood.scale.b in gu
 
 
 def test_ref_gpr(gp):
