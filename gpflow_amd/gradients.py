@@ -466,7 +466,18 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     M, D = Z.shape
     n, P = Y.shape
     dev = Z.device
-    s2 = float(noise_variance)
+    # het: `noise_variance` a tensor [n] of one sigma_n^2 per row of THIS shard (a heteroskedastic Gaussian likelihood, sgpr.py:207-211).
+    # With w_n = 1 / sigma_n^2 the statistics become S = At^T W At, a = At^T W err, e2 = sum w err^2, q = sum w |At_n|^2 and the bound is
+    # the constant-noise one with s2 = 1 plus -P/2 (sum log sigma_n^2 + var sum w_n); At_bar and d/dmean pick up w_n per row, and
+    #     dF/dw_n = (a_n^T (2 S_bar + 2 q_bar I) a_n) / 2 + sum_p (a_n . a_bar_p) err_np - sum_p err_np^2 / 2 - P var / 2,
+    #     dF/dsigma_n^2 = -w_n^2 dF/dw_n - P w_n / 2        (one entry per row; grads["noise_variance"] is then [n], local to the shard)
+    het = torch.is_tensor(noise_variance) and noise_variance.numel() > 1
+    if het:
+        wn = (1.0 / noise_variance.reshape(-1)).contiguous()
+        swn = torch.sqrt(wn)
+        s2 = 1.0
+    else:
+        s2 = float(noise_variance)
     N = int(num_data) if num_data is not None else n
     if not sharded and N != n:
         raise ValueError("num_data differs from the number of rows of a model that is not sharded")
@@ -491,24 +502,31 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     _, info = ops.potrf_(T, M, zero_upper=True, identity_rows=True)
     L, At, LinvT = T[:M], T[M:M + n], T[M + n:]
     err = (Y - mean_const).contiguous()
-    stats = torch.zeros(M * M + M * P + 2, dtype=torch.float64, device=dev)
+    stats = torch.zeros(M * M + M * P + 4, dtype=torch.float64, device=dev)
     if n:
         A = ops.transpose(At)                                                           # [M, n]
-        stats[:M * M] = torch.tril(splitk_gemm_nt(A, A, c_lower=True)).reshape(-1)
-        stats[M * M:M * M + M * P] = splitk_gemm_nt(A, err.t().contiguous()).reshape(-1)
-        stats[-2], stats[-1] = ops.sumsq(err)[0], ops.sumsq(At)[0]
-    all_reduce(stats)                                                                   # ---- exchange 1: S, a, e2, q
+        if het:   # rows scaled by 1 / sigma_n (elementwise glue on [n, M] / [n, P])
+            Aw = ops.transpose((At * swn[:, None]).contiguous())
+            errw = (err * swn[:, None]).contiguous()
+            stats[-4], stats[-3] = -torch.log(wn).sum(), wn.sum()                      # sum log sigma_n^2, sum 1 / sigma_n^2
+        else:
+            Aw, errw = A, err
+        stats[:M * M] = torch.tril(splitk_gemm_nt(Aw, Aw, c_lower=True)).reshape(-1)
+        stats[M * M:M * M + M * P] = splitk_gemm_nt(Aw, errw.t().contiguous()).reshape(-1)
+        stats[-2], stats[-1] = ops.sumsq(errw)[0], (ops.sumsq(Aw)[0] if het else ops.sumsq(At)[0])
+    all_reduce(stats)                                                                   # ---- exchange 1: S, a, e2, q (+ the two noise sums)
     Slow = stats[:M * M].reshape(M, M)
     S = Slow + torch.tril(Slow, -1).t()
     a = stats[M * M:M * M + M * P].reshape(M, P)
     e2, q = stats[-2], stats[-1]
+    sum_log_s2, sum_w = (stats[-4], stats[-3]) if het else (N * float(np.log(s2)), N / s2)
     T2 = torch.empty((2 * M + P, M), dtype=torch.float64, device=dev)
     T2[:M] = S / s2 + eye
     T2[M:M + P] = a.t() / s2
     _, info2 = ops.potrf_(T2, M, zero_upper=True, identity_rows=True)
     LB, ct, LBinvT = T2[:M], T2[M:M + P], T2[M + P:]
     half_logdet_b = ops.sum_log_diag(LB)[0]
-    F = (-0.5 * N * P * LOG2PI - P * (half_logdet_b + 0.5 * N * float(np.log(s2)) + 0.5 * (N * kdiag - q) / s2)
+    F = (-0.5 * N * P * LOG2PI - P * (half_logdet_b + 0.5 * sum_log_s2 + 0.5 * (kdiag * sum_w - q / s2))
          - 0.5 * (e2 / s2 - ops.sumsq(ct)[0]))
     # ---- backward: the M x M tail (replicated)
     Binv = ops.gemm_nt(LBinvT, LBinvT, b_tri=1, a_tri=1)                                # B^-1 = LB^-T LB^-1
@@ -523,9 +541,17 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     nl_tot = sum(nlsm)
     part = torch.zeros(M * M + nmem + nl_tot + M * D + 1, dtype=torch.float64, device=dev)
     o = M * M
+    g_noise_rows = None
     if n:
         Atb = ops.gemm_nt(err, abar)                                                    # err a_bar^T  [n, M]
-        ops.gemm_nt(At, Ssym, alpha=1.0, beta=1.0, C=Atb)                               # + At (2 S_bar + 2 q_bar I)
+        if het:
+            G = ops.gemm_nt(At, Ssym)                                                   # At (2 S_bar + 2 q_bar I)
+            Au = ops.gemm_nt(At, abar.t().contiguous())                                 # (a_n . a_bar_p)  [n, P]
+            dF_dw = 0.5 * (G * At).sum(1) + (Au * err).sum(1) - 0.5 * (err * err).sum(1) - 0.5 * P * kdiag
+            g_noise_rows = -(wn * wn) * dF_dw - 0.5 * P * wn
+            Atb = (Atb + G) * wn[:, None]
+        else:
+            ops.gemm_nt(At, Ssym, alpha=1.0, beta=1.0, C=Atb)                           # + At (2 S_bar + 2 q_bar I)
         Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)
         Kuf_bar = ops.transpose(Kfu_bar)
         part[:M * M] = torch.tril(splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)).reshape(-1)
@@ -533,7 +559,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
         part[o:o + nmem] = torch.cat(dv1)
         part[o + nmem:o + nmem + nl_tot] = torch.cat([d.reshape(-1) for d in dl1])
         part[o + nmem + nl_tot:o + nmem + nl_tot + M * D] = Zb1.reshape(-1)
-        part[-1] = (err / s2 - ops.gemm_nt(At, abar.t().contiguous())).sum()
+        part[-1] = ((err - Au) * wn[:, None]).sum() if het else (err / s2 - ops.gemm_nt(At, abar.t().contiguous())).sum()
     all_reduce(part)                                                                    # ---- exchange 2: the shards' sums
     Lbar = part[:o].reshape(M, M)
     dv1 = [part[o + i].reshape(1) for i in range(nmem)]
@@ -542,13 +568,16 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     Zb1, g_mean = part[o + nmem + nl_tot:o + nmem + nl_tot + M * D].reshape(M, D), part[-1]
     Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
     dv2, dl2, Zb2 = spec.adjoint(Z, Z, Kuu_bar, symmetric=True)
-    g_var, g_ls = spec.pack([a + b - 0.5 * P * N / s2 * dk for a, b, dk in zip(dv1, dv2, spec.dkdiag())],
+    g_var, g_ls = spec.pack([a + b - 0.5 * P * sum_w * dk for a, b, dk in zip(dv1, dv2, spec.dkdiag())],
                             [a + b for a, b in zip(dl1, dl2)])
-    wa, ww = (w * a).sum(), (w * w).sum()
-    g_noise = (-P * (-0.5 * (M - torch.diagonal(Binv).sum()) / s2 + 0.5 * N / s2 - 0.5 * (N * kdiag - q) / s2 ** 2)
-               + 0.5 * e2 / s2 ** 2 - 0.5 * wa / s2 ** 2 - 0.5 * ww / s2)
+    if het:
+        g_noise = g_noise_rows if g_noise_rows is not None else torch.zeros(0, dtype=torch.float64, device=dev)
+    else:
+        wa, ww = (w * a).sum(), (w * w).sum()
+        g_noise = (-P * (-0.5 * (M - torch.diagonal(Binv).sum()) / s2 + 0.5 * N / s2 - 0.5 * (N * kdiag - q) / s2 ** 2)
+                   + 0.5 * e2 / s2 ** 2 - 0.5 * wa / s2 ** 2 - 0.5 * ww / s2).reshape(1)
     status = torch.maximum(info, info2)
-    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise.reshape(1), "Z": Zb1 + Zb2,
+    grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise, "Z": Zb1 + Zb2,
              "mean_const": g_mean.reshape(1)}
     return F.reshape(1), grads, status
 

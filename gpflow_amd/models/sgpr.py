@@ -239,8 +239,24 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
         from .svgp import SVGP
         from ..kernels.base import Combination, gradient_spec
         kw, Xc, Zc, c, s2 = self._config()
-        if s2 is None or not self.likelihood.has_variance_parameter:
-            raise NotImplementedError("gradients: the reverse pass takes a constant noise variance held as a `variance` Parameter")
+        het = s2 is None
+        if not het and not self.likelihood.has_variance_parameter:
+            raise NotImplementedError("gradients: the reverse pass takes a noise variance held as a `variance` Parameter, or a noise "
+                                      "Function of the inputs")
+        if het:   # one sigma_n^2 per row of this (shard of the) data; dF/d sigma_n^2 comes back per row (gradients.sgpr_elbo_and_grad)
+            s2 = self._noise_rows().reshape(-1).contiguous()
+
+        def noise_pairs(g_noise):
+            if not het:
+                return [(self.likelihood.variance, g_noise.cpu().numpy())]
+            out_ = []
+            for par, gv in self.likelihood.noise_param_grads(self.data[0], g_noise):   # chain rule through the noise function: this shard's rows
+                gv = gv.contiguous()
+                if self.sharded:
+                    import torch.distributed as dist
+                    dist.all_reduce(gv, op=dist.ReduceOp.SUM, group=self.group)
+                out_.append((par, gv.cpu().numpy()))
+            return out_
         if isinstance(self.kernel, Combination):
             # a Sum / Product of stationary kernels (members possibly over different active_dims): the members' adjoints one by one
             spec, members = gradient_spec(self.kernel, self.data[0].shape[1])
@@ -249,11 +265,11 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
                                                       num_data=self.num_data, kernel_spec=spec)
             ops.check_info(info)
             gv = g["variance"].cpu().numpy()
-            host = {n: t.cpu().numpy() for n, t in g.items() if n not in ("variance", "lengthscales")}
+            host = {n: t.cpu().numpy() for n, t in g.items() if n not in ("variance", "lengthscales", "noise_variance")}
             pairs = []
             for i, (pv, pl) in enumerate(members):
                 pairs += [(pv, gv[i]), (pl, g["lengthscales"][i].cpu().numpy())]
-            pairs += [(self.likelihood.variance, host["noise_variance"]), (self.inducing_variable.Z, host["Z"])]
+            pairs += noise_pairs(g["noise_variance"]) + [(self.inducing_variable.Z, host["Z"])]
         else:
             if not (isinstance(self.kernel, IsotropicStationary) and self.kernel.family in ops.KERNEL_FAMILIES):
                 raise NotImplementedError("gradients: SquaredExponential / Matern kernel")
@@ -263,9 +279,9 @@ class SGPR(GPModel, InternalDataTrainingLossMixin):
                                                       mean_const=c, sharded=self.sharded, group=self.group,
                                                       num_data=self.num_data, variance=var, lengthscales=ls, family=family)
             ops.check_info(info)
-            host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items()}
+            host = {n: (scatter(t) if n == "Z" else t).cpu().numpy() for n, t in g.items() if n != "noise_variance"}
             pairs = [(self.kernel.variance, host["variance"]), (self.kernel.lengthscales, host["lengthscales"]),
-                     (self.likelihood.variance, host["noise_variance"]), (self.inducing_variable.Z, host["Z"])]
+                     (self.inducing_variable.Z, host["Z"])] + noise_pairs(g["noise_variance"])
         if isinstance(self.mean_function, Constant) and hasattr(self.mean_function, "c"):
             pairs.append((self.mean_function.c, host["mean_const"]))
         out = {}

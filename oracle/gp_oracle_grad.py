@@ -245,11 +245,12 @@ def natgrad_step(q_mu, q_sqrt, g_mu, g_sqrt, gamma, xi_transform="XiNat"):
 # ----------------------------------------------------------------------------- SGPR gradients (SURVEY 8f rows 1 + 3)
 def sgpr_elbo_torch(X, Y, Z, variance, lengthscales, noise_variance, *, jitter=1e-6, mean=0.0,
                     family="SquaredExponential", kfun=None, kdiag=None):
-    """SGPR.elbo (gpflow/models/sgpr.py:181-290) on torch fp64 tensors, constant noise variance.  kfun / kdiag: a kernel
-    combination (combination_kernel) instead of the single stationary kernel."""
+    """SGPR.elbo (gpflow/models/sgpr.py:181-290) on torch fp64 tensors; noise_variance a scalar or one value per data row [N]
+    (likelihood.variance_at(X), :207).  kfun / kdiag: a kernel combination (combination_kernel) instead of the single stationary kernel."""
     N, P = Y.shape
     M = Z.shape[0]
-    sigma = torch.sqrt(noise_variance)
+    nvr = noise_variance.reshape(-1).expand(N) if noise_variance.numel() in (1, N) else noise_variance
+    sigma = torch.sqrt(nvr)
     if kfun is None:
         kfun = lambda A_, B_: _rbf(A_, B_, variance, lengthscales, family)  # noqa: E731
     else:
@@ -260,9 +261,9 @@ def sgpr_elbo_torch(X, Y, Z, variance, lengthscales, noise_variance, *, jitter=1
     A = torch.linalg.solve_triangular(L, kuf / sigma, upper=False)
     AAT = A @ A.T
     LB = torch.linalg.cholesky(AAT + torch.eye(M, dtype=torch.float64))
-    trace = N * variance / noise_variance - torch.trace(AAT)
-    logdet = -P * (torch.log(torch.diagonal(LB)).sum() + 0.5 * N * torch.log(noise_variance) + 0.5 * trace)
-    err = (Y - mean) / sigma
+    trace = (variance / nvr).sum() - torch.trace(AAT)                                            # :236-242
+    logdet = -P * (torch.log(torch.diagonal(LB)).sum() + 0.5 * torch.log(nvr).sum() + 0.5 * trace)   # :245-251
+    err = (Y - mean) / sigma[:, None]
     c = torch.linalg.solve_triangular(LB, A @ err, upper=False)
     quad = -0.5 * ((err * err).sum() - (c * c).sum())
     return -0.5 * N * P * LOG2PI + logdet + quad
@@ -281,7 +282,7 @@ def sgpr_elbo_value_and_grads(X, Y, Z, *, variance, lengthscales, noise_variance
 
 def heteroskedastic_value_and_grads(model, X, Y, *, A, b, variance, lengthscales, Z=None, q_mu=None, q_sqrt=None, num_data=None,
                                     jitter=1e-6, mean=0.0, lower_bound=1e-6):
-    """GPR.log_marginal_likelihood ("gpr") or SVGP.elbo whitened ("svgp") / un-whitened ("svgp_unwhitened") under Gaussian(scale=Linear(A, b))
+    """GPR.log_marginal_likelihood ("gpr"), SGPR.elbo ("sgpr") or SVGP.elbo whitened ("svgp") / un-whitened ("svgp_unwhitened") under Gaussian(scale=Linear(A, b))
     (likelihoods/scalar_continuous.py:52-111: sigma_n^2 = max(x_n A + b, sqrt(lower bound))^2) and their gradients w.r.t. A, b and
     the other parameters, by autograd."""
     t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
@@ -292,11 +293,16 @@ def heteroskedastic_value_and_grads(model, X, Y, *, A, b, variance, lengthscales
     out = {}
     if model == "gpr":
         F = gpr_lml_torch(Xt, t(Y), var, ls, nv, t(mean))
+    elif model == "sgpr":
+        Zt = t(Z, True)
+        F = sgpr_elbo_torch(Xt, t(Y), Zt, var, ls, nv, jitter=jitter, mean=t(mean))
     else:
         Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
         F = svgp_elbo_torch(Xt, t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=t(mean), whiten=(model == "svgp"))
     F.backward()
     out.update(A=At.grad.numpy().copy(), b=bt.grad.numpy().copy(), variance=float(var.grad), lengthscales=ls.grad.numpy().copy())
-    if model != "gpr":
+    if model == "sgpr":
+        out.update(Z=Zt.grad.numpy().copy())
+    elif model != "gpr":
         out.update(Z=Zt.grad.numpy().copy(), q_mu=qm.grad.numpy().copy(), q_sqrt=qs.grad.numpy().copy())
     return float(F.detach()), out

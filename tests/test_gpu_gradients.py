@@ -898,3 +898,14 @@ def test_heteroskedastic_noise_in_the_reverse_pass(gpu, q_diag):
     chk(unc(su, su.kernel.variance, g), rg["variance"], 1e-7); chk(unc(su, su.kernel.lengthscales, g), rg["lengthscales"], 1e-7)
     if q_diag:
         chk(unc(su, su.q_sqrt, g), rg["q_sqrt"], 1e-7)
+    else:
+        # SGPR under the same likelihood (sgpr.py:207-211 with one sigma_n per row): dF/d sigma_n^2 per row from the reverse pass
+        sgm = gpflow.models.SGPR((X, Y), mk_k(), Z.copy(), likelihood=mk_lik())
+        v, g = sgm.objective_and_grad()
+        rv, rg = orcg.heteroskedastic_value_and_grads("sgpr", X, Y, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9], Z=Z)
+        assert abs(v - rv) <= 1e-9 * abs(rv) and abs(v - float(sgm.elbo().cpu())) <= 1e-9 * abs(v)
+        chk(g[sgm.likelihood.scale.A], rg["A"], 1e-7); chk(g[sgm.likelihood.scale.b], rg["b"], 1e-7)
+        chk(g[sgm.inducing_variable.Z], rg["Z"], 1e-7)
+        chk(unc(sgm, sgm.kernel.variance, g), rg["variance"], 1e-7); chk(unc(sgm, sgm.kernel.lengthscales, g), rg["lengthscales"], 1e-7)
+        res = gpflow.optimizers.Scipy().minimize(sgm, options=dict(maxiter=40))
+        assert -res.fun > v + 1.0

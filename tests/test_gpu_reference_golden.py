@@ -96,8 +96,9 @@ def test_ref_heteroskedastic_gaussian(gp):
     close(qmu, G["het_sgpr_qu_mu"], 1e-7); close(qcov, G["het_sgpr_qu_cov"], 1e-7)
     # the upper bound rescales every row by its own sigma_n^2 + c (sgpr.py:124-131): a second statistics pass
     np.testing.assert_allclose(float(sg.upper_bound()), float(G["het_sgpr_upper"]), rtol=1e-9)
-    with pytest.raises(NotImplementedError):
-        sg.objective_and_grad()
+    vs, gs = sg.objective_and_grad()          # (gradients through the noise function under SGPR: end of round 5)
+    np.testing.assert_allclose(vs, float(G["het_sgpr_elbo"]), rtol=1e-9)
+    assert sg.likelihood.scale.A in gs and sg.inducing_variable.Z in gs
     # gradients through the noise function: GPR and both SVGP parametrisations have them (tests/test_gpu_gradients.py); here the
     # un-whitened model's value from the reverse pass agrees with the reference's ELBO
     assert m.likelihood.scale.A in m.log_marginal_likelihood_and_grad()[1]
