@@ -203,6 +203,24 @@ def _sgpr_grad_worker(rank, world, port, q):
                 ref = np.ravel(rg[name]) * np.ravel(par.transform.forward_grad(u))
                 errs[name] = float(np.abs(np.ravel(g[par]) - ref).max() / max(1.0, np.abs(ref).max()))
             out.append((family, v, errs))
+        # a heteroskedastic likelihood on the row-sharded model: dF/d sigma_n^2 stays with the rows of the shard, the noise function's
+        # parameter gradients are summed over the ranks; the upper bound's second statistics pass needs the GLOBAL c of the first
+        from oracle import gp_oracle as orc
+        Xp = rng.random((N, 2)); Yp = np.sin(5 * Xp[:, :1]) + (0.7 - 0.5 * Xp[:, :1]) * rng.standard_normal((N, 1)); Zp = Xp[:M].copy()
+        A0, b0 = np.array([[-0.3], [0.05]]), np.array([0.6])
+        lo, hi = shard_bounds(N, world, rank)
+        mh = gpflow.models.SGPR((Xp[lo:hi], Yp[lo:hi]), gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.25, 0.9]), Zp.copy(),
+                                likelihood=gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=A0.copy(), b=b0.copy())), sharded=True)
+        v, g = mh.objective_and_grad()
+        rv, rg = orcg.heteroskedastic_value_and_grads("sgpr", Xp, Yp, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9], Z=Zp)
+        nv = np.maximum(Xp @ A0 + b0, 1e-3)[:, 0] ** 2
+        ub = float(mh.upper_bound())
+        rub = orc.sgpr_upper_bound(Xp, Yp, Zp, variance=1.1, lengthscales=np.array([0.25, 0.9]), noise_variance=nv)
+        errs = {"value": abs(v - rv) / abs(rv), "upper": abs(ub - rub) / abs(rub),
+                "A": float(np.abs(np.asarray(g[mh.likelihood.scale.A]).reshape(rg["A"].shape) - rg["A"]).max() / max(1.0, np.abs(rg["A"]).max())),
+                "b": float(np.abs(np.ravel(g[mh.likelihood.scale.b]) - np.ravel(rg["b"])).max() / max(1.0, np.abs(rg["b"]).max())),
+                "Z": float(np.abs(np.asarray(g[mh.inducing_variable.Z]) - rg["Z"]).max() / np.abs(rg["Z"]).max())}
+        out.append(("heteroskedastic", v, errs))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
