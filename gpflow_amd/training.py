@@ -46,7 +46,7 @@ class _Adam:
 
 class SVGPTrainer:
     """Adam on -ELBO for `model` (SVGP: whitened or un-whitened, full or diagonal q_sqrt, SquaredExponential / Matern kernel with
-    or without `active_dims`, Gaussian likelihood with a constant variance, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
+    or without `active_dims`, Gaussian likelihood with a constant variance or a noise Function of the inputs, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
     `Constant.c`).  A step whose Kuu factorisation fails raises and leaves variables and Adam moments untouched.
 
         trainer = SVGPTrainer(model, learning_rate=1e-3)
@@ -61,7 +61,7 @@ class SVGPTrainer:
         (optimizers/natgrad.py; natgrad.natgrad_update on the device) and Adam handles the remaining parameters -- the
         hybrid recipe of the reference's natural-gradient notebook, from ONE gradient evaluation per step."""
         # NotImplementedError outside the scope of the reverse pass
-        k, iv, c = model.gradient_config(allow_active_dims=True, allow_q_diag=True)
+        k, iv, c = model.gradient_config(allow_active_dims=True, allow_q_diag=True, allow_heteroskedastic=True)
         lik = model.likelihood
         self.kernel = k
         self.q_diag = model.q_sqrt.numpy().ndim == 2
@@ -76,7 +76,19 @@ class SVGPTrainer:
         self.family = k.family
         self.opt = _Adam(learning_rate, beta_1, beta_2, epsilon)
         # host side: unconstrained scalars (their constrained values are host arguments of the C-ABI)
-        self.host = {"variance": k.variance, "lengthscales": k.lengthscales, "noise_variance": lik.variance}
+        self.host = {"variance": k.variance, "lengthscales": k.lengthscales}
+        # noise: a constant variance, or (a heteroskedastic Gaussian likelihood, likelihoods/scalar_continuous.py:52-111) the Parameters of
+        # the noise Function -- they stay on the host like the other hyper-parameters; sigma_n^2 at the minibatch rows is formed on the
+        # device every step and dF/d sigma_n^2 comes back per row, chained through the Function there (Gaussian.noise_param_grads)
+        self.het = lik.is_heteroskedastic
+        self.noise_pars = []
+        if self.het:
+            fn = lik.variance if lik.variance is not None else lik.scale       # (is_heteroskedastic: a Function)
+            self.noise_pars = list(fn.parameters)
+            for i, p in enumerate(self.noise_pars):
+                self.host[f"noise_fn_{i}"] = p
+        else:
+            self.host["noise_variance"] = lik.variance
         from .mean_functions import Constant
         mf = model.mean_function
         if isinstance(mf, Constant) and hasattr(mf, "c"):   # (Zero is a Constant without a parameter, functions.py:195-204)
@@ -146,7 +158,12 @@ class SVGPTrainer:
         scale = 1.0 if self.model.num_data is None else float(self.model.num_data) / float(rows)
         var = float(self.constrained("variance"))
         ls = self.constrained("lengthscales")
-        noise = float(self.constrained("noise_variance"))
+        if self.het:
+            for i, p in enumerate(self.noise_pars):              # the Function reads its Parameters: the trainer's current values
+                p.assign_unconstrained(self.u[f"noise_fn_{i}"])
+            noise = self.model.likelihood.noise_for(Xb)          # sigma_n^2 at the rows of this (shard of the) minibatch  [B]
+        else:
+            noise = float(self.constrained("noise_variance"))
         if "mean_const" in self.host:
             self.mean_const = float(np.ravel(self.constrained("mean_const"))[0])
         fn = gradients.svgp_elbo_and_grad if self.model.whiten else gradients.svgp_elbo_and_grad_unwhitened
@@ -158,6 +175,15 @@ class SVGPTrainer:
             noise_variance=noise, jitter=config.default_jitter(), scale=scale, mean_const=self.mean_const,
             kl_weight=1.0 / world, family=self.family)
         g = dict(g)
+        if self.het:
+            # per-row dF/d sigma_n^2 -> the noise Function's parameters (this shard's rows; summed over the ranks below)
+            rows_g = g.pop("noise_variance")
+            acc = {}
+            for par, gv in self.model.likelihood.noise_param_grads(Xb, rows_g):
+                acc[id(par)] = acc[id(par)] + gv if id(par) in acc else gv
+            for i, p in enumerate(self.noise_pars):
+                g[f"noise_fn_{i}"] = acc[id(p)].reshape(-1).contiguous() if id(p) in acc else \
+                    torch.zeros(int(np.size(self.u[f"noise_fn_{i}"])), dtype=torch.float64, device=Xb.device)
         g["Z"] = scatter(g["Z"])
         if self.q_diag:
             g["q_sqrt"] = g["q_sqrt"] * torch.sigmoid(self.dev["q_sqrt"])      # d softplus(u) / du
@@ -168,9 +194,10 @@ class SVGPTrainer:
         # reference raises from tf.linalg.cholesky at this point).  It rides in the step's one read-back and, with
         # several ranks, in the packed gradient all-reduce (summed), so every rank takes the same decision.
         status = g.pop("_status")
-        small = torch.cat([g["variance"].reshape(-1), g["lengthscales"].reshape(-1), g["noise_variance"].reshape(-1),
-                           g["mean_const"].reshape(-1)[:1], status])
-        small = small.cpu().numpy()                              # the step's one read-back: 4 + |lengthscales| doubles
+        hnames = list(self.host)                                 # variance, lengthscales, noise (constant or Function parameters), [mean]
+        hsizes = [1 if n == "mean_const" else int(g[n].numel()) for n in hnames]
+        small = torch.cat([g[n].reshape(-1)[:sz] for n, sz in zip(hnames, hsizes)] + [status])
+        small = small.cpu().numpy()                              # the step's one read-back: 4 + |lengthscales| doubles (+ the noise Function's)
         self.last_info = int(small[-1])
         if self.last_info != 0:
             from ._lib import GpkError
@@ -201,8 +228,8 @@ class SVGPTrainer:
         for name in adam_names:                                  # minimise -F
             if self.dev_params[name].trainable:
                 self.opt.update_device(name, self.dev[name], -g[name])
-        parts = {"variance": small[0:1], "lengthscales": small[1:-3], "noise_variance": small[-3:-2],
-                 "mean_const": small[-2:-1]}
+        offs = np.concatenate([[0], np.cumsum(hsizes)])
+        parts = {n: small[offs[i]:offs[i + 1]] for i, n in enumerate(hnames)}
         for name, p in self.host.items():
             if not p.trainable:
                 continue

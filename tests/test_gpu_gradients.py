@@ -909,3 +909,22 @@ def test_heteroskedastic_noise_in_the_reverse_pass(gpu, q_diag):
         chk(unc(sgm, sgm.kernel.variance, g), rg["variance"], 1e-7); chk(unc(sgm, sgm.kernel.lengthscales, g), rg["lengthscales"], 1e-7)
         res = gpflow.optimizers.Scipy().minimize(sgm, options=dict(maxiter=40))
         assert -res.fun > v + 1.0
+    # the device-resident trainer under the same likelihood: the noise Function's Parameters are host-side hyper-parameters, sigma_n^2 at
+    # the minibatch rows is formed on the device every step.  Its first objective is elbo_and_grad's, its first Adam step moves every
+    # noise parameter by the learning rate along the gradient (m / sqrt(v) = sign(g) at t = 1), and it improves the bound.
+    from gpflow_amd import training
+    for wh in (True, False):
+        mt = gpflow.models.SVGP(mk_k(), mk_lik(), Z.copy(), q_mu=q_mu, q_sqrt=qs, q_diag=q_diag, whiten=wh, num_data=5 * N)
+        v0, g0 = mt.elbo_and_grad((X, Y))
+        pars = list(mt.likelihood.scale.parameters)
+        u_before = [np.array(p.unconstrained_variable, dtype=np.float64, copy=True) for p in pars]
+        tr = training.SVGPTrainer(mt, learning_rate=1e-2)
+        f0 = float(tr.step((X, Y)).cpu()[0])
+        assert abs(f0 - v0) <= 1e-9 * abs(v0)
+        for i, p in enumerate(pars):
+            du = tr.u[f"noise_fn_{i}"] - u_before[i]
+            np.testing.assert_allclose(du, 1e-2 * np.sign(np.asarray(g0[p]).reshape(du.shape)), rtol=0, atol=1e-6)
+        fs = [float(tr.step((X, Y)).cpu()[0]) for _ in range(20)]
+        assert fs[-1] > f0
+        tr.sync_to_model()
+        assert abs(float(mt.elbo((X, Y)).cpu()) - float(tr.step((X, Y)).cpu()[0])) <= 1e-8 * abs(fs[-1])
