@@ -164,8 +164,8 @@ se_kernel_adjoint = stationary_kernel_adjoint   # (the name of rounds 1-2)
 
 
 class KernelSpec:
-    """What the reverse pass needs to know about the covariance function: ONE stationary kernel, or a flat Sum / Product of
-    stationary kernels over the same input columns (gpflow/kernels/base.py:216-220 `Sum`, :305-315 `Product`; the reference
+    """What the reverse pass needs to know about the covariance function: ONE stationary kernel, or a Sum / Product of
+    stationary kernels -- flat, or nested (a Product of Sums, ...: `op` a tree, see __init__) -- over the same or different input columns (gpflow/kernels/base.py:216-220 `Sum`, :305-315 `Product`; the reference
     differentiates `tf.add_n` / `tf.multiply` of the member matrices with autodiff).  members: [(family, variance,
     lengthscales)], op: None | "add" | "mul".
 
@@ -179,8 +179,15 @@ class KernelSpec:
         list, kernels/base.py:90-109) or None for all of them.  Members that see different columns are built and differentiated on
         their own column slices; their input gradients are scattered back into the full columns and add up."""
         self.members = [(f, float(v), np.asarray(ls, dtype=np.float64)) for f, v, ls in members]
+        # op: "add" | "mul" for a flat combination of all members, or a TREE for nested ones (a Product of Sums, ...):
+        # (op, [children]) with a child either a member index or another such pair -- e.g. ("mul", [("add", [0, 1]), 2]) is
+        # (k0 + k1) * k2 (kernels/base.py:223-329: a Combination holds kernels, which may be Combinations of the other kind)
+        self.tree = None
+        if isinstance(op, (tuple, list)):
+            self.tree = self._check_tree(op, len(self.members))
+            op = None
         self.op = op if len(self.members) > 1 else None
-        if len(self.members) > 1 and op not in ("add", "mul"):
+        if self.tree is None and len(self.members) > 1 and op not in ("add", "mul"):
             raise ValueError("a kernel combination needs op 'add' or 'mul'")
         cols = [None] * len(self.members) if cols is None else list(cols)
         if len(cols) != len(self.members):
@@ -191,6 +198,85 @@ class KernelSpec:
     @staticmethod
     def single(variance, lengthscales, family="SquaredExponential"):
         return KernelSpec([(family, variance, lengthscales)], None)
+
+    @staticmethod
+    def _check_tree(node, n):
+        seen = []
+
+        def walk(nd):
+            if isinstance(nd, (int, np.integer)):
+                seen.append(int(nd))
+                return int(nd)
+            op, ch = nd
+            if op not in ("add", "mul") or len(ch) < 1:
+                raise ValueError("a combination node is ('add' | 'mul', [children])")
+            return (op, [walk(c) for c in ch])
+        out = walk(node)
+        if sorted(seen) != list(range(n)):
+            raise ValueError("every member must appear exactly once in the combination tree")
+        return out
+
+    # ---- nested combinations: the same three operations, recursively over the tree -----------------------------------
+    def _build_node(self, node, X1, X2, out):
+        if isinstance(node, int):
+            f, v, ls = self.members[node]
+            return ops.kernel_matrix(self._sl(node, X1), self._sl(node, X2), variance=v, lengthscales=ls, family=f, diag_add=0.0,
+                                     lower_only=False, out=out)
+        op, ch = node
+        out = self._build_node(ch[0], X1, X2, out)
+        for c in ch[1:]:
+            if isinstance(c, int):      # a stationary member folds in place (K recomputed in registers, no second matrix)
+                f, v, ls = self.members[c]
+                ops.kernel_matrix_combine(self._sl(c, X1), self._sl(c, X2), out, op=op, variance=v, lengthscales=ls, family=f,
+                                          diag_add=0.0, out=out)
+            else:                        # a sub-combination needs its own matrix once
+                tmp = self._build_node(c, X1, X2, None)
+                out.add_(tmp) if op == "add" else out.mul_(tmp)
+        return out
+
+    def _kd_node(self, node) -> float:
+        if isinstance(node, int):
+            return self.members[node][1]
+        vals = [self._kd_node(c) for c in node[1]]
+        return float(np.prod(vals)) if node[0] == "mul" else float(np.sum(vals))
+
+    def _dkd_node(self, node) -> dict:
+        if isinstance(node, int):
+            return {node: 1.0}
+        op, ch = node
+        out = {}
+        kds = [self._kd_node(c) for c in ch]
+        for ci, c in enumerate(ch):
+            fac = float(np.prod([k for j, k in enumerate(kds) if j != ci])) if op == "mul" else 1.0
+            for i, d in self._dkd_node(c).items():
+                out[i] = fac * d
+        return out
+
+    def _adjoint_node(self, node, A, Bm, Kbar, symmetric, acc):
+        if isinstance(node, int):
+            f, v, ls = self.members[node]
+            Ai = self._sl(node, A)
+            Bi = Ai if (symmetric and Bm is A) else self._sl(node, Bm)
+            dv, dl, Ab = stationary_kernel_adjoint(Ai, Bi, Kbar, symmetric=symmetric, variance=v, lengthscales=ls, family=f)
+            if np.ndim(ls) == 0 or np.size(ls) == 1:
+                dl = dl.sum().reshape(1)
+            acc[node] = (dv.reshape(1), dl, Ab)
+            return
+        op, ch = node
+        for c in ch:
+            Kb = Kbar
+            if op == "mul":          # d/dK_c = Kbar .* prod of the OTHER children's matrices
+                Kb = Kbar.clone()
+                for o in ch:
+                    if o is c:
+                        continue
+                    if isinstance(o, int):
+                        fo, vo, lo = self.members[o]
+                        ops.kernel_matrix_combine(self._sl(o, A), None if symmetric else self._sl(o, Bm), Kb, op="mul", variance=vo,
+                                                  lengthscales=lo, family=fo, out=Kb)
+                    else:
+                        Kb.mul_(self._build_node(o, A, None if symmetric else Bm, None))
+            self._adjoint_node(c, A, Bm, Kb, symmetric, acc)
 
     @property
     def n(self) -> int:
@@ -206,6 +292,11 @@ class KernelSpec:
         return X.index_select(1, self._idx[key]).contiguous()
 
     def build(self, X1, X2, out=None, diag_add: float = 0.0):
+        if self.tree is not None:
+            out = self._build_node(self.tree, X1, X2, out)
+            if diag_add != 0.0 and X2 is None:
+                out.diagonal().add_(float(diag_add))
+            return out
         last = self.n - 1
         f, v, ls = self.members[0]
         out = ops.kernel_matrix(self._sl(0, X1), self._sl(0, X2), variance=v, lengthscales=ls, family=f,
@@ -216,10 +307,15 @@ class KernelSpec:
         return out
 
     def kdiag(self) -> float:
+        if self.tree is not None:
+            return self._kd_node(self.tree)
         vs = [v for _, v, _ in self.members]
         return float(np.prod(vs)) if self.op == "mul" else float(np.sum(vs))
 
     def dkdiag(self):
+        if self.tree is not None:
+            d = self._dkd_node(self.tree)
+            return [d[i] for i in range(self.n)]
         if self.op == "mul":
             kd = self.kdiag()
             return [kd / v for _, v, _ in self.members]
@@ -234,6 +330,24 @@ class KernelSpec:
     def adjoint(self, A, Bm, Kbar, symmetric: bool):
         dvs, dls, Abar = [], [], None
         full = all(c is None for c in self.cols)
+        if self.tree is not None:
+            acc = {}
+            self._adjoint_node(self.tree, A, Bm, Kbar, symmetric, acc)
+            for i in range(self.n):
+                dv, dl, Ab = acc[i]
+                dvs.append(dv)
+                dls.append(dl)
+                if full:
+                    Abar = Ab if Abar is None else Abar + Ab
+                else:
+                    if Abar is None:
+                        Abar = torch.zeros_like(A)
+                    if self.cols[i] is None:
+                        Abar += Ab
+                    else:
+                        self._sl(i, A)    # (makes sure the index tensor of member i exists on this device)
+                        Abar.index_add_(1, self._idx[(i, str(A.device))], Ab)
+            return dvs, dls, Abar
         for i, (f, v, ls) in enumerate(self.members):
             Kb = Kbar
             if self.op == "mul":

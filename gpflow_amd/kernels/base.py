@@ -165,7 +165,8 @@ class Combination(Kernel):
 
 def gradient_spec(kernel, input_dim=None):
     """gradients.KernelSpec + [(variance Parameter, lengthscales Parameter)] for the kernels the reverse pass covers beyond a
-    single stationary one: a flat Sum / Product of isotropic-stationary members (kernels/base.py:216-220, 305-315).  Members may
+    single stationary one: a Sum / Product of isotropic-stationary members, flat or nested (kernels/base.py:216-220, 305-315; the
+    end of round 5: a Product of Sums and the like -- the spec then carries the combination tree).  Members may
     carry their own `active_dims` (kernels/base.py:90-109): the spec then builds and differentiates each member on its own columns
     and scatters its input gradient back (round 5) -- `input_dim`, the number of input columns, resolves slices.  None if `kernel`
     is not such a combination."""
@@ -173,10 +174,19 @@ def gradient_spec(kernel, input_dim=None):
     from .. import gradients
     if not isinstance(kernel, Combination):
         return None
-    ks = list(kernel.kernels)
-    if not all(isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES for k in ks):
-        raise NotImplementedError("gradients of a kernel combination: a flat Sum / Product of SquaredExponential / Matern members "
-                                  "(kernels/base.py:216-220, 305-315)")
+    # leaves in traversal order + the tree over their indices (a flat combination: one node)
+    ks = []
+
+    def walk(k):
+        if isinstance(k, Combination):
+            return (k._op, [walk(c) for c in k.kernels])
+        if not (isinstance(k, IsotropicStationary) and k.family in ops.KERNEL_FAMILIES):
+            raise NotImplementedError("gradients of a kernel combination: Sums / Products (possibly nested) of SquaredExponential / "
+                                      "Matern members (kernels/base.py:216-220, 305-315)")
+        ks.append(k)
+        return len(ks) - 1
+    tree = walk(kernel)
+    nested = any(not isinstance(c, int) for c in tree[1])
     cols = []
     for k in ks:
         if k.has_default_active_dims:
@@ -187,7 +197,7 @@ def gradient_spec(kernel, input_dim=None):
             cols.append(np.arange(int(input_dim))[k.active_dims])
         else:
             cols.append(np.asarray(k.active_dims, dtype=np.int64))
-    spec = gradients.KernelSpec([k.hyper() for k in ks], kernel._op, cols=cols)
+    spec = gradients.KernelSpec([k.hyper() for k in ks], tree if nested else kernel._op, cols=cols)
     return spec, [(k.variance, k.lengthscales) for k in ks]
 
 

@@ -46,18 +46,23 @@ def combination_kernel(members, op, cols=None):
     torch tensors: kernels/base.py:216-220 (tf.add_n of the member matrices), :305-315 (their elementwise product).  cols[i]: the
     input columns member i sees (its active_dims, kernels/base.py:90-109; each member slices for itself, :283-293), None = all."""
     cols = [None] * len(members) if cols is None else cols
+    # op a string: flat; else a tree (op, [children]) over member indices -- nested Combinations (kernels/base.py:223-329)
+    tree = (op, list(range(len(members)))) if isinstance(op, str) else op
+    sl = lambda T_, c: T_ if c is None else T_[:, list(c)]  # noqa: E731
+
+    def reduce(node, leaf):
+        if isinstance(node, (int, np.integer)):
+            return leaf(int(node))
+        o, ch = node
+        vals = [reduce(c, leaf) for c in ch]
+        out = vals[0]
+        for v_ in vals[1:]:
+            out = out + v_ if o == "add" else out * v_
+        return out
 
     def kfun(A, Bm):
-        sl = lambda T_, c: T_ if c is None else T_[:, list(c)]  # noqa: E731
-        mats = [_rbf(sl(A, c), sl(Bm, c), v, ls, f) for (f, v, ls), c in zip(members, cols)]
-        out = mats[0]
-        for m_ in mats[1:]:
-            out = out + m_ if op == "add" else out * m_
-        return out
-    vs = [v for _, v, _ in members]
-    kd = vs[0]
-    for v in vs[1:]:
-        kd = kd + v if op == "add" else kd * v
+        return reduce(tree, lambda i: _rbf(sl(A, cols[i]), sl(Bm, cols[i]), members[i][1], members[i][2], members[i][0]))
+    kd = reduce(tree, lambda i: members[i][1])
     return kfun, kd
 
 

@@ -280,6 +280,30 @@ def build():  # noqa: C901
         out[f"g_sgpr_d{name}"] = richardson(lambda x, n=name: sgpr_elbo_of(**{n: x}), th[name])
     out["g_sgpr_dZ"] = richardson(lambda x: sgpr_elbo_of(Z=x), Zg)
 
+    # ---- a NESTED kernel combination, (SquaredExponential + Matern32[dim 1]) * Matern52 (kernels/base.py:223-329): GPR LML and the
+    # whitened SVGP ELBO with Richardson gradients w.r.t. the three variances and the lengthscales of the first and last member
+    nth = dict(v0=np.array(1.3), v1=np.array(0.6), v2=np.array(0.9), ls0=np.array([0.9, 1.4]), ls2=np.array(1.2))
+    out.update({f"nest_{k}": v for k, v in nth.items()})
+
+    def nest_kernel(v):
+        return (gpflow.kernels.SquaredExponential(variance=float(v["v0"]), lengthscales=np.array(v["ls0"]))
+                + gpflow.kernels.Matern32(variance=float(v["v1"]), lengthscales=0.8, active_dims=[1])) \
+            * gpflow.kernels.Matern52(variance=float(v["v2"]), lengthscales=float(v["ls2"]))
+
+    def nest_gpr(**kw):
+        v = dict(nth); v.update(kw)
+        return float(gpflow.models.GPR((Xg, Yg[:, :1]), nest_kernel(v), noise_variance=0.15).log_marginal_likelihood())
+
+    def nest_svgp(**kw):
+        v = dict(nth); v.update(kw)
+        mdl = gpflow.models.SVGP(nest_kernel(v), gpflow.likelihoods.Gaussian(variance=0.15), Zg.copy(), q_mu=qmg, q_sqrt=qsg, num_latent_gps=Pg,
+                                 num_data=500)
+        return float(mdl.elbo((Xg, Yg)))
+    out["nest_gpr_lml"], out["nest_svgp_elbo"] = nest_gpr(), nest_svgp()
+    for name in nth:
+        out[f"nest_gpr_d{name}"] = richardson(lambda x, n=name: nest_gpr(**{n: x}), nth[name])
+        out[f"nest_svgp_d{name}"] = richardson(lambda x, n=name: nest_svgp(**{n: x}), nth[name])
+
     # ---- MAP objective: parameter priors (base.py:201-224, models/model.py:47-76) ---------------------------------------------
     # a prior on the constrained value (Gamma / LogNormal) and one on the UNCONSTRAINED value (Normal + log|Jacobian|); value
     # of log_prior_density / log_posterior_density / training_loss from the reference's statements, and the gradient of the

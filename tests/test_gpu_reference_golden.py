@@ -271,6 +271,37 @@ def test_ref_gradients(gp):
 
 
 
+def test_ref_nested_kernel_combination(gp):
+    """(SquaredExponential + Matern32[dim 1]) * Matern52 -- a Product holding a Sum (kernels/base.py:223-329) -- through the model
+    surface: GPR.log_marginal_likelihood, the whitened SVGP.elbo, and their gradients (the reverse pass walks the combination tree:
+    gradients.KernelSpec with a tree) against the reference's values and Richardson differences of its forward code."""
+    def kern():
+        return (gp.kernels.SquaredExponential(variance=float(G["nest_v0"]), lengthscales=G["nest_ls0"])
+                + gp.kernels.Matern32(variance=float(G["nest_v1"]), lengthscales=0.8, active_dims=[1])) \
+            * gp.kernels.Matern52(variance=float(G["nest_v2"]), lengthscales=float(G["nest_ls2"]))
+    X, Y = G["g_X"], G["g_Y"]
+    m = gp.models.GPR((X, Y[:, :1]), kern(), noise_variance=0.15)
+    np.testing.assert_allclose(float(m.log_marginal_likelihood()), float(G["nest_gpr_lml"]), rtol=1e-9)
+    s = gp.models.SVGP(kern(), gp.likelihoods.Gaussian(0.15), G["g_Z"].copy(), q_mu=G["g_q_mu"], q_sqrt=G["g_q_sqrt"], num_latent_gps=2,
+                       num_data=500)
+    np.testing.assert_allclose(float(s.elbo((X, Y))), float(G["nest_svgp_elbo"]), rtol=1e-9)
+    for mdl, pre, call in ((m, "nest_gpr", lambda: m.objective_and_grad()), (s, "nest_svgp", lambda: s.elbo_and_grad((X, Y)))):
+        v, g = call()
+        np.testing.assert_allclose(v, float(G[f"{pre}_lml" if pre == "nest_gpr" else f"{pre}_elbo"]), rtol=1e-9)
+        ks = mdl.kernel.kernels            # [Sum(SE, M32), M52]
+        leaves = [ks[0].kernels[0], ks[0].kernels[1], ks[1]]
+        for i, k in enumerate(leaves):     # d/d(constrained) = d/d(unconstrained) / forward_grad
+            par = k.variance
+            got = float(np.ravel(g[par])[0] / np.ravel(par.transform.forward_grad(par.unconstrained_variable))[0])
+            ref = float(G[f"{pre}_dv{i}"])
+            assert abs(got - ref) <= 1e-6 * max(1.0, abs(ref)), (pre, i, got, ref)
+        for i, nm in ((0, "ls0"), (2, "ls2")):
+            par = leaves[i].lengthscales
+            got = np.ravel(g[par]) / np.ravel(par.transform.forward_grad(par.unconstrained_variable))
+            ref = np.atleast_1d(G[f"{pre}_d{nm}"])
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (pre, nm)
+
+
 def test_ref_map_objective_with_priors(gp):
     """MAP objective against the reference's own statements (gpflow/base.py:201-224, models/model.py:47-76 run through the
     shim): log_prior_density with a prior on the constrained value (Gamma, LogNormal) and one on the unconstrained value

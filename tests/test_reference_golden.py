@@ -243,6 +243,32 @@ def test_gradient_oracle_pinned_to_reference_finite_differences():
         chk(g[n], G[f"g_sgpr_d{n}"])
 
 
+def _nested_members():
+    members = [("SquaredExponential", float(G["nest_v0"]), G["nest_ls0"]), ("Matern32", float(G["nest_v1"]), np.array(0.8)),
+               ("Matern52", float(G["nest_v2"]), np.array(float(G["nest_ls2"])))]
+    return members, ("mul", [("add", [0, 1]), 2]), [None, [1], None]
+
+
+def test_nested_combination_oracle_pinned_to_reference():
+    """(SquaredExponential + Matern32[dim 1]) * Matern52 (kernels/base.py:223-329: a Product holding a Sum): the autograd oracle's
+    GPR LML / whitened SVGP ELBO and their gradients w.r.t. the members' variances and lengthscales against the reference's own
+    forward code and its Richardson differences."""
+    from oracle import gp_oracle_grad as og
+    members, tree, cols = _nested_members()
+    X, Y, Z, qm, qs = G["g_X"], G["g_Y"], G["g_Z"], G["g_q_mu"], G["g_q_sqrt"]
+    v, g = og.combination_value_and_grads("gpr", X, Y[:, :1], members, tree, noise_variance=0.15, cols=cols)
+    np.testing.assert_allclose(v, float(G["nest_gpr_lml"]), rtol=1e-12)
+    v2, g2 = og.combination_value_and_grads("svgp", X, Y, members, tree, noise_variance=0.15, Z=Z, q_mu=qm, q_sqrt=qs, num_data=500, cols=cols)
+    np.testing.assert_allclose(v2, float(G["nest_svgp_elbo"]), rtol=1e-12)
+    for gg, pre in ((g, "nest_gpr"), (g2, "nest_svgp")):
+        for i in range(3):
+            ref = float(G[f"{pre}_dv{i}"])
+            assert abs(gg["variance"][i] - ref) <= 1e-7 * max(1.0, abs(ref)), (pre, i)
+        for i, nm in ((0, "ls0"), (2, "ls2")):
+            ref = np.atleast_1d(G[f"{pre}_d{nm}"])
+            assert np.abs(np.ravel(gg["lengthscales"][i]) - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max()), (pre, nm)
+
+
 def test_natgrad_conversions_pinned_to_reference():
     """The natural-gradient parameter conversions restated in oracle/gp_oracle_grad.py (which the natural-gradient oracle
     differentiates) against the reference's own functions run through the shim (optimizers/natgrad.py:429-516)."""
