@@ -413,22 +413,24 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
         c = mf.constant_value()
         # (a diagonal q_sqrt [M, P] goes through the same two reverse passes: the covariance spec and the q_diag branches of
         #  gradients.svgp_elbo_and_grad / _unwhitened are independent of each other)
-        if not (isinstance(lik, Gaussian) and lik.has_variance_parameter and isinstance(iv, InducingPoints) and c is not None):
-            raise NotImplementedError("gradients with a kernel combination: Gaussian likelihood with a variance parameter, "
-                                      "InducingPoints, constant mean")
+        het = isinstance(lik, Gaussian) and lik.is_heteroskedastic   # (per-row dF/d sigma_n^2 chained through the noise Function)
+        if not (isinstance(lik, Gaussian) and (lik.has_variance_parameter or het) and isinstance(iv, InducingPoints) and c is not None):
+            raise NotImplementedError("gradients with a kernel combination: Gaussian likelihood (a variance parameter or a noise "
+                                      "Function), InducingPoints, constant mean")
         X, Y = ops.to_device(data[0]), ops.to_device(data[1])
         scale = 1.0 if self.num_data is None else float(self.num_data) / float(X.shape[0])
         fn = gradients.svgp_elbo_and_grad if self.whiten else gradients.svgp_elbo_and_grad_unwhitened
         F, g, info = fn(iv.Z.device_value(), X.contiguous(), Y, self.q_mu.device_value(), self.q_sqrt.device_value(),
-                        noise_variance=lik.noise_variance(), jitter=config.default_jitter(), scale=scale,
+                        noise_variance=lik.noise_for(X), jitter=config.default_jitter(), scale=scale,
                         mean_const=float(c), kernel_spec=spec)
         ops.check_info(info)
         gv = g["variance"].cpu().numpy()
         pairs = []
         for i, (pv, pl) in enumerate(members):
             pairs += [(pv, gv[i]), (pl, g["lengthscales"][i].cpu().numpy())]
-        pairs += [(iv.Z, g["Z"].cpu().numpy()), (lik.variance, g["noise_variance"].cpu().numpy()),
-                  (self.q_mu, g["q_mu"].cpu().numpy()), (self.q_sqrt, g["q_sqrt"].cpu().numpy())]
+        pairs += [(iv.Z, g["Z"].cpu().numpy()), (self.q_mu, g["q_mu"].cpu().numpy()), (self.q_sqrt, g["q_sqrt"].cpu().numpy())]
+        pairs += [(par, gv.cpu().numpy()) for par, gv in lik.noise_param_grads(X, g["noise_variance"])] if het else \
+            [(lik.variance, g["noise_variance"].cpu().numpy())]
         if isinstance(mf, Constant) and hasattr(mf, "c"):   # (Zero is a Constant without a parameter, functions.py:195-204)
             pairs.append((mf.c, g["mean_const"].cpu().numpy()))
         out = {}

@@ -285,27 +285,40 @@ def sgpr_elbo_value_and_grads(X, Y, Z, *, variance, lengthscales, noise_variance
     return float(F.detach()), {k: v.detach().numpy().copy() for k, v in g.items()}
 
 
-def heteroskedastic_value_and_grads(model, X, Y, *, A, b, variance, lengthscales, Z=None, q_mu=None, q_sqrt=None, num_data=None,
-                                    jitter=1e-6, mean=0.0, lower_bound=1e-6):
+def heteroskedastic_value_and_grads(model, X, Y, *, A, b, variance=None, lengthscales=None, Z=None, q_mu=None, q_sqrt=None, num_data=None,
+                                    jitter=1e-6, mean=0.0, lower_bound=1e-6, combination=None):
     """GPR.log_marginal_likelihood ("gpr"), SGPR.elbo ("sgpr") or SVGP.elbo whitened ("svgp") / un-whitened ("svgp_unwhitened") under Gaussian(scale=Linear(A, b))
     (likelihoods/scalar_continuous.py:52-111: sigma_n^2 = max(x_n A + b, sqrt(lower bound))^2) and their gradients w.r.t. A, b and
     the other parameters, by autograd."""
     t = lambda a, g=False: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=g)  # noqa: E731
     At, bt = t(np.atleast_2d(A), True), t(np.atleast_1d(b), True)
-    var, ls = t(variance, True), t(np.atleast_1d(lengthscales), True)
     Xt = t(X)
     nv = torch.clamp(Xt @ At + bt, min=float(np.sqrt(lower_bound)))[:, 0] ** 2
     out = {}
+    kw = {}
+    if combination is not None:     # (members, op or tree, cols): a Sum / Product of stationary kernels under the same likelihood
+        members, op, cols = combination
+        vs = [t(v, True) for _, v, _ in members]
+        lss = [t(np.atleast_1d(l_), True) for _, _, l_ in members]
+        kfun, kd = combination_kernel([(f, v, l_) for (f, _, _), v, l_ in zip(members, vs, lss)], op, cols)
+        var = ls = None
+        kw = dict(kfun=kfun, kdiag=kd) if model != "gpr" else dict(kfun=kfun)
+    else:
+        var, ls = t(variance, True), t(np.atleast_1d(lengthscales), True)
     if model == "gpr":
-        F = gpr_lml_torch(Xt, t(Y), var, ls, nv, t(mean))
+        F = gpr_lml_torch(Xt, t(Y), var, ls, nv, t(mean), **kw)
     elif model == "sgpr":
         Zt = t(Z, True)
-        F = sgpr_elbo_torch(Xt, t(Y), Zt, var, ls, nv, jitter=jitter, mean=t(mean))
+        F = sgpr_elbo_torch(Xt, t(Y), Zt, var, ls, nv, jitter=jitter, mean=t(mean), **kw)
     else:
         Zt, qm, qs = t(Z, True), t(q_mu, True), t(q_sqrt, True)
-        F = svgp_elbo_torch(Xt, t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=t(mean), whiten=(model == "svgp"))
+        F = svgp_elbo_torch(Xt, t(Y), Zt, qm, qs, var, ls, nv, num_data=num_data, jitter=jitter, mean=t(mean), whiten=(model == "svgp"), **kw)
     F.backward()
-    out.update(A=At.grad.numpy().copy(), b=bt.grad.numpy().copy(), variance=float(var.grad), lengthscales=ls.grad.numpy().copy())
+    out.update(A=At.grad.numpy().copy(), b=bt.grad.numpy().copy())
+    if combination is not None:
+        out.update(variance=np.array([float(v.grad) for v in vs]), lengthscales=[l_.grad.numpy().copy() for l_ in lss])
+    else:
+        out.update(variance=float(var.grad), lengthscales=ls.grad.numpy().copy())
     if model == "sgpr":
         out.update(Z=Zt.grad.numpy().copy())
     elif model != "gpr":

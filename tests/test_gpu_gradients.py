@@ -844,6 +844,54 @@ def test_combinations_over_different_active_dims_and_under_sgpr_and_the_unwhiten
     chk(gdup[ksh.variance] / ksh.variance.transform.forward_grad(ksh.variance.unconstrained_variable), rg["variance"].sum())
 
 
+def test_heteroskedastic_noise_under_a_kernel_combination(gpu):
+    """Gaussian(scale=Linear(A, b)) together with a NESTED kernel combination, (SquaredExponential + Matern32[dim 1]) * Matern52, through
+    the model surface of GPR, both SVGP parametrisations and SGPR: value and the gradients w.r.t. the noise Function's parameters, every
+    member's variance and lengthscales and Z against torch autograd over the restated model (1e-7: the un-whitened / SGPR chains)."""
+    import gpflow_amd as gpflow
+    rng = np.random.default_rng(20220701)
+    N, M, P = 200, 24, 1
+    X = rng.random((N, 2)); Y = np.sin(5 * X[:, :1]) + (0.7 - 0.6 * X[:, :1]) * rng.standard_normal((N, 1))
+    A0, b0 = np.array([[-0.3], [0.05]]), np.array([0.6])
+    Z = X[:M] + 0.02 * rng.normal(size=(M, 2)); q_mu = 0.2 * rng.normal(size=(M, P))
+    qs = np.tril(0.1 * rng.normal(size=(P, M, M))) + 0.5 * np.eye(M)
+    members = [("SquaredExponential", 1.1, np.array([0.25, 0.9])), ("Matern32", 0.6, np.array(0.8)), ("Matern52", 0.9, np.array(1.2))]
+    combo = (members, ("mul", [("add", [0, 1]), 2]), [None, [1], None])
+    mk_lik = lambda: gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=A0.copy(), b=b0.copy()))  # noqa: E731
+
+    def mk_k():
+        return (gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.25, 0.9])
+                + gpflow.kernels.Matern32(variance=0.6, lengthscales=0.8, active_dims=[1])) * gpflow.kernels.Matern52(variance=0.9, lengthscales=1.2)
+
+    def check(model, v, g, rv, rg, with_z):
+        assert abs(v - rv) <= 1e-7 * abs(rv), (v, rv)
+        ks = model.kernel.kernels
+        leaves = [ks[0].kernels[0], ks[0].kernels[1], ks[1]]
+        lik = model.likelihood
+
+        def rel(got, ref):
+            got = np.asarray(got, dtype=np.float64).reshape(np.shape(ref))
+            return np.abs(got - ref).max() / max(1.0, np.abs(np.asarray(ref)).max())
+        assert rel(g[lik.scale.A], rg["A"]) <= 1e-7 and rel(g[lik.scale.b], rg["b"]) <= 1e-7
+        for i, k in enumerate(leaves):
+            for par, ref in ((k.variance, rg["variance"][i]), (k.lengthscales, rg["lengthscales"][i])):
+                got = np.ravel(g[par]) / np.ravel(par.transform.forward_grad(par.unconstrained_variable))
+                assert rel(got, np.ravel(ref)) <= 1e-7, (i, par.name)
+        if with_z:
+            assert rel(g[model.inducing_variable.Z], rg["Z"]) <= 1e-7
+    m = gpflow.models.GPR((X, Y), mk_k(), likelihood=mk_lik())
+    v, g = m.objective_and_grad()
+    check(m, v, g, *orcg.heteroskedastic_value_and_grads("gpr", X, Y, A=A0, b=b0, combination=combo), with_z=False)
+    for wh, name in ((True, "svgp"), (False, "svgp_unwhitened")):
+        s = gpflow.models.SVGP(mk_k(), mk_lik(), Z.copy(), q_mu=q_mu, q_sqrt=qs, whiten=wh, num_data=5 * N)
+        v, g = s.elbo_and_grad((X, Y))
+        check(s, v, g, *orcg.heteroskedastic_value_and_grads(name, X, Y, A=A0, b=b0, Z=Z, q_mu=q_mu, q_sqrt=qs, num_data=5 * N,
+                                                              combination=combo), with_z=True)
+    sg = gpflow.models.SGPR((X, Y), mk_k(), Z.copy(), likelihood=mk_lik())
+    v, g = sg.objective_and_grad()
+    check(sg, v, g, *orcg.heteroskedastic_value_and_grads("sgpr", X, Y, A=A0, b=b0, Z=Z, combination=combo), with_z=True)
+
+
 @pytest.mark.parametrize("q_diag", [False, True])
 def test_heteroskedastic_noise_in_the_reverse_pass(gpu, q_diag):
     """Gaussian(scale=Linear(A, b)) (the reference's tests/integration/test_linear_noise.py recipe; likelihoods/scalar_continuous.py:
