@@ -46,7 +46,7 @@ class _Adam:
 
 class SVGPTrainer:
     """Adam on -ELBO for `model` (SVGP: whitened or un-whitened, full or diagonal q_sqrt, SquaredExponential / Matern kernel with
-    or without `active_dims`, Gaussian likelihood with a constant variance or a noise Function of the inputs, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
+    or without `active_dims` -- or a Sum / Product of such kernels, flat or nested --, Gaussian likelihood with a constant variance or a noise Function of the inputs, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
     `Constant.c`).  A step whose Kuu factorisation fails raises and leaves variables and Adam moments untouched.
 
         trainer = SVGPTrainer(model, learning_rate=1e-3)
@@ -61,7 +61,23 @@ class SVGPTrainer:
         (optimizers/natgrad.py; natgrad.natgrad_update on the device) and Adam handles the remaining parameters -- the
         hybrid recipe of the reference's natural-gradient notebook, from ONE gradient evaluation per step."""
         # NotImplementedError outside the scope of the reverse pass
-        k, iv, c = model.gradient_config(allow_active_dims=True, allow_q_diag=True, allow_heteroskedastic=True)
+        # a Sum / Product of stationary kernels (flat or nested, members over their own columns): the covariance spec is rebuilt from the
+        # trainer's current member values every step (gradients.KernelSpec); one stationary kernel keeps the scalar arguments
+        from .kernels.base import Combination, gradient_spec
+        self.combo = None
+        if isinstance(model.kernel, Combination):
+            from .inducing_variables import InducingPoints
+            from .likelihoods import Gaussian
+            iv, c = model.inducing_variable, model.mean_function.constant_value()
+            lik0 = model.likelihood
+            if not (isinstance(iv, InducingPoints) and c is not None and isinstance(lik0, Gaussian)
+                    and (lik0.has_variance_parameter or lik0.is_heteroskedastic)):
+                raise NotImplementedError("the trainer with a kernel combination: Gaussian likelihood, InducingPoints, constant mean")
+            spec0, members = gradient_spec(model.kernel, int(iv.Z.shape[1]))   # (raises for members outside the reverse pass)
+            self.combo = (spec0, members)
+            k = None
+        else:
+            k, iv, c = model.gradient_config(allow_active_dims=True, allow_q_diag=True, allow_heteroskedastic=True)
         lik = model.likelihood
         self.kernel = k
         self.q_diag = model.q_sqrt.numpy().ndim == 2
@@ -73,10 +89,23 @@ class SVGPTrainer:
         self.model, self.group = model, group
         self.natgrad_gamma = None if natgrad_gamma is None else float(natgrad_gamma)
         self.mean_const = float(c)
-        self.family = k.family
+        self.family = k.family if k is not None else None
         self.opt = _Adam(learning_rate, beta_1, beta_2, epsilon)
         # host side: unconstrained scalars (their constrained values are host arguments of the C-ABI)
-        self.host = {"variance": k.variance, "lengthscales": k.lengthscales}
+        if self.combo is None:
+            self.host = {"variance": k.variance, "lengthscales": k.lengthscales}
+        else:
+            # one host entry per distinct Parameter (a Parameter shared by several members -- k + k, tied lengthscales -- collects the
+            # SUM of its members' gradients, as autodiff returns it); member i reads "kvar_<a>" / "kls_<b>"
+            self.host, self.member_names, seen = {}, [], {}
+            for pv, pl in self.combo[1]:
+                names = []
+                for par, pre in ((pv, "kvar"), (pl, "kls")):
+                    if id(par) not in seen:
+                        seen[id(par)] = f"{pre}_{len(seen)}"
+                        self.host[seen[id(par)]] = par
+                    names.append(seen[id(par)])
+                self.member_names.append(tuple(names))
         # noise: a constant variance, or (a heteroskedastic Gaussian likelihood, likelihoods/scalar_continuous.py:52-111) the Parameters of
         # the noise Function -- they stay on the host like the other hyper-parameters; sigma_n^2 at the minibatch rows is formed on the
         # device every step and dF/d sigma_n^2 comes back per row, chained through the Function there (Gaussian.noise_param_grads)
@@ -156,8 +185,9 @@ class SVGPTrainer:
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
         rows = int(global_batch) if global_batch is not None else Xb.shape[0] * world
         scale = 1.0 if self.model.num_data is None else float(self.model.num_data) / float(rows)
-        var = float(self.constrained("variance"))
-        ls = self.constrained("lengthscales")
+        if self.combo is None:
+            var = float(self.constrained("variance"))
+            ls = self.constrained("lengthscales")
         if self.het:
             for i, p in enumerate(self.noise_pars):              # the Function reads its Parameters: the trainer's current values
                 p.assign_unconstrained(self.u[f"noise_fn_{i}"])
@@ -168,13 +198,31 @@ class SVGPTrainer:
             self.mean_const = float(np.ravel(self.constrained("mean_const"))[0])
         fn = gradients.svgp_elbo_and_grad if self.model.whiten else gradients.svgp_elbo_and_grad_unwhitened
         from .models.svgp import SVGP
-        Zs, Xs, scatter = SVGP._sliced(self.kernel, self.dev["Z"], Xb)          # active_dims (kernels/base.py:90-109)
         q_sqrt = torch.nn.functional.softplus(self.dev["q_sqrt"]) + self.q_lower if self.q_diag else self.dev["q_sqrt"]
-        F, g, info = fn(
-            Zs, Xs, Yb, self.dev["q_mu"], q_sqrt, variance=var, lengthscales=ls,
-            noise_variance=noise, jitter=config.default_jitter(), scale=scale, mean_const=self.mean_const,
-            kl_weight=1.0 / world, family=self.family)
-        g = dict(g)
+        if self.combo is None:
+            Zs, Xs, scatter = SVGP._sliced(self.kernel, self.dev["Z"], Xb)      # active_dims (kernels/base.py:90-109)
+            F, g, info = fn(
+                Zs, Xs, Yb, self.dev["q_mu"], q_sqrt, variance=var, lengthscales=ls,
+                noise_variance=noise, jitter=config.default_jitter(), scale=scale, mean_const=self.mean_const,
+                kl_weight=1.0 / world, family=self.family)
+            g = dict(g)
+        else:
+            spec0 = self.combo[0]
+            members = [(f, float(np.ravel(self.constrained(nv))[0]), self.constrained(nl))
+                       for (f, _, _), (nv, nl) in zip(spec0.members, self.member_names)]
+            spec = gradients.KernelSpec(members, spec0.tree if spec0.tree is not None else spec0.op, spec0.cols)
+            scatter = lambda gz: gz  # noqa: E731  (the spec slices for its members and scatters their input gradients itself)
+            F, g, info = fn(self.dev["Z"], Xb.contiguous(), Yb, self.dev["q_mu"], q_sqrt, noise_variance=noise,
+                            jitter=config.default_jitter(), scale=scale, mean_const=self.mean_const, kl_weight=1.0 / world,
+                            kernel_spec=spec)
+            g = dict(g)
+            gv, gl = g.pop("variance"), g.pop("lengthscales")
+            if spec.n == 1:
+                gv, gl = gv.reshape(1), [gl]
+            for i, (nv, nl) in enumerate(self.member_names):    # per-member gradients onto their (possibly shared) Parameters
+                g[nv] = g[nv] + gv[i].reshape(1) if nv in g else gv[i].reshape(1)
+                gli = gl[i].reshape(-1)
+                g[nl] = g[nl] + gli if nl in g else gli
         if self.het:
             # per-row dF/d sigma_n^2 -> the noise Function's parameters (this shard's rows; summed over the ranks below)
             rows_g = g.pop("noise_variance")

@@ -844,6 +844,37 @@ def test_combinations_over_different_active_dims_and_under_sgpr_and_the_unwhiten
     chk(gdup[ksh.variance] / ksh.variance.transform.forward_grad(ksh.variance.unconstrained_variable), rg["variance"].sum())
 
 
+@pytest.mark.parametrize("shared", [False, True])
+def test_trainer_with_kernel_combinations(gpu, shared):
+    """SVGPTrainer under a kernel combination (refused until the end of round 5): (SquaredExponential + Matern32[dim 1]) * Matern52, and
+    k + k with SHARED Parameters (one host entry per distinct Parameter; it collects the sum of its members' gradients).  The first objective
+    is SVGP.elbo_and_grad's, the first Adam step moves every kernel parameter by the learning rate along that gradient, the bound improves."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import training
+    rng = np.random.default_rng(3)
+    N, M, P = 200, 20, 2
+    X = rng.normal(size=(N, 3)); Y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(N, P))
+    Z = X[:M].copy(); q_mu = 0.2 * rng.normal(size=(M, P)); qs = np.tril(0.1 * rng.normal(size=(P, M, M))) + 0.5 * np.eye(M)
+    for wh in (True, False):
+        k0 = gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.9, 1.1, 1.3])
+        kern = (k0 + k0) if shared else (k0 + gpflow.kernels.Matern32(variance=0.6, lengthscales=0.8, active_dims=[1])) \
+            * gpflow.kernels.Matern52(variance=0.9, lengthscales=1.2)
+        m = gpflow.models.SVGP(kern, gpflow.likelihoods.Gaussian(0.2), Z.copy(), q_mu=q_mu, q_sqrt=qs, whiten=wh, num_latent_gps=P, num_data=5 * N)
+        v0, g0 = m.elbo_and_grad((X, Y))
+        tr = training.SVGPTrainer(m, learning_rate=1e-2)
+        assert len(tr.host) == (3 if shared else 7)            # distinct kernel Parameters + the noise variance
+        before = {n: np.array(p.unconstrained_variable, dtype=np.float64, copy=True) for n, p in tr.host.items()}
+        f0 = float(tr.step((X, Y)).cpu()[0])
+        assert abs(f0 - v0) <= 1e-9 * abs(v0)
+        for n, p in tr.host.items():
+            du = tr.u[n] - before[n]
+            np.testing.assert_allclose(du, 1e-2 * np.sign(np.asarray(g0[p]).reshape(du.shape)), rtol=0, atol=1e-6, err_msg=n)
+        fs = [float(tr.step((X, Y)).cpu()[0]) for _ in range(12)]
+        assert fs[-1] > f0
+        tr.sync_to_model()
+        assert abs(float(m.elbo((X, Y)).cpu()) - float(tr.step((X, Y)).cpu()[0])) <= 1e-8 * abs(fs[-1])
+
+
 def test_heteroskedastic_noise_under_a_kernel_combination(gpu):
     """Gaussian(scale=Linear(A, b)) together with a NESTED kernel combination, (SquaredExponential + Matern32[dim 1]) * Matern52, through
     the model surface of GPR, both SVGP parametrisations and SGPR: value and the gradients w.r.t. the noise Function's parameters, every

@@ -229,8 +229,6 @@ def test_gradient_entry_points_refuse_unsupported_models_before_touching_the_dev
     qdiag = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(), lik, Z, q_diag=True)
     sliced = gpflow.models.SVGP(gpflow.kernels.SquaredExponential(active_dims=[0]), lik, Z)
     data = (np.zeros((4, 2)), np.zeros((4, 1)))
-    with pytest.raises(NotImplementedError):
-        training.SVGPTrainer(summed)
     with pytest.raises(NotImplementedError):      # natural gradients need the full q_sqrt (optimizers/natgrad.py)
         training.SVGPTrainer(qdiag, natgrad_gamma=0.1)
     for m in (summed, qdiag, sliced):
