@@ -873,6 +873,24 @@ def test_trainer_with_kernel_combinations(gpu, shared):
         assert fs[-1] > f0
         tr.sync_to_model()
         assert abs(float(m.elbo((X, Y)).cpu()) - float(tr.step((X, Y)).cpu()[0])) <= 1e-8 * abs(fs[-1])
+    if not shared:
+        # ... and together with a heteroskedastic likelihood: the noise Function's Parameters join the kernel members' on the host
+        Xh = rng.random((N, 2)); Yh = np.sin(5 * Xh[:, :1]) + (0.7 - 0.6 * Xh[:, :1]) * rng.standard_normal((N, 1))
+        for wh in (True, False):
+            kern = (gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.25, 0.9])
+                    + gpflow.kernels.Matern32(variance=0.6, lengthscales=0.8, active_dims=[1])) * gpflow.kernels.Matern52(variance=0.9, lengthscales=1.2)
+            lik = gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=np.array([[-0.3], [0.05]]), b=np.array([0.6])))
+            mh = gpflow.models.SVGP(kern, lik, Xh[:M].copy(), q_mu=q_mu[:, :1], q_sqrt=qs[:1], whiten=wh, num_data=5 * N)
+            v0, g0 = mh.elbo_and_grad((Xh, Yh))
+            tr = training.SVGPTrainer(mh, learning_rate=1e-2)
+            assert len(tr.host) == 8                            # six kernel Parameters + A + b
+            before = {n: np.array(p.unconstrained_variable, dtype=np.float64, copy=True) for n, p in tr.host.items()}
+            f0 = float(tr.step((Xh, Yh)).cpu()[0])
+            assert abs(f0 - v0) <= 1e-7 * abs(v0)
+            for n, p in tr.host.items():
+                du = tr.u[n] - before[n]
+                np.testing.assert_allclose(du, 1e-2 * np.sign(np.asarray(g0[p]).reshape(du.shape)), rtol=0, atol=1e-6, err_msg=n)
+            assert float(tr.step((Xh, Yh)).cpu()[0]) > f0 or [float(tr.step((Xh, Yh)).cpu()[0]) for _ in range(8)][-1] > f0
 
 
 def test_heteroskedastic_noise_under_a_kernel_combination(gpu):
