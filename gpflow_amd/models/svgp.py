@@ -300,7 +300,8 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
             return None
         c = self.mean_function.constant_value()
         if not (all(isinstance(kk, IsotropicStationary) and kk.family in ops.KERNEL_FAMILIES for kk in k.kernels) and all(isinstance(v, InducingPoints) for v in ivs)
-                and isinstance(lik, Gaussian) and lik.has_variance_parameter and c is not None and self.q_sqrt.numpy().ndim == 3
+                and isinstance(lik, Gaussian) and (lik.has_variance_parameter or lik.is_heteroskedastic) and c is not None
+                and self.q_sqrt.numpy().ndim == 3
                 and len(ivs) == len(k.kernels)):
             raise NotImplementedError("gradients: SeparateIndependent needs SquaredExponential / Matern members over InducingPoints, a "
                                       "Gaussian likelihood, full q_sqrt and a constant mean")
@@ -384,6 +385,8 @@ class SVGP(GPModel, ExternalDataTrainingLossMixin):
                 g_qmu[:, p_:p_ + 1] = host["q_mu"]
                 g_qs[p_:p_ + 1] = host["q_sqrt"]
             pairs += list(zgrads.values())
+            if het:   # the latents share the likelihood: their per-row dF/d sigma_n^2 add up before the noise Function's reverse pass
+                pairs += [(par, gv.cpu().numpy()) for par, gv in lik.noise_param_grads(X, ops.to_device(np.asarray(g_noise)))]
         if not het:
             pairs.append((lik.variance, g_noise))
         pairs += [(self.q_mu, g_qmu), (self.q_sqrt, g_qs)]

@@ -893,6 +893,34 @@ def test_trainer_with_kernel_combinations(gpu, shared):
             assert float(tr.step((Xh, Yh)).cpu()[0]) > f0 or [float(tr.step((Xh, Yh)).cpu()[0]) for _ in range(8)][-1] > f0
 
 
+def test_heteroskedastic_noise_with_separate_kernels_per_latent(gpu):
+    """SeparateIndependent kernels over shared inducing points under Gaussian(scale=Linear(A, b)): the latents share the likelihood, so
+    their per-row dF/d sigma_n^2 add up before the noise Function's reverse pass.  Oracle: the sum over the latents of the single-output
+    autograd problems (conditionals/util.py:566-629 treats them as independent problems)."""
+    import gpflow_amd as gpflow
+    rng = np.random.default_rng(9)
+    N, M, P = 160, 18, 2
+    X = rng.random((N, 2)); Y = np.sin(5 * X[:, :1]) + (0.7 - 0.6 * X[:, :1]) * rng.standard_normal((N, P))
+    A0, b0 = np.array([[-0.3], [0.05]]), np.array([0.6])
+    Z = X[:M].copy(); q_mu = 0.2 * rng.normal(size=(M, P)); qs = np.tril(0.1 * rng.normal(size=(P, M, M))) + 0.5 * np.eye(M)
+    hy = [(1.1, [0.25, 0.9]), (0.7, [0.4, 0.6])]
+    for wh in (True, False):
+        kern = gpflow.kernels.SeparateIndependent([gpflow.kernels.SquaredExponential(variance=v, lengthscales=l_) for v, l_ in hy])
+        iv = gpflow.inducing_variables.SharedIndependentInducingVariables(gpflow.inducing_variables.InducingPoints(Z.copy()))
+        m = gpflow.models.SVGP(kern, gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=A0.copy(), b=b0.copy())), iv, q_mu=q_mu,
+                               q_sqrt=qs, whiten=wh, num_latent_gps=P, num_data=5 * N)
+        v, g = m.elbo_and_grad((X, Y))
+        rv, gA, gb, gZ = 0.0, 0.0, 0.0, 0.0
+        for p in range(P):
+            r, rg = orcg.heteroskedastic_value_and_grads("svgp" if wh else "svgp_unwhitened", X, Y[:, p:p + 1], A=A0, b=b0, variance=hy[p][0],
+                                                         lengthscales=hy[p][1], Z=Z, q_mu=q_mu[:, p:p + 1], q_sqrt=qs[p:p + 1], num_data=5 * N)
+            rv += r; gA = gA + rg["A"]; gb = gb + rg["b"]; gZ = gZ + rg["Z"]
+        assert abs(v - rv) <= 1e-7 * abs(rv) and abs(v - float(m.elbo((X, Y)).cpu())) <= 1e-7 * abs(v)
+        for got, ref in ((g[m.likelihood.scale.A], gA), (g[m.likelihood.scale.b], gb), (g[iv.inducing_variable.Z], gZ)):
+            got = np.asarray(got, dtype=np.float64).reshape(np.shape(ref))
+            assert np.abs(got - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max())
+
+
 def test_heteroskedastic_noise_under_a_kernel_combination(gpu):
     """Gaussian(scale=Linear(A, b)) together with a NESTED kernel combination, (SquaredExponential + Matern32[dim 1]) * Matern52, through
     the model surface of GPR, both SVGP parametrisations and SGPR: value and the gradients w.r.t. the noise Function's parameters, every
