@@ -46,7 +46,7 @@ class _Adam:
 
 class SVGPTrainer:
     """Adam on -ELBO for `model` (SVGP: whitened or un-whitened, full or diagonal q_sqrt, SquaredExponential / Matern kernel with
-    or without `active_dims` -- or a Sum / Product of such kernels, flat or nested --, Gaussian likelihood with a constant variance or a noise Function of the inputs, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
+    or without `active_dims` -- or a Sum / Product of such kernels, flat or nested, or one kernel per latent over shared inducing points --, Gaussian likelihood with a constant variance or a noise Function of the inputs, InducingPoints, constant or zero mean).  Honours `Parameter.trainable` (including a trainable
     `Constant.c`).  A step whose Kuu factorisation fails raises and leaves variables and Adam moments untouched.
 
         trainer = SVGPTrainer(model, learning_rate=1e-3)
@@ -65,7 +65,20 @@ class SVGPTrainer:
         # trainer's current member values every step (gradients.KernelSpec); one stationary kernel keeps the scalar arguments
         from .kernels.base import Combination, gradient_spec
         self.combo = None
-        if isinstance(model.kernel, Combination):
+        self.sep = None
+        from .kernels import SeparateIndependent
+        if isinstance(model.kernel, SeparateIndependent):
+            # one kernel per latent over SHARED inducing points (BASELINE config C5, separate): P single-output problems that share Z, the
+            # likelihood, the mean constant and the minibatch rows; their objectives and shared gradients add up (conditionals/util.py:566-629)
+            from .inducing_variables import SharedIndependentInducingVariables
+            if not isinstance(model.inducing_variable, SharedIndependentInducingVariables):
+                raise NotImplementedError("the trainer with separate kernels per latent: shared inducing points")
+            sepc = model._separate_gradient_config()             # (raises outside the reverse pass)
+            members, c = sepc
+            self.sep = [k_ for k_, _ in members]
+            iv = members[0][1]
+            k = None
+        elif isinstance(model.kernel, Combination):
             from .inducing_variables import InducingPoints
             from .likelihoods import Gaussian
             iv, c = model.inducing_variable, model.mean_function.constant_value()
@@ -92,7 +105,17 @@ class SVGPTrainer:
         self.family = k.family if k is not None else None
         self.opt = _Adam(learning_rate, beta_1, beta_2, epsilon)
         # host side: unconstrained scalars (their constrained values are host arguments of the C-ABI)
-        if self.combo is None:
+        if self.sep is not None:
+            self.host, self.member_names, seen = {}, [], {}
+            for k_ in self.sep:                                   # (a Parameter shared by several latents' kernels: one entry, summed gradient)
+                names = []
+                for par, pre in ((k_.variance, "kvar"), (k_.lengthscales, "kls")):
+                    if id(par) not in seen:
+                        seen[id(par)] = f"{pre}_{len(seen)}"
+                        self.host[seen[id(par)]] = par
+                    names.append(seen[id(par)])
+                self.member_names.append(tuple(names))
+        elif self.combo is None:
             self.host = {"variance": k.variance, "lengthscales": k.lengthscales}
         else:
             # one host entry per distinct Parameter (a Parameter shared by several members -- k + k, tied lengthscales -- collects the
@@ -185,7 +208,7 @@ class SVGPTrainer:
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
         rows = int(global_batch) if global_batch is not None else Xb.shape[0] * world
         scale = 1.0 if self.model.num_data is None else float(self.model.num_data) / float(rows)
-        if self.combo is None:
+        if self.combo is None and self.sep is None:
             var = float(self.constrained("variance"))
             ls = self.constrained("lengthscales")
         if self.het:
@@ -199,7 +222,29 @@ class SVGPTrainer:
         fn = gradients.svgp_elbo_and_grad if self.model.whiten else gradients.svgp_elbo_and_grad_unwhitened
         from .models.svgp import SVGP
         q_sqrt = torch.nn.functional.softplus(self.dev["q_sqrt"]) + self.q_lower if self.q_diag else self.dev["q_sqrt"]
-        if self.combo is None:
+        if self.sep is not None:
+            P_ = len(self.sep)
+            scatter = lambda gz: gz  # noqa: E731  (each latent's input gradient is scattered below)
+            F, info = None, None
+            g = {"Z": torch.zeros_like(self.dev["Z"]), "q_mu": torch.zeros_like(self.dev["q_mu"]), "q_sqrt": torch.zeros_like(q_sqrt)}
+            for p_, (k_, (nv_, nl_)) in enumerate(zip(self.sep, self.member_names)):
+                Zs, Xs, sc = SVGP._sliced(k_, self.dev["Z"], Xb)
+                Fp, gp, ip = fn(Zs, Xs, Yb[:, p_:p_ + 1].contiguous(), self.dev["q_mu"][:, p_:p_ + 1].contiguous(),
+                                q_sqrt[p_:p_ + 1].contiguous(), variance=float(np.ravel(self.constrained(nv_))[0]),
+                                lengthscales=self.constrained(nl_), noise_variance=noise, jitter=config.default_jitter(), scale=scale,
+                                mean_const=self.mean_const, kl_weight=1.0 / world, family=k_.family)
+                F = Fp if F is None else F + Fp
+                info = ip if info is None else torch.maximum(info, ip)
+                g["Z"] += sc(gp["Z"])
+                g["q_mu"][:, p_:p_ + 1] = gp["q_mu"]
+                g["q_sqrt"][p_:p_ + 1] = gp["q_sqrt"]
+                for name in ("noise_variance", "mean_const"):
+                    g[name] = g[name] + gp[name] if name in g else gp[name]
+                gvp, glp = gp["variance"].reshape(1), gp["lengthscales"].reshape(-1)
+                g[nv_] = g[nv_] + gvp if nv_ in g else gvp
+                g[nl_] = g[nl_] + glp if nl_ in g else glp
+            assert P_ == Yb.shape[1]
+        elif self.combo is None:
             Zs, Xs, scatter = SVGP._sliced(self.kernel, self.dev["Z"], Xb)      # active_dims (kernels/base.py:90-109)
             F, g, info = fn(
                 Zs, Xs, Yb, self.dev["q_mu"], q_sqrt, variance=var, lengthscales=ls,

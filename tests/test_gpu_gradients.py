@@ -893,6 +893,42 @@ def test_trainer_with_kernel_combinations(gpu, shared):
             assert float(tr.step((Xh, Yh)).cpu()[0]) > f0 or [float(tr.step((Xh, Yh)).cpu()[0]) for _ in range(8)][-1] > f0
 
 
+@pytest.mark.parametrize("het", [False, True])
+def test_trainer_with_separate_kernels_per_latent(gpu, het):
+    """SVGPTrainer with one kernel per latent over SHARED inducing points (BASELINE config C5, separate; conditionals/util.py:566-629: P
+    independent single-output problems that share Z, the likelihood and the minibatch rows), with a constant noise variance or a noise
+    Function: first objective == SVGP.elbo_and_grad, first Adam step == learning rate along that gradient for every kernel / noise
+    parameter and for Z, the bound improves, and the synced model reproduces the trainer's next objective."""
+    import gpflow_amd as gpflow
+    from gpflow_amd import training
+    rng = np.random.default_rng(9)
+    N, M, P = 160, 18, 2
+    X = rng.random((N, 2)); Y = np.sin(5 * X[:, :1]) + 0.2 * rng.standard_normal((N, P))
+    Z = X[:M].copy(); q_mu = 0.2 * rng.normal(size=(M, P)); qs = np.tril(0.1 * rng.normal(size=(P, M, M))) + 0.5 * np.eye(M)
+    for wh in (True, False):
+        ks = [gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.25, 0.9]),
+              gpflow.kernels.Matern32(variance=0.7, lengthscales=0.5, active_dims=[0])]
+        lik = gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=np.array([[-0.3], [0.05]]), b=np.array([0.6]))) if het \
+            else gpflow.likelihoods.Gaussian(0.2)
+        iv = gpflow.inducing_variables.SharedIndependentInducingVariables(gpflow.inducing_variables.InducingPoints(Z.copy()))
+        m = gpflow.models.SVGP(gpflow.kernels.SeparateIndependent(ks), lik, iv, q_mu=q_mu, q_sqrt=qs, whiten=wh, num_latent_gps=P, num_data=5 * N)
+        v0, g0 = m.elbo_and_grad((X, Y))
+        tr = training.SVGPTrainer(m, learning_rate=1e-2)
+        assert len(tr.host) == (6 if het else 5)
+        before = {n: np.array(p.unconstrained_variable, dtype=np.float64, copy=True) for n, p in tr.host.items()}
+        Z0 = tr.dev["Z"].clone()
+        f0 = float(tr.step((X, Y)).cpu()[0])
+        assert abs(f0 - v0) <= 1e-7 * abs(v0)
+        for n, p in tr.host.items():
+            du = tr.u[n] - before[n]
+            np.testing.assert_allclose(du, 1e-2 * np.sign(np.asarray(g0[p]).reshape(du.shape)), rtol=0, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose((tr.dev["Z"] - Z0).cpu().numpy(), 1e-2 * np.sign(np.asarray(g0[iv.inducing_variable.Z])), rtol=0, atol=1e-5)
+        fs = [float(tr.step((X, Y)).cpu()[0]) for _ in range(10)]
+        assert fs[-1] > f0
+        tr.sync_to_model()
+        assert abs(float(m.elbo((X, Y)).cpu()) - float(tr.step((X, Y)).cpu()[0])) <= 1e-7 * abs(fs[-1])
+
+
 def test_heteroskedastic_noise_with_separate_kernels_per_latent(gpu):
     """SeparateIndependent kernels over shared inducing points under Gaussian(scale=Linear(A, b)): the latents share the likelihood, so
     their per-row dF/d sigma_n^2 add up before the noise Function's reverse pass.  Oracle: the sum over the latents of the single-output
