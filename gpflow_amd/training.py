@@ -223,7 +223,8 @@ class SVGPTrainer:
         from .models.svgp import SVGP
         q_sqrt = torch.nn.functional.softplus(self.dev["q_sqrt"]) + self.q_lower if self.q_diag else self.dev["q_sqrt"]
         if self.sep is not None:
-            P_ = len(self.sep)
+            if Yb.shape[1] != len(self.sep):
+                raise ValueError(f"{len(self.sep)} separate kernels need {len(self.sep)} output columns, got {Yb.shape[1]}")
             scatter = lambda gz: gz  # noqa: E731  (each latent's input gradient is scattered below)
             F, info = None, None
             g = {"Z": torch.zeros_like(self.dev["Z"]), "q_mu": torch.zeros_like(self.dev["q_mu"]), "q_sqrt": torch.zeros_like(q_sqrt)}
@@ -243,7 +244,6 @@ class SVGPTrainer:
                 gvp, glp = gp["variance"].reshape(1), gp["lengthscales"].reshape(-1)
                 g[nv_] = g[nv_] + gvp if nv_ in g else gvp
                 g[nl_] = g[nl_] + glp if nl_ in g else glp
-            assert P_ == Yb.shape[1]
         elif self.combo is None:
             Zs, Xs, scatter = SVGP._sliced(self.kernel, self.dev["Z"], Xb)      # active_dims (kernels/base.py:90-109)
             F, g, info = fn(
