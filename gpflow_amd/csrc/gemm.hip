@@ -1244,9 +1244,9 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
   a.strideE = strideE; a.strideEo = strideEo; a.strideL = strideL; a.strideX = strideX;
   a.stage_barrier = GPK_TUNE(GS2_STAGE_BARRIER, 0);
   a.j0 = j0; a.j1 = j1;
-  // Which kernel: the pipelined one (32 rows per workgroup) runs its 10 block products in ~70 us whatever the row count; the
+  // Which kernel: the pipelined one (32 rows per workgroup) runs its 10 block products in ~63 us whatever the row count; the
   // staged one (16 rows) needs ~45 us per ROUND of 256 workgroups (one per CU).  tools/group_solve_probe.py, 512 columns, us:
-  //   rows 1024: 41 / 70   2048: 47 / 70   4096: 54 / 73   8192: 101 / 82   (staged / pipelined)
+  //   rows 1024: 41 / 62   2048: 47 / 64   4096: 54 / 66   8192: 101 / 74   (staged / pipelined)
   // so the pipelined kernel takes over where the staged one would need a second round.  (The first version of this switch sent
   // everything to the pipelined kernel: the 1024- / 2048- / 4096-row rank shards of the strong-scaling workload lost 5 / 9 / 5 %.)
   const bool partial = j0 > 0 || j1 < nb;
