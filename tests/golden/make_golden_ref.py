@@ -375,6 +375,9 @@ def build():  # noqa: C901
         hs = gpflow.models.SVGP(hk(), gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=hA, b=hb)), Zh, q_mu=hq_mu, q_sqrt=hq_sqrt,
                                 whiten=wh, num_data=400)
         out[f"het_svgp_elbo_{'white' if wh else 'unwhite'}"] = float(hs.elbo((X, Y)))
+        if wh:   # predictions THROUGH the likelihood at new inputs (likelihoods/base.py predict_mean_and_var / predict_log_density)
+            symu, syvar = hs.predict_y(Xs)
+            out.update(het_svgp_ymu=_n(symu), het_svgp_yvar=_n(syvar), het_svgp_logdens=_n(hs.predict_log_density((Xs, np.cos(Xs[:, :1])))))
     out.update(het_Z=Zh, het_q_mu=hq_mu, het_q_sqrt=hq_sqrt)
     # variance as a Function, clipped at the lower bound where the polynomial goes negative (parameter_or_function.py:52-56)
     pw = np.array([[0.02, 0.3, -0.4, 0.0, 0.0, 0.0]])
@@ -387,6 +390,8 @@ def build():  # noqa: C901
     # SGPR under the same likelihood (the reference's tests/integration/test_linear_noise.py recipe, sgpr.py:181-384 with sigma_n per row)
     hsg = gpflow.models.SGPR((X, Y), hk(), Zh, likelihood=gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=hA, b=hb)))
     smu, svar = hsg.predict_f(Xs); squ, sqc = hsg.compute_qu()
+    sgymu, sgyvar = hsg.predict_y(Xs)
+    out.update(het_sgpr_ymu=_n(sgymu), het_sgpr_yvar=_n(sgyvar), het_sgpr_logdens=_n(hsg.predict_log_density((Xs, np.cos(Xs[:, :1])))))
     out.update(het_sgpr_elbo=float(hsg.elbo()), het_sgpr_mu=_n(smu), het_sgpr_var=_n(svar), het_sgpr_qu_mu=_n(squ), het_sgpr_qu_cov=_n(sqc),
                het_sgpr_upper=float(hsg.upper_bound()))   # sgpr.py:85-148 with sigma_n^2 + c per row (:124-131)
     return out

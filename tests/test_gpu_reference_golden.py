@@ -80,6 +80,10 @@ def test_ref_heteroskedastic_gaussian(gp):
     for wh, name in ((True, "white"), (False, "unwhite")):
         s = gp.models.SVGP(mk_k(), mk_lik(), G["het_Z"], q_mu=G["het_q_mu"], q_sqrt=G["het_q_sqrt"], whiten=wh, num_data=400)
         np.testing.assert_allclose(float(s.elbo((X, Y))), float(G[f"het_svgp_elbo_{name}"]), rtol=1e-9)
+        if wh:   # predictions through the likelihood: the noise Function evaluated at the NEW inputs
+            symu, syvar = s.predict_y(Xs)
+            close(symu, G["het_svgp_ymu"], 1e-8); close(syvar, G["het_svgp_yvar"], 1e-8)
+            close(s.predict_log_density((Xs, np.cos(Xs[:, :1]))), G["het_svgp_logdens"], 1e-8)
     likp = lambda: gp.likelihoods.Gaussian(variance=gp.functions.Polynomial(2, input_dim=2, w=G["het_poly_w"]),  # noqa: E731
                                            variance_lower_bound=1e-3)
     close(likp().variance_at(X), G["het_poly_variance_at"], 1e-14)
@@ -94,6 +98,9 @@ def test_ref_heteroskedastic_gaussian(gp):
     close(smu, G["het_sgpr_mu"], 1e-8); close(svar, G["het_sgpr_var"], 1e-8)
     qmu, qcov = sg.compute_qu()
     close(qmu, G["het_sgpr_qu_mu"], 1e-7); close(qcov, G["het_sgpr_qu_cov"], 1e-7)
+    gymu, gyvar = sg.predict_y(Xs)
+    close(gymu, G["het_sgpr_ymu"], 1e-8); close(gyvar, G["het_sgpr_yvar"], 1e-8)
+    close(sg.predict_log_density((Xs, np.cos(Xs[:, :1]))), G["het_sgpr_logdens"], 1e-8)
     # the upper bound rescales every row by its own sigma_n^2 + c (sgpr.py:124-131): a second statistics pass
     np.testing.assert_allclose(float(sg.upper_bound()), float(G["het_sgpr_upper"]), rtol=1e-9)
     vs, gs = sg.objective_and_grad()          # (gradients through the noise function under SGPR: end of round 5)

@@ -98,6 +98,11 @@ def test_heteroskedastic_gaussian():
     for wh, name in ((True, "white"), (False, "unwhite")):
         close(orc.svgp_elbo(X, Y, G["het_Z"], G["het_q_mu"], G["het_q_sqrt"], noise_variance=nv, whiten=wh, num_data=400, **kw),
               G[f"het_svgp_elbo_{name}"])
+    # predictions through the likelihood at new inputs: sigma^2 evaluated THERE (likelihoods/base.py, scalar_continuous.py:107-148)
+    smu_, svar_ = orc.svgp_predict_f(Xs, G["het_Z"], G["het_q_mu"], G["het_q_sqrt"], whiten=True, **kw)
+    symu, syvar = orc.gaussian_predict_mean_and_var(smu_, svar_, nvs)
+    close(symu, G["het_svgp_ymu"]); close(syvar, G["het_svgp_yvar"])
+    close(orc.gaussian_predict_log_density(smu_, svar_, np.cos(Xs[:, :1]), nvs), G["het_svgp_logdens"])
     # variance as a polynomial that dips below the lower bound: clipped at 1e-3 when evaluated (parameter_or_function.py:52-56)
     w = G["het_poly_w"]
     poly = lambda X_: w[0, 0] + w[0, 1] * X_[:, 1:2] + w[0, 2] * X_[:, 1:2] ** 2   # noqa: E731  (powers (0,0), (0,1), (0,2))
@@ -115,6 +120,9 @@ def test_heteroskedastic_gaussian():
     qmu, qcov = orc.sgpr_compute_qu(X, Y, G["het_Z"], **skw)
     close(qmu, G["het_sgpr_qu_mu"], 1e-10); close(qcov, G["het_sgpr_qu_cov"], 1e-10)
     close(orc.sgpr_upper_bound(X, Y, G["het_Z"], **skw), G["het_sgpr_upper"])   # every row rescaled by its own sigma_n^2 + c
+    gymu, gyvar = orc.gaussian_predict_mean_and_var(smu, svar, nvs)
+    close(gymu, G["het_sgpr_ymu"]); close(gyvar, G["het_sgpr_yvar"], 1e-11)
+    close(orc.gaussian_predict_log_density(smu, svar, np.cos(Xs[:, :1]), nvs), G["het_sgpr_logdens"], 1e-11)
     assert float(G["het_sgpr_elbo"]) < float(G["het_gpr_lml"]) < float(G["het_sgpr_upper"])
 
 
