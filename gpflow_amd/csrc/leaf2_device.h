@@ -24,25 +24,31 @@
 //     and then catches up with the panels already published.  The critical path per diagonal tile is four panels of pivot
 //     arithmetic plus ~2 MFMA latencies of hand-over -- no barrier, LDS round trip or tile product is on it.
 //
-//   helper waves 2 .. 7 do everything else, two phases per diagonal tile k ("window k"):
-//     alpha   L(i,k) = A(i,k) X_kk^T for the rows below the chain's two, and the last product of row block k of the inverse,
-//             X(k,j) = -X_kk T(k,j): both are final results and go to global memory straight from the registers;
-//     gamma   LEFT-LOOKING, each tile one multi-term product accumulated in registers (an LDS tile is read once and written once;
-//             the right-looking form of the first version was bound by LDS bandwidth, 20 LDS operations per tile product):
-//             the three tiles of row k+3 through column block k (what the trailing wave of tile k+2 picks up), the tiles of
-//             column block k+1 below them, row block k+1 of T(i,j) = sum_{t=j}^{i-1} L(i,t) X(t,j).  All of them end with term
-//             t = k; the terms t < k need nothing of window k and are accumulated BEFORE the helper waits for A_k ("early terms"),
-//             so that after A_k only one product per task is left.  Tasks are dealt to the helpers, two slots each, by weight
-//             (longest first) when the kernel starts.  Then the stores of the chain's tiles of column block k and the zeros right
-//             of row block k of the inverse.
-//   After the last diagonal tile one tile product per wave and two tiles of stores remain (round 5: three levels of recursive
-//   doubling, 3.7 us, and a 2.9-us store phase).
+//   helper waves 2 .. 7 each OWN ONE TILE ROW I of the block (rows 7, 6, 5, 2, 3, 4: the heavy rows on the SIMDs without a chain
+//   wave) and keep everything of that row in registers -- its finished tiles L(I,s) as MFMA operands, the running sums
+//   T(I,j) = sum_{t=j}^{I-1} L(I,t) X(t,j) of its row of the inverse, the three tiles the chain picks up.  Per diagonal tile t
+//   ("window t") an owner
+//     (a) accumulates  C = sum_{s<t} L(I,s) L(t,s)^T  (operands final one window earlier; nothing to wait for),
+//     (d) once X_tt is published forms  L(I,t) = (A(I,t) - C) X_tt^T  in one MFMA chain, in fragment layout, without an LDS round
+//         trip, and stores it (LDS for the other rows, global memory: it is final),
+//     (e) adds term t to the look-ahead tiles (I,I-2), (I,I-1), (I,I); after term I-3 they go to LDS and the trailing wave of
+//         tile I-1 is released (one flag per row),
+//     (f) adds term t to its T(I,j), j <= t: t+1 independent MFMA chains -- the work on the inverse is spread evenly over the
+//         windows (the just-in-time form of the previous version had 28 of 112 products in the last window); after term I-1 the
+//         sums are parked in LDS and every helper finalises one tile X(I,j) = -X_II T(I,j) when X_II appears.
+//   There is no barrier between helpers: an owner waits for the chain's flags, for "column block t of L complete" before (e), and
+//   for "row block t of X complete" before (f).
+//   (Versions 2 - 6 of this file, all bit-correct and measured with tools/leaf_probe.hip: barrier phases with right-looking
+//    read-modify-write tile products were bound by LDS bandwidth (20 LDS operations per product) and by scalar task decoding;
+//    left-looking multi-term tasks by the 160-cycle latency of a dependent v_mfma_f64_16x16x4 and by the imbalance between the
+//    SIMDs; profiles/r06_leaf_probe_*.txt.)
 //
 //   Synchronisation (LDS words, monotonic within the kernel; every wait is bounded and a wait that expires marks the leaf as failed):
-//     flag     panels published by the pivot wave                     tdone   tiles finished by the trailing wave (X_kk, L(k+1,k))
-//     pdone    diagonal tiles stored by the pivot wave                lrdone  L(k+2,k) stored by the trailing wave of tile k+1
-//     hdone    helpers that finished a window (6 per window)          hB      helpers that finished an alpha phase
-//     rowrdy   finished tiles of the row the next trailing wave needs (3 per window)   row2   helpers that have rows 32 .. 47 in LDS
+//     flag     panels published by the pivot wave            tdone   tiles finished by the trailing wave (X_kk, L(k+1,k))
+//     pdone    diagonal tiles stored by the pivot wave       lrdone  L(k+2,k) stored by the trailing wave of tile k+1
+//     lcol[t]  tiles of column block t stored by owners      xrowc[t]  finalised tiles of row block t of the inverse
+//     tpark[t] row block t of T parked                       rowf[i]   look-ahead tiles of row i in LDS
+//     row2 / loaded   helpers that have rows 32 .. 49 / all rows in LDS
 //
 //   The 4 x 4 inverse of a panel is a forward substitution carried out for its four columns at once, one column per 16-lane group
 //   (10 VALU instructions + 3 selects; round 5: 16 + 10 selects), and the pivot test is one compare per diagonal tile on the
@@ -58,11 +64,11 @@ constexpr int NHELP = NW - NCHAIN;    // helper waves 2 .. 7
 constexpr int HT = NHELP * 64;        // helper threads
 // LDS: the round-5 image (block + dense diagonal tiles of X) + the published panels (4 x (Y, lp) x 64 lanes) + sync words
 constexpr int PUB_OFF = LDS_DOUBLES;
-constexpr int SYNC_OFF = PUB_OFF + 4 * 128;      // 16 ints
-constexpr int TAB_W = 2 * NHELP;                 // gamma tasks of one window: two slots per helper
-constexpr size_t LEAF2_LDS = (size_t)(SYNC_OFF + 8) * sizeof(double);
+constexpr int SYNC_OFF = PUB_OFF + 4 * 128;      // 48 ints
+constexpr size_t LEAF2_LDS = (size_t)(SYNC_OFF + 24) * sizeof(double);
 static_assert(LEAF2_LDS <= 160 * 1024, "leaf LDS");
-enum { W_FLAG = 0, W_PDONE, W_TDONE, W_LRDONE, W_HDONE, W_HB, W_ROWRDY, W_BAD0, W_BAD1, W_TIMEOUT, W_ROW2 };
+enum { W_FLAG = 0, W_PDONE, W_TDONE, W_LRDONE, W_ROW2, W_LOADED, W_BAD0, W_BAD1, W_TIMEOUT, W_LCOL = 16, W_XROWC = 24, W_TPARK = 32,
+       W_ROWF = 40, W_NWORDS = 48 };
 
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 // (LDS operations of one wave execute in order: data stores issued before a flag store / counter add are visible before it)
@@ -82,6 +88,23 @@ __device__ __forceinline__ void word_wait(int* sync, int idx, int want) {
   }
   compiler_fence();
 }
+// A wave's SNAPSHOT of all sync words (lane l holds word l): one LDS round trip (~250 cycles here) serves every check until a word
+// is found too small -- the words only grow, so a stale snapshot errs on the safe side.
+struct Snap {
+  int v;
+  __device__ __forceinline__ void refresh(int* sync, int lane) {
+    compiler_fence();
+    v = __atomic_load_n(sync + (lane < W_NWORDS ? lane : 0), __ATOMIC_RELAXED);
+    compiler_fence();
+  }
+  __device__ __forceinline__ void need(int* sync, int lane, int idx, int want) {
+    int spin = 0;
+    while (__builtin_amdgcn_readlane(v, idx) < want) {
+      refresh(sync, lane);
+      if (++spin > SPIN_MAX) { __atomic_store_n(sync + W_TIMEOUT, 1, __ATOMIC_RELAXED); break; }
+    }
+  }
+};
 
 // ---- pivot wave: one 4-column panel of the diagonal tile held in d (d[e] of lane (c, g) = S[g+4e][c], symmetric) --------------
 // publishes yop = inv(L4) as an A-operand (lanes m = c < 4, k = g) and lp (register 0 of lane (n, g) = L[n][4P+g])
@@ -170,7 +193,7 @@ struct Out {
   double* __restrict__ A; long lda; int nb;
   double* __restrict__ inv;
 };
-// register tile v (v[e] of lane (c, g) = element [g+4e][c]) -> global
+// register tile v in the MFMA C/D layout (v[e] of lane (c, g) = element [g+4e][c]) -> global
 __device__ __forceinline__ void store_L_tile(const Out& o, int ti, int tj, d4 v, int lane) {
   const int c = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -184,127 +207,189 @@ __device__ __forceinline__ void store_X_tile(const Out& o, int ti, int tj, d4 v,
 #pragma unroll
   for (int e = 0; e < 4; ++e) o.inv[(ti * SB + g + 4 * e) * NB + tj * SB + c] = v[e];
 }
-
-// alpha task t of window k: rows k+3 .. of column block k, then row block k of the inverse
-__device__ __forceinline__ void run_alpha(double* __restrict__ S, int t, int k, int n8, int lane, const Out& o) {
-  const int nB = n8 - (k + 3) > 0 ? n8 - (k + 3) : 0;
-  Frag f;
-  d4 acc = {0.0, 0.0, 0.0, 0.0};
-  if (t < nB) {            // L(i,k) = A(i,k) X_kk^T
-    const int i = k + 3 + t;
-    frag_load(S, tile_L(i, k), tile_Xd(k), lane, f);
-    acc = frag_mma<false>(f, acc);
-    tile_store(S, tile_L(i, k), lane, acc);
-    store_L_tile(o, i, k, acc, lane);
-  } else {                 // X(k,j) = -X_kk T(k,j)
-    const int j = t - nB;
-    frag_load(S, tile_Xd(k), tr(tile_X(k, j)), lane, f);
-    acc = frag_mma<true>(f, acc);
-    tile_store(S, tile_X(k, j), lane, acc);
-    store_X_tile(o, k, j, acc, lane);
-  }
-}
-
-// gamma tasks of window k, packed (kind << 8 | i << 4 | j; 0 = empty slot):
-//   kind 1   tile (i,j) = A(i,j) - sum_{t=0}^{k} L(i,t) L(j,t)^T        row k+3: j = k+1, k+2, k+3; column block k+1: i = k+4 ..
-//   kind 2   T(k+1,j) = sum_{t=j}^{k} L(k+1,t) X(t,j),  j = 0 .. k
-// They are dealt to the helpers' slots at COMPILE time, for every block size: longest first, each to the helper with the least work
-// so far (the two helpers that share a SIMD with a chain wave count their work 3/2).
-struct TaskTable { int t[NSB + 1][NSB - 1][TAB_W]; };
-constexpr TaskTable make_task_table() {
-  TaskTable T{};
-  for (int n8 = 1; n8 <= NSB; ++n8)
-    for (int k = 0; k + 1 < n8; ++k) {
-      int load2[NHELP] = {}, nslot[NHELP] = {};   // work in products, slots used
-      const int nrow = (k + 3 < n8) ? 3 : 0, ncol = n8 - (k + 4) > 0 ? n8 - (k + 4) : 0;
-      const int ntask = nrow + ncol + (k + 1);
-      for (int t = 0; t < ntask; ++t) {   // (already in non-increasing order of weight)
-        int task = 0, w = 0;
-        if (t < nrow) { task = (1 << 8) | ((k + 3) << 4) | (k + 1 + t); w = k + 1; }
-        else if (t < nrow + ncol) { task = (1 << 8) | ((k + 4 + t - nrow) << 4) | (k + 1); w = k + 1; }
-        else { const int j = t - nrow - ncol; task = (2 << 8) | ((k + 1) << 4) | j; w = k + 1 - j; }
-        int best = -1, bestc = 1 << 30;
-        for (int q = 0; q < NHELP; ++q) {
-          if (nslot[q] >= 2) continue;
-          const int cst = (load2[q] + w) * ((q == 2 || q == 3) ? 3 : 2);
-          if (cst < bestc) { bestc = cst; best = q; }
-        }
-        T.t[n8][k][2 * best + nslot[best]] = task;
-        nslot[best] += 1;
-        load2[best] += w;
-      }
-    }
-  return T;
-}
-static __device__ const TaskTable g_leaf2_tasks = make_task_table();
-
 __device__ __forceinline__ d4 add4(d4 a, d4 b) { return (d4){a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]}; }
 __device__ __forceinline__ d4 sub4(d4 a, d4 b) { return (d4){a[0] - b[0], a[1] - b[1], a[2] - b[2], a[3] - b[3]}; }
 
-// One multi-term task.  Both kinds accumulate  sum_t  tile(i,t) * tile(j,t)^T  over ROW-MAJOR tiles of the LDS block: for the
-// inverse, X(t,j) is parked transposed in the upper triangle, i.e. AS tile (j,t); only its first term (t == j) reads the dense
-// diagonal tile X(j,j) instead.  Two accumulators (kk even / odd): the four MFMAs of a term issue back to back.
-struct HTask {
-  int kind, i, j;      // wave-uniform
-  d4 p0, p1;
-};
-struct HFrag { double a[4], b[4]; };
-__device__ __forceinline__ void htask_load(const double* __restrict__ S, const HTask& h, int t, int lane, HFrag& f) {
-  const int r = lane & 15, kq = lane >> 4;
-  const double* __restrict__ pa = S + (h.i * SB + r) * LD + t * SB + kq;
+// FRAGMENT layout of a 16 x 16 tile M: register e of lane (c, g) = M[c][4e+g] -- an MFMA A- or B-operand (kk = e) as it stands
+__device__ __forceinline__ d4 frag_rm(const double* __restrict__ S, int ti, int tj, int lane) {   // row-major tile (ti, tj) of the block
+  const double* __restrict__ p = S + (ti * SB + (lane & 15)) * LD + tj * SB + (lane >> 4);
+  return (d4){p[0], p[4], p[8], p[12]};
+}
+__device__ __forceinline__ d4 frag_xd(const double* __restrict__ S, int k, int lane) {             // X_kk
+  const double* __restrict__ p = S + XD_OFF + k * (SB * XLD) + (lane & 15) * XLD + (lane >> 4);
+  return (d4){p[0], p[4], p[8], p[12]};
+}
+__device__ __forceinline__ d4 frag_xdt(const double* __restrict__ S, int k, int lane) {            // X_kk^T
+  const double* __restrict__ p = S + XD_OFF + k * (SB * XLD) + (lane >> 4) * XLD + (lane & 15);
+  return (d4){p[0], p[4 * XLD], p[8 * XLD], p[12 * XLD]};
+}
+__device__ __forceinline__ void store_frag_rm(double* __restrict__ S, int ti, int tj, d4 v, int lane) {
+  double* __restrict__ p = S + (ti * SB + (lane & 15)) * LD + tj * SB + (lane >> 4);
+  p[0] = v[0]; p[4] = v[1]; p[8] = v[2]; p[12] = v[3];
+}
+// D[m][n] (+)= sum_q A[m][q] B[n][q] with both operands in fragment layout; kk even / odd in two accumulators (half the chain)
+__device__ __forceinline__ void mma2(d4 a, d4 b, d4& p0, d4& p1) {
+  p0 = mfma4(a[0], b[0], p0);
+  p1 = mfma4(a[1], b[1], p1);
+  p0 = mfma4(a[2], b[2], p0);
+  p1 = mfma4(a[3], b[3], p1);
+}
+__device__ __forceinline__ d4 mma1(d4 a, d4 b, d4 acc) {
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) f.a[kk] = pa[4 * kk];
-  if (h.kind == 2 && t == h.j) {   // X(j,j)[q][n] as B[n][q]: dense tile, transposed view
-    const double* __restrict__ pb = S + XD_OFF + h.j * (SB * XLD) + kq * XLD + r;
+  for (int kk = 0; kk < 4; ++kk) acc = mfma4(a[kk], b[kk], acc);
+  return acc;
+}
+
+// duty of every helper (and, for the last row block, of the chain waves): X(t,j) = -X_tt T(t,j) for its share of row block t
+__device__ __forceinline__ void finalize_tile(double* __restrict__ S, int t, int j, int lane, const Out& o, int* __restrict__ sync) {
+  const d4 xd = frag_xd(S, t, lane);
+  const d4 tt = frag_rm(S, j, t, lane);   // T(t,j) is parked transposed, i.e. as tile (j, t): Bnt[n][q] = T[q][n]
+  d4 p0 = {0.0, 0.0, 0.0, 0.0}, p1 = p0;
+  mma2(-xd, tt, p0, p1);
+  const d4 x = add4(p0, p1);
+  tile_store(S, tile_X(t, j), lane, x);
+  store_X_tile(o, t, j, x, lane);
+  word_add(sync + W_XROWC + t, lane);
+}
+
+// The owner of tile row I (compile time).  `mine` = the row exists (I < n8); the duties are done either way.
+// DUTY 1 (the helper of row 2): the chain's tiles of column block t to global memory, and row 1 of the inverse (it has no owner).
+// DUTY 2 (the helper of row 3): the zeros right of row block t of the inverse.
+template <int I, int DUTY, bool STAMPS>
+__device__ __forceinline__ void owner_row(double* __restrict__ S, int h, int lane, int n8, const Out& out, int* __restrict__ sync,
+                                          long long* __restrict__ dbg) {
+  constexpr int NL = I >= 3 ? I - 2 : 1;   // own tiles L(I,s), s = 0 .. I-3
+  const bool mine = I < n8;
+  const d4 zero = {0.0, 0.0, 0.0, 0.0};
+  d4 Lown[NL], T[I], R[3];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) f.b[kk] = pb[4 * kk * XLD];
-  } else {
-    const double* __restrict__ pb = S + (h.j * SB + r) * LD + t * SB + kq;
+  for (int s = 0; s < NL; ++s) Lown[s] = zero;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) f.b[kk] = pb[4 * kk];
+  for (int j = 0; j < I; ++j) T[j] = zero;
+  R[0] = zero; R[1] = zero; R[2] = zero;
+  Snap sn;
+  sn.refresh(sync, lane);
+  for (int t = 0; t < n8; ++t) {
+    auto stamp = [&](int q) { if constexpr (STAMPS) { if (h == 0 && lane == 0) dbg[144 + 8 * t + q] = clock64(); } };
+    stamp(0);
+    // ---- (a) C = sum_{s<t} L(I,s) L(t,s)^T, transposed (so that it comes out in fragment layout): D[m][n] = sum L(t,s)[m][q] L(I,s)[n][q]
+    d4 c0 = zero, c1 = zero;
+    const bool col = mine && t <= I - 3;
+    if (col && t >= 1) {
+      sn.need(sync, lane, W_TDONE, t);                       // L(t,t-1)
+      if (t >= 2) sn.need(sync, lane, W_LRDONE, t - 1);      // L(t,t-2)
+      if (t >= 3) sn.need(sync, lane, W_LCOL + t - 3, n8 - t);   // L(t,t-3) (column block t-3 complete: n8 - (t-3) - 3 tiles)
+#pragma unroll
+      for (int s = 0; s < NL; ++s)
+        if (s < t) mma2(frag_rm(S, t, s, lane), Lown[s], c0, c1);
+    }
+    stamp(1);
+    // ---- (b) A_t: X_tt, L(t+1,t) and L(t,t) are in LDS
+    sn.need(sync, lane, W_TDONE, t + 1);
+    sn.need(sync, lane, W_PDONE, t + 1);
+    stamp(2);
+    // ---- (d) L(I,t) = (A(I,t) - C) X_tt^T:  D[m][n] = sum_q X[m][q] Cc[n][q], again in fragment layout
+    d4 lr = zero;
+    if (col) {
+      const d4 cc = sub4(frag_rm(S, I, t, lane), add4(c0, c1));
+      d4 p0 = zero, p1 = zero;
+      mma2(frag_xd(S, t, lane), cc, p0, p1);
+      lr = add4(p0, p1);
+      store_frag_rm(S, I, t, lr, lane);
+      word_add(sync + W_LCOL + t, lane);
+      {  // final: to global memory (register e of lane (c, g) = L[c][4e+g])
+        const int row = I * SB + (lane & 15);
+        if (row < out.nb) {
+          double* __restrict__ dst = out.A + (long)row * out.lda + t * SB + (lane >> 4);
+          dst[0] = lr[0]; dst[4] = lr[1]; dst[8] = lr[2]; dst[12] = lr[3];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NL; ++s)
+        if (s == t) Lown[s] = lr;
+    }
+    stamp(3);
+    // ---- (e) look-ahead tiles of row I: term t of  sum_{s <= I-3} L(I,s) L(j',s)^T,  j' = I-2, I-1, I
+    if constexpr (I >= 3) {
+      if (col) {
+        sn.need(sync, lane, W_LCOL + t, n8 - t - 3);         // rows I-2, I-1 of column block t from their owners ...
+        if (t + 2 < n8) sn.need(sync, lane, W_LRDONE, t + 1);   // ... or from the chain: L(t+2,t); L(t+1,t) came with A_t
+        const d4 b0 = frag_rm(S, I - 2, t, lane), b1 = frag_rm(S, I - 1, t, lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          R[0] = mfma4(lr[kk], b0[kk], R[0]);
+          R[1] = mfma4(lr[kk], b1[kk], R[1]);
+          R[2] = mfma4(lr[kk], lr[kk], R[2]);
+        }
+        if (t == I - 3) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) tile_store(S, tile_L(I, I - 2 + q), lane, sub4(tile_load(S, tile_L(I, I - 2 + q), lane), R[q]));
+          word_set(sync + W_ROWF + I, 1);
+        }
+      }
+    }
+    stamp(4);
+    // ---- duties of window t
+    if (t >= 1) {   // finalise my share of row block t of the inverse (all eight waves share the last one)
+      const bool last = t == n8 - 1;
+      sn.need(sync, lane, W_TPARK + t, 1);
+      for (int j = h; j < t; j += (last ? NW : NHELP)) finalize_tile(S, t, j, lane, out, sync);
+    }
+    if constexpr (DUTY == 1) {
+      store_L_tile(out, t, t, tile_load(S, tile_L(t, t), lane), lane);
+      store_X_tile(out, t, t, tile_load(S, tile_Xd(t), lane), lane);
+      if (t + 1 < n8) store_L_tile(out, t + 1, t, tile_load(S, tile_L(t + 1, t), lane), lane);
+      if (t >= 1 && t + 1 < n8) store_L_tile(out, t + 1, t - 1, tile_load(S, tile_L(t + 1, t - 1), lane), lane);   // L(t+1,t-1): stored before A_t
+      if (t == 0 && n8 > 1) {   // row 1 of the inverse: T(1,0) = L(1,0) X_00
+        d4 p0 = zero, p1 = zero;
+        mma2(frag_rm(S, 1, 0, lane), frag_xdt(S, 0, lane), p0, p1);
+        tile_store(S, tile_X(1, 0), lane, add4(p0, p1));
+        word_set(sync + W_TPARK + 1, 1);
+      }
+    }
+    if constexpr (DUTY == 2) {
+      const int zp = (NB - (t + 1) * SB) / 2;   // column pairs right of the diagonal tile
+      for (int r = 0; r < SB; ++r)
+        for (int q = lane; q < zp; q += 64) *reinterpret_cast<d2*>(&out.inv[(t * SB + r) * NB + (t + 1) * SB + 2 * q]) = (d2){0.0, 0.0};
+    }
+    stamp(5);
+    // ---- (f) term t of T(I,j), j <= t:  D[m][n] += sum_q L(I,t)[m][q] X(t,j)[q][n]   (X(t,j) parked transposed = tile (j,t))
+    if (mine && t < I) {
+      d4 aop = lr;
+      if (t == I - 2) { sn.need(sync, lane, W_LRDONE, I - 1); aop = frag_rm(S, I, t, lane); }   // L(I,I-2) from the trailing wave
+      if (t == I - 1) aop = frag_rm(S, I, t, lane);                                          // L(I,I-1): came with A_t
+      if (t >= 1) sn.need(sync, lane, W_XROWC + t, t);
+#pragma unroll
+      for (int j0 = 0; j0 < I; j0 += 2) {
+        if (j0 <= t) {   // pairs of tiles: two independent chains per block; the second operand is zeroed beyond the diagonal
+          const d4 b0 = (j0 == t) ? frag_xdt(S, t, lane) : frag_rm(S, j0, t, lane);
+          d4 b1 = zero;
+          if (j0 + 1 < I) {
+            if (j0 + 1 == t) b1 = frag_xdt(S, t, lane);
+            else if (j0 + 1 < t) b1 = frag_rm(S, j0 + 1, t, lane);
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            T[j0] = mfma4(aop[kk], b0[kk], T[j0]);
+            if (j0 + 1 < I) T[j0 + 1] = mfma4(aop[kk], b1[kk], T[j0 + 1]);
+          }
+        }
+      }
+      if (t == I - 1) {
+#pragma unroll
+        for (int j = 0; j < I; ++j) tile_store(S, tile_X(I, j), lane, T[j]);
+        word_set(sync + W_TPARK + I, 1);
+      }
+    }
+    stamp(6);
   }
-}
-__device__ __forceinline__ void htask_mma(HTask& h, const HFrag& f) {
-  h.p0 = mfma4(f.a[0], f.b[0], h.p0);
-  h.p1 = mfma4(f.a[1], f.b[1], h.p1);
-  h.p0 = mfma4(f.a[2], f.b[2], h.p0);
-  h.p1 = mfma4(f.a[3], f.b[3], h.p1);
-}
-// terms t0 .. t1 (inclusive), operands of term t+1 in flight during the MFMAs of term t
-__device__ __forceinline__ void htask_terms(const double* __restrict__ S, HTask& h, int t0, int t1, int lane) {
-  if (h.kind == 0 || t0 > t1) return;
-  HFrag f, n;
-  htask_load(S, h, t0, lane, f);
-  int t = t0;
-  for (; t + 2 <= t1; t += 2) {
-    htask_load(S, h, t + 1, lane, n);
-    htask_mma(h, f);
-    htask_load(S, h, t + 2, lane, f);
-    htask_mma(h, n);
-  }
-  if (t + 1 <= t1) {
-    htask_load(S, h, t + 1, lane, n);
-    htask_mma(h, f);
-    htask_mma(h, n);
-  } else {
-    htask_mma(h, f);
-  }
-}
-__device__ __forceinline__ void htask_open(HTask& h, int packed) {
-  h.kind = packed >> 8; h.i = (packed >> 4) & 15; h.j = packed & 15;
-  h.p0 = (d4){0.0, 0.0, 0.0, 0.0}; h.p1 = h.p0;
-}
-__device__ __forceinline__ void htask_close(double* __restrict__ S, const HTask& h, int lane) {
-  if (h.kind == 1) tile_store(S, tile_L(h.i, h.j), lane, sub4(tile_load(S, tile_L(h.i, h.j), lane), add4(h.p0, h.p1)));
-  else if (h.kind == 2) tile_store(S, tile_X(h.i, h.j), lane, add4(h.p0, h.p1));
 }
 
 // The leaf (NOT already factored): one workgroup of NT threads, LDS block S of LEAF2_LDS bytes.
 // STAMPS (tools/leaf_probe.hip only): shader-clock time stamps.  dbg[16 + 8 k + q], written by the PIVOT wave of tile k: 0 tile
 // started, 1 .. 3 panels 0 .. 2 done, 4 panel 3 done and L stored; dbg[80 + 8 k + q], by the TRAILING wave of tile k: 0 start, 1
-// inputs there (waits done), 2 L(k+1,k-1) stored, 3 look-ahead pair formed, 4 last panel followed (s2 final); dbg[144 + 8 k + q],
-// helper wave 2 in window k: 0 window entered, 1 early terms done, 2 A_k reached, 3 alpha done, 4 B_k reached, 5 last terms done,
-// 6 stores issued.
+// inputs there (waits done), 2 L(k+1,k-1) stored, 3 look-ahead pair formed, 4 last panel followed (s2 final); dbg[144 + 8 t + q], the
+// owner of row 7 in window t: 0 entered, 1 (a) done, 2 A_t reached, 3 (d) done, 4 (e) done, 5 duties done, 6 (f) done.
 template <bool STAMPS = false>
 __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __restrict__ A, long lda, int nb,
                                            double* __restrict__ inv, int* __restrict__ info, int col0,
@@ -317,7 +402,7 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
   const Out out{A, lda, nb, inv};
   double* __restrict__ pub = S + PUB_OFF;
   int* __restrict__ sync = reinterpret_cast<int*>(S + SYNC_OFF);
-  if (tid < 16) sync[tid] = (tid == W_BAD0 || tid == W_BAD1) ? 0x7fffffff : 0;
+  if (tid < W_NWORDS) sync[tid] = (tid == W_BAD0 || tid == W_BAD1) ? 0x7fffffff : 0;
   __syncthreads();   // the only workgroup barrier
 
   if (wave < NCHAIN) {
@@ -385,7 +470,7 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
           // X_{k-1,k-1} and L(k,k-1) from the other chain wave; row k+1 of the block up to date through column block k-2
           word_wait(sync, W_TDONE, k);
           if (ahead) {
-            if (k == 1) word_wait(sync, W_ROW2, NHELP); else word_wait(sync, W_ROWRDY, 3 * (k - 1));
+            if (k == 1) word_wait(sync, W_ROW2, NHELP); else word_wait(sync, W_ROWF + k + 1, 1);
           }
         }
         stamp(1);
@@ -452,17 +537,15 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
     const int htid = tid - 64 * NCHAIN;  // 0 .. 383
     const int rows_used = n8 * SB;
     // load: lower triangle of A from row 32 on (identity beyond nb) into LDS -- tiles (0,0), (1,0), (1,1) go to the chain waves'
-    // registers only; all loads issued up front
+    // registers only.  One row per wave and iteration (1 KB, one 16-byte load per lane), all loads issued up front.
     {
       const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-      constexpr int ROW0 = 2 * SB;
-      constexpr int PAIRS = (NB - ROW0) * (NB / 2);  // (row, column pair)
-      constexpr int NIT = (PAIRS + HT - 1) / HT;     // 16
+      constexpr int ROW0 = 2 * SB, NIT = (NB - ROW0) / NHELP;   // 16 rows per wave
+      const int jp = 2 * lane;
       d2 v[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int e = htid + HT * it;
-        const int i = ROW0 + e / (NB / 2), jp = 2 * (e % (NB / 2));
+        const int i = ROW0 + h + NHELP * it;
         v[it] = (d2){0.0, 0.0};
         if (i < nb && jp <= i) {
           const double* src = A + (long)i * lda + jp;
@@ -473,17 +556,16 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
       // while they fly: for a ragged block the identity rows of the inverse
       if (n8 < NSB) {
         for (int e = htid; e < NB * (NB / 2); e += HT) {
-          const int i = e / (NB / 2), jp = 2 * (e % (NB / 2));
+          const int i = e / (NB / 2), jq = 2 * (e % (NB / 2));
           if (i >= rows_used) {
-            d2 z = {(jp == i) ? 1.0 : 0.0, (jp + 1 == i) ? 1.0 : 0.0};
-            *reinterpret_cast<d2*>(&inv[i * NB + jp]) = z;
+            d2 z = {(jq == i) ? 1.0 : 0.0, (jq + 1 == i) ? 1.0 : 0.0};
+            *reinterpret_cast<d2*>(&inv[i * NB + jq]) = z;
           }
         }
       }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int e = htid + HT * it;
-        const int i = ROW0 + e / (NB / 2), jp = 2 * (e % (NB / 2));
+        const int i = ROW0 + h + NHELP * it;
         if (jp <= i && i < rows_used) {
           d2 w = v[it];
           if (i >= nb) w.x = (jp == i) ? 1.0 : 0.0;
@@ -493,69 +575,26 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
         if (it == 2) word_add(sync + W_ROW2, lane);   // rows 32 .. 49: what the trailing wave of tile 1 needs
       }
     }
-    word_add(sync + W_HDONE, lane);
-    for (int k = 0; k + 1 < n8; ++k) {
-      auto stamp = [&](int q) { if constexpr (STAMPS) { if (wave == NCHAIN && lane == 0) dbg[144 + 8 * k + q] = clock64(); } };
-      stamp(0);
-      // ---- early terms of this window's tasks (t < k): everything they read was final at B_{k-1}
-      HTask ta, tb;
-      htask_open(ta, g_leaf2_tasks.t[n8][k][2 * h]);
-      htask_open(tb, g_leaf2_tasks.t[n8][k][2 * h + 1]);
-      htask_terms(S, ta, ta.kind == 2 ? ta.j : 0, k - 1, lane);
-      htask_terms(S, tb, tb.kind == 2 ? tb.j : 0, k - 1, lane);
-      stamp(1);
-      // ---- A_k: every helper is through window k-1, the chain has stored L(k,k), X_kk, L(k+1,k)
-      word_wait(sync, W_HDONE, NHELP * (k + 1));
-      word_wait(sync, W_PDONE, k + 1);
-      word_wait(sync, W_TDONE, k + 1);
-      stamp(2);
-      // ---- alpha
-      {
-        const int nB = n8 - (k + 3) > 0 ? n8 - (k + 3) : 0;
-        for (int t = h; t < nB + k; t += NHELP) run_alpha(S, t, k, n8, lane, out);
-      }
-      word_add(sync + W_HB, lane);
-      stamp(3);
-      // ---- B_k: alpha of every helper is done, the trailing wave of tile k+1 has stored L(k+2,k)
-      word_wait(sync, W_HB, NHELP * (k + 1));
-      if (k + 2 < n8) word_wait(sync, W_LRDONE, k + 1);
-      stamp(4);
-      // ---- last term (t = k), results to LDS; the row tasks (what the next trailing wave waits for) sit in slot 0
-      htask_terms(S, ta, k, k, lane);
-      htask_close(S, ta, lane);
-      if (ta.kind == 1 && ta.i == k + 3) word_add(sync + W_ROWRDY, lane);
-      htask_terms(S, tb, k, k, lane);
-      htask_close(S, tb, lane);
-      if (tb.kind == 1 && tb.i == k + 3) word_add(sync + W_ROWRDY, lane);
-      stamp(5);
-      // ---- the chain's tiles of column block k (L(k,k), L(k+1,k), L(k+2,k), X_kk) and the zeros right of row block k of the inverse
-      for (int u = h; u < 4; u += NHELP) {
-        if (u < 3) { if (k + u < n8) store_L_tile(out, k + u, k, tile_load(S, tile_L(k + u, k), lane), lane); }
-        else store_X_tile(out, k, k, tile_load(S, tile_Xd(k), lane), lane);
-      }
-      const int zp = (NB - (k + 1) * SB) / 2;   // column pairs right of the diagonal tile
-      for (int r = h; r < SB; r += NHELP)
-        for (int q = lane; q < zp; q += 64) *reinterpret_cast<d2*>(&inv[(k * SB + r) * NB + (k + 1) * SB + 2 * q]) = (d2){0.0, 0.0};
-      stamp(6);
-      word_add(sync + W_HDONE, lane);
+    word_add(sync + W_LOADED, lane);
+    word_wait(sync, W_LOADED, NHELP);
+    // rows by weight (products: 65, 49, 35, 23, 13, 5): the two heaviest on the SIMDs without a chain wave, each with a light one
+    switch (h) {
+      case 0: owner_row<7, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 1: owner_row<6, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 2: owner_row<5, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 3: owner_row<2, 1, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 4: owner_row<3, 2, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      default: owner_row<4, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
     }
   }
-  // ================================== tail (all eight waves): last row block of the inverse ==================================
-  {
-    const int k = n8 - 1;
-    word_wait(sync, W_HDONE, NHELP * n8);
+  // ================================== tail ==================================
+  if (wave < NCHAIN) {
+    const int t = n8 - 1;
     word_wait(sync, W_PDONE, n8);
     word_wait(sync, W_TDONE, n8);
-    const long long t_factored = dbg ? wall_clock64() : 0;
-    if (n8 < NSB) {
-      const int zp = (NB - (k + 1) * SB) / 2;
-      for (int r = wave; r < SB; r += NW)
-        for (int q = lane; q < zp; q += 64) *reinterpret_cast<d2*>(&inv[(k * SB + r) * NB + (k + 1) * SB + 2 * q]) = (d2){0.0, 0.0};
-    }
-    for (int t = wave; t < k + 2; t += NW) {
-      if (t < k) run_alpha(S, t, k, n8, lane, out);   // (no rows below: task t is X(k,t) = -X_kk T(k,t))
-      else if (t == k) store_L_tile(out, k, k, tile_load(S, tile_L(k, k), lane), lane);
-      else store_X_tile(out, k, k, tile_load(S, tile_Xd(k), lane), lane);
+    if (t >= 1) {   // the chain waves' share of the last row block of the inverse
+      word_wait(sync, W_TPARK + t, 1);
+      for (int j = NHELP + wave; j < t; j += NW) finalize_tile(S, t, j, lane, out, sync);
     }
     if (wave == 0 && lane == 0 && info) {                // first failing pivot of the matrix wins (an earlier leaf may have reported)
       const int b0 = sync[W_BAD0], b1 = sync[W_BAD1];
@@ -565,11 +604,10 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
         else if (sync[W_TIMEOUT]) info[0] = 0x7fffffff;  // a hand-off inside the leaf timed out (gpk.h: INT_MAX)
       }
     }
-    if (dbg && tid == 0) {
-      const long long t_end = wall_clock64();
-      dbg[0] = 0; dbg[1] = t_factored - t_begin; dbg[2] = 0;
-      dbg[3] = t_end - t_factored; dbg[4] = t_end - t_begin; dbg[5] = t_begin;
-    }
+  }
+  if (dbg && tid == 0) {
+    const long long t_end = wall_clock64();
+    dbg[0] = 0; dbg[1] = 0; dbg[2] = 0; dbg[3] = 0; dbg[4] = t_end - t_begin; dbg[5] = t_begin;
   }
 }
 

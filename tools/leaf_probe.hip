@@ -193,8 +193,8 @@ int main(int argc, char** argv) {
       const long long* q = st + 80 + 8 * k;
       printf("tile %d: %6lld | %6lld | %6lld | %6lld | %6lld -> %lld\n", k, q[0] - z, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[4] - z);
     }
-    printf("# helper wave 2, window k: entered at | early terms | wait A | alpha | wait B | last terms | stores (done at)\n");
-    for (int k = 0; k < 7; ++k) {
+    printf("# owner of row 7, window t: entered at | (a) early terms | wait A_t | (d) L(7,t) | (e) look-ahead tiles | duties | (f) inverse sums (done at)\n");
+    for (int k = 0; k < 8; ++k) {
       const long long* q = st + 144 + 8 * k;
       printf("window %d: %6lld | %6lld | %6lld | %6lld | %6lld | %6lld | %6lld (%lld)\n", k, q[0] - z, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3],
              q[5] - q[4], q[6] - q[5], q[6] - z);
