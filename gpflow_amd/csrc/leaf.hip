@@ -26,14 +26,13 @@
 namespace {
 using namespace gpk_leaf;
 
-// FACTORED = false: the round-6 leaf (leaf2_device.h: pivot wave free of barriers, helpers in phases; the description above is the
-// round 1 - 5 leaf, which still inverts the diagonal blocks of an existing factor -- FACTORED = true -- and is the A/B baseline
-// `v1` of the experimental build, GPK_LEAF_V1=1).
+// The round 1 - 5 leaf described above: still what inverts the diagonal blocks of an existing factor (FACTORED = true) and, with
+// FACTORED = false, the A/B baseline of the experimental build (GPK_LEAF_V1=1).  The product factors with leaf2_kernel below.
 template <bool FACTORED>
 __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, long lda, long strideA, int nb,
                                                    double* __restrict__ invbase, long strideInv,
                                                    int* __restrict__ info, int col0,
-                                                   long long* __restrict__ dbg, int fake_ticks, int v1) {
+                                                   long long* __restrict__ dbg, int fake_ticks) {
   extern __shared__ __attribute__((aligned(16))) double S[];
 #ifdef GPK_EXPERIMENTAL
   if (fake_ticks > 0) {
@@ -51,20 +50,17 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
     return;
   }
 #endif
-  if constexpr (FACTORED) {
-    leaf_body<true>(S, Abase + (long)blockIdx.x * strideA, lda, nb, invbase + (long)blockIdx.x * strideInv,
-                    info ? info + blockIdx.x : nullptr, col0, dbg);
-  } else {
-#ifdef GPK_EXPERIMENTAL
-    if (v1) {
-      leaf_body<false>(S, Abase + (long)blockIdx.x * strideA, lda, nb, invbase + (long)blockIdx.x * strideInv,
-                       info ? info + blockIdx.x : nullptr, col0, dbg);
-      return;
-    }
-#endif
-    gpk_leaf2::leaf2_body<false>(S, Abase + (long)blockIdx.x * strideA, lda, nb, invbase + (long)blockIdx.x * strideInv,
-                          info ? info + blockIdx.x : nullptr, col0, dbg);
-  }
+  leaf_body<FACTORED>(S, Abase + (long)blockIdx.x * strideA, lda, nb, invbase + (long)blockIdx.x * strideInv,
+                      info ? info + blockIdx.x : nullptr, col0, dbg);
+}
+
+// the round-6 leaf (leaf2_device.h): twelve waves
+__global__ __launch_bounds__(gpk_leaf2::NT2) void leaf2_kernel(double* __restrict__ Abase, long lda, long strideA, int nb,
+                                                                double* __restrict__ invbase, long strideInv,
+                                                                int* __restrict__ info, int col0, long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double S[];
+  gpk_leaf2::leaf2_body<false>(S, Abase + (long)blockIdx.x * strideA, lda, nb, invbase + (long)blockIdx.x * strideInv,
+                               info ? info + blockIdx.x : nullptr, col0, dbg);
 }
 
 }  // namespace
@@ -98,31 +94,40 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
   // (function-local statics: initialised once, thread-safe)
   static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_kernel<true>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
-  constexpr size_t LDS0 = gpk_leaf2::LEAF2_LDS > LEAF_LDS ? gpk_leaf2::LEAF2_LDS : LEAF_LDS;
   static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_kernel<false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS0);
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+  static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(leaf2_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)gpk_leaf2::LEAF2_LDS);
   GPK_HIP(attr1);
   GPK_HIP(attr0);
+  GPK_HIP(attr2);
   dim3 grid((unsigned)(batch > 0 ? batch : 1));
   const int fake = kGpkExp ? GPK_TUNE(LEAF_FAKE_US, 0) * 100 : 0;
-  const int v1 = kGpkExp ? GPK_TUNE(LEAF_V1, 0) : 0;
+  const int v1 = kGpkExp ? (GPK_TUNE(LEAF_V1, 0) || fake > 0) : 0;
 #ifdef GPK_EXPERIMENTAL
   // phase timers of every leaf launch (GPK_LEAF_DBG=1; printed by gpk_exp_leaf_dbg_dump): load / factor / invert / store
   if (!already_factored && GPK_TUNE(LEAF_DBG, 0) && g_dbg_n < DBG_CAP) {
     if (!g_dbg) GPK_HIP(hipMalloc(&g_dbg, sizeof(long long) * 8 * DBG_CAP));
     g_dbg_col[g_dbg_n] = col0;
-    hipLaunchKernelGGL((leaf_kernel<false>), grid, dim3(NT), LDS0, s, A, lda, strideA, nb, invd, strideInv, info, col0,
-                       g_dbg + 8 * (g_dbg_n++), fake, v1);
+    if (v1)
+      hipLaunchKernelGGL((leaf_kernel<false>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd, strideInv, info, col0,
+                         g_dbg + 8 * (g_dbg_n++), fake);
+    else
+      hipLaunchKernelGGL(leaf2_kernel, grid, dim3(gpk_leaf2::NT2), gpk_leaf2::LEAF2_LDS, s, A, lda, strideA, nb, invd, strideInv, info,
+                         col0, g_dbg + 8 * (g_dbg_n++));
     GPK_LAUNCH_CHECK();
     return 0;
   }
 #endif
   if (already_factored)
     hipLaunchKernelGGL((leaf_kernel<true>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd,
-                       strideInv, info, col0, nullptr, 0, 0);
+                       strideInv, info, col0, nullptr, 0);
+  else if (v1)
+    hipLaunchKernelGGL((leaf_kernel<false>), grid, dim3(NT), LEAF_LDS, s, A, lda, strideA, nb, invd,
+                       strideInv, info, col0, nullptr, fake);
   else
-    hipLaunchKernelGGL((leaf_kernel<false>), grid, dim3(NT), LDS0, s, A, lda, strideA, nb, invd,
-                       strideInv, info, col0, nullptr, fake, v1);
+    hipLaunchKernelGGL(leaf2_kernel, grid, dim3(gpk_leaf2::NT2), gpk_leaf2::LEAF2_LDS, s, A, lda, strideA, nb, invd, strideInv, info,
+                       col0, nullptr);
   GPK_LAUNCH_CHECK();
   return 0;
 }

@@ -24,8 +24,9 @@
 //     and then catches up with the panels already published.  The critical path per diagonal tile is four panels of pivot
 //     arithmetic plus ~2 MFMA latencies of hand-over -- no barrier, LDS round trip or tile product is on it.
 //
-//   helper waves 2 .. 7 each OWN ONE TILE ROW I of the block (rows 7, 6, 5, 2, 3, 4: the heavy rows on the SIMDs without a chain
-//   wave) and keep everything of that row in registers -- its finished tiles L(I,s) as MFMA operands, the running sums
+//   helper waves 2 .. 11 OWN TILE ROWS of the block -- rows 7, 6, 5 two waves each (one for the row of L and the look-ahead tiles,
+//   steps a, d, e below; one for the row of the inverse, step f), rows 4, 3, 2 one wave each; the heavy ones on the SIMDs without a
+//   chain wave -- and keep everything of their row in registers -- its finished tiles L(I,s) as MFMA operands, the running sums
 //   T(I,j) = sum_{t=j}^{I-1} L(I,t) X(t,j) of its row of the inverse, the three tiles the chain picks up.  Per diagonal tile t
 //   ("window t") an owner
 //     (a) accumulates  C = sum_{s<t} L(I,s) L(t,s)^T  (operands final one window earlier; nothing to wait for),
@@ -59,8 +60,13 @@
 namespace gpk_leaf2 {
 using namespace gpk_leaf;
 
+#ifndef LEAF2_CHAIN_PRIO
+#define LEAF2_CHAIN_PRIO 3
+#endif
+constexpr int NT2 = 768;              // twelve waves, three per SIMD
+constexpr int NW2 = NT2 / 64;
 constexpr int NCHAIN = 2;             // chain waves 0, 1
-constexpr int NHELP = NW - NCHAIN;    // helper waves 2 .. 7
+constexpr int NHELP = NW2 - NCHAIN;   // helper waves 2 .. 11
 constexpr int HT = NHELP * 64;        // helper threads
 // LDS: the round-5 image (block + dense diagonal tiles of X) + the published panels (4 x (Y, lp) x 64 lanes) + sync words
 constexpr int PUB_OFF = LDS_DOUBLES;
@@ -253,12 +259,14 @@ __device__ __forceinline__ void finalize_tile(double* __restrict__ S, int t, int
 }
 
 // The owner of tile row I (compile time).  `mine` = the row exists (I < n8); the duties are done either way.
-// DUTY 1 (the helper of row 2): the chain's tiles of column block t to global memory, and row 1 of the inverse (it has no owner).
-// DUTY 2 (the helper of row 3): the zeros right of row block t of the inverse.
-template <int I, int DUTY, bool STAMPS>
+// MODE 0: the whole row; 1: its tiles of L and the look-ahead tiles (a, d, e); 2: its row of the inverse (f); 3: duties only.
+// DUTY 1: the chain's tiles of column block t to global memory, and row 1 of the inverse (it has no owner).
+// DUTY 2: the zeros right of row block t of the inverse.
+template <int I, int MODE, int DUTY, bool STAMPS>
 __device__ __forceinline__ void owner_row(double* __restrict__ S, int h, int lane, int n8, const Out& out, int* __restrict__ sync,
                                           long long* __restrict__ dbg) {
   constexpr int NL = I >= 3 ? I - 2 : 1;   // own tiles L(I,s), s = 0 .. I-3
+  constexpr bool DO_L = MODE == 0 || MODE == 1, DO_X = MODE == 0 || MODE == 2;
   const bool mine = I < n8;
   const d4 zero = {0.0, 0.0, 0.0, 0.0};
   d4 Lown[NL], T[I], R[3];
@@ -270,11 +278,13 @@ __device__ __forceinline__ void owner_row(double* __restrict__ S, int h, int lan
   Snap sn;
   sn.refresh(sync, lane);
   for (int t = 0; t < n8; ++t) {
-    auto stamp = [&](int q) { if constexpr (STAMPS) { if (h == 0 && lane == 0) dbg[144 + 8 * t + q] = clock64(); } };
+    auto stamp = [&](int q) {
+      if constexpr (STAMPS) { if ((h == 0 || h == 1) && lane == 0) dbg[144 + 64 * h + 8 * t + q] = clock64(); }
+    };
     stamp(0);
     // ---- (a) C = sum_{s<t} L(I,s) L(t,s)^T, transposed (so that it comes out in fragment layout): D[m][n] = sum L(t,s)[m][q] L(I,s)[n][q]
     d4 c0 = zero, c1 = zero;
-    const bool col = mine && t <= I - 3;
+    const bool col = DO_L && mine && t <= I - 3;
     if (col && t >= 1) {
       sn.need(sync, lane, W_TDONE, t);                       // L(t,t-1)
       if (t >= 2) sn.need(sync, lane, W_LRDONE, t - 1);      // L(t,t-2)
@@ -333,7 +343,7 @@ __device__ __forceinline__ void owner_row(double* __restrict__ S, int h, int lan
     if (t >= 1) {   // finalise my share of row block t of the inverse (all eight waves share the last one)
       const bool last = t == n8 - 1;
       sn.need(sync, lane, W_TPARK + t, 1);
-      for (int j = h; j < t; j += (last ? NW : NHELP)) finalize_tile(S, t, j, lane, out, sync);
+      for (int j = h; j < t; j += (last ? NW2 : NHELP)) finalize_tile(S, t, j, lane, out, sync);
     }
     if constexpr (DUTY == 1) {
       store_L_tile(out, t, t, tile_load(S, tile_L(t, t), lane), lane);
@@ -354,8 +364,11 @@ __device__ __forceinline__ void owner_row(double* __restrict__ S, int h, int lan
     }
     stamp(5);
     // ---- (f) term t of T(I,j), j <= t:  D[m][n] += sum_q L(I,t)[m][q] X(t,j)[q][n]   (X(t,j) parked transposed = tile (j,t))
-    if (mine && t < I) {
+    if (DO_X && mine && t < I) {
       d4 aop = lr;
+      if constexpr (MODE == 2) {   // the row of L is another wave's: column block t complete, then from LDS
+        if (t <= I - 3) { sn.need(sync, lane, W_LCOL + t, n8 - t - 3); aop = frag_rm(S, I, t, lane); }
+      }
       if (t == I - 2) { sn.need(sync, lane, W_LRDONE, I - 1); aop = frag_rm(S, I, t, lane); }   // L(I,I-2) from the trailing wave
       if (t == I - 1) aop = frag_rm(S, I, t, lane);                                          // L(I,I-1): came with A_t
       if (t >= 1) sn.need(sync, lane, W_XROWC + t, t);
@@ -385,11 +398,12 @@ __device__ __forceinline__ void owner_row(double* __restrict__ S, int h, int lan
   }
 }
 
-// The leaf (NOT already factored): one workgroup of NT threads, LDS block S of LEAF2_LDS bytes.
+// The leaf (NOT already factored): one workgroup of NT2 threads, LDS block S of LEAF2_LDS bytes.
 // STAMPS (tools/leaf_probe.hip only): shader-clock time stamps.  dbg[16 + 8 k + q], written by the PIVOT wave of tile k: 0 tile
 // started, 1 .. 3 panels 0 .. 2 done, 4 panel 3 done and L stored; dbg[80 + 8 k + q], by the TRAILING wave of tile k: 0 start, 1
 // inputs there (waits done), 2 L(k+1,k-1) stored, 3 look-ahead pair formed, 4 last panel followed (s2 final); dbg[144 + 8 t + q], the
-// owner of row 7 in window t: 0 entered, 1 (a) done, 2 A_t reached, 3 (d) done, 4 (e) done, 5 duties done, 6 (f) done.
+// owner of the inverse's row 7 in window t: 0 entered, 1 (a) done, 2 A_t reached, 3 (d) done, 4 (e) done, 5 duties done, 6 (f)
+// done; dbg[208 + 8 t + q]: the same for the owner of row 7 of L; dbg[8 .. 10]: helper 0 loads issued / rows in LDS / all loaded.
 template <bool STAMPS = false>
 __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __restrict__ A, long lda, int nb,
                                            double* __restrict__ inv, int* __restrict__ info, int col0,
@@ -402,14 +416,17 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
   const Out out{A, lda, nb, inv};
   double* __restrict__ pub = S + PUB_OFF;
   int* __restrict__ sync = reinterpret_cast<int*>(S + SYNC_OFF);
-  if (tid < W_NWORDS) sync[tid] = (tid == W_BAD0 || tid == W_BAD1) ? 0x7fffffff : 0;
-  __syncthreads();   // the only workgroup barrier
-
+  if constexpr (STAMPS) { if (tid == 0) dbg[11] = clock64(); }
+  // ---- every wave issues its global loads FIRST (~1 us of latency: everything up to the first use overlaps with it)
+  constexpr int ROW0 = 2 * SB, NIT = (NB - ROW0 + NHELP - 1) / NHELP;   // helpers: 10 rows per wave, one row (1 KB) per iteration
+  const int h = wave - NCHAIN;         // helper index 0 .. 9
+  const int htid = tid - 64 * NCHAIN;
+  const int rows_used = n8 * SB;
+  const int jp = 2 * lane;
+  d4 d = {0.0, 0.0, 0.0, 0.0}, a2 = d, s2 = d;
+  d2 v[NIT];
   if (wave < NCHAIN) {
-    // ================================================= chain waves =================================================
-    __builtin_amdgcn_s_setprio(3);
-    d4 d = {0.0, 0.0, 0.0, 0.0}, a2 = d, s2 = d;
-    // tiles (0,0) [wave 0] and (1,0), (1,1) [wave 1] straight from global memory (identity beyond nb)
+    // tiles (0,0) [wave 0] and (1,0), (1,1) [wave 1] straight from global memory into registers (identity beyond nb)
     auto gsym = [&](int t0, int e) -> double {   // element [g+4e][c] of the symmetric diagonal tile t0, from its lower half
       const int r = g + 4 * e;
       const int hi = t0 * SB + (r > c ? r : c), lo = t0 * SB + (r > c ? c : r);
@@ -425,6 +442,40 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
         s2[e] = gsym(1, e);
       }
     }
+  } else {
+    // lower triangle of A from row 32 on (tiles (0,0), (1,0), (1,1) go to the chain waves' registers only)
+    const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    if (vec && nb == NB) {   // the usual case: no per-element edge tests, pointer increments
+      const double* src = A + (long)(ROW0 + h) * lda + jp;
+      const long step = (long)NHELP * lda;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = ROW0 + h + NHELP * it;
+        v[it] = (d2){0.0, 0.0};
+        if (i < NB && jp <= i) v[it] = *reinterpret_cast<const d2*>(src);
+        src += step;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = ROW0 + h + NHELP * it;
+        v[it] = (d2){0.0, 0.0};
+        if (i < nb && jp <= i) {
+          const double* src = A + (long)i * lda + jp;
+          if (vec && jp + 1 < nb) v[it] = *reinterpret_cast<const d2*>(src);
+          else { v[it].x = src[0]; if (jp + 1 < nb) v[it].y = src[1]; }
+        }
+      }
+    }
+    if constexpr (STAMPS) { if (h == 0 && lane == 0) dbg[8] = clock64(); }
+  }
+  if (tid < W_NWORDS) sync[tid] = (tid == W_BAD0 || tid == W_BAD1) ? 0x7fffffff : 0;
+  __syncthreads();   // the only workgroup barrier
+  if constexpr (STAMPS) { if (lane == 0 && wave >= NCHAIN) dbg[288 + wave - NCHAIN] = clock64(); }
+
+  if (wave < NCHAIN) {
+    // ================================================= chain waves =================================================
+    __builtin_amdgcn_s_setprio(LEAF2_CHAIN_PRIO);
     double ind[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) ind[q] = (g == q && c < 4) ? 1.0 : 0.0;
@@ -533,58 +584,48 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
     __builtin_amdgcn_s_setprio(0);
   } else {
     // ===================================================== helpers =====================================================
-    const int h = wave - NCHAIN;         // 0 .. 5
-    const int htid = tid - 64 * NCHAIN;  // 0 .. 383
-    const int rows_used = n8 * SB;
-    // load: lower triangle of A from row 32 on (identity beyond nb) into LDS -- tiles (0,0), (1,0), (1,1) go to the chain waves'
-    // registers only.  One row per wave and iteration (1 KB, one 16-byte load per lane), all loads issued up front.
-    {
-      const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-      constexpr int ROW0 = 2 * SB, NIT = (NB - ROW0) / NHELP;   // 16 rows per wave
-      const int jp = 2 * lane;
-      d2 v[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int i = ROW0 + h + NHELP * it;
-        v[it] = (d2){0.0, 0.0};
-        if (i < nb && jp <= i) {
-          const double* src = A + (long)i * lda + jp;
-          if (vec && jp + 1 < nb) v[it] = *reinterpret_cast<const d2*>(src);
-          else { v[it].x = src[0]; if (jp + 1 < nb) v[it].y = src[1]; }
+    // for a ragged block the identity rows of the inverse; then the loaded rows into LDS (identity beyond nb)
+    if (n8 < NSB) {
+      for (int e = htid; e < NB * (NB / 2); e += HT) {
+        const int i = e / (NB / 2), jq = 2 * (e % (NB / 2));
+        if (i >= rows_used) {
+          d2 z = {(jq == i) ? 1.0 : 0.0, (jq + 1 == i) ? 1.0 : 0.0};
+          *reinterpret_cast<d2*>(&inv[i * NB + jq]) = z;
         }
-      }
-      // while they fly: for a ragged block the identity rows of the inverse
-      if (n8 < NSB) {
-        for (int e = htid; e < NB * (NB / 2); e += HT) {
-          const int i = e / (NB / 2), jq = 2 * (e % (NB / 2));
-          if (i >= rows_used) {
-            d2 z = {(jq == i) ? 1.0 : 0.0, (jq + 1 == i) ? 1.0 : 0.0};
-            *reinterpret_cast<d2*>(&inv[i * NB + jq]) = z;
-          }
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int i = ROW0 + h + NHELP * it;
-        if (jp <= i && i < rows_used) {
-          d2 w = v[it];
-          if (i >= nb) w.x = (jp == i) ? 1.0 : 0.0;
-          if (jp + 1 > i) w.y = 0.0; else if (i >= nb) w.y = (jp + 1 == i) ? 1.0 : 0.0;
-          *reinterpret_cast<d2*>(&S[i * LD + jp]) = w;
-        }
-        if (it == 2) word_add(sync + W_ROW2, lane);   // rows 32 .. 49: what the trailing wave of tile 1 needs
       }
     }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = ROW0 + h + NHELP * it;
+      if (jp <= i && i < rows_used && i < NB) {
+        d2 w = v[it];
+        if (i >= nb) w.x = (jp == i) ? 1.0 : 0.0;
+        if (jp + 1 > i) w.y = 0.0; else if (i >= nb) w.y = (jp + 1 == i) ? 1.0 : 0.0;
+        *reinterpret_cast<d2*>(&S[i * LD + jp]) = w;
+      }
+      if (it == 1) word_add(sync + W_ROW2, lane);   // rows 32 .. 51: what the trailing wave of tile 1 needs
+    }
+    if constexpr (STAMPS) { if (lane == 0) { dbg[272 + h] = clock64(); if (h == 0) dbg[9] = clock64(); } }
     word_add(sync + W_LOADED, lane);
     word_wait(sync, W_LOADED, NHELP);
-    // rows by weight (products: 65, 49, 35, 23, 13, 5): the two heaviest on the SIMDs without a chain wave, each with a light one
+    if constexpr (STAMPS) { if (h == 0 && lane == 0) dbg[10] = clock64(); }
+    // Roles (weights in tile products).  With 768 threads the waves go to SIMDs 3, 0, 2, 1, 3, 0, ... (tools/leaf_probe.hip prints
+    // the HW_ID of each): the chain waves sit on SIMDs 3 and 0 and keep their fp64 VALU busy, so the helpers there (h 2, 6 and
+    // 3, 7) get the work nobody waits for -- two rows of the inverse, the stores -- and everything the chain or another owner
+    // waits for (rows of L, look-ahead tiles) runs on SIMDs 2 and 1:
+    //   SIMD 2: h 0 inverse row 7 (33)   h 4 L row 6 (22)   h 8 row 3 (13)        SIMD 3: h 2 inverse row 5 (20)   h 6 zero fill
+    //   SIMD 1: h 1 L row 7 (30)         h 5 row 4 (24)     h 9 L row 5 (15)      SIMD 0: h 3 inverse row 6 (26)   h 7 row 2 + chain stores
     switch (h) {
-      case 0: owner_row<7, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
-      case 1: owner_row<6, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
-      case 2: owner_row<5, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
-      case 3: owner_row<2, 1, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
-      case 4: owner_row<3, 2, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
-      default: owner_row<4, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 0: owner_row<7, 2, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 1: owner_row<7, 1, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 2: owner_row<5, 2, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 3: owner_row<6, 2, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 4: owner_row<6, 1, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 5: owner_row<4, 0, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 6: owner_row<2, 3, 2, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 7: owner_row<2, 0, 1, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      case 8: owner_row<3, 0, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
+      default: owner_row<5, 1, 0, STAMPS>(S, h, lane, n8, out, sync, dbg); break;
     }
   }
   // ================================== tail ==================================
@@ -594,7 +635,7 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
     word_wait(sync, W_TDONE, n8);
     if (t >= 1) {   // the chain waves' share of the last row block of the inverse
       word_wait(sync, W_TPARK + t, 1);
-      for (int j = NHELP + wave; j < t; j += NW) finalize_tile(S, t, j, lane, out, sync);
+      for (int j = NHELP + wave; j < t; j += NW2) finalize_tile(S, t, j, lane, out, sync);
     }
     if (wave == 0 && lane == 0 && info) {                // first failing pivot of the matrix wins (an earlier leaf may have reported)
       const int b0 = sync[W_BAD0], b1 = sync[W_BAD1];

@@ -13,7 +13,7 @@
 using namespace gpk_leaf;
 
 template <int V>
-__global__ __launch_bounds__(NT) void k_leaf(double* A, long lda, int nb, double* inv, int* info, long long* dbg) {
+__global__ __launch_bounds__(V == 1 ? NT : gpk_leaf2::NT2) void k_leaf(double* A, long lda, int nb, double* inv, int* info, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) double S[];
   if constexpr (V == 1) leaf_body<false>(S, A, lda, nb, inv, info, 0, dbg);
   else if constexpr (V == 2) gpk_leaf2::leaf2_body<false>(S, A, lda, nb, inv, info, 0, dbg);
@@ -53,7 +53,7 @@ static void host_chol(const std::vector<double>& A, int n, std::vector<double>& 
 
 template <int V>
 static void launch(double* dA, long lda, int nb, double* dinv, int* dinfo, long long* ddbg) {
-  hipLaunchKernelGGL((k_leaf<V>), dim3(1), dim3(NT), gpk_leaf2::LEAF2_LDS, 0, dA, lda, nb, dinv, dinfo, ddbg);
+  hipLaunchKernelGGL((k_leaf<V>), dim3(1), dim3(V == 1 ? NT : gpk_leaf2::NT2), gpk_leaf2::LEAF2_LDS, 0, dA, lda, nb, dinv, dinfo, ddbg);
 }
 
 int main(int argc, char** argv) {
@@ -64,11 +64,11 @@ int main(int argc, char** argv) {
   const int lda = 136;
   double *dA, *dinv; int* dinfo; long long* ddbg; int* dhw;
   CK(hipMalloc(&dA, sizeof(double) * 128 * lda)); CK(hipMalloc(&dinv, sizeof(double) * 128 * 128));
-  CK(hipMalloc(&dinfo, sizeof(int))); CK(hipMalloc(&ddbg, sizeof(long long) * 256)); CK(hipMemset(ddbg, 0, sizeof(long long) * 256)); CK(hipMalloc(&dhw, sizeof(int) * 8));
-  hipLaunchKernelGGL(k_hwid, dim3(1), dim3(512), 0, 0, dhw);
-  int hw[8]; CK(hipMemcpy(hw, dhw, sizeof(hw), hipMemcpyDeviceToHost));
-  printf("# HW_ID of waves 0..7 of a 512-thread block: SIMD ids");
-  for (int w = 0; w < 8; ++w) printf(" %d", (hw[w] >> 4) & 3);
+  CK(hipMalloc(&dinfo, sizeof(int))); CK(hipMalloc(&ddbg, sizeof(long long) * 320)); CK(hipMemset(ddbg, 0, sizeof(long long) * 320)); CK(hipMalloc(&dhw, sizeof(int) * 16));
+  hipLaunchKernelGGL(k_hwid, dim3(1), dim3(768), 0, 0, dhw);
+  int hw[12]; CK(hipMemcpy(hw, dhw, sizeof(hw), hipMemcpyDeviceToHost));
+  printf("# HW_ID of waves 0..11 of a 768-thread block: SIMD ids");
+  for (int w = 0; w < 12; ++w) printf(" %d", (hw[w] >> 4) & 3);
   printf("\n");
   int fails = 0;
   const int nbs[] = {128, 127, 113, 112, 100, 64, 33, 17, 16, 5, 1};
@@ -180,7 +180,7 @@ int main(int argc, char** argv) {
       launch<3>(dA, lda, nb, dinv, dinfo, ddbg);
       CK(hipDeviceSynchronize());
     }
-    long long st[256];
+    long long st[320];
     CK(hipMemcpy(st, ddbg, sizeof(st), hipMemcpyDeviceToHost));
     const long long z = st[16];
     printf("# pivot wave of tile k, shader cycles: panel 0 | 1 | 2 | 3 + store   (start .. end since the first tile's start)\n");
@@ -193,11 +193,20 @@ int main(int argc, char** argv) {
       const long long* q = st + 80 + 8 * k;
       printf("tile %d: %6lld | %6lld | %6lld | %6lld | %6lld -> %lld\n", k, q[0] - z, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[4] - z);
     }
-    printf("# owner of row 7, window t: entered at | (a) early terms | wait A_t | (d) L(7,t) | (e) look-ahead tiles | duties | (f) inverse sums (done at)\n");
-    for (int k = 0; k < 8; ++k) {
-      const long long* q = st + 144 + 8 * k;
-      printf("window %d: %6lld | %6lld | %6lld | %6lld | %6lld | %6lld | %6lld (%lld)\n", k, q[0] - z, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3],
-             q[5] - q[4], q[6] - q[5], q[6] - z);
+    printf("# kernel entered at %lld; helper 0: loads issued at %lld, rows in LDS at %lld, all helpers loaded at %lld\n", st[11] - z, st[8] - z, st[9] - z, st[10] - z);
+    printf("# helpers 0..9 past the first barrier at:");
+    for (int q = 0; q < 10; ++q) printf(" %lld", st[288 + q] - z);
+    printf("\n# helpers 0..9 rows in LDS at:");
+    for (int q = 0; q < 10; ++q) printf(" %lld", st[272 + q] - z);
+    printf("\n");
+    for (int w = 0; w < 2; ++w) {
+      printf(w == 0 ? "# owner of row 7 of the INVERSE, window t: entered at | - | wait A_t | - | - | duties | (f) inverse sums (done at)\n"
+                    : "# owner of row 7 of L, window t: entered at | (a) early terms | wait A_t | (d) L(7,t) | (e) look-ahead tiles | duties | - (done at)\n");
+      for (int k = 0; k < 8; ++k) {
+        const long long* q = st + 144 + 64 * w + 8 * k;
+        printf("window %d: %6lld | %6lld | %6lld | %6lld | %6lld | %6lld | %6lld (%lld)\n", k, q[0] - z, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3],
+               q[5] - q[4], q[6] - q[5], q[6] - z);
+      }
     }
   }
   printf(fails ? "FAILURES: %d\n" : "all ok (%d)\n", fails);
