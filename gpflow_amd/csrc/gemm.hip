@@ -110,6 +110,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
   constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
   constexpr int A_CH = Cfg::A_CH, B_CH = Cfg::B_CH;
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  // entry signal of a stream hand-off without queue packets (GemmArgs::sig_ptr, as in gemm_nt_small): "everything queued before
+  // this kernel on its stream has completed"
+  if (p.sig_ptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    __hip_atomic_store(p.sig_ptr, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -591,6 +595,8 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
 template <int EPI, bool PAIR>
 __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int gy, int total, int compact) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (p.sig_ptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)   // entry signal (GemmArgs::sig_ptr)
+    __hip_atomic_store(p.sig_ptr, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if constexpr (!PAIR) {
     // De-phasing: the two workgroups that share a CU are dispatched together and, with equal tile times, stay in
     // lock-step -- both in their load/store prologue and epilogue at the same moment, when neither feeds the MFMA

@@ -86,7 +86,7 @@ struct GemmArgs {
   // event record / wait between two kernels of one stream costs 4.6 / 6.3 us on MI355X, back-to-back kernels 0.3 us:
   //   sig_ptr:  workgroup (0,0,0) stores sig_val there on entry -- "everything queued before this kernel on its stream has
   //             completed" (in-order queue: the previous kernel's end-of-kernel release is done), read by
-  //             hipStreamWaitValue32 on other streams;
+  //             hipStreamWaitValue32 on other streams or by another kernel's wait_ptr (every GEMM kernel honours sig_ptr);
   //   wait_ptr: every workgroup spins (bounded) until (int)(*wait_ptr - wait_val) >= 0, then acquires at agent scope: the
   //             word is written by hipStreamWriteValue32 behind the producing kernel on ITS stream.
   int* sig_ptr; int sig_val;
@@ -137,6 +137,8 @@ int gpk_launch_set_identity(hipStream_t s, double* A, int n, long lda, int batch
 int gpk_launch_diag_add_scalar(hipStream_t s, double* A, int n, long lda, double v);   // A[i,i] += v
 int gpk_probe_concurrent_kernels(hipStream_t a, hipStream_t b, int* scratch, int* concurrent);   // init-time probe (reduce.hip)
 int gpk_launch_noop(hipStream_t s);  // empty kernel (stream hand-off probe)
+int gpk_launch_wait_flag(hipStream_t s, const int* ptr, int val, int* info);   // one-wave gate: returns when (int)(*ptr - val) >= 0 (bounded)
+int gpk_launch_set_flag(hipStream_t s, int* ptr, int val);                     // one-thread store behind everything queued on s
 int gpk_launch_sum_parts(hipStream_t s, const double* part, int nt, int rows, long stridePart, int P,
                          double* ssq);
 int gpk_launch_final(hipStream_t s, int nterms, const double* const* part, const int* count,

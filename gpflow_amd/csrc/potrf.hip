@@ -561,6 +561,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
                          aux->concurrent == 1;
   int* flagF = aux->flags;
   int* flagR = aux->flags + kMaxFlagPanels;
+  const bool gate_kernels = GPK_TUNE(GATE_KERNELS, 1) != 0;
   const int epoch = ++aux->epoch;
   bool rest_flagged = false;   // the most recent rest-update was followed by a write of R[last_rest]
   std::vector<char> panel_flagged(npanels, 0);
@@ -659,31 +660,25 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       if (rc) return rc;
     }
     // (what the other streams wait for: the flag word of a flagged panel, else the event)
+    // (a flagged panel: our own one-wave gate kernel, 0.3 us behind its predecessor, instead of the runtime's wait packet, 5 - 7 us;
+    //  never on the CU-masked stream, whose stream memory operations were seen out of order -- see above)
     auto wait_panel = [&](hipStream_t st) -> int {
-      if (panel_flagged[p]) GPK_HIP(hipStreamWaitValue32(st, flagF + p, (uint32_t)epoch, hipStreamWaitValueGte, 0xffffffffu));
-      else GPK_HIP(hipStreamWaitEvent(st, evF[p], 0));
+      if (panel_flagged[p]) {
+        if (gate_kernels) return gpk_launch_wait_flag(st, flagF + p, epoch, info);
+        GPK_HIP(hipStreamWaitValue32(st, flagF + p, (uint32_t)epoch, hipStreamWaitValueGte, 0xffffffffu));
+      } else GPK_HIP(hipStreamWaitEvent(st, evF[p], 0));
+      return 0;
+    };
+    auto write_rest_flag = [&](hipStream_t st) -> int {
+      if (gate_kernels) return gpk_launch_set_flag(st, flagR + p, epoch);
+      GPK_HIP(hipStreamWriteValue32(st, flagR + p, (uint32_t)epoch, 0));
       return 0;
     };
     // ---- B: rest of the outer trailing update  A[c2:, c2:] -= P[c2:] P[c2:]^T, lower tiles only --------
     // While the trailing matrix is large the factorisation is bound by these GEMMs (masked stream B); they start as soon
     // as panel p is solved.
     if (c2 < n) {
-      hipStream_t Bp = B;
-      if (narrow) {
-        // the unmasked stream of the SVGP-size scheme.  (A stream masked to half the CUs would keep CUs free for the leaf,
-        // but its hand-offs to P took ~55 us instead of ~5: 190 us per panel instead of 56, GPR N = 16384 36.6 vs 32.0 ms.)
-        Bp = aux->Bs;
-        rc = wait_panel(Bp);
-        if (rc) return rc;
-        if (last_rest >= 0 && last_bulk != Bp) {
-          rc = need_evr();
-          if (rc) return rc;
-          GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
-        }
-      } else {
-        rc = wait_panel(B);
-        if (rc) return rc;
-      }
+      hipStream_t Bp = narrow ? aux->Bs : B;
       const double* P2 = A + (long)c2 * lda + c0;
       GemmArgs u = gemm_base(R - c2, n - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0,
                              A + (long)c2 * lda + c2, lda, batch, strideA, strideA, strideA);
@@ -698,11 +693,64 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
         // persistent workgroups (two per CU of the masked stream) that walk the tile list: no workgroup launch per tile
         if (GPK_TUNE(TRAIL_PERSIST, 0)) u.max_wgs = GPK_TUNE(TRAIL_PERSIST, 0) * aux->bulk_cus;
       }
-      rc = gpk_launch_gemm(Bp, u);
-      if (rc) return rc;
-      rest_flagged = use_flags && p < kMaxFlagPanels && Bp != aux->B;
-      if (rest_flagged) GPK_HIP(hipStreamWriteValue32(Bp, flagR + p, (uint32_t)epoch, 0));
-      else GPK_HIP(hipEventRecord(evR[p], Bp));
+      // Split rest-update (round 6).  With the 25-us leaf the chain of a single-leaf panel is leaf 25 + solve 7 + strip 8 = 40 us,
+      // and the rest-update stream had become the longer one: wait packet 6 + one 30-us tiled launch + write packet 7 + the
+      // in-kernel wait of the next strip = 45 us per panel (profiles/r06_rows1024_new_leaf_timeline.txt).  The next strip only
+      // needs the NEXT block column of the rest-update, so that column goes first, on the one-shot latency kernel (~8 us, beside
+      // strip p) behind a gate on "panel p solved"; the remainder follows on the same stream and announces the
+      // column on ITS entry (GemmArgs::sig_ptr) -- no packet in between, and the remainder has a whole panel period of slack.
+      // ("waiting for panel p solved": the one-wave gate kernel of wait_panel.)
+      const int c3 = (p + 3 <= npanels) ? cuts[p + 3] : n;
+      GemmArgs ua = gemm_base(R - c2, c3 - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0, A + (long)c2 * lda + c2, lda, batch, strideA,
+                              strideA, strideA);
+      ua.c_lower = 1;
+      const bool split = GPK_TUNE(REST_SPLIT, 1) && use_flags && p < kMaxFlagPanels && Bp != aux->B && panel_flagged[p] && !u.no_small &&
+                         !u.small_loop && (c2 - c1) <= NB && gpk_gemm_takes_latency_kernel(ua) &&
+                         !(last_rest >= 0 && last_bulk != Bp);
+      if (split) {
+        // (the gate, not an in-kernel wait: up to 120 workgroups of 150 KB spinning from the moment they are enqueued -- a leaf and
+        //  a solve before their flag -- would hold the compute units the chain and the extra-row stream need)
+        rc = wait_panel(Bp);
+        if (rc) return rc;
+        rc = gpk_launch_gemm(Bp, ua);
+        if (rc) return rc;
+        if (c3 < n) {
+          const double* P3 = A + (long)c3 * lda + c0;
+          GemmArgs ub = gemm_base(R - c3, n - c3, c1 - c0, -1.0, P3, lda, P3, lda, 1.0, A + (long)c3 * lda + c3, lda, batch,
+                                  strideA, strideA, strideA);
+          ub.c_lower = 1;
+          ub.sig_ptr = flagR + p;
+          ub.sig_val = epoch;
+          rc = gpk_launch_gemm(Bp, ub);
+          if (rc) return rc;
+        } else {
+          rc = write_rest_flag(Bp);
+          if (rc) return rc;
+        }
+        rest_flagged = true;
+      } else {
+        if (narrow) {
+          // the unmasked stream of the SVGP-size scheme.  (A stream masked to half the CUs would keep CUs free for the leaf,
+          // but its hand-offs to P took ~55 us instead of ~5: 190 us per panel instead of 56, GPR N = 16384 36.6 vs 32.0 ms.)
+          rc = wait_panel(Bp);
+          if (rc) return rc;
+          if (last_rest >= 0 && last_bulk != Bp) {
+            rc = need_evr();
+            if (rc) return rc;
+            GPK_HIP(hipStreamWaitEvent(Bp, evR[last_rest], 0));
+          }
+        } else {
+          rc = wait_panel(B);
+          if (rc) return rc;
+        }
+        rc = gpk_launch_gemm(Bp, u);
+        if (rc) return rc;
+        rest_flagged = use_flags && p < kMaxFlagPanels && Bp != aux->B;
+        if (rest_flagged) {
+          rc = write_rest_flag(Bp);
+          if (rc) return rc;
+        } else GPK_HIP(hipEventRecord(evR[p], Bp));
+      }
       evr_recorded = !rest_flagged;   // (a flagged rest-update gets its event only if somebody asks for it: need_evr)
       last_bulk = Bp;
       last_rest = p;

@@ -370,6 +370,41 @@ int gpk_launch_noop(hipStream_t s) {
   return 0;
 }
 
+// ---- gate / signal kernels of the chain flags (potrf.hip, round 6) ---------------------------------------------------------
+// hipStreamWaitValue32 / hipStreamWriteValue32 run as the runtime's own one-workgroup kernels behind queue packets: 5 - 7 us
+// each between two kernels of a stream (rocprofv3: __amd_rocclr_streamOpsWait / Write).  A kernel of ours that follows another
+// on its stream starts 0.3 us later.  So a stream that has to wait for a flag word enqueues this gate -- one wave, no LDS, one
+// lane polling with s_sleep, bounded like the in-kernel waits of the GEMM kernels (0.5 s, then the status word becomes
+// INT_MAX) -- and a stream that has to publish one enqueues the one-thread store.  The end-of-kernel release of whatever ran
+// before the store / the acquire at the start of whatever follows the gate order the data as the packets did.
+namespace {
+__global__ void wait_flag_kernel(const int* __restrict__ ptr, int val, int* __restrict__ info) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();   // 100 MHz
+    while ((int)(__hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - val) < 0) {
+      if (wall_clock64() - t0 >= 50000000LL) {
+        if (info) atomicMax(info, 0x7fffffff);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+__global__ void set_flag_kernel(int* __restrict__ ptr, int val) {
+  __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+int gpk_launch_wait_flag(hipStream_t s, const int* ptr, int val, int* info) {
+  hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, s, ptr, val, info);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+int gpk_launch_set_flag(hipStream_t s, int* ptr, int val) {
+  hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, s, ptr, val);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- can two kernels of this process run at the same time? -----------------------------------------------------------------
 // The chain flags of potrf.hip let a kernel wait in-kernel for a word that a kernel (or stream write) on ANOTHER stream sets.
 // Under a tool that serialises kernel execution (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL) the producer would never start while the
