@@ -669,7 +669,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       } else GPK_HIP(hipStreamWaitEvent(st, evF[p], 0));
       return 0;
     };
+    // (A/B build only, GPK_FAULT_DROP_REST_FLAG=p: the "rest-update p done" word is never written -- the next strip's bounded
+    //  in-kernel wait must expire, the status word become INT_MAX and the call return instead of hanging: tests/test_gpu_handoff.py)
+    const bool drop_rest_flag = kGpkExp && GPK_TUNE(FAULT_DROP_REST_FLAG, -1) == p;
     auto write_rest_flag = [&](hipStream_t st) -> int {
+      if (drop_rest_flag) return 0;
       if (gate_kernels) return gpk_launch_set_flag(st, flagR + p, epoch);
       GPK_HIP(hipStreamWriteValue32(st, flagR + p, (uint32_t)epoch, 0));
       return 0;
@@ -719,8 +723,10 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
           GemmArgs ub = gemm_base(R - c3, n - c3, c1 - c0, -1.0, P3, lda, P3, lda, 1.0, A + (long)c3 * lda + c3, lda, batch,
                                   strideA, strideA, strideA);
           ub.c_lower = 1;
-          ub.sig_ptr = flagR + p;
-          ub.sig_val = epoch;
+          if (!drop_rest_flag) {
+            ub.sig_ptr = flagR + p;
+            ub.sig_val = epoch;
+          }
           rc = gpk_launch_gemm(Bp, ub);
           if (rc) return rc;
         } else {
@@ -847,7 +853,8 @@ extern "C" int gpk_chain_handoff_mode(void) {
   std::lock_guard<std::recursive_mutex> lock(g_aux[dev].mu);
   const Aux& a = g_aux[dev];
   if (!a.ready || a.concurrent < 0) return -1;
-  return (GPK_TUNE(CHAIN_FLAGS, 1) && a.concurrent == 1) ? 1 : 0;
+  if (!(GPK_TUNE(CHAIN_FLAGS, 1) && a.concurrent == 1)) return 0;
+  return GPK_TUNE(GATE_KERNELS, 1) ? 2 : 1;
 }
 
 extern "C" int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch,

@@ -1,7 +1,9 @@
 """Functions of the inputs (gpflow/functions.py:38-330): mean functions AND the variance / scale of a heteroskedastic Gaussian
-likelihood (likelihoods/scalar_continuous.py:52-111).  Each row of X is one datum; f(X) has one row per datum.  O(N D Q)
-elementwise host-issued device arithmetic (torch glue) -- nothing here is on the O(N^3) / O(M^2 B) path; `constant_value()` tells
-the fused C-ABI drivers when a function is a scalar constant so that it can ride inside them."""
+likelihood (likelihoods/scalar_continuous.py:52-111).  Each row of X is one datum; f(X) has one row per datum.  O(N D Q) work --
+nothing here is on the O(N^3) / O(M^2 B) path.  The matrix products (X A, the polynomial's feature-weight product and their
+reverse passes) go through the library's own GEMM (gpk_gemm_nt) like every other product of the package: no rocBLAS call is made
+from this file; what is left to torch is elementwise (powers, sums, broadcasts).  `constant_value()` tells the fused C-ABI drivers
+when a function is a scalar constant so that it can ride inside them."""
 from __future__ import annotations
 
 import itertools
@@ -12,6 +14,13 @@ import torch
 
 from . import ops
 from .base import Module, Parameter
+
+
+def _mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A [n, k] times B[q, k]^T -> [n, q] on the library's GEMM (rows of both operands contiguous)."""
+    if A.shape[0] == 0 or B.shape[0] == 0:
+        return torch.zeros((A.shape[0], B.shape[0]), dtype=torch.float64, device=A.device)
+    return ops.gemm_nt(A.contiguous(), B.contiguous())
 
 
 class Function(Module):
@@ -98,11 +107,12 @@ class Linear(MeanFunction):
         X = ops.to_device(X)
         A = ops.to_device(np.asarray(self.A.numpy(), dtype=np.float64))
         b = ops.to_device(np.atleast_1d(np.asarray(self.b.numpy(), dtype=np.float64)))
-        return torch.tensordot(X, A, dims=([-1], [0])) + b
+        lead = X.shape[:-1]
+        return _mm_nt(X.reshape(-1, X.shape[-1]), A.t()).reshape(lead + (A.shape[1],)) + b     # X A (+ b), leading dims flattened
 
     def backward(self, X, gbar):
         X = ops.to_device(X)
-        gA = X.t() @ gbar                                       # [D, Q']: Q' = Q, or 1 when A broadcasts over the outputs
+        gA = _mm_nt(X.t(), gbar.t())                            # X^T gbar  [D, Q']: Q' = Q, or 1 when A broadcasts over the outputs
         A_shape, b_shape = tuple(self.A.shape), tuple(np.atleast_1d(self.b.numpy()).shape)
         if gA.shape[1] != A_shape[1]:
             gA = gA.sum(1, keepdim=True)
@@ -210,12 +220,14 @@ class Polynomial(MeanFunction):
         powers = ops.to_device(self.powers)
         raised = torch.pow(X[..., None, :], powers)            # [..., n_terms, input_dim]
         prod = torch.prod(raised, dim=-1)                      # [..., n_terms]
-        return torch.einsum("...i,ji->...j", prod, ops.to_device(self.w.numpy()))
+        w = ops.to_device(np.asarray(self.w.numpy(), dtype=np.float64))                        # [Q, n_terms]
+        lead = prod.shape[:-1]
+        return _mm_nt(prod.reshape(-1, prod.shape[-1]), w).reshape(lead + (w.shape[0],))       # sum_i prod[..., i] w[j, i]
 
     def backward(self, X, gbar):
         X = ops.to_device(X)
         prod = torch.prod(torch.pow(X[..., None, :], ops.to_device(self.powers)), dim=-1)      # [N, n_terms]
-        gw = gbar.t() @ prod                                                                    # [Q', n_terms]
+        gw = _mm_nt(gbar.t(), prod.t())                                                         # gbar^T prod  [Q', n_terms]
         if gw.shape[0] != self.w.shape[0]:
             gw = gw.expand(self.w.shape[0], -1) if gw.shape[0] == 1 else gw.sum(0, keepdim=True)
         return [(self.w, gw)]

@@ -430,7 +430,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     # ---------------------------------------------------------------- backward
     # het: one noise variance per row (a heteroskedastic Gaussian likelihood, round 5): dF/dfvar is a per-row vector, applied as a
     # row scaling of the factors it multiplied as a scalar (elementwise glue on [B, M] arrays); the scalar path is unchanged
-    het = torch.is_tensor(noise_variance) and noise_variance.numel() > 1
+    het = torch.is_tensor(noise_variance) and noise_variance.dim() >= 1
     if het:
         nv = noise_variance.reshape(-1)
         cvec = (-0.5 * scale) / nv                                                      # dF/dfvar per row [B]
@@ -532,7 +532,7 @@ def gpr_lml_and_grad(X: torch.Tensor, Y: torch.Tensor, *, variance: float = None
     spec = kernel_spec if kernel_spec is not None else KernelSpec.single(variance, lengthscales, family)
     spec.warm(dev, D)   # (device copies of the lengthscales BEFORE the first kernel is enqueued: see ls_device)
     T = torch.empty((N + P + N, N), dtype=torch.float64, device=dev)
-    het = torch.is_tensor(noise_variance) and noise_variance.numel() > 1   # one variance per data row (heteroskedastic likelihood)
+    het = torch.is_tensor(noise_variance) and noise_variance.dim() >= 1   # one variance per data row (heteroskedastic likelihood)
     if het:
         spec.build(X, None, T[:N])
         ops.diag_add_(T[:N], noise_variance)                                            # add_likelihood_noise_cov, model_utils.py:46-50
@@ -585,7 +585,7 @@ def sgpr_elbo_and_grad(Z: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, *, var
     # the constant-noise one with s2 = 1 plus -P/2 (sum log sigma_n^2 + var sum w_n); At_bar and d/dmean pick up w_n per row, and
     #     dF/dw_n = (a_n^T (2 S_bar + 2 q_bar I) a_n) / 2 + sum_p (a_n . a_bar_p) err_np - sum_p err_np^2 / 2 - P var / 2,
     #     dF/dsigma_n^2 = -w_n^2 dF/dw_n - P w_n / 2        (one entry per row; grads["noise_variance"] is then [n], local to the shard)
-    het = torch.is_tensor(noise_variance) and noise_variance.numel() > 1
+    het = torch.is_tensor(noise_variance) and noise_variance.dim() >= 1
     if het:
         wn = (1.0 / noise_variance.reshape(-1)).contiguous()
         swn = torch.sqrt(wn)
@@ -759,7 +759,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     # ---- backward
     # het: one noise variance per row (a heteroskedastic Gaussian likelihood): dF/dfvar is a per-row vector c_b, applied as a row
     # scaling of the factors the scalar multiplied (same treatment as the whitened pass); the scalar path is unchanged
-    het = torch.is_tensor(noise_variance) and noise_variance.numel() > 1
+    het = torch.is_tensor(noise_variance) and noise_variance.dim() >= 1
     if het:
         nv = noise_variance.reshape(-1)
         cvec = (-0.5 * scale) / nv

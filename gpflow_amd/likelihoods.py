@@ -44,8 +44,9 @@ class Gaussian(Likelihood):
         """prepare_parameter_or_function (utilities/parameter_or_function.py:27-39)"""
         if isinstance(value, Function):
             return value
-        if isinstance(value, Parameter):
-            return value
+        # (a Parameter handed in is re-wrapped like any other value, as the reference does: the NEW Parameter carries the lower-bound
+        #  transform -- an identity- or otherwise-transformed one would let the optimiser take the variance below the bound --
+        #  and inherits prior / trainable, base.py:155-161)
         return Parameter(value, transform=positive(lower=lower_bound))
 
     @property

@@ -60,6 +60,9 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
     return int(max(t.shape[1], 1))
 
 
+INFO_HANDOFF_TIMEOUT = 2 ** 31 - 1   # include/gpk.h: status of a factorisation whose internal hand-off never arrived
+
+
 def _ws(nbytes: int) -> torch.Tensor:
     return torch.empty((max(int(nbytes), 8) + 7) // 8, dtype=torch.float64, device=device())
 
@@ -232,6 +235,9 @@ def check_info(info: torch.Tensor, what: str = "Cholesky") -> None:
     bad = info.cpu().numpy()
     if np.any(bad != 0):
         j = int(bad[np.nonzero(bad)[0][0]])
+        if j >= INFO_HANDOFF_TIMEOUT:   # include/gpk.h, "info": an internal stream hand-off of the factorisation timed out
+            raise _lib.GpkError(f"{what} decomposition failed: an internal stream hand-off timed out (status INT_MAX); "
+                                "the result is undefined")
         raise _lib.GpkError(f"{what} decomposition was not successful: non-positive pivot at column {j - 1}")
 
 

@@ -212,6 +212,10 @@ class SVGPTrainer:
             var = float(self.constrained("variance"))
             ls = self.constrained("lengthscales")
         if self.het:
+            # SIDE EFFECT, by design: the noise Function evaluates itself from its own Parameters, so the trainer's current values of
+            # them are written into the model on every step -- unlike the kernel / Z / q parameters, which reach the model only through
+            # sync_to_model().  Between steps the model therefore holds the NEW noise parameters next to the kernel, Z and q of the last
+            # sync: call sync_to_model() before evaluating model.elbo() / predict_* mid-training.
             for i, p in enumerate(self.noise_pars):              # the Function reads its Parameters: the trainer's current values
                 p.assign_unconstrained(self.u[f"noise_fn_{i}"])
             noise = self.model.likelihood.noise_for(Xb)          # sigma_n^2 at the rows of this (shard of the) minibatch  [B]
@@ -294,6 +298,10 @@ class SVGPTrainer:
         self.last_info = int(small[-1])
         if self.last_info != 0:
             from ._lib import GpkError
+            # (summed over the ranks: pivot columns are far below 2^31, so a sum that reaches INT_MAX contains a timed-out hand-off)
+            if self.last_info >= ops.INFO_HANDOFF_TIMEOUT:
+                raise GpkError("the factorisation of Kuu failed: an internal stream hand-off timed out (status INT_MAX)" +
+                               ("" if world == 1 else " on at least one rank") + "; the step was NOT applied")
             raise GpkError("Cholesky decomposition of Kuu was not successful" +
                            (f" (non-positive pivot at column {self.last_info - 1})" if world == 1 else
                             " on at least one rank") + "; the step was NOT applied")

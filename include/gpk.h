@@ -124,10 +124,18 @@ int gpk_potrf(void* stream, double* A, int n, int extra, long lda, int batch, lo
  * stream set (us_first[3]); *recreated = 1 if the first set was slow (> 30 us: two active hardware queues on one
  * microengine pipe) and the streams were created again.  GPK_E_UNSUPPORTED before the first factorisation with n > 128. */
 int gpk_stream_selfcheck(double* us_now, double* us_first, int* recreated);
-/* How the factorisation's latency chain hands over between the internal streams on the current device: 1 = stream memory
- * operations + in-kernel polls (no event packets between the chain's kernels), 0 = events -- chosen by the first factorisation,
- * which checks that kernels of two streams really run at the same time (a tool that serialises kernels, e.g. rocprofv3 --pmc,
- * would deadlock the polls) -- , -1 = no factorisation with n > 128 has been issued on this device yet. */
+/* How the factorisation's latency chain hands over between the internal streams on the current device:
+ *    2 = flag words in device memory, written and awaited by KERNELS only -- the entry signal of a GEMM kernel, a one-thread store
+ *        kernel, a one-wave gate kernel, the bounded in-kernel poll of the strip -- with no queue packet between the chain's
+ *        kernels (the product library, round 6);
+ *    1 = the same words written / awaited with hipStreamWriteValue32 / hipStreamWaitValue32 (rounds 5; the A/B build with
+ *        GPK_GATE_KERNELS=0).  Observed on ROCm 7.2.0 / gfx950: on a CU-MASKED stream such a write overtook the kernel queued
+ *        before it (a wrong factor at n = 5000) -- stream memory operations were therefore only ever used on plain streams, and the
+ *        product no longer uses them at all: kernels of one stream execute in order by definition;
+ *    0 = events -- when the first factorisation finds that kernels of two streams do NOT run at the same time (a tool that
+ *        serialises kernels, e.g. rocprofv3 --pmc, would deadlock the polls);
+ *   -1 = no factorisation with n > 128 has been issued on this device yet.
+ * Every wait is bounded (0.5 s); one that expires sets the status word to INT_MAX (see "info") and the call returns. */
 int gpk_chain_handoff_mode(void);
 
 /* gpk_potrf for callers that also need the explicit inverse factor (the reverse pass: gradients.py; the reference

@@ -208,19 +208,24 @@ def _sgpr_grad_worker(rank, world, port, q):
         from oracle import gp_oracle as orc
         Xp = rng.random((N, 2)); Yp = np.sin(5 * Xp[:, :1]) + (0.7 - 0.5 * Xp[:, :1]) * rng.standard_normal((N, 1)); Zp = Xp[:M].copy()
         A0, b0 = np.array([[-0.3], [0.05]]), np.array([0.6])
-        lo, hi = shard_bounds(N, world, rank)
-        mh = gpflow.models.SGPR((Xp[lo:hi], Yp[lo:hi]), gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.25, 0.9]), Zp.copy(),
-                                likelihood=gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=A0.copy(), b=b0.copy())), sharded=True)
-        v, g = mh.objective_and_grad()
         rv, rg = orcg.heteroskedastic_value_and_grads("sgpr", Xp, Yp, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9], Z=Zp)
         nv = np.maximum(Xp @ A0 + b0, 1e-3)[:, 0] ** 2
-        ub = float(mh.upper_bound())
         rub = orc.sgpr_upper_bound(Xp, Yp, Zp, variance=1.1, lengthscales=np.array([0.25, 0.9]), noise_variance=nv)
-        errs = {"value": abs(v - rv) / abs(rv), "upper": abs(ub - rub) / abs(rub),
-                "A": float(np.abs(np.asarray(g[mh.likelihood.scale.A]).reshape(rg["A"].shape) - rg["A"]).max() / max(1.0, np.abs(rg["A"]).max())),
-                "b": float(np.abs(np.ravel(g[mh.likelihood.scale.b]) - np.ravel(rg["b"])).max() / max(1.0, np.abs(rg["b"]).max())),
-                "Z": float(np.abs(np.asarray(g[mh.inducing_variable.Z]) - rg["Z"]).max() / np.abs(rg["Z"]).max())}
-        out.append(("heteroskedastic", v, errs))
+        # ... also with a rank that holds ONE row and one that holds NONE: a per-row noise vector with one entry (or none) is still a
+        # per-row vector -- the reverse pass once took the constant-noise branch for it: inconsistent ELBOs across the ranks, and a
+        # rank without rows raised before the all-reduce the others were waiting in
+        for tag, (lo, hi) in (("heteroskedastic", shard_bounds(N, world, rank)),
+                              ("heteroskedastic, one row on rank 1", (0, N - 1) if rank == 0 else (N - 1, N)),
+                              ("heteroskedastic, no rows on rank 1", (0, N) if rank == 0 else (N, N))):
+            mh = gpflow.models.SGPR((Xp[lo:hi], Yp[lo:hi]), gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.25, 0.9]), Zp.copy(),
+                                    likelihood=gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=A0.copy(), b=b0.copy())), sharded=True)
+            v, g = mh.objective_and_grad()
+            ub = float(mh.upper_bound())
+            errs = {"value": abs(v - rv) / abs(rv), "upper": abs(ub - rub) / abs(rub),
+                    "A": float(np.abs(np.asarray(g[mh.likelihood.scale.A]).reshape(rg["A"].shape) - rg["A"]).max() / max(1.0, np.abs(rg["A"]).max())),
+                    "b": float(np.abs(np.ravel(g[mh.likelihood.scale.b]) - np.ravel(rg["b"])).max() / max(1.0, np.abs(rg["b"]).max())),
+                    "Z": float(np.abs(np.asarray(g[mh.inducing_variable.Z]) - rg["Z"]).max() / np.abs(rg["Z"]).max())}
+            out.append((tag, v, errs))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()

@@ -1093,3 +1093,35 @@ def test_heteroskedastic_noise_in_the_reverse_pass(gpu, q_diag):
         assert fs[-1] > f0
         tr.sync_to_model()
         assert abs(float(mt.elbo((X, Y)).cpu()) - float(tr.step((X, Y)).cpu()[0])) <= 1e-8 * abs(fs[-1])
+
+
+@pytest.mark.parametrize("rows", [1, 2])
+def test_heteroskedastic_noise_on_a_one_row_minibatch(gpu, rows):
+    """A per-row noise vector with ONE entry is still a per-row vector (the last minibatch when N mod B == 1): the reverse passes
+    used to take the constant-noise branch for it and fail on float(np.log(tensor)).  SVGP whitened / un-whitened and GPR on 1 (and,
+    as the control, 2) rows against torch autograd over the restated likelihood (likelihoods/scalar_continuous.py:92-148)."""
+    import gpflow_amd as gpflow
+    rng = np.random.default_rng(7)
+    M = 12
+    X = rng.random((rows, 2)); Y = rng.standard_normal((rows, 1))
+    A0, b0 = np.array([[-0.3], [0.05]]), np.array([0.6])
+    Z = rng.random((M, 2)); q_mu = 0.2 * rng.normal(size=(M, 1))
+    qs = np.tril(0.1 * rng.normal(size=(1, M, M))) + 0.5 * np.eye(M)
+    mk_lik = lambda: gpflow.likelihoods.Gaussian(scale=gpflow.functions.Linear(A=A0.copy(), b=b0.copy()))  # noqa: E731
+    mk_k = lambda: gpflow.kernels.SquaredExponential(variance=1.1, lengthscales=[0.25, 0.9])  # noqa: E731
+
+    def chk(got, ref, tol=1e-8):
+        got = np.asarray(got, dtype=np.float64).reshape(np.shape(ref))
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (np.abs(got - ref).max(), np.abs(ref).max())
+    for whiten, name, tol in ((True, "svgp", 1e-8), (False, "svgp_unwhitened", 1e-7)):
+        s = gpflow.models.SVGP(mk_k(), mk_lik(), Z.copy(), q_mu=q_mu, q_sqrt=qs, whiten=whiten, num_data=50)
+        v, g = s.elbo_and_grad((X, Y))
+        rv, rg = orcg.heteroskedastic_value_and_grads(name, X, Y, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9], Z=Z, q_mu=q_mu,
+                                                      q_sqrt=qs, num_data=50)
+        assert abs(v - rv) <= tol * abs(rv)
+        chk(g[s.likelihood.scale.A], rg["A"], tol); chk(g[s.likelihood.scale.b], rg["b"], tol); chk(g[s.q_mu], rg["q_mu"], tol)
+    m = gpflow.models.GPR((X, Y), mk_k(), likelihood=mk_lik())
+    v, g = m.objective_and_grad()
+    rv, rg = orcg.heteroskedastic_value_and_grads("gpr", X, Y, A=A0, b=b0, variance=1.1, lengthscales=[0.25, 0.9])
+    assert abs(v - rv) <= 1e-9 * max(1.0, abs(rv))
+    chk(g[m.likelihood.scale.A], rg["A"]); chk(g[m.likelihood.scale.b], rg["b"])

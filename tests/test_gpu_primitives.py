@@ -593,9 +593,10 @@ def test_host_mailbox(gpu):
 
 
 def test_chain_handoff_mode_and_serialised_kernels(gpu):
-    """The factorisation's chain hands over with stream memory operations + in-kernel polls (gpk_chain_handoff_mode() == 1) when
-    kernels of two streams really run concurrently, and falls back to events when a tool serialises kernels -- there the polls
-    would deadlock inside the runtime's stream-wait kernel (seen with rocprofv3 --pmc).  AMD_SERIALIZE_KERNEL=3 makes the HIP
+    """The factorisation's chain hands over through flag words written and awaited by kernels only -- entry signals, gate / store
+    kernels, bounded in-kernel polls (gpk_chain_handoff_mode() == 2, include/gpk.h) -- when kernels of two streams really run
+    concurrently, and falls back to events when a tool serialises kernels: there the polls could never be satisfied (seen with
+    rocprofv3 --pmc).  AMD_SERIALIZE_KERNEL=3 makes the HIP
     runtime wait around every launch: a child process under it must finish, report mode 0 and the same factor."""
     import subprocess
     import sys
@@ -605,7 +606,7 @@ def test_chain_handoff_mode_and_serialised_kernels(gpu):
     T = _t(np.vstack([K, rng.normal(size=(300, 1100))]))
     _, info = ops.potrf_(T, 1100, zero_upper=True)
     ops.check_info(info)
-    assert _lib.load().gpk_chain_handoff_mode() == 1
+    assert _lib.load().gpk_chain_handoff_mode() == 2
     code = (
         "import os, sys, numpy as np\n"
         "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"

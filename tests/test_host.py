@@ -291,3 +291,28 @@ def test_bench_refuses_fewer_devices_than_ranks():
     assert r.returncode != 0
     assert "needs 2 HIP devices" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_gaussian_rewraps_a_parameter_with_the_lower_bound_transform():
+    """prepare_parameter_or_function (utilities/parameter_or_function.py:27-39) wraps ANY non-Function value -- a Parameter too --
+    in Parameter(value, transform=positive(lower_bound)): a variance handed in with an identity transform must not be able to
+    leave the bound, and prior / trainable carry over (base.py:155-161)."""
+    import numpy as np
+    import gpflow_amd as gpflow
+    from gpflow_amd.base import Parameter
+    raw = Parameter(0.3, trainable=False)                      # identity transform
+    lik = gpflow.likelihoods.Gaussian(variance=raw)
+    assert lik.variance is not raw and lik.variance.trainable is False
+    assert abs(float(lik.variance.numpy()) - 0.3) < 1e-15
+    lik.variance.assign_unconstrained(np.array(-50.0))        # far below anything an optimiser would reach
+    assert float(lik.variance.numpy()) > lik.variance_lower_bound * (1 - 1e-12)
+
+
+def test_check_info_names_a_timed_out_handoff():
+    """include/gpk.h "info": INT_MAX is a timed-out internal hand-off, not a pivot column."""
+    import torch
+    from gpflow_amd import _lib, ops
+    with pytest.raises(_lib.GpkError, match="hand-off timed out"):
+        ops.check_info(torch.tensor([2 ** 31 - 1], dtype=torch.int32))
+    with pytest.raises(_lib.GpkError, match="non-positive pivot at column 4"):
+        ops.check_info(torch.tensor([5], dtype=torch.int32))
