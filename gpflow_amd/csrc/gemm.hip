@@ -760,7 +760,13 @@ bool fast_ok(const GemmArgs& a) {
 // only overwrites rows the workgroup alone has read.
 constexpr int SM_BM = 16, SM_BN = 128, SM_THREADS = 512;
 
-__global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk) {
+// kparts = 2 (round 6): K is staged in two halves -- (16 + 128) rows of 64 + 2 doubles = 74 KB instead of 146 KB -- so that a
+// workgroup of this kernel FITS BESIDE a capped bulk workgroup of the extra-row stream (84 KB, launch_fast) on the same compute
+// unit.  With the whole-K image the chain's solve / strip needed compute units free of bulk work: 32 of 256 during the capped
+// updates of an SVGP step, i.e. three rounds of ~10 us for 88 workgroups (profiles/r06_step_timeline.txt: 18 - 50 us per
+// launch instead of 7.5).  One more staging round trip per launch (~2 us) when the chip is empty, which is why it is a choice of
+// the caller (GemmArgs::small_kparts).
+__global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk, int kparts) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -808,24 +814,6 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk)
   for (int mb = blockIdx.y; mb < nmb; mb += gridDim.y) {
     const int m0 = mb * SM_BM;
     if (p.c_lower && n0 > m0 + SM_BM - 1) continue;  // (workgroup-uniform)
-    // ---- stage: row q of the 144 (16 A rows, 128 B rows: first pass only), one LDS-DMA instruction each ----------
-    if (2 * lane < kc) {
-      for (int q = wave; q < (first ? SM_BM + SM_BN : SM_BM); q += SM_THREADS / 64) {
-        const double* src;
-        if (q < SM_BM) {
-          int rr = m0 + q;
-          rr = rr < p.m ? rr : p.m - 1;
-          src = A + (long)rr * p.lda + kb;
-        } else {
-          int rr = n0 + q - SM_BM;
-          rr = rr < p.n ? rr : p.n - 1;
-          src = B + (long)rr * p.ldb + kb;
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * lane),
-                                         (__attribute__((address_space(3))) void*)(smem + q * ldk), 16, 0, 0);
-      }
-    }
-    first = false;
     // ---- this wave's 16x16 output tile: columns n0 + 16 wave .. ------------------------------------------
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     if (p.beta != 0.0) {
@@ -838,18 +826,42 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk)
         acc0[e] = sc * C[(long)row * p.ldc + cc];
       }
     }
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the LDS-DMA rows of this wave have landed
-    __syncthreads();
-    const double* ap = As + r * ldk + g;
-    const double* bp = Bs + (wave * 16 + r) * ldk + g;
-    const int nkk = kc >> 2;
+    const int kch = kc / kparts;   // (kparts == 2: the launcher made sure kc is a multiple of 32)
+    for (int part = 0; part < kparts; ++part) {
+      const int kbp = kb + part * kch;
+      // ---- stage: row q of the 144 (16 A rows; 128 B rows: first pass only unless K is staged in parts), one LDS-DMA
+      // instruction each ----------------------------------------------------------------------------------------------
+      if (2 * lane < kch) {
+        for (int q = wave; q < ((first || kparts > 1) ? SM_BM + SM_BN : SM_BM); q += SM_THREADS / 64) {
+          const double* src;
+          if (q < SM_BM) {
+            int rr = m0 + q;
+            rr = rr < p.m ? rr : p.m - 1;
+            src = A + (long)rr * p.lda + kbp;
+          } else {
+            int rr = n0 + q - SM_BM;
+            rr = rr < p.n ? rr : p.n - 1;
+            src = B + (long)rr * p.ldb + kbp;
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * lane),
+                                           (__attribute__((address_space(3))) void*)(smem + q * ldk), 16, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the LDS-DMA rows of this wave have landed (and the C preload)
+      __syncthreads();
+      const double* ap = As + r * ldk + g;
+      const double* bp = Bs + (wave * 16 + r) * ldk + g;
+      const int nkk = kch >> 2;
 #pragma unroll 4
-    for (int kk = 0; kk < nkk; kk += 2) {
-      const double a0 = ap[kk * 4], b0 = bp[kk * 4];
-      const double a1 = ap[kk * 4 + 4], b1 = bp[kk * 4 + 4];
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+      for (int kk = 0; kk < nkk; kk += 2) {
+        const double a0 = ap[kk * 4], b0 = bp[kk * 4];
+        const double a1 = ap[kk * 4 + 4], b1 = bp[kk * 4 + 4];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+      }
+      if (part + 1 < kparts) __syncthreads();  // the image in LDS is about to be replaced by the next part
     }
+    first = false;
     if (col < p.n) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -862,7 +874,11 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk)
 }
 
 int launch_small(hipStream_t s, const GemmArgs& a) {
-  const int ldk = a.k + 2;
+  // K staged in two halves (GemmArgs::small_kparts == 2) when every K range of the launch splits into whole 16-slabs: plain
+  // K = 64 / 128 operands, or the single-column-tile triangular solve against a leaf's block inverse (b_tri 2, K range = n <= 128)
+  const bool parts2 = a.small_kparts == 2 && !(a.k & 31) && (!a.b_tri || (a.b_tri == 2 && a.n <= SM_BN && a.b_tri_off == 0 && !(a.n & 31)));
+  const int kparts = parts2 ? 2 : 1;
+  const int ldk = a.k / kparts + 2;
   const size_t lds = (size_t)(SM_BM + SM_BN) * ldk * sizeof(double);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -874,7 +890,7 @@ int launch_small(hipStream_t s, const GemmArgs& a) {
   else if (a.small_loop && a.max_wgs <= 0 && gy * gxs > 512u) gy = (512u + gxs - 1) / gxs;
   dim3 grid(gxs, gy, (unsigned)(a.batch > 0 ? a.batch : 1));
   g_last_kind = 1;
-  hipLaunchKernelGGL(gemm_nt_small, grid, dim3(SM_THREADS), lds, s, a, ldk);
+  hipLaunchKernelGGL(gemm_nt_small, grid, dim3(SM_THREADS), lds, s, a, ldk, kparts);
   GPK_LAUNCH_CHECK();
   return 0;
 }

@@ -80,6 +80,8 @@ struct GemmArgs {
   int no_small;     // never take the one-shot LDS-DMA latency kernel (150 KB of LDS per workgroup: needs a CU free of GEMM workgroups)
   int small_loop;   // K <= 128 launches with MORE than 512 row slivers may still take the one-shot latency kernel: its workgroups
                     // then walk the row blocks with their B tile staged once (the in-group updates of the extra rows)
+  int small_kparts; // one-shot latency kernel only: 2 = stage K in two halves (74 KB of LDS per workgroup instead of 146: it then fits
+                    // beside a capped bulk workgroup on the same compute unit), else the whole K at once
   int max_wgs;      // fast path only: cap on the number of (persistent) workgroups per batch entry, 0 = one per tile
   int pair_k_align; // set by the launcher for paired triangular-K launches: time-aligned K traversal (gemm_nt_fast)
   // In-kernel stream hand-offs of the factorisation's latency chain (one-shot latency kernel only; potrf.hip, round 5).  An

@@ -71,8 +71,12 @@ constexpr int HT = NHELP * 64;        // helper threads
 // LDS: the round-5 image (block + dense diagonal tiles of X) + the published panels (4 x (Y, lp) x 64 lanes) + sync words
 constexpr int PUB_OFF = LDS_DOUBLES;
 constexpr int SYNC_OFF = PUB_OFF + 4 * 128;      // 48 ints
-constexpr size_t LEAF2_LDS = (size_t)(SYNC_OFF + 24) * sizeof(double);
-static_assert(LEAF2_LDS <= 160 * 1024, "leaf LDS");
+constexpr size_t LEAF2_LDS_USED = (size_t)(SYNC_OFF + 24) * sizeof(double);
+// The launch asks for a WHOLE compute unit's LDS (160 KB): with the 151 KB it uses, workgroups of LDS-light kernels (the covariance
+// builder beside the first leaves of an SVGP step) were placed on the leaf's CU and took issue slots from its chain waves -- the
+// first two leaves of a step ran 50 us instead of 25 (profiles/r06_step_timeline.txt).
+constexpr size_t LEAF2_LDS = 160 * 1024;
+static_assert(LEAF2_LDS_USED <= LEAF2_LDS, "leaf LDS");
 enum { W_FLAG = 0, W_PDONE, W_TDONE, W_LRDONE, W_ROW2, W_LOADED, W_BAD0, W_BAD1, W_TIMEOUT, W_LCOL = 16, W_XROWC = 24, W_TPARK = 32,
        W_ROWF = 40, W_NWORDS = 48 };
 

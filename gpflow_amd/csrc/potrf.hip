@@ -275,7 +275,7 @@ int current_device(int* dev) {
 
 // factor the outer panel [c0,c1) of the square part (rows up to `rows`) on stream s
 int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, int batch, long strideA,
-                 double* invd, long strideInv, int* info, int chain_wgs = 0) {
+                 double* invd, long strideInv, int* info, int chain_wgs = 0, int chain_kparts = 0) {
   int rc;
   for (int j0 = c0; j0 < c1; j0 += NB) {
     const int j1 = (j0 + NB < c1) ? j0 + NB : c1;
@@ -292,6 +292,7 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
                            strideInv, strideA);
     g.b_tri = 2;
     g.max_wgs = chain_wgs;
+    g.small_kparts = chain_kparts;
     rc = gpk_launch_gemm(s, g);
     if (rc) return rc;
     const int ncols = c1 - j1;
@@ -299,6 +300,7 @@ int factor_panel(hipStream_t s, double* A, int rows, int c0, int c1, long lda, i
       GemmArgs u = gemm_base(below, ncols, nb, -1.0, panel, lda, panel, lda, 1.0,
                              A + (long)j1 * lda + j1, lda, batch, strideA, strideA, strideA);
       u.c_lower = 1;
+      u.small_kparts = chain_kparts;
       rc = gpk_launch_gemm(s, u);
       if (rc) return rc;
     }
@@ -519,7 +521,17 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // (round 5, with the packet-free chain: 224 -- one workgroup on 224 compute units, 32 left to the chain's one-shot kernels --
   //  is level with 320 on the whitened step and 2 - 5 % faster on the un-whitened one, whose extra-row stream is a quarter
   //  longer; a batch of problems keeps 320: C5 separate 2.04 against 2.02 ms; 240 / 248 lose 5 %, profiles/r05_ab_caps.log)
-  if (!large) bulk.cap = batch > 1 ? GPK_TUNE(EXTRA_MAX_WGS_BATCHED, 320) : GPK_TUNE(EXTRA_MAX_WGS, 224);
+  // (round 6 EXPERIMENT, off.)  With many extra rows the chain's one-shot kernels can stage K in two halves (gemm_nt_small, kparts = 2:
+  // 74 KB of LDS) so that they fit BESIDE a capped bulk workgroup (84 KB) on the same compute unit instead of queueing through the few
+  // CUs the cap leaves free (three rounds of ~10 us per launch while an update holds 224 CUs, profiles/r06_step_timeline.txt), and the
+  // cap could then go up.  Measured, same box (profiles/r06_ab_halfk.log): Cm 1.76 ms without, 1.80 with it at the same cap of
+  // 224, 1.85 / 1.88 at caps of 240 / 254 -- the second staging round trip costs more than the queueing, and more bulk workgroups
+  // slow the extra-row stream itself.  Kept as an A/B knob (GPK_CHAIN_HALFK=1).
+  const bool chain_halfk = useX && !large && batch == 1 && nbo == NB && extra >= GPK_TUNE(CHAIN_HALFK_MIN_ROWS, 6144) &&
+                           GPK_TUNE(CHAIN_HALFK, 0);
+  const int chain_kparts = chain_halfk ? 2 : 0;
+  if (!large) bulk.cap = batch > 1 ? GPK_TUNE(EXTRA_MAX_WGS_BATCHED, 320)
+                                   : (chain_halfk ? GPK_TUNE(EXTRA_MAX_WGS_HALFK, 248) : GPK_TUNE(EXTRA_MAX_WGS, 224));
   if (!large) bulk.group_cap = GPK_TUNE(GROUP_SOLVE_MAX_WGS, 0);
   if (!large) bulk.kmin = GPK_TUNE(EXTRA_CAP_KMIN, 256);
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
@@ -606,7 +618,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     const bool narrow = large && (c1 - c0 <= NB) && nbo > NB;  // single-leaf panel in the chain-bound end of a large factorisation
     // ---- P: the critical path.  Panel p, then the strip = columns of panel p+1 (look-ahead) -----------
     const int chain_wgs = (!large && batch == 1) ? GPK_TUNE(CHAIN_MAX_WGS, 0) : 0;
-    rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info, chain_wgs);
+    rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info, chain_wgs, chain_kparts);
     if (rc) return rc;
     const double* Pn = A + (long)c1 * lda + c0;  // rows c1.. of the solved panel
     GemmArgs strip{};
@@ -615,6 +627,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
                         strideA, strideA);
       strip.c_lower = 1;
       strip.max_wgs = chain_wgs;
+      strip.small_kparts = chain_kparts;
     }
     // Chain flags (round 5).  Between two kernels of the panel stream an event record costs 4.6 us and an event wait 6.3 us of
     // queue-packet processing (rocprofv3 timelines, profiles/r05_rows1024_events_timeline.txt, r05_ab_chain_flags.log); two kernels back to back start
@@ -708,6 +721,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       GemmArgs ua = gemm_base(R - c2, c3 - c2, c1 - c0, -1.0, P2, lda, P2, lda, 1.0, A + (long)c2 * lda + c2, lda, batch, strideA,
                               strideA, strideA);
       ua.c_lower = 1;
+      ua.small_kparts = chain_kparts;
       const bool split = GPK_TUNE(REST_SPLIT, 1) && use_flags && p < kMaxFlagPanels && Bp != aux->B && panel_flagged[p] && !u.no_small &&
                          !u.small_loop && (c2 - c1) <= NB && gpk_gemm_takes_latency_kernel(ua) &&
                          !(last_rest >= 0 && last_bulk != Bp);
