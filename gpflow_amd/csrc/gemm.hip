@@ -873,6 +873,149 @@ __global__ __launch_bounds__(SM_THREADS) void gemm_nt_small(GemmArgs p, int ldk,
   }
 }
 
+// =====================================================================================================
+// Fused panel kernel of a single-leaf panel of the latency chain (round 6): the in-place panel solve  S = A21 X^T  AND the strip
+//  C[:, next block column] -= S S_top^T  in ONE launch -- the two one-shot launches above, back to back on the panel stream, cost
+// 7.3 + 7.7 us, most of it launch ramp, a second staging round trip of the rows a workgroup had just produced, and the drain
+// of the first kernel.  A workgroup owns 16 rows as before.  Phase 1 is gemm_nt_small's solve (same staging, same arithmetic:
+// two alternating accumulators over K = 128); the solved rows go to global memory AND stay in LDS as the A operand of phase 2.
+// Phase 2 needs the solved rows of the NEXT diagonal block (the first `nbw` workgroups' rows) as its B tile: those workgroups
+// count themselves in `cnt[0]` once their rows are released; everybody polls it (bounded), then stages the B tile from L2 and
+// runs gemm_nt_small's update on it.  The last workgroup through phase 1 (`cnt[1]`) publishes "panel solved" (sig_ptr) -- earlier
+// than the strip's entry signal used to.  Workgroups are dispatched in index order, so the producers (indices 0 .. nbw-1)
+// are resident before any consumer can occupy a compute unit; the results are bit-identical to the two-launch form.
+struct PanelFusedArgs {
+  double* P; long lda;            // rows below the leaf of the panel's columns: [m, 128] (in / out)
+  const double* X;                // the leaf's block inverse [128, 128], row stride 128
+  double* C;                      // the next block column of the same rows: [m, n2]
+  int m, n2;                      // rows; columns of the strip (<= 128)
+  int* cnt;                       // two zeroed words: producers done, workgroups through phase 1
+  int* sig_ptr; int sig_val;      // "panel solved"
+  const int* wait_ptr; int wait_val; int* wait_info;   // "previous rest-update done" (before C is touched)
+};
+
+__global__ __launch_bounds__(SM_THREADS) void panel_fused_kernel(PanelFusedArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int K = 128, ldk = K + 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * SM_BM;
+  const int nwg = gridDim.x, nbw = (p.n2 + SM_BM - 1) / SM_BM < nwg ? (p.n2 + SM_BM - 1) / SM_BM : nwg;
+  double* As = smem;
+  double* Bs = smem + SM_BM * ldk;
+  // ---- phase 1: S = A21 X^T (X lower triangular: b_tri 2 with one column tile = the whole K) ----------------------------------
+  for (int q = wave; q < SM_BM + SM_BN; q += SM_THREADS / 64) {
+    const double* src;
+    if (q < SM_BM) {
+      int rr = m0 + q;
+      rr = rr < p.m ? rr : p.m - 1;
+      src = p.P + (long)rr * p.lda;
+    } else {
+      src = p.X + (long)(q - SM_BM) * K;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * lane),
+                                     (__attribute__((address_space(3))) void*)(smem + q * ldk), 16, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();
+  const double* ap = As + r * ldk + g;
+  const double* bp = Bs + (wave * 16 + r) * ldk + g;
+  d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll 4
+  for (int kk = 0; kk < K / 4; kk += 2) {
+    const double a0 = ap[kk * 4], b0 = bp[kk * 4];
+    const double a1 = ap[kk * 4 + 4], b1 = bp[kk * 4 + 4];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+  }
+  double sv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sv[e] = 1.0 * (acc0[e] + acc1[e]);
+    const int row = m0 + g + 4 * e;
+    if (row < p.m) p.P[(long)row * p.lda + wave * 16 + r] = sv[e];
+  }
+  __syncthreads();                       // every wave is done reading As / Bs
+#pragma unroll
+  for (int e = 0; e < 4; ++e) As[(g + 4 * e) * ldk + wave * 16 + r] = sv[e];   // the solved rows: A operand of phase 2
+  __threadfence();                       // the rows written above are visible to the device before the counters move
+  __syncthreads();
+  if (tid == 0) {
+    if ((int)blockIdx.x < nbw) __hip_atomic_fetch_add(p.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const int done = __hip_atomic_fetch_add(p.cnt + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == nwg - 1 && p.sig_ptr) __hip_atomic_store(p.sig_ptr, p.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- wait: the B tile's rows are solved; the previous rest-update has left the strip's columns
+    const long long t0 = wall_clock64();
+    bool timed_out = false;
+    while (__hip_atomic_load(p.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbw) {
+      if (wall_clock64() - t0 >= 50000000LL) { timed_out = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (p.wait_ptr) {
+      while ((int)(__hip_atomic_load(p.wait_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.wait_val) < 0) {
+        if (wall_clock64() - t0 >= 50000000LL) { timed_out = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    if (timed_out && p.wait_info) atomicMax(p.wait_info, 0x7fffffff);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // ---- phase 2: C[rows, 0:n2] -= S S_top^T, lower tiles only (c_lower: a workgroup whose rows lie above the block is skipped) ----
+  if (p.n2 <= 0) return;
+  for (int q = wave; q < SM_BN; q += SM_THREADS / 64) {
+    int rr = q < p.n2 ? q : p.n2 - 1;
+    rr = rr < p.m ? rr : p.m - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.P + (long)rr * p.lda + 2 * lane),
+                                     (__attribute__((address_space(3))) void*)(Bs + q * ldk), 16, 0, 0);
+  }
+  const int col = wave * 16 + r;
+  d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0;
+  {
+    const int cc = col < p.n2 ? col : p.n2 - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int row = m0 + g + 4 * e;
+      row = row < p.m ? row : p.m - 1;
+      c0[e] = -1.0 * p.C[(long)row * p.lda + cc];     // (beta / alpha) C with alpha = -1, beta = 1, as gemm_nt_small does
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();
+#pragma unroll 4
+  for (int kk = 0; kk < K / 4; kk += 2) {
+    const double a0 = ap[kk * 4], b0 = bp[kk * 4];
+    const double a1 = ap[kk * 4 + 4], b1 = bp[kk * 4 + 4];
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+  }
+  if (col < p.n2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = m0 + g + 4 * e;
+      if (row < p.m) p.C[(long)row * p.lda + col] = -1.0 * (c0[e] + c1[e]);
+    }
+  }
+}
+
+bool gpk_panel_fused_ok(const double* P, long lda, const double* X, int m, int nb, int n2) {
+  return nb == 128 && m > 0 && n2 > 0 && n2 <= 128 && !(lda & 1) && !(reinterpret_cast<uintptr_t>(P) & 15) &&
+         !(reinterpret_cast<uintptr_t>(X) & 15) && gpk_cdiv(m, SM_BM) <= GPK_TUNE(SMALL_MAX_WGS, 512) && lda <= (1L << 21);
+}
+
+int gpk_launch_panel_fused(hipStream_t s, double* P, long lda, const double* X, double* C, int m, int n2, int* cnt, int* sig_ptr,
+                           int sig_val, const int* wait_ptr, int wait_val, int* wait_info) {
+  constexpr size_t lds = (size_t)(SM_BM + SM_BN) * 130 * sizeof(double);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  GPK_HIP(attr);
+  PanelFusedArgs a{P, lda, X, C, m, n2, cnt, sig_ptr, sig_val, wait_ptr, wait_val, wait_info};
+  hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)gpk_cdiv(m, SM_BM)), dim3(SM_THREADS), lds, s, a);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_small(hipStream_t s, const GemmArgs& a) {
   // K staged in two halves (GemmArgs::small_kparts == 2) when every K range of the launch splits into whole 16-slabs: plain
   // K = 64 / 128 operands, or the single-column-tile triangular solve against a leaf's block inverse (b_tri 2, K range = n <= 128)

@@ -105,6 +105,11 @@ bool gpk_gemm_takes_latency_kernel(const GemmArgs& a);   // the launch would run
 int gpk_launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, long ldeo, int rows, const double* Lgg, long ldl,
                            const double* X, int nb, int batch = 1, long strideE = 0, long strideEo = 0, long strideL = 0,
                            long strideX = 0, int max_wgs = 0, int j0 = 0, int j1 = -1);   // max_wgs > 0: at most that many workgroups, walking the 16-row slivers
+// fused panel solve + strip of a single-leaf panel (gemm.hip, round 6): P rows below the leaf [m, 128] (solved in place), X the
+// leaf's block inverse, C the next block column of the same rows [m, n2]; cnt: two zeroed device words of this launch
+bool gpk_panel_fused_ok(const double* P, long lda, const double* X, int m, int nb, int n2);
+int gpk_launch_panel_fused(hipStream_t s, double* P, long lda, const double* X, double* C, int m, int n2, int* cnt, int* sig_ptr,
+                           int sig_val, const int* wait_ptr, int wait_val, int* wait_info);
 int gpk_gemm_tiles_n(int n);   // number of column tiles the launcher will use for n columns
 int gpk_profile_gemm_is_on();  // per-launch event timing active (bench roofline leg)
 int gpk_prof_begin(hipStream_t s, double flops, int kind);   // same facility for other kernels; returns a record index or -1

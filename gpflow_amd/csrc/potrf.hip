@@ -90,6 +90,7 @@ struct Aux {
   // packet-free hand-offs of the latency chain (potrf_core, "chain flags"): one word per panel for "panel solved" (F) and for
   // "rest-update done" (R), written with the epoch of the factorisation that owns them (monotonic per device)
   int* flags = nullptr;
+  int* cnt = nullptr;    // two counters per panel for the fused panel kernel (producers done / workgroups through the solve), zeroed per call
   int epoch = 0;
   int concurrent = -1;   // 1: kernels of two streams were seen running at the same time (init-time probe); 0: serialised by a tool
 };
@@ -241,8 +242,9 @@ int aux_get(int dev, int need, Aux** out) {
     a.ready = true;
   }
   if (!a.flags) {
-    GPK_HIP(hipMalloc((void**)&a.flags, sizeof(int) * 2 * kMaxFlagPanels));
-    GPK_HIP(hipMemset(a.flags, 0, sizeof(int) * 2 * kMaxFlagPanels));
+    GPK_HIP(hipMalloc((void**)&a.flags, sizeof(int) * 4 * kMaxFlagPanels));
+    GPK_HIP(hipMemset(a.flags, 0, sizeof(int) * 4 * kMaxFlagPanels));
+    a.cnt = a.flags + 2 * kMaxFlagPanels;
     // in-kernel hand-offs need kernels of two streams to RUN concurrently: under rocprofv3 --pmc (or any tool that serialises
     // kernels) they would deadlock, so the chain then keeps its events (gpk_probe_concurrent_kernels: <= 2 ms, once per device)
     int conc = 0;
@@ -555,6 +557,9 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     rc = (*p_prologue)(P);
     if (rc) return rc;
   }
+  const bool panel_fused_on = GPK_TUNE(PANEL_FUSED, 1) && batch == 1 && aux->cnt != nullptr;
+  if (panel_fused_on)   // the fused panel kernels' counters (everything of earlier calls that used them has completed: P waited for the fork)
+    GPK_HIP(hipMemsetAsync(aux->cnt, 0, sizeof(int) * 2 * (size_t)std::min(npanels, kMaxFlagPanels), P));
   hipStream_t last_bulk = B;
   int last_rest = -1;  // panel index whose evR marks the most recent rest-update
   hipEvent_t evBpro = aux->ev[2 * npanels + 4];
@@ -618,8 +623,27 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     const bool narrow = large && (c1 - c0 <= NB) && nbo > NB;  // single-leaf panel in the chain-bound end of a large factorisation
     // ---- P: the critical path.  Panel p, then the strip = columns of panel p+1 (look-ahead) -----------
     const int chain_wgs = (!large && batch == 1) ? GPK_TUNE(CHAIN_MAX_WGS, 0) : 0;
-    rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info, chain_wgs, chain_kparts);
-    if (rc) return rc;
+    const bool tail_zone = !large && (nbo == NB) && (n >= 8 * NB) && (extra < tail_zone_max_rows);
+    const int xgroup_now = (xg0 == 0 && !large) ? xgroup_first : xgroup;
+    const bool x_waits_here = useX && (c1 == n || ((c1 - xg0) >= xgroup_now || (large && c1 - xg0 >= nbo)) ||
+                                       (tail_zone && (c1 == n - 2 * NB || c1 == n - NB)));
+    // Fused panel kernel (round 6): a full single-leaf panel that hands over with flags runs  leaf -> ONE kernel (panel solve +
+    // strip, gemm.hip: panel_fused_kernel)  instead of  leaf -> solve -> strip.  "Panel solved" is published by the last workgroup
+    // through the solve; the wait for the previous rest-update sits between the two phases.
+    double* const invb_p = invd + (long)(c0 / NB) * NB * NB;
+    const bool fused_panel = panel_fused_on && use_flags && p < kMaxFlagPanels && c1 < n && (c1 - c0) == NB && !bpro_pending &&
+                             chain_wgs == 0 && chain_kparts == 0 && !(x_waits_here && X == aux->B) && (last_rest < 0 || rest_flagged) &&
+                             gpk_panel_fused_ok(A + (long)c1 * lda + c0, lda, invb_p, R - c1, NB, c2 - c1);
+    if (fused_panel) {
+      rc = gpk_launch_leaf(P, A + (long)c0 * lda + c0, lda, strideA, NB, invb_p, strideInv, info, c0, batch, 0);
+      if (rc) return rc;
+      rc = gpk_launch_panel_fused(P, A + (long)c1 * lda + c0, lda, invb_p, A + (long)c1 * lda + c1, R - c1, c2 - c1, aux->cnt + 2 * p,
+                                  flagF + p, epoch, last_rest >= 0 ? flagR + last_rest : nullptr, epoch, info);
+      if (rc) return rc;
+    } else {
+      rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info, chain_wgs, chain_kparts);
+      if (rc) return rc;
+    }
     const double* Pn = A + (long)c1 * lda + c0;  // rows c1.. of the solved panel
     GemmArgs strip{};
     if (c1 < n) {
@@ -640,15 +664,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     // (stream memory operations only on the plain streams: on the CU-masked bulk stream of large factorisations a
     // hipStreamWriteValue32 was observed to overtake the kernel queued before it -- wrong factor at n = 5000 -- so a panel whose
     // extra-row group waits on that stream keeps its event, and so does a strip whose rest-update ran there)
-    const bool tail_zone = !large && (nbo == NB) && (n >= 8 * NB) && (extra < tail_zone_max_rows);
-    const int xgroup_now = (xg0 == 0 && !large) ? xgroup_first : xgroup;
-    const bool x_waits_here = useX && (c1 == n || ((c1 - xg0) >= xgroup_now || (large && c1 - xg0 >= nbo)) ||
-                                       (tail_zone && (c1 == n - 2 * NB || c1 == n - NB)));
-    const bool flagged = use_flags && p < kMaxFlagPanels && c1 < n && (c1 - c0) <= NB && gpk_gemm_takes_latency_kernel(strip) &&
-                         !(x_waits_here && X == aux->B);
+    const bool flagged = fused_panel || (use_flags && p < kMaxFlagPanels && c1 < n && (c1 - c0) <= NB &&
+                                         gpk_gemm_takes_latency_kernel(strip) && !(x_waits_here && X == aux->B));
     panel_flagged[p] = flagged ? 1 : 0;
     if (!flagged) GPK_HIP(hipEventRecord(evF[p], P));
-    if (c1 < n) {
+    if (c1 < n && !fused_panel) {
       if (bpro_pending) {   // the strip is the first kernel of the chain that leaves the first panel's columns
         GPK_HIP(hipStreamWaitEvent(P, evBpro, 0));
         bpro_pending = false;
