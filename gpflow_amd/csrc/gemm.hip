@@ -929,22 +929,29 @@ __global__ __launch_bounds__(SM_THREADS) void panel_fused_kernel(PanelFusedArgs 
     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
   }
+  // The producers of the B tile (the first nbw workgroups) write their rows THROUGH to memory (agent-scope stores) and count
+  // themselves in; everybody else stores normally -- their rows are released by the end of the kernel, and "panel solved" is
+  // announced by the entry signal of the next kernel of the panel stream (the next leaf).  (A __threadfence() per workgroup --
+  // an L2 write-back each -- made the first version of this kernel 10 us slower than the two launches it replaces.)
+  const bool producer = (int)blockIdx.x < nbw;
   double sv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     sv[e] = 1.0 * (acc0[e] + acc1[e]);
     const int row = m0 + g + 4 * e;
-    if (row < p.m) p.P[(long)row * p.lda + wave * 16 + r] = sv[e];
+    if (row < p.m) {
+      double* dst = p.P + (long)row * p.lda + wave * 16 + r;
+      if (producer) __hip_atomic_store(dst, sv[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *dst = sv[e];
+    }
   }
+  if (producer) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): this thread's write-through stores have been acknowledged
   __syncthreads();                       // every wave is done reading As / Bs
 #pragma unroll
   for (int e = 0; e < 4; ++e) As[(g + 4 * e) * ldk + wave * 16 + r] = sv[e];   // the solved rows: A operand of phase 2
-  __threadfence();                       // the rows written above are visible to the device before the counters move
   __syncthreads();
   if (tid == 0) {
-    if ((int)blockIdx.x < nbw) __hip_atomic_fetch_add(p.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const int done = __hip_atomic_fetch_add(p.cnt + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == nwg - 1 && p.sig_ptr) __hip_atomic_store(p.sig_ptr, p.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (producer) __hip_atomic_fetch_add(p.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     // ---- wait: the B tile's rows are solved; the previous rest-update has left the strip's columns
     const long long t0 = wall_clock64();
     bool timed_out = false;
@@ -999,6 +1006,8 @@ __global__ __launch_bounds__(SM_THREADS) void panel_fused_kernel(PanelFusedArgs 
   }
 }
 
+}  // namespace
+
 bool gpk_panel_fused_ok(const double* P, long lda, const double* X, int m, int nb, int n2) {
   return nb == 128 && m > 0 && n2 > 0 && n2 <= 128 && !(lda & 1) && !(reinterpret_cast<uintptr_t>(P) & 15) &&
          !(reinterpret_cast<uintptr_t>(X) & 15) && gpk_cdiv(m, SM_BM) <= GPK_TUNE(SMALL_MAX_WGS, 512) && lda <= (1L << 21);
@@ -1015,6 +1024,8 @@ int gpk_launch_panel_fused(hipStream_t s, double* P, long lda, const double* X, 
   GPK_LAUNCH_CHECK();
   return 0;
 }
+
+namespace {
 
 int launch_small(hipStream_t s, const GemmArgs& a) {
   // K staged in two halves (GemmArgs::small_kparts == 2) when every K range of the launch splits into whole 16-slabs: plain

@@ -132,8 +132,9 @@ int gpk_launch_svgp_mega(hipStream_t s, int proto, int ncu, double* T, long ld, 
 
 // ---- leaf (leaf.hip): NB x NB Cholesky + inverse of the diagonal block --------------------------
 // A: pointer to the diagonal block (row-major, lda); nb <= NB valid rows/cols.
+// sig_ptr: chain-flag word the leaf stores sig_val into on ENTRY ("everything queued before it on s has completed"), or nullptr
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
-                    long strideInv, int* info, int col0, int batch, int already_factored);
+                    long strideInv, int* info, int col0, int batch, int already_factored, int* sig_ptr = nullptr, int sig_val = 0);
 
 // ---- rbf.hip ---------------------------------------------------------------------------------
 // (entry point gpk_kernel_matrix is defined there)

@@ -57,8 +57,11 @@ __global__ __launch_bounds__(NT) void leaf_kernel(double* __restrict__ Abase, lo
 // the round-6 leaf (leaf2_device.h): twelve waves
 __global__ __launch_bounds__(gpk_leaf2::NT2) void leaf2_kernel(double* __restrict__ Abase, long lda, long strideA, int nb,
                                                                 double* __restrict__ invbase, long strideInv,
-                                                                int* __restrict__ info, int col0, long long* __restrict__ dbg) {
+                                                                int* __restrict__ info, int col0, long long* __restrict__ dbg,
+                                                                int* __restrict__ sig_ptr, int sig_val) {
   extern __shared__ __attribute__((aligned(16))) double S[];
+  // entry signal of the chain flags (potrf.hip): "everything queued before this leaf on the panel stream has completed"
+  if (sig_ptr && threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(sig_ptr, sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   gpk_leaf2::leaf2_body<false>(S, Abase + (long)blockIdx.x * strideA, lda, nb, invbase + (long)blockIdx.x * strideInv,
                                info ? info + blockIdx.x : nullptr, col0, dbg);
 }
@@ -89,7 +92,7 @@ extern "C" __attribute__((visibility("default"))) int gpk_exp_leaf_dbg_dump(int 
 #endif
 
 int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, double* invd,
-                    long strideInv, int* info, int col0, int batch, int already_factored) {
+                    long strideInv, int* info, int col0, int batch, int already_factored, int* sig_ptr, int sig_val) {
   if (nb <= 0 || nb > NB) return GPK_E_ARG;
   // (function-local statics: initialised once, thread-safe)
   static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_kernel<true>),
@@ -104,6 +107,11 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
   dim3 grid((unsigned)(batch > 0 ? batch : 1));
   const int fake = kGpkExp ? GPK_TUNE(LEAF_FAKE_US, 0) * 100 : 0;
   const int v1 = kGpkExp ? (GPK_TUNE(LEAF_V1, 0) || fake > 0) : 0;
+  if (sig_ptr && (already_factored || v1)) {   // (only the round-6 kernel carries the entry signal)
+    const int rcs = gpk_launch_set_flag(s, sig_ptr, sig_val);
+    if (rcs) return rcs;
+    sig_ptr = nullptr;
+  }
 #ifdef GPK_EXPERIMENTAL
   // phase timers of every leaf launch (GPK_LEAF_DBG=1; printed by gpk_exp_leaf_dbg_dump): load / factor / invert / store
   if (!already_factored && GPK_TUNE(LEAF_DBG, 0) && g_dbg_n < DBG_CAP) {
@@ -114,7 +122,7 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
                          g_dbg + 8 * (g_dbg_n++), fake);
     else
       hipLaunchKernelGGL(leaf2_kernel, grid, dim3(gpk_leaf2::NT2), gpk_leaf2::LEAF2_LDS, s, A, lda, strideA, nb, invd, strideInv, info,
-                         col0, g_dbg + 8 * (g_dbg_n++));
+                         col0, g_dbg + 8 * (g_dbg_n++), sig_ptr, sig_val);
     GPK_LAUNCH_CHECK();
     return 0;
   }
@@ -127,7 +135,7 @@ int gpk_launch_leaf(hipStream_t s, double* A, long lda, long strideA, int nb, do
                        strideInv, info, col0, nullptr, fake);
   else
     hipLaunchKernelGGL(leaf2_kernel, grid, dim3(gpk_leaf2::NT2), gpk_leaf2::LEAF2_LDS, s, A, lda, strideA, nb, invd, strideInv, info,
-                       col0, nullptr);
+                       col0, nullptr, sig_ptr, sig_val);
   GPK_LAUNCH_CHECK();
   return 0;
 }

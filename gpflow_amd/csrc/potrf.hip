@@ -557,7 +557,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     rc = (*p_prologue)(P);
     if (rc) return rc;
   }
-  const bool panel_fused_on = GPK_TUNE(PANEL_FUSED, 1) && batch == 1 && aux->cnt != nullptr;
+  // (round 6 EXPERIMENT, off: the fused panel kernel -- solve + strip in one launch, gemm.hip -- is bit-identical and level with the two
+  //  launches it replaces: 1024-row shard 0.976 against 0.985 ms, Cm 1.795 / 1.79, C3 0.766 / 0.764 (profiles/r06_ab_panel_fused.log).  What
+  //  it saves in launch ramp and re-staging it spends on the cross-workgroup hand-over of the B tile through memory.  A/B: GPK_PANEL_FUSED=1.)
+  const bool panel_fused_on = GPK_TUNE(PANEL_FUSED, 0) && batch == 1 && aux->cnt != nullptr;
+  int* pending_sig = nullptr;   // "panel solved" word of a fused panel that the NEXT kernel of the panel stream still has to announce
   if (panel_fused_on)   // the fused panel kernels' counters (everything of earlier calls that used them has completed: P waited for the fork)
     GPK_HIP(hipMemsetAsync(aux->cnt, 0, sizeof(int) * 2 * (size_t)std::min(npanels, kMaxFlagPanels), P));
   hipStream_t last_bulk = B;
@@ -635,12 +639,20 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
                              chain_wgs == 0 && chain_kparts == 0 && !(x_waits_here && X == aux->B) && (last_rest < 0 || rest_flagged) &&
                              gpk_panel_fused_ok(A + (long)c1 * lda + c0, lda, invb_p, R - c1, NB, c2 - c1);
     if (fused_panel) {
-      rc = gpk_launch_leaf(P, A + (long)c0 * lda + c0, lda, strideA, NB, invb_p, strideInv, info, c0, batch, 0);
+      // ("panel p-1 solved" of a fused predecessor rides on this leaf's entry)
+      rc = gpk_launch_leaf(P, A + (long)c0 * lda + c0, lda, strideA, NB, invb_p, strideInv, info, c0, batch, 0, pending_sig, epoch);
+      pending_sig = nullptr;
       if (rc) return rc;
       rc = gpk_launch_panel_fused(P, A + (long)c1 * lda + c0, lda, invb_p, A + (long)c1 * lda + c1, R - c1, c2 - c1, aux->cnt + 2 * p,
-                                  flagF + p, epoch, last_rest >= 0 ? flagR + last_rest : nullptr, epoch, info);
+                                  nullptr, epoch, last_rest >= 0 ? flagR + last_rest : nullptr, epoch, info);
       if (rc) return rc;
+      pending_sig = flagF + p;   // announced by the entry of the next kernel on the panel stream
     } else {
+      if (pending_sig) {
+        rc = gpk_launch_set_flag(P, pending_sig, epoch);
+        pending_sig = nullptr;
+        if (rc) return rc;
+      }
       rc = factor_panel(P, A, R, c0, c1, lda, batch, strideA, invd, strideInv, info, chain_wgs, chain_kparts);
       if (rc) return rc;
     }
