@@ -127,6 +127,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
     tile_decode(p.tail_first1 - 1 + ((int)blockIdx.x >> 2), gx, gy, compact, tm, tn);
     tile_m = 2 * tm + (((int)blockIdx.x >> 1) & 1);
     tile_n = 2 * tn + ((int)blockIdx.x & 1);
+  } else if (p.tile_snake) {
+    // under-filled triangular-K launches (every workgroup resident at once, column tile 0 the heaviest): workgroups x, x + 256,
+    // x + 512, ... land on the same compute unit (round-robin placement), so round 0 takes the heaviest 256 tiles in falling
+    // order, round 1 the LIGHTEST 256 in rising order, round 2 the next heaviest, ... -- every CU gets the same K total.
+    // (A batch of problems with ONE round each alternates the direction from problem to problem instead.)
+    const int r = (int)blockIdx.x >> 8, c = (int)blockIdx.x & 255, R = (int)gridDim.x >> 8;
+    const int rr = (r & 1) ? R - 1 - (r >> 1) : (r >> 1);
+    if (p.tile_snake == 2) {
+      // ... and each XCD (workgroup x runs on XCD x % 8) keeps gy / 8 row tiles to itself: A is read by one L2 only
+      const int xcd = c & 7, s = c >> 3, rpx = gy >> 3;
+      const int q = rr * 32 + (((r ^ bz) & 1) ? 31 - s : s);
+      tile_n = q / rpx;
+      tile_m = xcd * rpx + (q - tile_n * rpx);
+    } else {
+      const int nl = rr * 256 + ((r & 1) ? 255 - c : c);
+      if (nl >= total) return;
+      tile_n = nl / gy;
+      tile_m = nl - tile_n * gy;
+    }
   } else {
     tile_order(blockIdx.x, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
   }
@@ -305,8 +324,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 8);
         // one partial per 64 columns of the output: tile_n * (BN / 64) + (this wave's 64-column slot within the tile)
-        if ((lane & 15) == 0 && row < p.m) part[(long)(tile_n * (BN / 64) + (wn * WN) / 64) * p.part_ld + row] = s;
+        if constexpr (WN >= 64) {
+          if ((lane & 15) == 0 && row < p.m) part[(long)(tile_n * (BN / 64) + (wn * WN) / 64) * p.part_ld + row] = s;
+        } else {
+          // several waves share a 64-column slot: their partial sums meet in LDS (free after the K loop) and are added in wave order
+          if ((lane & 15) == 0) smem[wn * BM + (row - m0)] = s;
+        }
       }
+    if constexpr (WN < 64) {
+      constexpr int WPS = 64 / WN;   // waves per slot
+      __syncthreads();
+      if (wn % WPS == 0 && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row_base + i * 16 + 4 * r;
+            double s = smem[wn * BM + (row - m0)];
+#pragma unroll
+            for (int u = 1; u < WPS; ++u) s += smem[(wn + u) * BM + (row - m0)];
+            if (row < p.m) part[(long)(tile_n * (BN / 64) + (wn * WN) / 64) * p.part_ld + row] = s;
+          }
+      }
+    }
   }
 }
 
@@ -609,7 +649,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
     // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
       int tile_m, tile_n;
-      tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+      if (EPI == 1 && p.tile_snake) {
+        // a triangular-K projection whose PAIRS would not fill the chip twice (launch_fast): one tile per workgroup, workgroups x and
+        // x + total / 2 -- the same compute unit under round-robin placement -- take column tiles j and gx-1-j of one row tile
+        const int q = t / gy, half = gx >> 1;
+        tile_m = t - q * gy;
+        tile_n = q < half ? q : gx - 1 - (q - half);
+      } else {
+        tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+      }
       fast_tile<EPI>(p, tile_m, tile_n, smem);
       if (t + (int)gridDim.x < total) __syncthreads();  // both LDS buffers are about to be refilled
     }
@@ -662,6 +710,19 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   {
     const bool pair_ok = (EPI == 1) ? (a.b_tri == 1)
                                     : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0);
+    // (round 6) pairs that fill the chip at most once -- C3's projection: 4 x 64 = 256 workgroups, one per CU, whose K loop runs at
+    // 79 % alone -- run unpaired instead, heavy and light tile of a pair as TWO workgroups of one CU (88 % together)
+    if (EPI == 1 && pair_ok && gx >= 4 && !(gx & 1) && a.b_tri_rows >= a.n && a.max_wgs == 0 &&
+        (long)(gx / 2) * gy * nb <= GPK_TUNE(PROJ_UNPAIR_UPTO, 256)) {
+      GemmArgs b = a;
+      b.tile_snake = 1;
+      b.stagger_first = 256;
+      b.stagger_ticks = 0;
+      g_last_kind = 2 + 2 * EPI;
+      hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3((unsigned)total, nb, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total, compact);
+      GPK_LAUNCH_CHECK();
+      return 0;
+    }
     if (pair_ok && gx >= 4 && a.b_tri_rows >= a.n) {
       total = ((gx + 1) / 2) * gy;
       g_last_kind = 2 + 2 * EPI + 1;
@@ -1476,9 +1537,18 @@ int launch_cfg(hipStream_t s, const GemmArgs& a) {
     }
     if (total <= 0) return 0;
   }
-  dim3 grid((unsigned)total, (unsigned)(a.batch > 0 ? a.batch : 1), 1);
+  GemmArgs b = a;
+  unsigned gridx = (unsigned)total;
+  if (b.tile_snake) {   // (see the kernel: needs whole rounds of 256 workgroups per batch entry, or a single problem)
+    const int nbatch = a.batch > 0 ? a.batch : 1;
+    if (a.b_tri != 1 || compact || total < 256 || (total == 256 && nbatch < 2)) b.tile_snake = 0;
+    else if ((gy & 7) == 0 && (total & 255) == 0) b.tile_snake = 2;
+    else if (nbatch == 1) { b.tile_snake = 1; gridx = (unsigned)((total + 255) & ~255); }
+    else b.tile_snake = 0;
+  }
+  dim3 grid(gridx, (unsigned)(a.batch > 0 ? a.batch : 1), 1);
   g_last_kind = 6;
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN>), grid, dim3(256), Cfg::LDS_BYTES, s, a, gx, gy, total,
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WGM, WGN>), grid, dim3(256), Cfg::LDS_BYTES, s, b, gx, gy, total,
                      compact);
   GPK_LAUNCH_CHECK();
   return 0;
@@ -1670,8 +1740,13 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
     if (pairs < GPK_TUNE(PROJ_SMALL_TILE_BELOW, 200)) {
       // (every 64-column partial slot the reduction reads must be written: 64-wide tiles only if they cover the same
       // slots as the 128-wide ones, else 64 x 128 tiles)
-      if (gpk_cdiv(a.n, 64) == 2 * gpk_cdiv(a.n, 128)) return launch_cfg<64, 64, 4, 1>(s, a);
-      return launch_cfg<64, 128, 2, 2>(s, a);
+      GemmArgs b = a;
+      b.tile_snake = GPK_TUNE(PROJ_SNAKE, 1);
+      if (gpk_cdiv(a.n, 64) == 2 * gpk_cdiv(a.n, 128)) {
+        if (pairs < GPK_TUNE(PROJ_TILE32_BELOW, 100)) return launch_cfg<32, 64, 2, 2>(s, b);
+        return launch_cfg<64, 64, 4, 1>(s, b);
+      }
+      return launch_cfg<64, 128, 2, 2>(s, b);
     }
   }
   if (fast_ok(a) && (a.epi == 1 || (a.n > 64 && (tiles >= 24 || a.m <= 64)))) {

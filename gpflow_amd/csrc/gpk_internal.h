@@ -94,6 +94,7 @@ struct GemmArgs {
   int* sig_ptr; int sig_val;
   const int* wait_ptr; int wait_val;
   int* wait_info;   // device int that receives INT_MAX if the bounded wait expires (the factorisation's status word)
+  int tile_snake;   // set by the launcher only (generic kernel, under-filled triangular-K projections): heavy / light tiles alternate per CU
   int tail_first1;  // set by the launcher only (generic 64 x 64 kernel; launch_fast, "tail split"): 1 + first position, 0 = off
 };
 int gpk_launch_gemm(hipStream_t s, const GemmArgs& a);

@@ -590,8 +590,15 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // (512 columns for M = 2048: 256 / 384 measured slower there.  For M <= 1024 the extra-row stream would start after half of
   // the chain: 256 columns for a batch of problems -- C5 separate 2.036 -> 1.977 ms -- and 128 for a single one -- C3 0.834 ->
   // 0.803 ms, C5 shared 1.314 -> 1.30 ms, but C5 separate 1.97 -> 2.11; profiles/r04_ab_c5.log, r04_ab_xgroup_small.log)
-  const int xgroup_small = batch > 1 ? GPK_TUNE(XGROUP_SMALL_BATCH, 256) : GPK_TUNE(XGROUP_SMALL, 128);
-  const int xgroup = std::max(NB, ((n <= 1024 ? xgroup_small : GPK_TUNE(XGROUP, NBO)) / NB) * NB);
+  // (round 6, with the chain at 41 us per panel instead of 62 the extra-row stream is the longer of the two at M = 1024 and wider groups
+  //  -- fewer, longer-K updates of its 8192 rows -- win: 128 / 256 / 384 / 512 columns: C3 0.757 / 0.713 / 0.688 / 0.716 ms, C5 shared
+  //  1.24 / 1.20 / 1.19 / 1.21 ms, two repetitions each on one box, profiles/r06_ab_extra_row_groups.log)
+  const int xgroup_small = batch > 1 ? GPK_TUNE(XGROUP_SMALL_BATCH, 256) : GPK_TUNE(XGROUP_SMALL, 384);
+  // (round 6: with FEW extra rows -- a rank's shard of a strong-scaled step -- M = 2048 prefers 256-column groups too: 4096 / 2048 / 1024
+  //  rows 1.353 / 1.049 / 0.938 -> 1.308 / 1.019 / 0.918 ms, while 8192 rows lose 5 %: tools/strong_scaling_emulation.py under GPK_XGROUP,
+  //  profiles/r06_ab_extra_row_groups.log)
+  const int xgroup_wide = (batch == 1 && n < 4096 && extra < GPK_TUNE(XGROUP_FEW_ROWS_BELOW, 6144)) ? GPK_TUNE(XGROUP_FEW_ROWS, 256) : GPK_TUNE(XGROUP, NBO);
+  const int xgroup = std::max(NB, ((n <= 1024 ? xgroup_small : xgroup_wide) / NB) * NB);
   // (round 5 knobs: width of the FIRST extra-row group -- the extra-row stream idles until it is factored -- and the row count above
   //  which the shrinking groups at the end are dropped: with many rows that stream, not the chain, finishes last)
   const int xgroup_first = std::max(NB, (GPK_TUNE(XGROUP_FIRST, 0) > 0 ? (GPK_TUNE(XGROUP_FIRST, 0) / NB) * NB : xgroup));

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpflow_amd import ops  # noqa: E402
 
 rng = np.random.default_rng(0)
-for rows, m, P in [(1024, 2048, 1), (300, 1024, 2), (2048, 2048, 1), (4096, 2048, 1), (1024, 1024, 4)]:
+for rows, m, P in [(1024, 2048, 1), (300, 1024, 2), (2048, 2048, 1), (4096, 2048, 1), (1024, 1024, 4), (8192, 1024, 1), (8192, 2048, 1)]:
     At = rng.normal(size=(rows, m))
     q = rng.normal(size=(P, m, m))
     LqT = ops.transpose(ops.to_device(q), mode=1)
