@@ -1720,6 +1720,7 @@ int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
 
 static int launch_select(hipStream_t s, const GemmArgs& a) {
   const long tiles = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
+  if (a.tile64 && a.epi == 0) return launch_cfg<64, 64, 4, 1>(s, a);
   if (!a.no_small && small_ok(a)) return launch_small(s, a);  // K <= 128, <= 512 workgroups: the latency path
   if (a.epi == 1 && a.beta != 0.0 && a.C && !fast_ok(a)) return GPK_E_UNSUPPORTED;  // only the fast tile preloads C for epi 1
   if (a.epi == 0 && a.k >= 1024 && a.m > 64 && a.n > 64) {

@@ -94,6 +94,7 @@ struct GemmArgs {
   int* sig_ptr; int sig_val;
   const int* wait_ptr; int wait_val;
   int* wait_info;   // device int that receives INT_MAX if the bounded wait expires (the factorisation's status word)
+  int tile64;       // epi 0 only: take the generic kernel's 64 x 64 tiles (36 KB of LDS per workgroup: fits beside any other workgroup on a CU)
   int tile_snake;   // set by the launcher only (generic kernel, under-filled triangular-K projections): heavy / light tiles alternate per CU
   int tail_first1;  // set by the launcher only (generic 64 x 64 kernel; launch_fast, "tail split"): 1 + first position, 0 = off
 };
@@ -154,11 +155,16 @@ int gpk_launch_final(hipStream_t s, int nterms, const double* const* part, const
                      const double* scale, double add, double* out);
 int gpk_launch_sumsq_stage1(hipStream_t s, const double* A, int rows, int cols, long lda,
                             int upper_only, double* part, int* count);
+struct VarexpExtra {   // optional inputs of the variational-expectation stage (reduce.hip, round 6)
+  const double* ssq_part = nullptr; int ssq_nt = 0; long ssq_stride = 0;   // ssq as the projection's slot partials [P][nt][rows]
+  const int* wait_ptr = nullptr; int wait_val = 0; int* wait_info = nullptr;   // word of the row statistics' stream (bounded wait)
+};
 int gpk_launch_varexp_stage1(hipStream_t s, const double* Y, long ldy, const double* fmean, int rows,
                              int P, const double* s0, int s0_per_latent, const double* ssq,
                              const double* knn_host, int knn_per_latent, double noise,
                              double mean_const, double* fvar_out, double* part, int* count,
-                             const double* noise_rows = nullptr);   // per-row noise variances [rows] or nullptr (constant `noise`)
+                             const double* noise_rows = nullptr,   // per-row noise variances [rows] or nullptr (constant `noise`)
+                             const VarexpExtra* ex = nullptr);
 int gpk_launch_kl_white_stage1(hipStream_t s, const double* q_mu, const double* q_sqrt, int m, int P,
                                int q_diag, double* part, int* count);
 int gpk_launch_kl_unwhite_diag_stage1(hipStream_t s, const double* LinvT, long ldl, int m, const double* W, int P, double* part,

@@ -242,8 +242,8 @@ int aux_get(int dev, int need, Aux** out) {
     a.ready = true;
   }
   if (!a.flags) {
-    GPK_HIP(hipMalloc((void**)&a.flags, sizeof(int) * 4 * kMaxFlagPanels));
-    GPK_HIP(hipMemset(a.flags, 0, sizeof(int) * 4 * kMaxFlagPanels));
+    GPK_HIP(hipMalloc((void**)&a.flags, sizeof(int) * (4 * kMaxFlagPanels + 8)));   // F, R, the fused panels' counters, the x_tail words
+    GPK_HIP(hipMemset(a.flags, 0, sizeof(int) * (4 * kMaxFlagPanels + 8)));
     a.cnt = a.flags + 2 * kMaxFlagPanels;
     // in-kernel hand-offs need kernels of two streams to RUN concurrently: under rocprofv3 --pmc (or any tool that serialises
     // kernels) they would deadlock, so the chain then keeps its events (gpk_probe_concurrent_kernels: <= 2 ms, once per device)
@@ -427,11 +427,27 @@ int solve_group_bwd(hipStream_t s, double* Bm, long ldb, int rows, const double*
 // per panel against ~55 us of kernels -- so every launch issued there delays the chain (round 5: the second leaf started 52 us
 // after the first strip had finished), and the rest-update stream has a leaf's time of slack per panel.
 typedef std::function<int(hipStream_t)> StreamWork;
+// x_tail (round 6): work of the CALLER that reads the solved extra rows and that the caller's NEXT kernel does not need -- the SVGP
+// drivers' row statistics (28 us of HBM reads at Cm) beside the projection GEMM.  If the factorisation hands its extra rows over with
+// flag words (small sizes, gate kernels) it enqueues the work on the extra-row stream right behind the last solve, publishes a second
+// word behind it and reports that word: the caller's consumer waits for it in-kernel (VarexpExtra).  The caller's stream is released by a
+// one-wave gate on the first word (~1 us behind the solve; the event pair it replaces cost ~10 us).  Otherwise `used` stays false and
+// the caller runs the work itself.  MEASURED (profiles/r06_ab_x_tail.log, two repetitions per setting on one box): no gain -- Cm 1.79 / 1.80 ms
+// without / with it, C3 0.70 / 0.73: the 2048 light workgroups of the statistics take the wave slots the projection's first tiles want and
+// the projection ends as much later as it started earlier.  Likewise the slot partials summed inside the variational-expectation kernel
+// instead of a sum_parts launch (level).  Both are A/B knobs (GPK_XTAIL, GPK_VAREXP_SUMS_PARTS), off.
+struct XTail {
+  const StreamWork* work = nullptr;
+  bool used = false;
+  const int* done_ptr = nullptr;
+  int done_val = 0;
+};
 struct PotrfHooks {
   const StreamWork* x_prologue = nullptr;
   const StreamWork* b_prologue = nullptr;
   const StreamWork* p_prologue = nullptr;
   const StreamWork* late_work = nullptr;
+  XTail* x_tail = nullptr;
 };
 
 int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, long strideA, double* invd, int zero_upper,
@@ -761,8 +777,18 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
                               strideA, strideA);
       ua.c_lower = 1;
       ua.small_kparts = chain_kparts;
-      const bool split = GPK_TUNE(REST_SPLIT, 1) && use_flags && p < kMaxFlagPanels && Bp != aux->B && panel_flagged[p] && !u.no_small &&
-                         !u.small_loop && (c2 - c1) <= NB && gpk_gemm_takes_latency_kernel(ua) &&
+      // In the tiled regime (many extra rows, above) the whole rest-update was ONE tiled launch that shares its compute units with the
+      // extra-row stream's capped workgroups and takes 60 - 95 us there instead of 30 (profiles/r06_step_timeline.txt) -- longer than the
+      // chain's own 41 us, and the next strip waited for all of it.  The same split there -- the next block column first, as 64 x 64 tiles
+      // of the generic kernel (36 KB of LDS: they fit beside anything), the remainder behind it -- was measured SLOWER: Cm 1.85 against 1.79 ms
+      // (latency kernel 1.84, 128 x 128 tiles 1.95; profiles/r06_ab_rest_split_tiled.log): the extra-row stream is co-critical and every extra
+      // launch beside it costs more than the strip gains.  A/B knob, off.
+      const int split_tiled = u.no_small ? GPK_TUNE(REST_SPLIT_TILED, 0) : 0;   // 1: 64 x 64 tiles, 2: latency kernel, 3: 128 x 128 tiles
+      if (split_tiled == 1) ua.tile64 = 1;
+      else if (split_tiled == 3) ua.no_small = 1;
+      const bool split = GPK_TUNE(REST_SPLIT, 1) && use_flags && p < kMaxFlagPanels && Bp != aux->B && panel_flagged[p] &&
+                         (!u.no_small || split_tiled) && !u.small_loop && (c2 - c1) <= NB &&
+                         (split_tiled == 1 || split_tiled == 3 || gpk_gemm_takes_latency_kernel(ua)) &&
                          !(last_rest >= 0 && last_bulk != Bp);
       if (split) {
         // (the gate, not an in-kernel wait: up to 120 workgroups of 150 KB spinning from the moment they are enqueued -- a leaf and
@@ -776,6 +802,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
           GemmArgs ub = gemm_base(R - c3, n - c3, c1 - c0, -1.0, P3, lda, P3, lda, 1.0, A + (long)c3 * lda + c3, lda, batch,
                                   strideA, strideA, strideA);
           ub.c_lower = 1;
+          ub.no_small = u.no_small;
           if (!drop_rest_flag) {
             ub.sig_ptr = flagR + p;
             ub.sig_val = epoch;
@@ -866,8 +893,24 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
     GPK_HIP(hipStreamWaitEvent(S, evJoinB, 0));
   }
   if (useX && X != last_bulk) {
-    GPK_HIP(hipEventRecord(evJoinX, X));
-    GPK_HIP(hipStreamWaitEvent(S, evJoinX, 0));
+    XTail* xt = hooks.x_tail;
+    if (xt && xt->work && use_flags && gate_kernels && !large && X != S && GPK_TUNE(XTAIL, 0)) {
+      int* flagE = aux->flags + 4 * kMaxFlagPanels;   // [2]: extra rows solved / tail work done
+      rc = gpk_launch_set_flag(X, flagE, epoch);
+      if (rc) return rc;
+      rc = gpk_launch_wait_flag(S, flagE, epoch, info);
+      if (rc) return rc;
+      rc = (*xt->work)(X);
+      if (rc) return rc;
+      rc = gpk_launch_set_flag(X, flagE + 1, epoch);
+      if (rc) return rc;
+      xt->used = true;
+      xt->done_ptr = flagE + 1;
+      xt->done_val = epoch;
+    } else {
+      GPK_HIP(hipEventRecord(evJoinX, X));
+      GPK_HIP(hipStreamWaitEvent(S, evJoinX, 0));
+    }
   }
   if (zero_upper) return gpk_launch_zero_upper(S, A, n, lda, batch, strideA);
   return 0;
@@ -991,20 +1034,30 @@ extern "C" size_t gpk_project_workspace_bytes(int rows, int m, int P) {
   return (size_t)P * 2 * gpk_gemm_tiles_n(m) * rows * sizeof(double);
 }
 
-extern "C" int gpk_project_batched(void* stream, const double* At, int rows, int m, long ldat, long strideAt,
-                                   const double* LqT, long ldl, int P, double* ssq, void* ws, size_t ws_bytes) {
-  if (!At || !LqT || !ssq || rows < 0 || m <= 0 || P <= 0 || strideAt < 0) return GPK_E_ARG;
+namespace {
+// the GEMM alone: partials [P][nt = 2 * tiles_n][rows] in ws, one per 64 output columns
+int project_parts(hipStream_t s, const double* At, int rows, int m, long ldat, long strideAt, const double* LqT, long ldl, int P, void* ws,
+                  size_t ws_bytes) {
+  if (!At || !LqT || rows < 0 || m <= 0 || P <= 0 || strideAt < 0) return GPK_E_ARG;
   if (!ws || ws_bytes < gpk_project_workspace_bytes(rows, m, P)) return GPK_E_WORKSPACE;
   if (rows == 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
   const int nt = 2 * gpk_gemm_tiles_n(m);
   GemmArgs g = gemm_base(rows, m, m, 1.0, At, ldat, LqT, ldl, 0.0, nullptr, 0, P, strideAt, (long)m * ldl, 0);
   g.b_tri = 1;  // LqT[j,k] = Lq[k,j] vanishes for k < j
   g.epi = 1; g.sq_cols = m; g.c2_cols = 0;
   g.part = (double*)ws; g.part_ld = rows; g.stridePart = (long)nt * rows;
   g.C2 = (double*)ws; g.ldc2 = 0; g.strideC2 = 0;
-  int rc = gpk_launch_gemm(s, g);
-  if (rc) return rc;
+  return gpk_launch_gemm(s, g);
+}
+}  // namespace
+
+extern "C" int gpk_project_batched(void* stream, const double* At, int rows, int m, long ldat, long strideAt,
+                                   const double* LqT, long ldl, int P, double* ssq, void* ws, size_t ws_bytes) {
+  if (!ssq) return GPK_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = project_parts(s, At, rows, m, ldat, strideAt, LqT, ldl, P, ws, ws_bytes);
+  if (rc || rows == 0) return rc;
+  const int nt = 2 * gpk_gemm_tiles_n(m);
   return gpk_launch_sum_parts(s, (const double*)ws, nt, rows, (long)nt * rows, P, ssq);
 }
 
@@ -1397,26 +1450,45 @@ extern "C" int gpk_svgp_elbo_shard(void* stream, int family, const double* Z, in
   hk.x_prologue = &prologue;
   hk.p_prologue = &kuu_build;
   hk.late_work = side ? &late : nullptr;
+  // s0 = sum_k A^2 (util.py:133), fmean = A^T q_mu (util.py:144), q_diag: ssq = sum (A q_sqrt)^2 (:149)
+  const std::function<int(hipStream_t)> stats = [&](hipStream_t xs) -> int {
+    return gpk_row_stats((void*)xs, Kfu, rows, m, l.ld, q_mu, q_diag ? q_sqrt : nullptr, P, 1.0, 0.0, s0, fmean, q_diag ? ssq : nullptr);
+  };
+  XTail xt;
+  if (!q_diag && rows > 0) {   // (beside the projection GEMM; with a diagonal q_sqrt nothing would run beside it)
+    xt.work = &stats;
+    hk.x_tail = &xt;
+  }
   rc = potrf_core(s, T, m, rows, l.ld, 1, 0, invd, 0, info, hk);
   if (rc) return rc;
-  // s0 = sum_k A^2 (util.py:133), fmean = A^T q_mu (util.py:144), q_diag: ssq = sum (A q_sqrt)^2 (:149)
-  rc = gpk_row_stats(stream, Kfu, rows, m, l.ld, q_mu, q_diag ? q_sqrt : nullptr, P, 1.0, 0.0, s0, fmean,
-                     q_diag ? ssq : nullptr);
-  if (rc) return rc;
+  if (!xt.used) {
+    rc = stats(s);
+    if (rc) return rc;
+  }
+  VarexpExtra ex;
+  if (xt.used) { ex.wait_ptr = xt.done_ptr; ex.wait_val = xt.done_val; ex.wait_info = info; }
   if (!q_diag) {
     // L = band_part(q_sqrt,-1,0); LTA = L^T A; ssq = sum LTA^2   (util.py:151-164)
     if (!side) {
       rc = gpk_transpose(stream, q_sqrt, m, m, m, LqT, l.ld, 1, P, (long)m * m, (long)m * l.ld);
       if (rc) return rc;
     }
-    rc = gpk_project(stream, Kfu, rows, m, l.ld, LqT, l.ld, P, ssq, w + l.off_proj,
-                     gpk_project_workspace_bytes(rows, m, P));
+    // (the column-slot partials of the projection are summed by the variational-expectation kernel: no sum_parts launch)
+    rc = project_parts(s, Kfu, rows, m, l.ld, 0, LqT, l.ld, P, w + l.off_proj, gpk_project_workspace_bytes(rows, m, P));
     if (rc) return rc;
+    if (rows > 0 && GPK_TUNE(VAREXP_SUMS_PARTS, 0)) {
+      ex.ssq_part = (const double*)(w + l.off_proj);
+      ex.ssq_nt = 2 * gpk_gemm_tiles_n(m);
+      ex.ssq_stride = (long)ex.ssq_nt * rows;
+    } else if (rows > 0) {
+      rc = gpk_launch_sum_parts(s, (const double*)(w + l.off_proj), 2 * gpk_gemm_tiles_n(m), rows, (long)2 * gpk_gemm_tiles_n(m) * rows, P, ssq);
+      if (rc) return rc;
+    }
   }
   // sum_b var_exp_b  (likelihoods/scalar_continuous.py:139-148, svgp.py:174,181)
   int c0 = 0;
   rc = gpk_launch_varexp_stage1(s, Yb, ldyb, fmean, rows, P, s0, 0, ssq, &variance, 0, noise_variance,
-                                mean_const, nullptr, part0, &c0, noise_rows);
+                                mean_const, nullptr, part0, &c0, noise_rows, &ex);
   if (rc) return rc;
   const double* p0[1] = {part0};
   const double one = 1.0;

@@ -248,9 +248,27 @@ struct VarexpArgs {
   double knn[16]; int knn_per_latent;
   double noise, mean_const; double* fvar_out; double* part;
   const double* noise_rows;   // per-row noise variances [rows] (heteroskedastic Gaussian, scalar_continuous.py:92-111) or nullptr
+  // (round 6) ssq given as the projection's column-slot partials [P][nt][rows] instead: summed here, slot 0 first (what sum_parts_kernel did)
+  const double* ssq_part; int ssq_nt; long ssq_stride;
+  // s0 / fmean come from a kernel on ANOTHER stream (row statistics beside the projection): wait for its word first (bounded)
+  const int* wait_ptr; int wait_val; int* wait_info;
 };
 __global__ __launch_bounds__(RB) void varexp_kernel(VarexpArgs a) {
   __shared__ double sh[4];
+  if (a.wait_ptr) {
+    if (threadIdx.x == 0) {
+      const long long t0 = wall_clock64();   // 100 MHz
+      while ((int)(__hip_atomic_load(a.wait_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_val) < 0) {
+        if (wall_clock64() - t0 >= 50000000LL) {
+          if (a.wait_info) atomicMax(a.wait_info, 0x7fffffff);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (agent scope: the producer's end-of-kernel release made its stores visible)
+  }
   const double log2pi = 1.8378770664093453;
   const double c0 = -0.5 * log2pi - 0.5 * log(a.noise);
   double acc = 0.0;
@@ -259,7 +277,12 @@ __global__ __launch_bounds__(RB) void varexp_kernel(VarexpArgs a) {
     const int b = (int)(e / a.P), p = (int)(e - (long)b * a.P);
     double fv = a.knn[a.knn_per_latent ? p : 0];
     if (a.s0) fv -= a.s0_per_latent ? a.s0[(long)p * a.rows + b] : a.s0[b];
-    if (a.ssq) fv += a.ssq[(long)p * a.rows + b];
+    if (a.ssq_part) {
+      const double* q = a.ssq_part + (long)p * a.ssq_stride + b;
+      double t = 0.0;
+      for (int i = 0; i < a.ssq_nt; ++i) t += q[(long)i * a.rows];
+      fv += t;
+    } else if (a.ssq) fv += a.ssq[(long)p * a.rows + b];
     const double mu = a.fmean[e] + a.mean_const;
     const double dy = a.Y[(long)b * a.ldy + p] - mu;
     if (a.fvar_out) a.fvar_out[e] = fv;
@@ -693,8 +716,13 @@ int gpk_launch_sumsq_stage1(hipStream_t s, const double* A, int rows, int cols, 
 int gpk_launch_varexp_stage1(hipStream_t s, const double* Y, long ldy, const double* fmean, int rows,
                              int P, const double* s0, int s0_per_latent, const double* ssq,
                              const double* knn_host, int knn_per_latent, double noise,
-                             double mean_const, double* fvar_out, double* part, int* count, const double* noise_rows) {
+                             double mean_const, double* fvar_out, double* part, int* count, const double* noise_rows,
+                             const VarexpExtra* ex) {
   VarexpArgs a{};
+  if (ex) {
+    a.ssq_part = ex->ssq_part; a.ssq_nt = ex->ssq_nt; a.ssq_stride = ex->ssq_stride;
+    a.wait_ptr = ex->wait_ptr; a.wait_val = ex->wait_val; a.wait_info = ex->wait_info;
+  }
   a.Y = Y; a.ldy = ldy; a.fmean = fmean; a.rows = rows; a.P = P;
   a.s0 = s0; a.s0_per_latent = s0_per_latent; a.ssq = ssq;
   for (int i = 0; i < (knn_per_latent ? P : 1); ++i) a.knn[i] = knn_host[i];
