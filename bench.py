@@ -398,7 +398,8 @@ def gpr_leg(ops, lib, device, with_oracle: bool):  # noqa: C901
                             "issued in between -- the trailing updates plus the look-ahead panel (solves, inner updates, "
                             "strips) that shares the chip with them; leaf kernels not counted"},
                 "note": "sum of algorithmic flops / sum of HIP-event durations of these launches, recorded on the bulk "
-                        "stream (CU-masked: 240 of 256 CUs; the look-ahead panel runs beside them on the other 16)"}
+                        "stream (CU-masked: 224 of 256 CUs, persistent workgroups fed from a tile queue; the look-ahead panel "
+                        "runs beside them on the other 32), divided by the WHOLE chip's peak"}
     # (ii) predict_f at T = 4096 through the model surface (fused route), then the cached posterior
     m = gpflow.models.GPR((X, Y), gpflow.kernels.SquaredExponential(variance=1.0, lengthscales=ls), noise_variance=0.1)
     pred = {}

@@ -15,6 +15,7 @@
 // Block ids are remapped so that (a) each XCD gets a contiguous range of tiles (private L2s) and
 // (b) tiles are swept in 8-wide column groups (A/B panel reuse out of the 4 MiB L2).
 #include "gpk_internal.h"
+#include <mutex>
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int bz = blockIdx.y;
+  const int bz = p.k_off_step ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;   // (see fast_tile)
 
   int tile_m, tile_n;
   if (BM == 64 && BN == 64 && p.tail_first1 > 0) {
@@ -157,20 +158,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
   const double* __restrict__ B = p.B + (long)bz * p.strideB;
 
   int kb = 0, ke = p.k;
+  const int koff = bz * p.k_off_step;   // (K-split of a triangular product: this batch entry holds columns koff .. koff + k of the operands)
   if (p.b_tri && n0 + BN <= p.b_tri_rows) {
     if (p.b_tri == 1) {
-      int f = n0 + p.b_tri_off;
+      int f = n0 + p.b_tri_off - koff;
       kb = (f > 0 ? f : 0) & ~(BK - 1);
     } else {
-      int l = n0 + BN + p.b_tri_off;
+      int l = n0 + BN + p.b_tri_off - koff;
       ke = l < p.k ? l : p.k;
     }
   }
   if (p.a_tri == 1) {         // rows m0.. of an upper-triangular A are zero left of column m0
-    const int f = m0 & ~(BK - 1);
+    int f = m0 - koff;
+    f = (f > 0 ? f : 0) & ~(BK - 1);
     kb = kb > f ? kb : f;
   } else if (p.a_tri == 2) {  // rows ..m0+BM-1 of a lower-triangular A are zero right of column m0+BM-1
-    int l = (m0 + BM + BK - 1) & ~(BK - 1);
+    int l = ((m0 + BM + BK - 1) & ~(BK - 1)) - koff;
     l = l < p.k ? l : p.k;
     ke = ke < l ? ke : l;
   }
@@ -369,32 +372,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
 // rev != 0: the K slabs are walked from the LAST to the first (same slabs, same per-slab arithmetic; the sum over slabs is
 // taken in the opposite order).  Used by the paired triangular-K launches: see gemm_nt_fast.
 template <int EPI>
-__device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int tile_n, double* smem, int rev = 0) {
+__device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int tile_n, double* smem, int rev = 0, int bz_queue = -1) {
   constexpr int BM = 128, BN = 128;
   constexpr int BUF = (BM + BN) * LDSS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bz = blockIdx.y;
+  // (K-split of a triangular product: the LAST chunks hold the most non-empty tiles -- they are dispatched first)
+  const int bz = bz_queue >= 0 ? bz_queue : (p.k_off_step ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (p.c_lower && n0 > m0 + BM - 1) return;
 
   const double* __restrict__ A = p.A + (long)bz * p.strideA;
   const double* __restrict__ B = p.B + (long)bz * p.strideB;
   int kb = 0, ke = p.k;
+  const int koff = bz * p.k_off_step;   // (see gemm_nt_kernel)
   if (p.b_tri && n0 + BN <= p.b_tri_rows) {
     if (p.b_tri == 1) {
-      const int f = n0 + p.b_tri_off;
+      const int f = n0 + p.b_tri_off - koff;
       kb = (f > 0 ? f : 0) & ~(BK - 1);
     } else {
-      const int l = n0 + BN + p.b_tri_off;
+      const int l = n0 + BN + p.b_tri_off - koff;
       ke = l < p.k ? l : p.k;
     }
   }
   if (p.a_tri == 1) {         // (see gemm_nt_kernel)
-    const int f = m0 & ~(BK - 1);
+    int f = m0 - koff;
+    f = (f > 0 ? f : 0) & ~(BK - 1);
     kb = kb > f ? kb : f;
   } else if (p.a_tri == 2) {
-    int l = (m0 + BM + BK - 1) & ~(BK - 1);
+    int l = ((m0 + BM + BK - 1) & ~(BK - 1)) - koff;
     l = l < p.k ? l : p.k;
     ke = ke < l ? ke : l;
   }
@@ -646,6 +652,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
       const long long t0 = wall_clock64();
       while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
     }
+    if (p.queue) {
+      // Tile QUEUE (round 6): persistent workgroups take (batch entry, tile) pairs from a device counter, last batch entry first.  For
+      // launches whose tiles differ widely in K -- the K chunks of a triangular x triangular product: 480 of 1024 pairs non-empty, 8 to
+      // 32 slabs each -- a static assignment leaves the launch as long as its most loaded compute unit.  Every pair is computed by exactly
+      // one workgroup and written to its own output tile: results do not depend on who took what.
+      volatile int* s_next = reinterpret_cast<volatile int*>(&smem[BK]);   // (the padding of LDS row 0: no tile access touches it)
+      const int nbatch = p.batch > 0 ? p.batch : 1;
+      const int all = total * nbatch;
+      for (;;) {
+        if (threadIdx.x == 0) *s_next = (int)((unsigned)atomicAdd(p.queue, 1) - (unsigned)p.queue_base);
+        __syncthreads();
+        const int t = *s_next;
+        __syncthreads();   // (s_next is rewritten, and both LDS buffers refilled, only after everybody has read / finished)
+        if (t >= all || t < 0) break;
+        const int zq = t / total, tq = t - zq * total;
+        int tile_m, tile_n;
+        tile_order(tq, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+        fast_tile<EPI>(p, tile_m, tile_n, smem, 0, nbatch - 1 - zq);
+      }
+      return;
+    }
     // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
       int tile_m, tile_n;
@@ -655,6 +682,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
         const int q = t / gy, half = gx >> 1;
         tile_m = t - q * gy;
         tile_n = q < half ? q : gx - 1 - (q - half);
+      } else if (p.k_off_step) {
+        // K-split of a triangular product: the chunks of one output tile must not meet on one compute unit (workgroup x of every
+        // batch entry lands on about the same CU, and the tiles near the origin are non-empty in EVERY chunk: the launch would last
+        // as long as unsplit) -- each chunk walks the tile list from its own offset
+        int tt = t + (int)blockIdx.y * (total / (int)gridDim.y);
+        if (tt >= total) tt -= total;
+        tile_order(tt, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
       } else {
         tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
       }
@@ -676,6 +710,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
       fast_tile<EPI>(p, tile_m, gx - 1 - j, smem, 0);
     }
   }
+}
+
+// counters of the tile-queue launches: a ring of device words per device, never reset -- a launch of `fetches` fetches (one per tile
+// and one failing fetch per workgroup) on a word leaves it at a value the host knows, which is the base of the next launch on that
+// word (two launches would have to be 1024 launches apart AND in flight together to meet on a word).  No memset, no packet.
+int queue_slot(unsigned fetches, int** out, unsigned* base) {
+  constexpr int kRing = 1024, kMaxDev = 16;
+  static std::mutex mu;
+  static int* ring[kMaxDev] = {};
+  static unsigned* value[kMaxDev] = {};
+  static unsigned next[kMaxDev] = {};
+  int dev = 0;
+  GPK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDev) return GPK_E_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ring[dev]) {
+    GPK_HIP(hipMalloc((void**)&ring[dev], sizeof(int) * kRing));
+    GPK_HIP(hipMemset(ring[dev], 0, sizeof(int) * kRing));
+    value[dev] = (unsigned*)calloc(kRing, sizeof(unsigned));
+    if (!value[dev]) return GPK_E_ARG;
+  }
+  const unsigned slot = next[dev]++ % kRing;
+  *out = ring[dev] + slot;
+  *base = value[dev][slot];
+  value[dev][slot] += fetches;
+  return 0;
 }
 
 template <int EPI>
@@ -709,7 +769,7 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   // is lower-only or capped.
   {
     const bool pair_ok = (EPI == 1) ? (a.b_tri == 1)
-                                    : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0);
+                                    : ((a.b_tri == 1 || a.b_tri == 2) && !a.c_lower && a.max_wgs == 0 && a.b_tri_off == 0 && a.k_off_step == 0);
     // (round 6) pairs that fill the chip at most once -- C3's projection: 4 x 64 = 256 workgroups, one per CU, whose K loop runs at
     // 79 % alone -- run unpaired instead, heavy and light tile of a pair as TWO workgroups of one CU (88 % together)
     if (EPI == 1 && pair_ok && gx >= 4 && !(gx & 1) && a.b_tri_rows >= a.n && a.max_wgs == 0 &&
@@ -780,6 +840,22 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
   if (EPI == 0 && a.max_wgs > 0 && nwg < (unsigned)total && nb == 1) {
     const int kb = GPK_TUNE(CAP_EXCL_LDS_KB, 84);
     if (kb > 0 && kb <= 160 && (size_t)kb * 1024 > LDS_BYTES) lds_bytes = (size_t)kb * 1024;
+  }
+  if (EPI == 0 && tail_tiles == 0 && a.max_wgs == 0 &&
+      ((a.k_off_step && GPK_TUNE(KSPLIT_QUEUE, 1)) || (a.tile_queue && (long)total * nb > 512))) {
+    b.stagger_ticks = 0;
+    const long all = (long)total * nb;
+    const long qw = a.stagger_first > 0 ? 2L * a.stagger_first : GPK_TUNE(QUEUE_WGS, 512);   // (two per compute unit of the launch stream)
+    const unsigned wgs = (unsigned)(all < qw ? all : qw);
+    int* q = nullptr;
+    unsigned qbase = 0;
+    const int rcq = queue_slot((unsigned)all + wgs, &q, &qbase);
+    if (rcq) return rcq;
+    b.queue = q;
+    b.queue_base = (int)qbase;
+    hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(wgs, 1, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total, compact);
+    GPK_LAUNCH_CHECK();
+    return 0;
   }
   hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(nwg, nb, 1), dim3(256), lds_bytes, s, b, gx, gy, total,
                      compact);
@@ -1507,7 +1583,7 @@ int launch_group_solve(hipStream_t s, const double* E, long lde, double* Eo, lon
 // small-K latency path: K <= 128 in whole 16-slabs, 16-byte aligned rows, modest row count
 bool small_ok(const GemmArgs& a) {
   if (GPK_TUNE(GEMM_NO_SMALL, 0) || a.epi != 0) return false;
-  if (a.k <= 0 || a.k > 128 || (a.k & 15) || (a.b_tri && (a.b_tri_off & 15))) return false;
+  if (a.k <= 0 || a.k > 128 || (a.k & 15) || (a.b_tri && (a.b_tri_off & 15)) || a.k_off_step) return false;
   if ((a.lda & 1) || (a.ldb & 1) || (a.strideA & 1) || (a.strideB & 1)) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
   if (a.beta != 0.0 && a.alpha == 0.0) return false;
@@ -1773,9 +1849,16 @@ extern "C" int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, cons
   g.C = C; g.ldc = ldc; g.strideC = strideC;
   g.m = m; g.n = n; g.k = k; g.alpha = alpha; g.beta = beta;
   g.c_lower = c_lower; g.b_tri = b_tri & 3; g.b_tri_off = 0; g.b_tri_rows = n;
-  g.a_tri = (m <= k) ? ((b_tri >> 4) & 3) : 0;  // (a hint: ignoring it is always correct)
-  if ((b_tri & ~0x33) || g.b_tri == 3 || g.a_tri == 3) return GPK_E_ARG;
+  // bit 8: the batch is a K-SPLIT of one triangular product -- entry z holds columns z k .. (z + 1) k of both operands (strided views),
+  // and the triangular statements are about the UNSPLIT column index.  The caller sums the `batch` partial products.
+  const int ksplit = (b_tri >> 8) & 1;
+  g.a_tri = (m <= k * (ksplit ? (batch > 0 ? batch : 1) : 1)) ? ((b_tri >> 4) & 3) : 0;  // (a hint: ignoring it is always correct)
+  if ((b_tri & ~0x133) || g.b_tri == 3 || g.a_tri == 3 || (ksplit && (k & 15))) return GPK_E_ARG;
+  g.k_off_step = ksplit ? k : 0;
   g.epi = 0; g.batch = batch > 0 ? batch : 1;
+  // (A/B: the tile queue for every batched launch -- the split-K products of the reverse pass, 1088 equal tiles -- is level:
+  //  training step 5.89 / 6.01 without, 6.07 / 5.95 with it, profiles/r06_ab_train_tri_products.log)
+  g.tile_queue = (g.batch > 1 || GPK_TUNE(GEMM_NT_QUEUE_SINGLE, 0)) && GPK_TUNE(GEMM_NT_QUEUE_BATCH, 0);
   if (kGpkExp) g.max_wgs = GPK_TUNE(GEMM_NT_MAX_WGS, 0);   // (A/B build only: tools/capped_gemm_probe.py)
   return gpk_launch_gemm((hipStream_t)stream, g);
 }

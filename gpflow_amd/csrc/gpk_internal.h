@@ -68,6 +68,7 @@ struct GemmArgs {
   int a_tri;        // structure of A, a hint that only shortens the K range of a tile: 1 A[i,kk]==0 for kk<i (upper), 2 for kk>i (lower)
   int b_tri_off;    // the triangular structure is B[j,kk] vs kk - b_tri_off
   int b_tri_rows;   // structure applies to rows j < b_tri_rows of B only (rows beyond are dense)
+  int k_off_step;   // batch entry z is the K chunk [z k_off_step, z k_off_step + k) of ONE product: a_tri / b_tri refer to the unsplit column index
   // epilogue 1 ("project"): columns < sq_cols are squared and row-summed into part[(tile_n*2+wn), row];
   // columns >= sq_cols (the q_mu rows of the operand) are stored to C2[row, col - sq_cols]; C unused.
   int epi;
@@ -94,6 +95,8 @@ struct GemmArgs {
   int* sig_ptr; int sig_val;
   const int* wait_ptr; int wait_val;
   int* wait_info;   // device int that receives INT_MAX if the bounded wait expires (the factorisation's status word)
+  int tile_queue;   // fast path, epi 0: persistent workgroups that take their tiles from a device counter (launches with more than 512 tiles)
+  int* queue; int queue_base;   // set by the launcher only: that counter and its value before this launch
   int tile64;       // epi 0 only: take the generic kernel's 64 x 64 tiles (36 KB of LDS per workgroup: fits beside any other workgroup on a CU)
   int tile_snake;   // set by the launcher only (generic kernel, under-filled triangular-K projections): heavy / light tiles alternate per CU
   int tail_first1;  // set by the launcher only (generic 64 x 64 kernel; launch_fast, "tail split"): 1 + first position, 0 = off

@@ -127,7 +127,7 @@ int aux_create(Aux& a, int dev) {
   GPK_HIP(hipStreamCreateWithFlags(&a.X, hipStreamNonBlocking));
   GPK_HIP(hipStreamCreateWithFlags(&a.pad, hipStreamNonBlocking));
   GPK_HIP(hipStreamCreateWithFlags(&a.Bs, hipStreamNonBlocking));
-  int reserved = GPK_TUNE(RESERVED_CUS, 8);
+  int reserved = GPK_TUNE(RESERVED_CUS, 32);   // (8 until round 6: see the tile queue of the trailing updates, potrf_core)
   if (ncu > 1024 || reserved < 0 || reserved >= ncu) reserved = 0;
   int rc = masked_stream(&a.B, ncu, reserved, ncu);
   if (rc) return rc;
@@ -764,6 +764,13 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
         u.stagger_first = aux->bulk_cus;
         // persistent workgroups (two per CU of the masked stream) that walk the tile list: no workgroup launch per tile
         if (GPK_TUNE(TRAIL_PERSIST, 0)) u.max_wgs = GPK_TUNE(TRAIL_PERSIST, 0) * aux->bulk_cus;
+        // (round 6) persistent workgroups -- two per compute unit of the bulk stream -- that take their tiles from a device counter
+        // (gemm.hip, "Tile QUEUE"): no workgroup launch per tile and no drift between static tile lists; the kernel alone gains 7 %
+        // (as dispatched 0.591 -> 0.632 of the chip's peak from 240 CUs).  They never leave their CUs, though, so the look-ahead panel no
+        // longer finds gaps there and needs more CUs of its own: with 8 reserved the whole factorisation LOSES 7 % (33.0 against 30.8 ms),
+        // with 32 (four per XCD) it gains 1.7 % (29.94 / 30.07 against 30.58 / 30.43 ms; 24: 32.0, 40: 31.6;
+        // profiles/r06_ab_gpr_tile_queue.log).
+        u.tile_queue = GPK_TUNE(TRAIL_QUEUE, 1);
       }
       // Split rest-update (round 6).  With the 25-us leaf the chain of a single-leaf panel is leaf 25 + solve 7 + strip 8 = 40 us,
       // and the rest-update stream had become the longer one: wait packet 6 + one 30-us tiled launch + write packet 7 + the

@@ -26,6 +26,7 @@ from __future__ import annotations
 from typing import Dict, Optional, Tuple
 
 import collections
+import os
 
 import numpy as np
 import torch
@@ -38,12 +39,19 @@ LOG2PI = float(np.log(2.0 * np.pi))
 # each) and {Lm_bar -> Cholesky adjoint -> Kuu adjoint} (M^3 products of 256 tiles: one workgroup per CU, time of the
 # longest tile).  On a device they run on two streams so that the under-filled launches share the chip.
 OVERLAP_BRANCHES = True
+# the side branch's chip-filling GEMMs start only when the main branch's HBM-bound preparation is enqueued (svgp_elbo_and_grad)
+# K chunks of the triangular x triangular products of the Cholesky adjoint (1 = unsplit)
+TRI_PRODUCT_CHUNKS = int(os.environ.get("GPFLOW_AMD_TRI_PRODUCT_CHUNKS", "4"))
+TRI_PRODUCT_MIN_N = 1024   # below this the unsplit launches are short anyway
+GATE_SIDE_BRANCH = os.environ.get("GPFLOW_AMD_GATE_SIDE_BRANCH", "1") != "0"
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
 def _side_stream(dev: torch.device):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx not in _side_streams:
+        # (a LOW-priority side stream -- hipStreamCreateWithPriority, wrapped as an ExternalStream -- was tried in round 6 so that the main
+        #  branch's short kernels would win the freed slots: training step 6.02 -> 6.9 ms, profiles/r06_ab_train_side_branch.log)
         _side_streams[idx] = torch.cuda.Stream(device=dev)
     return _side_streams[idx]
 
@@ -90,15 +98,35 @@ def _phi_(T: torch.Tensor) -> torch.Tensor:
     return ops.combine_parts(T, lower=True, diag_scale=0.5)
 
 
-def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor) -> torch.Tensor:
+def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor, before_products=None) -> torch.Tensor:
     """Symmetric K_bar with  <K_bar, dK> = <L_bar, dL>  for K = L L^T:  K_bar = sym(L^-T Phi(L^T L_bar) L^-1), with
     LT = L^T, LinvT = L^-T (both upper, zero below the diagonal) and L_bar lower.  Three triangular-K GEMMs; the
-    explicit inverse comes for free from the factorisation (identity rows appended to the trapezoid)."""
+    explicit inverse comes for free from the factorisation (identity rows appended to the trapezoid).
+    before_products: called once the HBM-bound preparation is enqueued (see svgp_elbo_and_grad: the side branch's big GEMM is gated on it)."""
     # every B operand below is the transpose of a lower-triangular matrix: B[j, kk] = 0 for kk < j  -> b_tri = 1
     # (a_tri: A is triangular as well -- upper L^T / L^-T, lower Phi -- so a tile's K range is the intersection of both)
-    T1 = ops.gemm_nt(LT, ops.transpose(Lbar), b_tri=1, a_tri=1)          # L^T L_bar
-    Y = ops.gemm_nt(_phi_(T1), LinvT, b_tri=1, a_tri=2)                  # Phi L^-1        (lower)
-    S = ops.gemm_nt(LinvT, ops.transpose(Y, mode=1), b_tri=1, a_tri=1)   # L^-T (Phi L^-1)
+    LbarT = ops.transpose(Lbar)
+    if before_products is not None:
+        before_products()
+    n = LT.shape[0]
+    chunks = TRI_PRODUCT_CHUNKS if (TRI_PRODUCT_CHUNKS > 1 and n >= TRI_PRODUCT_MIN_N and n % (16 * TRI_PRODUCT_CHUNKS) == 0) else 1
+    if chunks == 1:
+        T1 = ops.gemm_nt(LT, LbarT, b_tri=1, a_tri=1)                        # L^T L_bar
+        Y = ops.gemm_nt(_phi_(T1), LinvT, b_tri=1, a_tri=2)                  # Phi L^-1        (lower)
+        S = ops.gemm_nt(LinvT, ops.transpose(Y, mode=1), b_tri=1, a_tri=1)   # L^-T (Phi L^-1)
+        return S.add_(ops.transpose(S)).mul_(0.5)
+    # Each of the three products is 256 output tiles whose K ranges differ by a factor of sixteen -- the launch lasts as long as the tile
+    # that walks all of K (245 us at M = 2048 for 5.7 GFLOP).  As K chunks in the batch dimension of ONE launch (strided views; the
+    # triangular hints refer to the unsplit column index, ops.gemm_nt k_split) the non-empty tiles fill the chip about once, and the sum of
+    # the partial products is the pass that applied Phi / tril anyway.
+    kc = n // chunks
+
+    def split(X):
+        return torch.as_strided(X, (chunks, X.shape[0], kc), (kc, X.stride(0), 1), X.storage_offset())
+
+    T1 = ops.combine_parts(ops.gemm_nt(split(LT), split(LbarT), b_tri=1, a_tri=1, k_split=True), lower=True, diag_scale=0.5)   # Phi(L^T L_bar)
+    Y = ops.combine_parts(ops.gemm_nt(split(T1), split(LinvT), b_tri=1, a_tri=2, k_split=True), lower=True)                   # Phi L^-1 (lower)
+    S = ops.combine_parts(ops.gemm_nt(split(LinvT), split(ops.transpose(Y)), b_tri=1, a_tri=1, k_split=True))               # L^-T (Phi L^-1)
     return S.add_(ops.transpose(S)).mul_(0.5)
 
 
@@ -458,23 +486,29 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)                                          # At_bar Lm^-1  [B, M]
     Kuf_bar = ops.transpose(Kfu_bar)                                                    # [M, B]
 
-    def branch_q():
+    # branch_q in two parts: its HBM-bound preparation (At^T r, the transposes of W) and its chip-filling GEMMs
+    def branch_q_prep():
         g_mu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                # At^T r - q_mu
+        if q_diag:
+            return g_mu, None, None
+        Wg, ag = (Wc, 2.0) if het else (W, 2.0 * c)
+        return g_mu, [ops.transpose(Wg[p]) for p in range(P)], ag
+
+    def branch_q_products(WgT, ag):
         if q_diag:   # d/dq = 2c colsum(At^2) q - (q - 1/q)   (KL of a diagonal q: kullback_leiblers.py:131-133,146-148)
             if het:
                 colsq2c = 2.0 * ((At * At) * cvec[:, None]).sum(0)                      # 2 sum_b c_b At[b, m]^2
-                return g_mu, colsq2c[:, None] * q_sqrt - kl_weight * (q_sqrt - 1.0 / q_sqrt)
+                return colsq2c[:, None] * q_sqrt - kl_weight * (q_sqrt - 1.0 / q_sqrt)
             colsq = ops.row_stats(A)[0]
-            return g_mu, (2.0 * c) * colsq[:, None] * q_sqrt - kl_weight * (q_sqrt - 1.0 / q_sqrt)
-        Wg, ag = (Wc, 2.0) if het else (W, 2.0 * c)
-        g = torch.stack([splitk_gemm_nt(A, ops.transpose(Wg[p]), c_lower=True, alpha=ag)
-                         for p in range(P)]) if P > 1 else \
-            splitk_gemm_nt(A, ops.transpose(Wg[0]), c_lower=True, alpha=ag).unsqueeze(0)
+            return (2.0 * c) * colsq[:, None] * q_sqrt - kl_weight * (q_sqrt - 1.0 / q_sqrt)
+        g = torch.stack([splitk_gemm_nt(A, WgT[p], c_lower=True, alpha=ag) for p in range(P)]) if P > 1 else \
+            splitk_gemm_nt(A, WgT[0], c_lower=True, alpha=ag).unsqueeze(0)
         g.sub_(Lq, alpha=kl_weight)                                                     # 2c tril(At^T W_p) - Lq_p
         g.diagonal(dim1=1, dim2=2).add_(kl_weight / Lq.diagonal(dim1=1, dim2=2))
-        return g_mu, g
+        return g
 
     side = _side_stream(dev) if (OVERLAP_BRANCHES and Z.is_cuda) else None
+    LT = ops.transpose(L, mode=1)
     if side is not None:
         # The side branch reads A, W, r, Lq, q_mu (allocated on the main stream) and allocates its split-K partials from
         # the side stream's pool (~270 MB per latent at M = 2048).  The join below sits in a `finally`: if anything on the
@@ -482,20 +516,41 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            g_qmu, g_qs = branch_q()
+            g_qmu, WgT, ag = branch_q_prep()
+        g_qs_box = []
+
+        # The main branch is the LONGER one (Lm_bar, three dependent M^3 products, two kernel adjoints: ~2.5 ms against ~1.6) and
+        # its short HBM-bound kernels starve while a chip-filling GEMM of the other stream has workgroups waiting for a slot: the
+        # combine / transpose pair behind the Lm_bar product took 298 + 239 us beside the side branch's GEMM, 41 + 11 us alone
+        # (profiles/r06_train_timeline_before.txt).  So the side branch's GEMMs wait until that preparation is enqueued; from
+        # there on the main branch only runs under-filled products that are bound by their longest tile, not by the CUs they get.
+        def release_side():
+            with torch.cuda.stream(side):
+                if GATE_SIDE_BRANCH:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                g_qs_box.append(branch_q_products(WgT, ag))
+        if not GATE_SIDE_BRANCH:
+            release_side()
+            release_side = None
+    else:
+        release_side = None
     try:
         Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)            # -tril(Kfu_bar^T At)
-        Kuu_bar = cholesky_adjoint(ops.transpose(L, mode=1), LinvT, Lbar)
+        Kuu_bar = cholesky_adjoint(LT, LinvT, Lbar, before_products=release_side)
         dv1, dl1, Zb1 = spec.adjoint(Z, Xb, Kuf_bar, symmetric=False)
         dv2, dl2, Zb2 = spec.adjoint(Z, Z, Kuu_bar, symmetric=True)
     finally:
         if side is not None:
             main.wait_stream(side)
     if side is not None:
+        g_qs = g_qs_box[0]
         g_qmu.record_stream(main)
         g_qs.record_stream(main)
     else:
-        g_qmu, g_qs = branch_q()
+        g_qmu, WgT, ag = branch_q_prep()
+        g_qs = branch_q_products(WgT, ag)
     dkd = spec.dkdiag()                                                                 # Knn = kdiag in every fvar
     csum = cvec.sum() * P if het else c * B * P
     g_var, g_ls = spec.pack([a + b + csum * dk for a, b, dk in zip(dv1, dv2, dkd)], [a + b for a, b in zip(dl1, dl2)])

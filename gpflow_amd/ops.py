@@ -278,9 +278,12 @@ def trsm_(B: torch.Tensor, L: torch.Tensor, invd: torch.Tensor, *, trans: int = 
 
 
 def gemm_nt(A: torch.Tensor, B: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
-            C: Optional[torch.Tensor] = None, b_tri: int = 0, c_lower: bool = False, a_tri: int = 0) -> torch.Tensor:
+            C: Optional[torch.Tensor] = None, b_tri: int = 0, c_lower: bool = False, a_tri: int = 0,
+            k_split: bool = False) -> torch.Tensor:
     """C = alpha A B^T + beta C.  A [m,k] or [b,m,k]; B [n,k] or [b,n,k].  b_tri: 1 B upper (B[j,kk] = 0 for kk < j),
-    2 B lower; a_tri: the same statement about A (1 upper, 2 lower) -- zeros must be stored; only the K ranges shrink."""
+    2 B lower; a_tri: the same statement about A (1 upper, 2 lower) -- zeros must be stored; only the K ranges shrink.
+    k_split: the batch entries are consecutive K chunks of ONE triangular product (strided views of its operands); b_tri / a_tri
+    then refer to the unsplit column index and the caller sums the partial products (combine_parts)."""
     lib = _lib.load()
     _chk(A, "A")
     _chk(B, "B")
@@ -304,7 +307,7 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, *, alpha: float = 1.0, beta: float
     sC = int(C3.stride(0)) if C3.shape[0] > 1 else 0
     rc = lib.gpk_gemm_nt(_stream(), m, n, k, float(alpha), A3.data_ptr(), _rowmajor(A3[0], "A"),
                          B3.data_ptr(), _rowmajor(B3[0], "B"), float(beta), C3.data_ptr(),
-                         _rowmajor(C3[0], "C"), int(b_tri) | (int(a_tri) << 4), int(c_lower), batch, sA, sB, sC)
+                         _rowmajor(C3[0], "C"), int(b_tri) | (int(a_tri) << 4) | (0x100 if k_split else 0), int(c_lower), batch, sA, sB, sC)
     _lib.check(rc, "gpk_gemm_nt")
     return C
 

@@ -170,7 +170,11 @@ int gpk_transpose_factor(void* stream, const double* L, long ldl, const double* 
  *        (A[i,kk] == 0 for kk < i), 32 = A is lower (A[i,kk] == 0 for kk > i), stored as zeros as well; a tile's K range
  *        is then the intersection of both structures -- the triangular x triangular products of the reverse pass
  *        (K^-1 = L^-T L^-1, the Cholesky adjoint) at half the multiply-adds.  c_lower: only tiles touching the lower
- *        triangle. */
+ *        triangle.  Bit 8 (256, round 6): the `batch` entries are consecutive K chunks of ONE triangular product -- entry z
+ *        holds columns z k .. (z + 1) k of both operands (strideA = strideB = k on the unsplit arrays), the triangular
+ *        statements refer to the unsplit column index, k must be a multiple of 16 -- and the caller sums the partial
+ *        products (gpk_combine_parts).  A 2048^3 triangular x triangular product is 256 output tiles whose longest walks
+ *        K = 2048 (245 us); as 4 chunks it is one round of 480 non-empty tiles (gradients.py, cholesky_adjoint). */
 int gpk_gemm_nt(void* stream, int m, int n, int k, double alpha, const double* A, long lda,
                 const double* B, long ldb, double beta, double* C, long ldc, int b_tri,
                 int c_lower, int batch, long strideA, long strideB, long strideC);

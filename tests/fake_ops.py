@@ -195,9 +195,11 @@ def trsm_(B, L, invd, *, trans=0):
     return B
 
 
-def gemm_nt(A, B, *, alpha=1.0, beta=0.0, C=None, b_tri=0, c_lower=False, a_tri=0):
+def gemm_nt(A, B, *, alpha=1.0, beta=0.0, C=None, b_tri=0, c_lower=False, a_tri=0, k_split=False):
+    if k_split:   # batch entries = consecutive K chunks of one product; the structure statements are about the unsplit column index
+        assert A.dim() == 3 and B.dim() == 3 and A.shape[0] == B.shape[0] and A.shape[2] % 16 == 0
     if a_tri:   # the hint must be TRUE: the device kernel skips the K range it declares zero
-        A2 = _np(A if A.dim() == 2 else A[0])
+        A2 = _np(torch.cat(list(A), dim=1)) if k_split else _np(A if A.dim() == 2 else A[0])
         assert np.all((np.tril(A2, -1) if a_tri == 1 else np.triu(A2, 1)) == 0), "a_tri set on a matrix without that structure"
     batched = A.dim() == 3 or B.dim() == 3
     A3 = A if A.dim() == 3 else A.unsqueeze(0)
@@ -218,10 +220,11 @@ def gemm_nt(A, B, *, alpha=1.0, beta=0.0, C=None, b_tri=0, c_lower=False, a_tri=
         for n0 in range(0, n, NB):
             n1 = min(n0 + NB, n)
             kb, ke = 0, k
+            koff = z * k if k_split else 0
             if b_tri == 1:
-                kb = min(n0 & ~15, k)
+                kb = min(max(n0 - koff, 0) & ~15, k)
             elif b_tri == 2:
-                ke = min(n0 + NB, k)
+                ke = max(min(n0 + NB - koff, k), kb)
             prod = a[:, kb:ke] @ b[n0:n1, kb:ke].T
             for m0 in range(0, m, NB):
                 m1 = min(m0 + NB, m)

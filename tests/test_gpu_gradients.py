@@ -30,6 +30,34 @@ def test_kernel_matrix_hadamard(gpu):
         np.testing.assert_array_equal(H.cpu().numpy(), K.cpu().numpy() * G)   # same K bits, one rounding each
 
 
+@pytest.mark.parametrize("n,chunks", [(256, 4), (384, 2), (2048, 4)])
+def test_cholesky_adjoint_k_split_products(gpu, monkeypatch, n, chunks):
+    """gradients.cholesky_adjoint with its three triangular x triangular products split along K (ops.gemm_nt k_split, the path
+    M >= 1024 takes) against the unsplit products and against torch autograd through torch.linalg.cholesky."""
+    import torch
+    from gpflow_amd import gradients, ops
+    if n > 512 and not torch.cuda.is_available():
+        pytest.skip("full size on the GPU only")
+    rng = np.random.default_rng(5)
+    R = rng.normal(size=(n, n))
+    K = R @ R.T / n + np.eye(n)
+    L = np.linalg.cholesky(K)
+    Lbar = np.tril(rng.normal(size=(n, n)))
+    t = ops.to_device
+    LT, LinvT, Lb = t(L.T.copy()), t(np.linalg.inv(L).T.copy()), t(Lbar)
+    monkeypatch.setattr(gradients, "TRI_PRODUCT_MIN_N", 64)
+    monkeypatch.setattr(gradients, "TRI_PRODUCT_CHUNKS", chunks)
+    got = gradients.cholesky_adjoint(LT, LinvT, Lb).cpu().numpy()
+    monkeypatch.setattr(gradients, "TRI_PRODUCT_CHUNKS", 1)
+    unsplit = gradients.cholesky_adjoint(LT, LinvT, Lb).cpu().numpy()
+    Kt = torch.tensor(K, dtype=torch.float64, requires_grad=True)
+    (torch.linalg.cholesky(Kt) * torch.tensor(Lbar)).sum().backward()
+    ref = 0.5 * (Kt.grad + Kt.grad.T).numpy()
+    tol = 1e-9 * max(1.0, np.abs(ref).max())
+    np.testing.assert_allclose(got, unsplit, rtol=0, atol=tol)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
+
+
 @pytest.mark.parametrize("M,B,D,P,ard", [(150, 300, 3, 2, True), (260, 140, 2, 1, False), (64, 500, 4, 3, True),
                                          (640, 2048, 8, 1, True)])
 def test_svgp_elbo_and_grad_vs_autograd_oracle(gpu, M, B, D, P, ard):

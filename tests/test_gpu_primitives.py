@@ -500,6 +500,31 @@ def test_gemm_nt_triangular_a_hint(gpu, n, a_tri, b_tri, c_lower):
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("n,chunks", [(2048, 4), (1024, 4), (1536, 2), (2048, 8)])
+@pytest.mark.parametrize("a_tri,b_tri", [(1, 1), (2, 1), (1, 2), (2, 2), (0, 1)])
+def test_gemm_nt_k_split_of_a_triangular_product(gpu, n, chunks, a_tri, b_tri):
+    """gpk_gemm_nt, b_tri bit 8: the batch entries are K chunks of one triangular x triangular product (strided views of the
+    operands), the structure hints refer to the unsplit column index; the sum of the partial products is the product."""
+    import torch
+    from gpflow_amd import ops
+    rng = np.random.default_rng(13)
+    A = rng.normal(size=(n, n)); B = rng.normal(size=(n, n))
+    if a_tri:
+        A = np.triu(A) if a_tri == 1 else np.tril(A)
+    B = np.triu(B) if b_tri == 1 else np.tril(B)
+    At, Bt = _t(A), _t(B)
+    kc = n // chunks
+    A3 = torch.as_strided(At, (chunks, n, kc), (kc, n, 1))
+    B3 = torch.as_strided(Bt, (chunks, n, kc), (kc, n, 1))
+    parts = ops.gemm_nt(A3, B3, alpha=0.75, b_tri=b_tri, a_tri=a_tri, k_split=True)
+    ref = 0.75 * (A @ B.T)
+    for z in range(chunks):   # every partial product is the product of its chunk (no tile left unwritten)
+        np.testing.assert_allclose(parts[z].cpu().numpy(), 0.75 * (A[:, z * kc:(z + 1) * kc] @ B[:, z * kc:(z + 1) * kc].T), rtol=0,
+                                   atol=1e-10 * max(1.0, np.abs(ref).max()))
+    out = ops.combine_parts(parts).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10 * max(1.0, np.abs(ref).max()))
+
+
 def test_two_host_threads_one_device(gpu):
     """include/gpk.h, "Internal state and threading": factorisations with n > 128 share per-device streams and events,
     calls from several host threads are serialised by a per-device mutex while they ENQUEUE (the work itself overlaps on
