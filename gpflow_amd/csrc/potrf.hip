@@ -38,8 +38,10 @@ struct Bulk {
   int cap = 0;    // cap on the persistent workgroups of the big (K >= 256) updates, 0 = one workgroup per tile
   int group_cap = 0;   // cap on the workgroups of the fused in-group solve, 0 = one per 16-row sliver
   int kmin = 256;      // updates with K below this are not capped
+  int queue_cus = 0;   // > 0: the big updates run as persistent workgroups fed from a tile queue, two per compute unit of this many CUs
   void apply(GemmArgs& g) const {
     if (cap > 0 && g.k >= kmin) g.max_wgs = cap;
+    if (queue_cus > 0 && g.k >= kmin) { g.tile_queue = 1; g.stagger_first = queue_cus; }
   }
 };
 }  // namespace
@@ -550,6 +552,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   const int chain_kparts = chain_halfk ? 2 : 0;
   if (!large) bulk.cap = batch > 1 ? GPK_TUNE(EXTRA_MAX_WGS_BATCHED, 320)
                                    : (chain_halfk ? GPK_TUNE(EXTRA_MAX_WGS_HALFK, 248) : GPK_TUNE(EXTRA_MAX_WGS, 224));
+  if (large && GPK_TUNE(XQUEUE_LARGE, 0)) bulk.queue_cus = aux->bulk_cus;   // (A/B, off: GPR predict's test-row updates, level at 54.4 - 55.0 ms)
   if (!large) bulk.group_cap = GPK_TUNE(GROUP_SOLVE_MAX_WGS, 0);
   if (!large) bulk.kmin = GPK_TUNE(EXTRA_CAP_KMIN, 256);
   hipEvent_t* evF = aux->ev;            // [npanels] panel p factored, rows below solved (recorded on P)
@@ -1010,8 +1013,10 @@ extern "C" int gpk_trsm(void* stream, int trans, const double* L, long ldl, cons
   const long strideInv = (long)gpk_cdiv(n, NB) * NB * NB;
   int rc;
   if (trans == 0) {
+    Bulk trsm_bulk;
+    if (batch <= 1 && n >= 4096 && GPK_TUNE(TRSM_QUEUE, 0)) trsm_bulk.queue_cus = 256;   // (A/B, off: the cached-posterior solve 19.3 -> 20.2 ms with the queue)
     for (int g0 = 0; g0 < n; g0 += NBO) {
-      rc = solve_group_fwd(s, Bulk{}, B, ldb, B, ldb, m, L, ldl, invd, strideInv, n, g0, std::min(g0 + NBO, n), batch,
+      rc = solve_group_fwd(s, trsm_bulk, B, ldb, B, ldb, m, L, ldl, invd, strideInv, n, g0, std::min(g0 + NBO, n), batch,
                            strideB, strideB, strideL);
       if (rc) return rc;
     }
