@@ -1830,10 +1830,12 @@ int gpk_launch_gemm(hipStream_t s, const GemmArgs& a) {
 
 static int launch_select(hipStream_t s, const GemmArgs& a) {
   const long tiles = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
+  if (a.tile64 == 2 && a.epi == 0) return launch_cfg<32, 64, 2, 2>(s, a);
+  if (a.tile64 == 3 && a.epi == 0) return launch_cfg<64, 128, 1, 4>(s, a);
   if (a.tile64 && a.epi == 0) return launch_cfg<64, 64, 4, 1>(s, a);
   if (!a.no_small && small_ok(a)) return launch_small(s, a);  // K <= 128, <= 512 workgroups: the latency path
   if (a.epi == 1 && a.beta != 0.0 && a.C && !fast_ok(a)) return GPK_E_UNSUPPORTED;  // only the fast tile preloads C for epi 1
-  if (a.epi == 0 && a.k >= 1024 && a.m > 64 && a.n > 64) {
+  if (a.epi == 0 && a.k >= GPK_TUNE(HALF_TILE_KMIN, 1024) && a.m > 64 && a.n > 64 && (a.max_wgs == 0 || a.max_wgs >= tiles)) {
     // under-filled long-K launches (the M^3 triangular products of the reverse pass: 256 tiles of 128 x 128 = ONE
     // workgroup per CU, so the launch lasts as long as its longest tile, 283 us at M = 2048) go to 64 x 128 tiles:
     // twice the workgroups, half the longest tile.  Training step 7.15 -> 6.90 ms (same box, 300; 600: 7.00).

@@ -629,7 +629,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   // (all three "many extra rows" switches -- this one, the progressive first group, no shrinking groups at the end -- were measured
   //  at 8192 rows (gain) and 4096 rows (loss: 1.71 -> 1.82 ms for this one, tools/strong_scaling_emulation.py): threshold 6144)
   const bool rest_tiled = useX && !large && batch == 1 && extra >= GPK_TUNE(REST_TILED_MIN_ROWS, 6144);
-  const int rest_tiled_min_wgs = GPK_TUNE(REST_TILED_MIN_WGS, 150);
+  const int rest_tiled_min_wgs = n > 1024 ? GPK_TUNE(REST_TILED_MIN_WGS, 30) : GPK_TUNE(REST_TILED_MIN_WGS_SMALL, 150);
   const int rest_small_wgs = (useX && !large && batch == 1 && extra >= 6144) ? GPK_TUNE(REST_SMALL_WGS, 0) : 0;
   const int prog_end = std::min(xgroup_first, n);
   const int prog_cap = GPK_TUNE(XFIRST_PART_WGS, 128);
@@ -761,7 +761,15 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       // (round 5) While the extra-row stream's capped updates hold 224 compute units, a rest-update on the one-shot latency kernel
       // -- up to 512 workgroups of 150 KB each -- queues through the 32 free ones for ~140 us and the chain's strips queue behind
       // it; the tiled kernel's 74-KB workgroups fit beside the capped ones.
-      if (rest_tiled && (long)gpk_cdiv(u.m, 16) * gpk_cdiv(u.n, 128) >= rest_tiled_min_wgs) u.no_small = 1;
+      if (rest_tiled && (long)gpk_cdiv(u.m, 16) * gpk_cdiv(u.n, 128) >= rest_tiled_min_wgs) {
+        u.no_small = 1;
+        // (round 6, late) ... and there a 128 x 128 tile of the rest-update shares its compute unit with a capped MFMA-bound workgroup of the
+        // extra-row stream and takes 60 - 95 us instead of 30 -- longer than the chain's period, and every strip WAITS for the previous
+        // rest-update (the strips of the step timeline: 30 - 67 us, of which 8 are work).  As 64 x 64 tiles of the generic kernel (four times
+        // the workgroups, 36 KB of LDS: they fit anywhere) it is short again: Cm 1.771 -> 1.750 ms, with the tiled regime from 30
+        // workgroups on (M > 1024) 1.72 - 1.74; 32 x 64 and 64 x 128 tiles lose (profiles/r06_ab_rest_update_tile64.log).
+        u.tile64 = GPK_TUNE(REST_TILE64, 1);
+      }
       else if (rest_small_wgs > 0) { u.small_loop = 1; u.max_wgs = rest_small_wgs; }
       if (Bp == aux->B && large) {
         u.stagger_first = aux->bulk_cus;
@@ -813,6 +821,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
                                   strideA, strideA, strideA);
           ub.c_lower = 1;
           ub.no_small = u.no_small;
+          ub.tile64 = u.tile64;
           if (!drop_rest_flag) {
             ub.sig_ptr = flagR + p;
             ub.sig_val = epoch;
