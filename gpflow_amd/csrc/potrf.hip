@@ -628,7 +628,7 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   //  from 250: 1.886 1.896 | always: 1.883 1.897; caps of 16 / 32 / 64 walking workgroups on the latency kernel: 2.41 / 2.06 / 1.94)
   // (all three "many extra rows" switches -- this one, the progressive first group, no shrinking groups at the end -- were measured
   //  at 8192 rows (gain) and 4096 rows (loss: 1.71 -> 1.82 ms for this one, tools/strong_scaling_emulation.py): threshold 6144)
-  const bool rest_tiled = useX && !large && batch == 1 && extra >= GPK_TUNE(REST_TILED_MIN_ROWS, 6144);
+  const bool rest_tiled = useX && !large && batch == 1 && extra >= GPK_TUNE(REST_TILED_MIN_ROWS, 3000);   // (6144 until the 64 x 64 tiles below: 4096 rows 1.33 -> 1.27 ms with them, profiles/r06_ab_rest_update_tile64.log)
   const int rest_tiled_min_wgs = n > 1024 ? GPK_TUNE(REST_TILED_MIN_WGS, 30) : GPK_TUNE(REST_TILED_MIN_WGS_SMALL, 150);
   const int rest_small_wgs = (useX && !large && batch == 1 && extra >= 6144) ? GPK_TUNE(REST_SMALL_WGS, 0) : 0;
   const int prog_end = std::min(xgroup_first, n);
