@@ -898,6 +898,22 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
       for (int h0 = g0; h0 < c1; h0 += NBO) {
         const int h1 = std::min(h0 + NBO, c1);
         const int xrows = tri ? extra - tri + h1 : extra;  // (identity rows below column h1 are still exactly zero here)
+        // (round 6, late) The in-group solve of a later group is 256 workgroups of 132 KB for ~63 us: every compute unit is taken and
+        // the chain -- whose kernels all need a whole CU's LDS -- stands still for as long (leaves of 85 / 66 us in the step timeline
+        // exactly beside the solves of groups 1 and 2).  Block by block (the progressive form, all of it issued here: the panels are done)
+        // the chain gets a compute unit between two launches.  MEASURED: the four block launches sum to ~170 us against 63 for the fused one and
+        // the extra-row stream has no such slack: Cm 1.78 -> 1.84 ms (profiles/r06_ab_group_by_blocks.log).  A/B knob, off.
+        const int nbk = (h1 - h0) / NB;
+        const bool by_blocks = GPK_TUNE(XGROUP_BY_BLOCKS, 0) && progressive && h0 > 0 && c1 < n && nbk >= 2 && (h1 - h0) == nbk * NB &&
+                               group_solve_fused_ok(nbk, h0, h1, xrows, A, lda, invd, batch, strideA, strideInv);
+        if (by_blocks) {
+          for (int j = 0; j < nbk; ++j) {
+            rc = solve_group_fwd(X, bulk, E, lda, E, lda, xrows, A, lda, invd, strideInv, n, h0, h1, batch, strideA, strideA, strideA, j,
+                                 GPK_TUNE(XGROUP_BLOCK_WGS, 0));
+            if (rc) return rc;
+          }
+          continue;
+        }
         rc = solve_group_fwd(X, bulk, E, lda, E, lda, xrows, A, lda, invd, strideInv, n, h0, h1, batch, strideA, strideA,
                              strideA);
         if (rc) return rc;
