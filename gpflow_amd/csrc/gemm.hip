@@ -355,6 +355,160 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
 
 
 // =====================================================================================================
+// One-round-trip 64 x 64 tile for SHORT-K updates that run beside bulk work (round 6, late): the rest-update of a single-leaf
+// panel of the SVGP step is K = 128, beta = 1, lower tiles only -- 10 to 400 tiles of ~1 MFLOP.  On gemm_nt_kernel<64, 64, 4, 1>
+// every 16-wide slab is a dependent global-load round trip (8 of them, then the read-modify-write of C: 10 in a row), and while
+// the extra-row stream's capped GEMM keeps the memory pipes of 224 compute units full a round trip takes several microseconds:
+// 36 tiles took 60 us (profiles/r06_step_timeline.txt), longer than the chain's own 41-us period, and every strip waits for the
+// previous rest-update.  Here a thread issues ALL its loads -- eight slabs of A and B (32 x 16 bytes) and its 16 values of C --
+// before the first barrier; the slabs then go through the same two 18-KB LDS buffers with the same fragment layout, slab order
+// and epilogue arithmetic as the generic kernel (bit-identical results).  36 KB of LDS: fits beside any other workgroup.
+// prio: s_setprio of the whole workgroup (its waves share their SIMDs with MFMA-bound waves of the bulk kernel).
+__global__ __launch_bounds__(256, 2) void gemm_nt_pre64(GemmArgs p, int gx, int gy, int total, int compact, int prio) {
+  constexpr int BM = 64, BN = 64, MAXS = 8;
+  constexpr int BUF = (BM + BN) * LDSS;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (p.sig_ptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    __hip_atomic_store(p.sig_ptr, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave w: rows 16 w .. 16 w + 15, all 64 columns
+  const int bz = blockIdx.y;
+  int tile_m, tile_n;
+  tile_order(blockIdx.x, 0, gx, gy, total, compact, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (p.c_lower && n0 > m0 + BM - 1) return;
+  if (m0 >= p.m || n0 >= p.n) return;
+  const double* __restrict__ A = p.A + (long)bz * p.strideA;
+  const double* __restrict__ B = p.B + (long)bz * p.strideB;
+  double* __restrict__ C = p.C + (long)bz * p.strideC;
+  const int nkt = p.k / BK;   // (the launcher: k a multiple of 16, <= 128)
+
+  // staging slots as in gemm_nt_kernel: chunk c = tid + 256 q -> tile row c >> 3, k offset (c & 7) * 2; rows clamped, then zero-selected
+  d2 ra[MAXS][2], rb[MAXS][2];
+  const double* pa[2];
+  const double* pb[2];
+  bool va[2], vb[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = tid + 256 * q;
+    const int rowa = m0 + (c >> 3), rowb = n0 + (c >> 3);
+    va[q] = rowa < p.m;
+    vb[q] = rowb < p.n;
+    pa[q] = A + (long)(va[q] ? rowa : p.m - 1) * p.lda + (c & 7) * 2;
+    pb[q] = B + (long)(vb[q] ? rowb : p.n - 1) * p.ldb + (c & 7) * 2;
+  }
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < nkt) {   // (wave-uniform)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        ra[s][q] = *reinterpret_cast<const d2*>(pa[q] + s * BK);
+        rb[s][q] = *reinterpret_cast<const d2*>(pb[q] + s * BK);
+      }
+    }
+  // C of this lane's 16 outputs (D layout: col = lane & 15 (+ 16 j), row = (lane >> 4) + 4 r)
+  const int row_base = m0 + wave * 16 + (lane >> 4);
+  const int col_base = n0 + (lane & 15);
+  const double alpha = p.alpha, beta = p.beta;
+  double cpre[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = row_base + 4 * r, col = col_base + j * 16;
+      cpre[r][j] = (beta != 0.0 && row < p.m && col < p.n) ? C[(long)row * p.ldc + col] : 0.0;
+    }
+
+  const d2 zero2 = {0.0, 0.0};
+  auto lstore = [&](int buf, const d2 (&xa)[2], const d2 (&xb)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = tid + 256 * q;
+      *reinterpret_cast<d2*>(&smem[buf * BUF + (c >> 3) * LDSS + (c & 7) * 2]) = va[q] ? xa[q] : zero2;
+      *reinterpret_cast<d2*>(&smem[buf * BUF + (BM + (c >> 3)) * LDSS + (c & 7) * 2]) = vb[q] ? xb[q] : zero2;
+    }
+  };
+  d4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+  if (nkt > 0) {
+    lstore(0, ra[0], rb[0]);
+    __syncthreads();
+  }
+  const int frag_r = lane & 15, frag_k = lane >> 4;
+#pragma unroll
+  for (int kt = 0; kt < MAXS; ++kt)
+    if (kt < nkt) {
+      const int cur = kt & 1;
+      const double* as = smem + cur * BUF + (wave * 16 + frag_r) * LDSS + frag_k;
+      const double* bs = smem + cur * BUF + (BM + frag_r) * LDSS + frag_k;
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        const double a = as[kk * 4];
+        double b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = bs[j * 16 * LDSS + kk * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[j], 0, 0, 0);
+      }
+      if (kt + 1 < MAXS && kt + 1 < nkt) lstore(cur ^ 1, ra[kt + 1 < MAXS ? kt + 1 : 0], rb[kt + 1 < MAXS ? kt + 1 : 0]);
+      __syncthreads();
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row_base + 4 * r;
+    if (row < p.m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = col_base + j * 16;
+        if (col < p.n) {
+          double v = alpha * acc[j][r];
+          if (beta != 0.0) v += beta * cpre[r][j];
+          C[(long)row * p.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+bool pre64_ok(const GemmArgs& a) {
+  if (a.epi != 0 || a.k <= 0 || a.k > 128 || (a.k & 15) || a.b_tri || a.a_tri || a.k_off_step || a.tile_snake || a.tail_first1) return false;
+  if ((a.lda & 1) || (a.ldb & 1) || (a.strideA & 1) || (a.strideB & 1)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
+  return true;
+}
+
+int launch_pre64(hipStream_t s, const GemmArgs& a, int prio) {
+  constexpr size_t LDS_BYTES = 2 * (size_t)(64 + 64) * LDSS * sizeof(double);
+  const int gx = gpk_cdiv(a.n, 64), gy = gpk_cdiv(a.m, 64);
+  if (gx <= 0 || gy <= 0) return 0;
+  int total = gx * gy, compact = 0;
+  if (a.c_lower) {   // (the numbering of launch_cfg: tiles on or below the diagonal, column groups of GROUP_N)
+    compact = 1;
+    total = 0;
+    for (int first = 0; first < gx; first += GROUP_N) {
+      const int gsz = (gx - first) < GROUP_N ? (gx - first) : GROUP_N;
+      const int avail = gy - first;
+      if (avail <= 0) break;
+      const int tr = avail < gsz ? avail : gsz;
+      total += tr * (tr + 1) / 2 + (avail > gsz ? (avail - gsz) * gsz : 0);
+    }
+    if (total <= 0) return 0;
+  }
+  g_last_kind = 6;
+  // (A/B, level: few tiles asking for 80 KB of LDS so that they cannot share a compute unit with a capped bulk workgroup and run on the CUs
+  //  the cap leaves free -- Cm 1.734 - 1.745 against 1.741 - 1.758 ms, profiles/r06_ab_rest_pre64.log; s_setprio 1 / 3 likewise)
+  hipLaunchKernelGGL(gemm_nt_pre64, dim3((unsigned)total, (unsigned)(a.batch > 0 ? a.batch : 1), 1), dim3(256), LDS_BYTES, s, a, gx, gy,
+                     total, compact, prio);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// =====================================================================================================
 // Fast path: 128 x 128 x 16 tiles, every K range a multiple of 16, 16-byte aligned rows.
 //
 // v_mfma_f64_16x16x4_f64 occupies a SIMD's matrix pipe for 64 cycles (measured: 77.4 TFLOP/s chip-wide
@@ -1832,7 +1986,10 @@ static int launch_select(hipStream_t s, const GemmArgs& a) {
   const long tiles = (long)gpk_cdiv(a.m, 128) * gpk_cdiv(a.n, 128) * (a.batch > 0 ? a.batch : 1);
   if (a.tile64 == 2 && a.epi == 0) return launch_cfg<32, 64, 2, 2>(s, a);
   if (a.tile64 == 3 && a.epi == 0) return launch_cfg<64, 128, 1, 4>(s, a);
-  if (a.tile64 && a.epi == 0) return launch_cfg<64, 64, 4, 1>(s, a);
+  if (a.tile64 && a.epi == 0) {
+    if (GPK_TUNE(REST_PRE64, 1) && pre64_ok(a)) return launch_pre64(s, a, GPK_TUNE(REST_PRIO, 0));
+    return launch_cfg<64, 64, 4, 1>(s, a);
+  }
   if (!a.no_small && small_ok(a)) return launch_small(s, a);  // K <= 128, <= 512 workgroups: the latency path
   if (a.epi == 1 && a.beta != 0.0 && a.C && !fast_ok(a)) return GPK_E_UNSUPPORTED;  // only the fast tile preloads C for epi 1
   if (a.epi == 0 && a.k >= GPK_TUNE(HALF_TILE_KMIN, 1024) && a.m > 64 && a.n > 64 && (a.max_wgs == 0 || a.max_wgs >= tiles)) {
