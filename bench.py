@@ -162,7 +162,7 @@ def cpu_baseline_and_parity(Xb, Yb, Z, q_mu, q_sqrt, ls, n_data, gpu_elbo, budge
 def train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, n_data, b_rows, steps: int = 20):
     """SURVEY 8f row 1 (the caller of the hot path): one TRAINING step = forward + hand-written reverse pass
     (gpflow_amd/gradients.py) + Adam update, reported beside the headline ELBO metric (not part of it)."""
-    from gpflow_amd import gradients
+    from gpflow_amd import gradients, ops
     m_ind = Z.shape[0]
     kw = dict(variance=1.0, lengthscales=ls, noise_variance=0.1, jitter=1e-6, scale=float(n_data) / b_rows)
     n_batches = n_data // b_rows
@@ -174,10 +174,8 @@ def train_step_leg(X, Y, Z, q_mu, q_sqrt, ls, n_data, b_rows, steps: int = 20):
         lo = (s % n_batches) * b_rows
         F, g, info = gradients.svgp_elbo_and_grad(par["Z"], X[lo:lo + b_rows], Y[lo:lo + b_rows], par["q_mu"],
                                                   par["q_sqrt"], **kw)
-        for k in par:  # Adam (tf.keras defaults) on the device-resident variables
-            m[k].mul_(0.9).add_(g[k], alpha=-0.1)
-            v2[k].mul_(0.999).addcmul_(g[k], g[k], value=0.001)
-            par[k].addcdiv_(m[k], v2[k].sqrt().add_(1e-7), value=-1e-3)
+        for k in par:  # Adam (tf.keras defaults; step size without bias correction as before) on the device-resident variables
+            ops.adam_step_(par[k], g[k], m[k], v2[k], beta1=0.9, beta2=0.999, epsilon=1e-7, step=1e-3, maximise=True)
         small = torch.cat([g["variance"], g["lengthscales"], g["noise_variance"], F]).cpu()  # scalar grads + ELBO to host
         return float(small[-1]), int(info.cpu()[0])
 

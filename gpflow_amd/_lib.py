@@ -72,6 +72,12 @@ _SIGS = {
     "gpk_svgp_elbo_shard_sep": (c_int, [c_void_p, C.POINTER(c_int), _dp, c_int, c_long, c_long, _dp, _dp, c_int, c_long, c_long,
                                         c_int, c_int, C.POINTER(c_double), c_int, C.POINTER(c_double), c_double, _dp, c_double,
                                         c_double, _dp, _dp, _dp, _dp, _dp, c_size_t]),
+    "gpk_moment_rows": (c_int, [c_void_p, _dp, c_long, c_int, c_int, _dp, c_long]),
+    "gpk_stationary_adjoint_tail": (c_int, [c_void_p, _dp, c_long, _dp, c_long, c_int, c_int, _dp, c_double, c_int, _dp, _dp, c_long,
+                                            _dp, c_int, c_double]),
+    "gpk_adam_step": (c_int, [c_void_p, _dp, _dp, _dp, _dp, c_long, c_double, c_double, c_double, c_double, c_int]),
+    "gpk_lowrank_axpy": (c_int, [c_void_p, c_double, _dp, c_long, _dp, c_long, _dp, c_long, c_int, c_int, c_int, _dp, c_long]),
+    "gpk_symmetrize": (c_int, [c_void_p, _dp, c_int, c_long]),
     "gpk_publish_host": (c_int, [c_void_p, _dp, c_int, _dp, c_void_p, c_int]),
     "gpk_profile_gemm_enable": (None, [c_int]),
     "gpk_profile_gemm_collect": (c_int, [C.POINTER(c_double), C.POINTER(c_long), C.POINTER(c_double)]),

@@ -772,3 +772,199 @@ extern "C" int gpk_publish_host(void* stream, const double* src, int n, const in
   GPK_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- glue of the reverse pass as single launches (round 6, late) -------------------------------------------------------------
+// The tail of a training step was ~70 torch elementwise / reduction launches of 4 - 5 us each on arrays of a few thousand
+// elements (profiles/r06_train_timeline_gated_side_branch.txt: 0.44 ms behind the last GEMM).  Three kernels replace most of
+// them: the moment rows [1; B^T; (B^T)^2] of a stationary kernel's adjoint, the adjoint's tail (input gradient, lengthscale and
+// variance gradients from G [1, B, B^2]) and one Adam update per variable.
+namespace {
+__global__ __launch_bounds__(256) void moment_rows_kernel(const double* __restrict__ B, long ldb, int n2, int d, double* __restrict__ Vt,
+                                                          long ldv) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n2) return;
+  Vt[j] = 1.0;
+  for (int c = 0; c < d; ++c) {
+    const double b = B[(long)j * ldb + c];
+    Vt[(long)(1 + c) * ldv + j] = b;
+    Vt[(long)(1 + d + c) * ldv + j] = b * b;
+  }
+}
+
+constexpr int AT_THREADS = 1024;
+// one workgroup; thread t owns input dimension t % d and walks the rows t / d, t / d + rpp, ... (rpp = AT_THREADS / d rows per pass):
+// every partial sum has a fixed set of terms in a fixed order, and the partials meet in LDS in thread order -- deterministic
+__global__ __launch_bounds__(AT_THREADS) void adjoint_tail_kernel(const double* __restrict__ R, long ldr, const double* __restrict__ A,
+                                                                  long lda, int n1, int d, const double* __restrict__ ls, double variance,
+                                                                  int symmetric, const double* __restrict__ sum_kbar_k,
+                                                                  double* __restrict__ Abar, long ldab, double* __restrict__ small,
+                                                                  int accumulate, double dvar_add) {
+  __shared__ double sh[AT_THREADS];
+  __shared__ double sh_rs[AT_THREADS];
+  const int t = threadIdx.x;
+  const int rpp = AT_THREADS / d;
+  const int c = t % d, r0 = t / d;
+  double acc = 0.0, acc_rs = 0.0;
+  if (r0 < rpp) {
+    const double l = ls[c];
+    const double il2 = 1.0 / (l * l);
+    for (int i = r0; i < n1; i += rpp) {
+      const double* Ri = R + (long)i * ldr;
+      const double rs = Ri[0], gb = Ri[1 + c], gb2 = Ri[1 + d + c];
+      const double a = A[(long)i * lda + c];
+      const double T = gb - a * rs;
+      double ab;
+      if (symmetric) {
+        ab = 2.0 * T * il2;
+        acc += a * ab;
+      } else {
+        ab = T * il2;
+        acc += gb2 - a * (gb + T);
+      }
+      double* o = Abar + (long)i * ldab + c;
+      *o = accumulate ? *o + ab : ab;
+      if (c == 0) acc_rs += rs;
+    }
+  }
+  sh[t] = acc;
+  sh_rs[t] = acc_rs;
+  __syncthreads();
+  if (t < d) {   // (r0 == 0: this thread's own column)
+    double s = 0.0;
+    for (int q = 0; q < rpp; ++q) s += sh[q * d + t];
+    const double l = ls[t];
+    const double r = symmetric ? -s / l : s / (l * l * l);
+    small[1 + t] = accumulate ? small[1 + t] + r : r;
+  }
+  if (t == 0) {
+    double s = 0.0;
+    if (sum_kbar_k) s = sum_kbar_k[0];
+    else
+      for (int q = 0; q < rpp; ++q) s += sh_rs[q * d];
+    const double r = s / variance + dvar_add;
+    small[0] = accumulate ? small[0] + r : r;
+  }
+}
+
+// tf.keras Adam on one variable, minimising -F:  g is dF/dp  (m, v, p updated in place; step = lr sqrt(1 - b2^t) / (1 - b1^t) from the host)
+__global__ __launch_bounds__(256) void adam_kernel(double* __restrict__ p, const double* __restrict__ g, double* __restrict__ m,
+                                                   double* __restrict__ v, long n, double b1, double b2, double eps, double step,
+                                                   double gsign) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double gi = gsign * g[i];
+    const double mi = b1 * m[i] + (1.0 - b1) * gi;
+    const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step * mi / (sqrt(vi) + eps);
+  }
+}
+
+// out = alpha X + U V^T for a thin U [m, k], V [n, k], k <= 16: the start of At_bar = r q_mu^T - 2 c P At + ... (one pass over X
+// instead of a K = k GEMM plus an axpy pass)
+__global__ __launch_bounds__(256) void lowrank_axpy_kernel(double alpha, const double* __restrict__ X, long ldx, const double* __restrict__ U,
+                                                           long ldu, const double* __restrict__ V, long ldv, int m, int n, int k,
+                                                           double* __restrict__ out, long ldo) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= n) return;
+  const bool two = c + 1 < n;
+  double v0[16], v1[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    v0[q] = q < k ? V[(long)c * ldv + q] : 0.0;
+    v1[q] = (q < k && two) ? V[(long)(c + 1) * ldv + q] : 0.0;
+  }
+  const bool vec = two && !(ldx & 1) && !(ldo & 1) && !(reinterpret_cast<uintptr_t>(X) & 15) && !(reinterpret_cast<uintptr_t>(out) & 15);
+  for (int r = blockIdx.y; r < m; r += gridDim.y) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (q < k) {
+        const double u = U[(long)r * ldu + q];
+        s0 += u * v0[q];
+        s1 += u * v1[q];
+      }
+    const double* x = X + (long)r * ldx + c;
+    double* o = out + (long)r * ldo + c;
+    if (vec) {
+      const d2 xv = *reinterpret_cast<const d2*>(x);
+      *reinterpret_cast<d2*>(o) = (d2){alpha * xv.x + s0, alpha * xv.y + s1};
+    } else {
+      o[0] = alpha * x[0] + s0;
+      if (two) o[1] = alpha * x[1] + s1;
+    }
+  }
+}
+
+// out = (S + S^T) / 2 of a square matrix, in place: 32 x 32 tile pairs (bi >= bj), both tiles through LDS
+__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ S, int n, long lds) {
+  __shared__ double ta[32][33], tb[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    ta[r][tx] = (i < n && j < n) ? S[(long)i * lds + j] : 0.0;        // S[bi-block, bj-block]
+    const int i2 = bj * 32 + r, j2 = bi * 32 + tx;
+    tb[r][tx] = (i2 < n && j2 < n) ? S[(long)i2 * lds + j2] : 0.0;    // S[bj-block, bi-block]
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < n && j < n) S[(long)i * lds + j] = 0.5 * (ta[r][tx] + tb[tx][r]);
+    if (bi != bj) {
+      const int i2 = bj * 32 + r, j2 = bi * 32 + tx;
+      if (i2 < n && j2 < n) S[(long)i2 * lds + j2] = 0.5 * (tb[r][tx] + ta[tx][r]);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int gpk_moment_rows(void* stream, const double* B, long ldb, int n2, int d, double* Vt, long ldv) {
+  if (!B || !Vt || n2 < 0 || d <= 0 || ldb < d || ldv < n2) return GPK_E_ARG;
+  if (n2 == 0) return 0;
+  hipLaunchKernelGGL(moment_rows_kernel, dim3((unsigned)gpk_cdiv(n2, 256)), dim3(256), 0, (hipStream_t)stream, B, ldb, n2, d, Vt, ldv);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gpk_stationary_adjoint_tail(void* stream, const double* R, long ldr, const double* A, long lda, int n1, int d,
+                                           const double* ls_dev, double variance, int symmetric, const double* sum_kbar_k,
+                                           double* Abar, long ldab, double* small, int accumulate, double dvar_add) {
+  if (!R || !A || !ls_dev || !Abar || !small || n1 < 0 || d <= 0 || d > AT_THREADS || ldr < 1 + 2 * d || lda < d || ldab < d)
+    return GPK_E_ARG;
+  hipLaunchKernelGGL(adjoint_tail_kernel, dim3(1), dim3(AT_THREADS), 0, (hipStream_t)stream, R, ldr, A, lda, n1, d, ls_dev, variance,
+                     symmetric, sum_kbar_k, Abar, ldab, small, accumulate, dvar_add);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gpk_adam_step(void* stream, double* p, const double* g, double* m, double* v, long n, double beta1, double beta2,
+                             double epsilon, double step, int maximise) {
+  if (!p || !g || !m || !v || n < 0) return GPK_E_ARG;
+  if (n == 0) return 0;
+  const long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2,
+                     epsilon, step, maximise ? -1.0 : 1.0);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gpk_symmetrize(void* stream, double* S, int n, long lds) {
+  if (!S || n < 0 || lds < n) return GPK_E_ARG;
+  if (n == 0) return 0;
+  const unsigned nb = (unsigned)gpk_cdiv(n, 32);
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, (hipStream_t)stream, S, n, lds);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gpk_lowrank_axpy(void* stream, double alpha, const double* X, long ldx, const double* U, long ldu, const double* V, long ldv,
+                                int m, int n, int k, double* out, long ldo) {
+  if (!X || !U || !V || !out || m < 0 || n < 0 || k <= 0 || k > 16 || ldx < n || ldo < n || ldu < k || ldv < k) return GPK_E_ARG;
+  if (m == 0 || n == 0) return 0;
+  dim3 grid((unsigned)gpk_cdiv(gpk_cdiv(n, 2), 256), (unsigned)(m < 2048 ? m : 2048));
+  hipLaunchKernelGGL(lowrank_axpy_kernel, grid, dim3(256), 0, (hipStream_t)stream, alpha, X, ldx, U, ldu, V, ldv, m, n, k, out, ldo);
+  GPK_LAUNCH_CHECK();
+  return 0;
+}

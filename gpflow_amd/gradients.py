@@ -75,12 +75,12 @@ def splitk_gemm_nt(A: torch.Tensor, Bt: torch.Tensor, *, c_lower: bool = False, 
             and k // (chunks * 2) >= 256:
         chunks *= 2
     if chunks == 1:
-        R = ops.gemm_nt(A, Bt, c_lower=c_lower, alpha=alpha)
+        R = ops.gemm_nt(A, Bt, c_lower=c_lower, alpha=alpha, zero_skipped=False)   # (combine_parts(lower) never reads above the diagonal)
         return ops.combine_parts(R, lower=True, diag_scale=diag_scale) if c_lower else R
     kc = k // chunks
     A3 = torch.as_strided(A, (chunks, m, kc), (kc, A.stride(0), 1), A.storage_offset())
     B3 = torch.as_strided(Bt, (chunks, n, kc), (kc, Bt.stride(0), 1), Bt.storage_offset())
-    return ops.combine_parts(ops.gemm_nt(A3, B3, c_lower=c_lower), alpha=alpha, lower=c_lower, diag_scale=diag_scale)
+    return ops.combine_parts(ops.gemm_nt(A3, B3, c_lower=c_lower, zero_skipped=False), alpha=alpha, lower=c_lower, diag_scale=diag_scale)
 
 
 def _tril(x: torch.Tensor) -> torch.Tensor:
@@ -114,7 +114,7 @@ def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor, 
         T1 = ops.gemm_nt(LT, LbarT, b_tri=1, a_tri=1)                        # L^T L_bar
         Y = ops.gemm_nt(_phi_(T1), LinvT, b_tri=1, a_tri=2)                  # Phi L^-1        (lower)
         S = ops.gemm_nt(LinvT, ops.transpose(Y, mode=1), b_tri=1, a_tri=1)   # L^-T (Phi L^-1)
-        return S.add_(ops.transpose(S)).mul_(0.5)
+        return ops.symmetrize_(S)
     # Each of the three products is 256 output tiles whose K ranges differ by a factor of sixteen -- the launch lasts as long as the tile
     # that walks all of K (245 us at M = 2048 for 5.7 GFLOP).  As K chunks in the batch dimension of ONE launch (strided views; the
     # triangular hints refer to the unsplit column index, ops.gemm_nt k_split) the non-empty tiles fill the chip about once, and the sum of
@@ -127,7 +127,7 @@ def cholesky_adjoint(LT: torch.Tensor, LinvT: torch.Tensor, Lbar: torch.Tensor, 
     T1 = ops.combine_parts(ops.gemm_nt(split(LT), split(LbarT), b_tri=1, a_tri=1, k_split=True), lower=True, diag_scale=0.5)   # Phi(L^T L_bar)
     Y = ops.combine_parts(ops.gemm_nt(split(T1), split(LinvT), b_tri=1, a_tri=2, k_split=True), lower=True)                   # Phi L^-1 (lower)
     S = ops.combine_parts(ops.gemm_nt(split(LinvT), split(ops.transpose(Y)), b_tri=1, a_tri=1, k_split=True))               # L^-T (Phi L^-1)
-    return S.add_(ops.transpose(S)).mul_(0.5)
+    return ops.symmetrize_(S)
 
 
 _ls_cache: "collections.OrderedDict" = collections.OrderedDict()
@@ -150,7 +150,8 @@ def ls_device(lengthscales, D: int, device) -> torch.Tensor:
 
 
 def stationary_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Tensor, *, variance: float, lengthscales,
-                              symmetric: bool, family: str = "SquaredExponential"):
+                              symmetric: bool, family: str = "SquaredExponential", packed_into=None, dvar_add: float = 0.0,
+                              return_packed: bool = False):
     """Adjoint of K = variance * f(r(A / ls, Bm / ls)) [n1, n2] given Kbar [n1, n2], f one of the stationary families of
     `ops.KERNEL_FAMILIES` (stationaries.py:209-210 SquaredExponential, :254-313 Matern12 / 32 / 52).
 
@@ -171,20 +172,17 @@ def stationary_kernel_adjoint(A: torch.Tensor, Bm: torch.Tensor, Kbar: torch.Ten
         sum_kbar_k = G.sum()
         ops.kernel_matrix_combine(A, None if symmetric else Bm, Kbar, op="dr2", variance=variance,
                                   lengthscales=lengthscales, family=family, out=G)
-    Vt = torch.empty((1 + 2 * D, Bm.shape[0]), dtype=torch.float64, device=A.device)             # [1, B, B^2]^T
-    Vt[0] = 1.0
-    Vt[1:1 + D] = Bm.t()
-    torch.mul(Vt[1:1 + D], Vt[1:1 + D], out=Vt[1 + D:])
-    R = splitk_gemm_nt(G, Vt)                        # [n1, 1 + 2D] = G [1, B, B^2]
-    rs, GB, GB2 = R[:, 0:1], R[:, 1:1 + D], R[:, 1 + D:]
-    dvar = (rs.sum() if sum_kbar_k is None else sum_kbar_k) / variance
-    T = torch.addcmul(GB, A, rs, value=-1.0)         # G B - A rowsum(G)
-    if symmetric:   # both arguments: A_bar = 2 T / ls^2,  d/dls = (2 sum A^2 rs - 2 sum A GB) / ls^3 = -sum(A A_bar) / ls
-        Abar = T * (2.0 / (ls * ls))
-        dls = -(A * Abar).sum(0) / ls
-    else:           # d/dls = sum(GB2 - 2 A GB + A^2 rs) / ls^3 = sum(GB2 - A (GB + T)) / ls^3
-        Abar = T / (ls * ls)
-        dls = (GB2 - A * (GB + T)).sum(0) / ls ** 3
+    Vt = ops.moment_rows(Bm)                         # [1, B, B^2]^T
+    R = splitk_gemm_nt(G, Vt)                        # [n1, 1 + 2D] = G [1, B, B^2]: row sums rs, G B, G B^2
+    # one launch for what follows (it was a dozen elementwise / reduction launches on [n1, D] arrays):  T = G B - A rs;
+    # both arguments (symmetric):  A_bar = 2 T / ls^2,  d/dls = (2 sum A^2 rs - 2 sum A GB) / ls^3 = -sum(A A_bar) / ls
+    # else:  A_bar = T / ls^2,  d/dls = sum(GB2 - 2 A GB + A^2 rs) / ls^3 = sum(GB2 - A (GB + T)) / ls^3;  d/dvariance = sum(rs) / variance
+    # (packed_into = (small [1 + D], A_bar) of an earlier adjoint of the SAME kernel: the results are added to it in the same launch;
+    #  return_packed: (small, A_bar) instead of the three views)
+    dvar, dls, Abar = ops.stationary_adjoint_tail(R, A if A.is_contiguous() else A.contiguous(), ls, variance=variance,
+                                                  symmetric=symmetric, sum_kbar_k=sum_kbar_k, into=packed_into, dvar_add=dvar_add)
+    if return_packed:
+        return (packed_into[0] if packed_into is not None else dls._base), Abar
     return dvar, dls, Abar
 
 
@@ -453,7 +451,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     ve, _ = ops.gaussian_varexp_sum(Yb, fmean, s0=s0, ssq=ssq, knn=[spec.kdiag()], noise_variance=noise_variance,
                                     mean_const=mean_const)
     kl = ops.gauss_kl_white(q_mu, q_sqrt)
-    F = scale * ve - kl_weight * kl
+    F = torch.mul(ve, scale).sub_(kl, alpha=kl_weight)
 
     # ---------------------------------------------------------------- backward
     # het: one noise variance per row (a heteroskedastic Gaussian likelihood, round 5): dF/dfvar is a per-row vector, applied as a
@@ -466,8 +464,13 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
         r = (scale / nv)[:, None] * (Yb - fmean - mean_const)                           # dF/dfmean [B, P]
     else:
         c = -0.5 * scale / noise_variance                                               # dF/dfvar (every b, p)
-        r = (scale / noise_variance) * (Yb - fmean - mean_const)                        # dF/dfmean [B, P]
-    Atb = ops.gemm_nt(r, q_mu)                                                          # r q_mu^T  [B, M]
+        r = torch.sub(Yb, fmean)                                                        # dF/dfmean [B, P] = (scale / s2) (y - f - m)
+        if mean_const != 0.0:
+            r.sub_(mean_const)
+        r.mul_(scale / noise_variance)
+    plain = not q_diag and not het and P <= 16
+    # (plain: r q_mu^T - 2 c P At in ONE pass over At; it was a K = P GEMM, then an axpy pass behind the products below)
+    Atb = ops.lowrank_axpy(-2.0 * c * P, At, r, q_mu) if plain else ops.gemm_nt(r, q_mu)  # r q_mu^T  [B, M]
     if q_diag:                                                                          # + 2c At (sum_p q_p^2 - P) per column
         if het:
             Atb.addcmul_(At * (2.0 * cvec)[:, None], ((q_sqrt * q_sqrt).sum(1) - P)[None, :])
@@ -481,7 +484,8 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     else:
         for p in range(P):                                                              # + 2c W_p Lq_p^T (Lq_p lower: b_tri 2)
             ops.gemm_nt(W[p], Lq[p], alpha=2.0 * c, beta=1.0, C=Atb, b_tri=2)
-        Atb.add_(At, alpha=-2.0 * c * P)                                                # - 2 c P At
+        if not plain:
+            Atb.add_(At, alpha=-2.0 * c * P)                                            # - 2 c P At
     A = ops.transpose(At)                                                               # [M, B]
     Kfu_bar = ops.gemm_nt(Atb, LinvT, b_tri=1)                                          # At_bar Lm^-1  [B, M]
     Kuf_bar = ops.transpose(Kfu_bar)                                                    # [M, B]
@@ -539,8 +543,20 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     try:
         Lbar = splitk_gemm_nt(Kuf_bar, A, c_lower=True, alpha=-1.0)            # -tril(Kfu_bar^T At)
         Kuu_bar = cholesky_adjoint(LT, LinvT, Lbar, before_products=release_side)
-        dv1, dl1, Zb1 = spec.adjoint(Z, Xb, Kuf_bar, symmetric=False)
-        dv2, dl2, Zb2 = spec.adjoint(Z, Z, Kuu_bar, symmetric=True)
+        dkd = spec.dkdiag()                                                             # Knn = kdiag in every fvar
+        csum = cvec.sum() * P if het else c * B * P
+        one_kernel = spec.n == 1 and spec.tree is None and spec.cols[0] is None and not het
+        if one_kernel:
+            # one stationary kernel over all input columns: the second adjoint ADDS its variance / lengthscale / Z gradients to the
+            # first one's in its own tail launch, and the Knn term of d/dvariance rides along (no elementwise launches at all)
+            fam1, var1, ls1 = spec.members[0]
+            packed = stationary_kernel_adjoint(Z, Xb, Kuf_bar, variance=var1, lengthscales=ls1, symmetric=False, family=fam1,
+                                               dvar_add=csum * dkd[0], return_packed=True)
+            small_g, Zbar = stationary_kernel_adjoint(Z, Z, Kuu_bar, variance=var1, lengthscales=ls1, symmetric=True, family=fam1,
+                                                      packed_into=packed, return_packed=True)
+        else:
+            dv1, dl1, Zb1 = spec.adjoint(Z, Xb, Kuf_bar, symmetric=False)
+            dv2, dl2, Zb2 = spec.adjoint(Z, Z, Kuu_bar, symmetric=True)
     finally:
         if side is not None:
             main.wait_stream(side)
@@ -551,9 +567,12 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
     else:
         g_qmu, WgT, ag = branch_q_prep()
         g_qs = branch_q_products(WgT, ag)
-    dkd = spec.dkdiag()                                                                 # Knn = kdiag in every fvar
-    csum = cvec.sum() * P if het else c * B * P
-    g_var, g_ls = spec.pack([a + b + csum * dk for a, b, dk in zip(dv1, dv2, dkd)], [a + b for a, b in zip(dl1, dl2)])
+    if one_kernel:
+        g_var = small_g[0:1]
+        g_ls = small_g[1:] if not (np.ndim(ls1) == 0 or np.size(ls1) == 1) else small_g[1:].sum().reshape(1)
+    else:
+        g_var, g_ls = spec.pack([a + b + csum * dk for a, b, dk in zip(dv1, dv2, dkd)], [a + b for a, b in zip(dl1, dl2)])
+        Zbar = Zb1 + Zb2
     if het:
         # dF/d sigma_n^2 = scale sum_p (-1 / (2 s2_n) + ((y - f)^2 + fvar) / (2 s2_n^2)): one entry per row (likelihood parameters
         # are reached through Gaussian.noise_param_grads)
@@ -562,11 +581,11 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
         g_noise = scale * (-0.5 * P / nv + 0.5 * (resid * resid + fvar).sum(1) / (nv * nv))
     else:
         # sum_bp ((y - f)^2 + fvar) recovered from the forward value:  ve = B P k0 - Q / (2 s2)
+        #   d/ds2 = scale (-B P / (2 s2) + Q / (2 s2^2)) = (scale / s2) (B P (k0 - 1/2) - ve)          (two launches)
         k0 = -0.5 * LOG2PI - 0.5 * float(np.log(noise_variance))
-        Q = 2.0 * noise_variance * (B * P * k0 - ve)
-        g_noise = (scale * (-0.5 * B * P / noise_variance + 0.5 * Q / noise_variance ** 2)).reshape(1)
+        g_noise = torch.mul(ve, -scale / noise_variance).add_(scale / noise_variance * B * P * (k0 - 0.5)).reshape(1)
     grads = {"variance": g_var, "lengthscales": g_ls, "noise_variance": g_noise,
-             "Z": Zb1 + Zb2, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
+             "Z": Zbar, "q_mu": g_qmu, "q_sqrt": g_qs, "mean_const": r.sum().reshape(1)}
     return F, grads, info
 
 

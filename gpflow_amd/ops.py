@@ -279,11 +279,13 @@ def trsm_(B: torch.Tensor, L: torch.Tensor, invd: torch.Tensor, *, trans: int = 
 
 def gemm_nt(A: torch.Tensor, B: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
             C: Optional[torch.Tensor] = None, b_tri: int = 0, c_lower: bool = False, a_tri: int = 0,
-            k_split: bool = False) -> torch.Tensor:
+            k_split: bool = False, zero_skipped: bool = True) -> torch.Tensor:
     """C = alpha A B^T + beta C.  A [m,k] or [b,m,k]; B [n,k] or [b,n,k].  b_tri: 1 B upper (B[j,kk] = 0 for kk < j),
     2 B lower; a_tri: the same statement about A (1 upper, 2 lower) -- zeros must be stored; only the K ranges shrink.
     k_split: the batch entries are consecutive K chunks of ONE triangular product (strided views of its operands); b_tri / a_tri
-    then refer to the unsplit column index and the caller sums the partial products (combine_parts)."""
+    then refer to the unsplit column index and the caller sums the partial products (combine_parts).
+    c_lower without C: the tiles above the diagonal, which the kernel skips, are zero-filled first -- unless zero_skipped=False (a caller
+    that never reads them, e.g. combine_parts(lower=True) behind a split-K product: the fill of 8 x 2048^2 partials was 72 us)."""
     lib = _lib.load()
     _chk(A, "A")
     _chk(B, "B")
@@ -299,7 +301,7 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, *, alpha: float = 1.0, beta: float
         if beta != 0.0:
             raise ValueError("beta != 0 needs C")
         C = torch.empty((batch, m, n) if batched else (m, n), dtype=torch.float64, device=A.device)
-        if c_lower:
+        if c_lower and zero_skipped:
             C.zero_()
     C3 = C if C.dim() == 3 else C.unsqueeze(0)
     sA = int(A3.stride(0)) if A3.shape[0] > 1 else 0
@@ -482,6 +484,94 @@ def sumsq(A: torch.Tensor, *, upper_only: bool = False) -> torch.Tensor:
                        out.data_ptr(), ws.data_ptr(), ws.numel() * 8)
     _lib.check(rc, "gpk_sumsq")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ reverse-pass glue
+def moment_rows(B: torch.Tensor) -> torch.Tensor:
+    """[1; B^T; (B^T)^2] as [1 + 2 D, n2] for B [n2, D]: the right-hand side of G [1, B, B^2] (gradients.stationary_kernel_adjoint)."""
+    lib = _lib.load()
+    _chk(B, "B", 2)
+    n2, d = B.shape
+    Vt = torch.empty((1 + 2 * d, n2), dtype=torch.float64, device=B.device)
+    rc = lib.gpk_moment_rows(_stream(), B.data_ptr(), _rowmajor(B, "B"), n2, d, Vt.data_ptr(), n2)
+    _lib.check(rc, "gpk_moment_rows")
+    return Vt
+
+
+def stationary_adjoint_tail(R: torch.Tensor, A: torch.Tensor, ls: torch.Tensor, *, variance: float, symmetric: bool,
+                            sum_kbar_k: Optional[torch.Tensor] = None, into: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                            dvar_add: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(d/dvariance [1], d/dlengthscales [D], A_bar [n1, D]) from R [n1, 1 + 2 D] = G [1, B, B^2], the first kernel argument A
+    [n1, D] and the lengthscales as a [D] device tensor (include/gpk.h: gpk_stationary_adjoint_tail) -- one launch.
+    into = (small [1 + D], A_bar) of an earlier call: the results are ADDED to them (and views of them returned); dvar_add is added
+    to d/dvariance."""
+    lib = _lib.load()
+    _chk(R, "R", 2)
+    _chk(A, "A", 2)
+    _chk(ls, "ls", 1)
+    n1, d = A.shape
+    if R.shape != (n1, 1 + 2 * d) or ls.shape[0] != d or not ls.is_contiguous():
+        raise ValueError("stationary_adjoint_tail: R must be [n1, 1 + 2 D], ls a contiguous [D]")
+    if sum_kbar_k is not None:
+        _chk(sum_kbar_k, "sum_kbar_k")
+    if into is None:
+        Abar = torch.empty((n1, d), dtype=torch.float64, device=A.device)
+        small = torch.empty(1 + d, dtype=torch.float64, device=A.device)
+    else:
+        small, Abar = into
+        _chk(small, "into[0]", 1)
+        _chk(Abar, "into[1]", 2)
+        if small.shape[0] != 1 + d or tuple(Abar.shape) != (n1, d) or not small.is_contiguous():
+            raise ValueError("stationary_adjoint_tail: into must be (small [1 + D], A_bar [n1, D])")
+    rc = lib.gpk_stationary_adjoint_tail(_stream(), R.data_ptr(), _rowmajor(R, "R"), A.data_ptr(), _rowmajor(A, "A"), n1, d,
+                                         ls.data_ptr(), float(variance), int(bool(symmetric)),
+                                         None if sum_kbar_k is None else sum_kbar_k.data_ptr(), Abar.data_ptr(), _rowmajor(Abar, "A_bar"),
+                                         small.data_ptr(), int(into is not None), float(dvar_add))
+    _lib.check(rc, "gpk_stationary_adjoint_tail")
+    return small[0:1], small[1:], Abar
+
+
+def adam_step_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, beta1: float, beta2: float, epsilon: float,
+               step: float, maximise: bool = False) -> torch.Tensor:
+    """tf.keras Adam on one contiguous variable, in place (p, m, v): one launch instead of seven (include/gpk.h: gpk_adam_step).
+    step = lr sqrt(1 - beta2^t) / (1 - beta1^t); maximise=True takes g as the gradient of the quantity to MAXIMISE."""
+    lib = _lib.load()
+    for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, name)
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise ValueError(f"adam_step_: {name} must be contiguous and of the variable's size")
+    rc = lib.gpk_adam_step(_stream(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(beta1), float(beta2),
+                           float(epsilon), float(step), int(bool(maximise)))
+    _lib.check(rc, "gpk_adam_step")
+    return p
+
+
+def lowrank_axpy(alpha: float, X: torch.Tensor, U: torch.Tensor, V: torch.Tensor) -> torch.Tensor:
+    """alpha X + U V^T for X [m, n], thin U [m, k], V [n, k], k <= 16, as a fresh tensor: one pass over X (gpk_lowrank_axpy)."""
+    lib = _lib.load()
+    _chk(X, "X", 2)
+    _chk(U, "U", 2)
+    _chk(V, "V", 2)
+    m, n = X.shape
+    k = U.shape[1]
+    if U.shape[0] != m or tuple(V.shape) != (n, k) or not 0 < k <= 16:
+        raise ValueError("lowrank_axpy: X [m, n], U [m, k], V [n, k], k <= 16")
+    out = torch.empty((m, n), dtype=torch.float64, device=X.device)
+    rc = lib.gpk_lowrank_axpy(_stream(), float(alpha), X.data_ptr(), _rowmajor(X, "X"), U.data_ptr(), _rowmajor(U, "U"), V.data_ptr(),
+                              _rowmajor(V, "V"), m, n, k, out.data_ptr(), n)
+    _lib.check(rc, "gpk_lowrank_axpy")
+    return out
+
+
+def symmetrize_(S: torch.Tensor) -> torch.Tensor:
+    """S = (S + S^T) / 2 in place for a square S (one launch)."""
+    lib = _lib.load()
+    _chk(S, "S", 2)
+    if S.shape[0] != S.shape[1]:
+        raise ValueError("symmetrize_: square matrix expected")
+    rc = lib.gpk_symmetrize(_stream(), S.data_ptr(), S.shape[0], _rowmajor(S, "S"))
+    _lib.check(rc, "gpk_symmetrize")
+    return S
 
 
 # ------------------------------------------------------------------------------------------------ fused

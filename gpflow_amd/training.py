@@ -7,7 +7,7 @@ Adam moments stay in HBM, the handful of scalar hyper-parameters live on the hos
 constrained values are C-ABI arguments), and one step is
     gradients.svgp_elbo_and_grad  ->  (multi-GPU: one all-reduce of the packed gradient)  ->  Adam update.
 The update rule and defaults are tf.keras Adam's (lr 1e-3, beta 0.9 / 0.999, epsilon 1e-7, bias-corrected step size).
-The elementwise Adam arithmetic on the device tensors is torch glue.
+The Adam arithmetic on the device tensors is one launch per variable (`gpk_adam_step`).
 """
 from __future__ import annotations
 
@@ -32,9 +32,8 @@ class _Adam:
         if name not in self.m:
             self.m[name], self.v[name] = torch.zeros_like(p), torch.zeros_like(p)
         m, v = self.m[name], self.v[name]
-        m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
-        v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
-        p.addcdiv_(m, v.sqrt().add_(self.eps), value=-self.step_size())
+        # (one launch per variable -- gpk_adam_step -- instead of seven elementwise passes over q_sqrt's M^2 entries)
+        ops.adam_step_(p, g.contiguous(), m, v, beta1=self.b1, beta2=self.b2, epsilon=self.eps, step=self.step_size())
 
     def update_host(self, name: str, p: np.ndarray, g: np.ndarray) -> np.ndarray:
         if name not in self.m:

@@ -249,6 +249,37 @@ int gpk_sumsq(void* stream, const double* A, int rows, int cols, long lda, int u
 int gpk_combine_parts(void* stream, const double* parts, int nparts, long stride_part, int m, int n, long ldp,
                       double alpha, int lower, double diag_scale, double* out, long ldo);
 
+/* ---- glue of the reverse pass as single launches (round 6) -------------------------------------------------
+ * The reference gets all of this from TF autodiff and tf.optimizers.Adam (optimizers/scipy.py:322-331,
+ * gps_for_big_data.pct.py:207-228); here the reverse pass is written out (gpflow_amd/gradients.py) and these entry
+ * points replace ~70 elementwise launches of a few thousand elements each at the end of a training step.
+ *
+ * gpk_moment_rows:  Vt [1 + 2 d, n2] = [1; B^T; (B^T).^2] for B [n2, d] -- the right-hand side of G [1, B, B^2],
+ *   the contraction that turns G = Kbar .* K into lengthscale / input gradients (stationaries.py:209-210 under autodiff). */
+int gpk_moment_rows(void* stream, const double* B, long ldb, int n2, int d, double* Vt, long ldv);
+/* gpk_stationary_adjoint_tail:  from R [n1, 1 + 2 d] = G [1, B, B^2] (columns: row sums, G B, G B^2), the first kernel
+ *   argument A [n1, d] and the lengthscales ls_dev [d] (device):
+ *     T = R[:, 1:1+d] - A .* R[:, 0]
+ *     symmetric != 0 (B is A, Kbar symmetric):  Abar = 2 T / ls^2,  d/dls = -colsum(A .* Abar) / ls
+ *     else:                                      Abar = T / ls^2,    d/dls = colsum(R[:, 1+d:] - A .* (R[:, 1:1+d] + T)) / ls^3
+ *     d/dvariance = (sum_kbar_k ? sum_kbar_k[0] : sum(R[:, 0])) / variance
+ *   Abar [n1, d]; small [1 + d] = (d/dvariance + dvar_add, d/dls).  accumulate != 0: both are ADDED to what Abar / small
+ *   hold (the two adjoints of one kernel -- Kuf and Kuu -- leave their sum).  One workgroup, fixed summation order. */
+int gpk_stationary_adjoint_tail(void* stream, const double* R, long ldr, const double* A, long lda, int n1, int d,
+                                const double* ls_dev, double variance, int symmetric, const double* sum_kbar_k,
+                                double* Abar, long ldab, double* small, int accumulate, double dvar_add);
+/* gpk_adam_step:  tf.keras Adam on one variable of n doubles, in place:  g' = maximise ? -g : g,
+ *   m = beta1 m + (1 - beta1) g',  v = beta2 v + (1 - beta2) g'^2,  p -= step m / (sqrt(v) + epsilon),
+ *   step = lr sqrt(1 - beta2^t) / (1 - beta1^t) computed by the caller. */
+int gpk_adam_step(void* stream, double* p, const double* g, double* m, double* v, long n, double beta1, double beta2,
+                  double epsilon, double step, int maximise);
+/* gpk_lowrank_axpy:  out [m, n] = alpha X + U V^T  for thin U [m, k], V [n, k], k <= 16 (out may be X): the first two terms of
+ *   At_bar = r q_mu^T - 2 c P At + 2 c sum_p W_p Lq_p^T in one pass (the GEMM that adds the third has beta = 1). */
+int gpk_lowrank_axpy(void* stream, double alpha, const double* X, long ldx, const double* U, long ldu, const double* V, long ldv,
+                     int m, int n, int k, double* out, long ldo);
+/* gpk_symmetrize:  S = (S + S^T) / 2 in place, S [n, n] -- the last step of the Cholesky adjoint. */
+int gpk_symmetrize(void* stream, double* S, int n, long lds);
+
 /* ---- fused drivers -----------------------------------------------------------------------------------
  * GPR.log_marginal_likelihood (gpr.py:91-107), stationary kernel, Gaussian noise, constant mean:
  * builds K(X,X)+noise*I (lower) with (Y-mean)^T as extra rows into ws, factors, reduces.

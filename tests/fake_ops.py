@@ -195,7 +195,7 @@ def trsm_(B, L, invd, *, trans=0):
     return B
 
 
-def gemm_nt(A, B, *, alpha=1.0, beta=0.0, C=None, b_tri=0, c_lower=False, a_tri=0, k_split=False):
+def gemm_nt(A, B, *, alpha=1.0, beta=0.0, C=None, b_tri=0, c_lower=False, a_tri=0, k_split=False, zero_skipped=True):
     if k_split:   # batch entries = consecutive K chunks of one product; the structure statements are about the unsplit column index
         assert A.dim() == 3 and B.dim() == 3 and A.shape[0] == B.shape[0] and A.shape[2] % 16 == 0
     if a_tri:   # the hint must be TRUE: the device kernel skips the K range it declares zero
@@ -211,8 +211,8 @@ def gemm_nt(A, B, *, alpha=1.0, beta=0.0, C=None, b_tri=0, c_lower=False, a_tri=
     if C is None:
         assert beta == 0.0
         C = torch.zeros((batch, m, n) if batched else (m, n), dtype=torch.float64)
-        if not c_lower:
-            C.fill_(float("nan"))     # every entry must be written by the kernel
+        if not c_lower or not zero_skipped:
+            C.fill_(float("nan"))     # every entry must be written by the kernel (zero_skipped=False: skipped tiles stay uninitialised)
     C3 = C if C.dim() == 3 else C.unsqueeze(0)
     for z in range(batch):
         a = _np(A3[z if A3.shape[0] > 1 else 0])
@@ -473,3 +473,47 @@ def svgp_elbo_shard(Z, Xb, Yb, q_mu, q_sqrt, *, variance, lengthscales, noise_va
         out.copy_(res)
         res = out
     return res, inf
+
+
+# ---- reverse-pass glue (include/gpk.h: gpk_moment_rows, gpk_stationary_adjoint_tail, gpk_adam_step, gpk_symmetrize) ----
+def moment_rows(B):
+    Bt = B.t()
+    return torch.cat([torch.ones((1, B.shape[0]), dtype=torch.float64), Bt, Bt * Bt], 0).contiguous()
+
+
+def stationary_adjoint_tail(R, A, ls, *, variance, symmetric, sum_kbar_k=None, into=None, dvar_add=0.0):
+    D = A.shape[1]
+    rs, GB, GB2 = R[:, 0:1], R[:, 1:1 + D], R[:, 1 + D:]
+    T = GB - A * rs
+    if symmetric:
+        Abar = T * (2.0 / (ls * ls))
+        dls = -(A * Abar).sum(0) / ls
+    else:
+        Abar = T / (ls * ls)
+        dls = (GB2 - A * (GB + T)).sum(0) / ls ** 3
+    dvar = (rs.sum() if sum_kbar_k is None else sum_kbar_k.reshape(())) / variance + dvar_add
+    if into is not None:
+        small, acc = into
+        small[0:1] += dvar.reshape(1)
+        small[1:] += dls
+        acc += Abar
+        return small[0:1], small[1:], acc
+    small = torch.cat([dvar.reshape(1), dls])
+    return small[0:1], small[1:], Abar
+
+
+def adam_step_(p, g, m, v, *, beta1, beta2, epsilon, step, maximise=False):
+    gg = -g if maximise else g
+    m.mul_(beta1).add_(gg, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1.0 - beta2)
+    p.addcdiv_(m, v.sqrt().add_(epsilon), value=-step)
+    return p
+
+
+def symmetrize_(S):
+    S.copy_(0.5 * (S + S.t()))
+    return S
+
+
+def lowrank_axpy(alpha, X, U, V):
+    return alpha * X + U @ V.t()

@@ -650,3 +650,85 @@ def test_chain_handoff_mode_and_serialised_kernels(gpu):
     assert r.returncode == 0, r.stdout + r.stderr
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("MODE")][0].split()
     assert int(line[1]) == 0 and float(line[3]) < 5e-12, line
+
+
+# ---- reverse-pass glue as single launches (include/gpk.h: gpk_moment_rows, gpk_stationary_adjoint_tail, gpk_adam_step,
+# gpk_symmetrize).  The reference has no counterpart (TF autodiff / tf.optimizers.Adam): the checker is the plain
+# NumPy arithmetic each header comment states.
+@pytest.mark.parametrize("n2,d", [(1, 1), (300, 3), (8192, 8), (1000, 16)])
+def test_moment_rows(gpu, n2, d):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(1)
+    B = rng.normal(size=(n2, d))
+    Vt = ops.moment_rows(_t(B)).cpu().numpy()
+    ref = np.vstack([np.ones((1, n2)), B.T, (B * B).T])
+    np.testing.assert_array_equal(Vt, ref)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("n1,d,with_sum", [(1, 1, False), (77, 3, True), (2048, 8, False), (5000, 16, False), (300, 100, True)])
+def test_stationary_adjoint_tail(gpu, symmetric, n1, d, with_sum):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(2)
+    R, A = rng.normal(size=(n1, 1 + 2 * d)), rng.normal(size=(n1, d))
+    ls = 0.6 + 0.05 * np.arange(d)
+    sk = np.array([3.25]) if with_sum else None
+    dvar, dls, Abar = ops.stationary_adjoint_tail(_t(R), _t(A), _t(ls), variance=1.7, symmetric=symmetric,
+                                                  sum_kbar_k=None if sk is None else _t(sk))
+    rs, GB, GB2 = R[:, :1], R[:, 1:1 + d], R[:, 1 + d:]
+    T = GB - A * rs
+    if symmetric:
+        Ab = 2.0 * T / ls ** 2
+        dl = -(A * Ab).sum(0) / ls
+    else:
+        Ab = T / ls ** 2
+        dl = (GB2 - A * (GB + T)).sum(0) / ls ** 3
+    dv = (rs.sum() if sk is None else sk[0]) / 1.7
+    np.testing.assert_allclose(Abar.cpu().numpy(), Ab, rtol=1e-14, atol=1e-14)
+    scale = np.abs(R).sum() + 1.0   # (sums of n1 terms of mixed sign: tolerance relative to the magnitude summed)
+    np.testing.assert_allclose(dls.cpu().numpy(), dl, rtol=0, atol=1e-13 * scale / ls.min() ** 3)
+    np.testing.assert_allclose(dvar.cpu().numpy(), [dv], rtol=0, atol=1e-13 * scale)
+
+
+@pytest.mark.parametrize("n,maximise", [(1, False), (1000, True), (2048 * 2048 + 3, False)])
+def test_adam_step(gpu, n, maximise):
+    import torch
+    from gpflow_amd import ops
+    rng = np.random.default_rng(3)
+    p, g, m, v = rng.normal(size=n), rng.normal(size=n), 0.1 * rng.normal(size=n), np.abs(rng.normal(size=n))
+    P, G, Mm, V = _t(p), _t(g), _t(m), _t(v)
+    ops.adam_step_(P, G, Mm, V, beta1=0.9, beta2=0.999, epsilon=1e-7, step=2.5e-3, maximise=maximise)
+    gg = -g if maximise else g
+    m2 = 0.9 * m + (1.0 - 0.9) * gg
+    v2 = 0.999 * v + (1.0 - 0.999) * gg * gg
+    p2 = p - 2.5e-3 * m2 / (np.sqrt(v2) + 1e-7)
+    # (fused multiply-adds on the device: a few ulp of the terms, which cancel in m)
+    np.testing.assert_allclose(Mm.cpu().numpy(), m2, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(V.cpu().numpy(), v2, rtol=1e-14, atol=1e-300)
+    np.testing.assert_allclose(P.cpu().numpy(), p2, rtol=1e-13, atol=1e-14)
+    assert torch.equal(G.cpu(), torch.from_numpy(g))
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 100, 2048])
+def test_symmetrize(gpu, n):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(4)
+    S = rng.normal(size=(n, n))
+    out = ops.symmetrize_(_t(S)).cpu().numpy()
+    np.testing.assert_array_equal(out, 0.5 * (S + S.T))
+    # a strided view (row stride > n): only the n x n block is touched
+    big = rng.normal(size=(n, n + 5))
+    Tb = _t(big)
+    ops.symmetrize_(Tb[:, :n])
+    res = Tb.cpu().numpy()
+    np.testing.assert_array_equal(res[:, :n], 0.5 * (big[:, :n] + big[:, :n].T))
+    np.testing.assert_array_equal(res[:, n:], big[:, n:])
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (300, 77, 3), (8192, 2048, 1), (513, 1001, 16)])
+def test_lowrank_axpy(gpu, m, n, k):
+    from gpflow_amd import ops
+    rng = np.random.default_rng(6)
+    X, U, V = rng.normal(size=(m, n)), rng.normal(size=(m, k)), rng.normal(size=(n, k))
+    out = ops.lowrank_axpy(-0.7, _t(X), _t(U), _t(V)).cpu().numpy()
+    np.testing.assert_allclose(out, -0.7 * X + U @ V.T, rtol=0, atol=1e-14 * k)
