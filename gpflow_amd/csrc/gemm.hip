@@ -806,54 +806,83 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
       const long long t0 = wall_clock64();
       while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
     }
-    // Tile QUEUE (round 6): persistent workgroups take (batch entry, tile) pairs from a device counter, last batch entry first.  For
-    // launches whose tiles differ widely in K -- the K chunks of a triangular x triangular product: 480 of 1024 pairs non-empty, 8 to
-    // 32 slabs each -- a static assignment leaves the launch as long as its most loaded compute unit.  Every pair is computed by exactly
-    // one workgroup and written to its own output tile: results do not depend on who took what.
-    // (One queue per XCD -- a contiguous eighth of the tile sequence per L2, workgroups helping the other queues when theirs is empty --
-    //  was measured and removed: FETCH_SIZE of the first N = 16384 trailing update is 50 % higher with the single queue, but C2 30.85 /
-    //  30.99 against 30.72 / 30.73 ms, profiles/r06_ab_gpr_tile_queue.log.)
-    // Static walk otherwise (gridDim.x < total: persistent workgroups, each with stride gridDim.x).  ONE call site of the tile for both:
-    // with one inlined copy per way of finding the next tile the kernel was 25 000 instructions and spilled 241 registers.
-    volatile int* s_next = reinterpret_cast<volatile int*>(&smem[BK]);   // (the padding of LDS row 0: no tile access touches it)
-    const bool queued = p.queue != nullptr;
-    const int nbatch = p.batch > 0 ? p.batch : 1;
-    const int all = total * nbatch;
-    for (int t = blockIdx.x;;) {
-      int tile_m, tile_n, bzq = -1;
-      if (queued) {
+    // (ONE call site of the tile -- a single loop that either fetches from the queue or walks statically -- brings the kernel from 25 000
+    //  instructions and 241 spilled registers (all outside the K loop) to 19 000 and 84, and is 2 % SLOWER on every workload: Cm 1.79 - 1.81
+    //  against 1.75 - 1.77 ms, GPR C2 30.9 - 31.0 against 30.3 - 30.6 ms, same box, profiles/r06_ab_single_call_site.log.  The copies stay.)
+    if (p.queue) {
+      // Tile QUEUE (round 6): persistent workgroups take (batch entry, tile) pairs from a device counter, last batch entry first.  For
+      // launches whose tiles differ widely in K -- the K chunks of a triangular x triangular product: 480 of 1024 pairs non-empty, 8 to
+      // 32 slabs each -- a static assignment leaves the launch as long as its most loaded compute unit.  Every pair is computed by exactly
+      // one workgroup and written to its own output tile: results do not depend on who took what.
+      volatile int* s_next = reinterpret_cast<volatile int*>(&smem[BK]);   // (the padding of LDS row 0: no tile access touches it)
+      const int nbatch = p.batch > 0 ? p.batch : 1;
+      const int all = total * nbatch;
+      if (p.queue_xcd) {
+        // (A/B knob, off: FETCH_SIZE of the first trailing update rose from 2.75e6 to 4.17e6 KB with the single queue -- tiles no longer stay on
+        //  "their" XCD -- but the per-XCD queues below bought nothing: C2 30.85 / 30.99 against 30.72 / 30.73 ms, profiles/r06_ab_gpr_tile_queue.log)
+        // One queue per XCD (single problems): tile_order gives XCD x -- workgroups with blockIdx.x % 8 == x -- a contiguous eighth of the
+        // tile sequence so that neighbouring tiles share operand panels in that XCD's L2; a workgroup drains its home queue first and
+        // then helps the others.  Every queue holds L = ceil(total / 8) entries (the last may be a phantom) and every workgroup fails
+        // exactly once on every queue: all eight words advance by L + gridDim.x per launch, which is what the host books.
+        const int L = (total + 7) >> 3;
+        int cur = (int)blockIdx.x & 7;
+        unsigned exhausted = 0;   // (thread 0 only)
+        for (;;) {
+          if (threadIdx.x == 0) {
+            int lin = -1;
+            while (exhausted != 0xffu) {
+              const int local = (int)((unsigned)atomicAdd(p.queue + cur, 1) - (unsigned)p.queue_base);
+              if (local >= 0 && local < L) { lin = local * 8 + cur; break; }
+              exhausted |= 1u << cur;
+              for (int i = 0; i < 8 && (exhausted >> cur & 1u); ++i) cur = (cur + 1) & 7;
+            }
+            *s_next = lin;
+          }
+          __syncthreads();
+          const int t = *s_next;
+          __syncthreads();
+          if (t < 0) break;
+          if (t >= total) continue;   // (phantom entry of a queue one short)
+          int tile_m, tile_n;
+          tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+          fast_tile<EPI>(p, tile_m, tile_n, smem, 0, 0);
+        }
+        return;
+      }
+      for (;;) {
         if (threadIdx.x == 0) *s_next = (int)((unsigned)atomicAdd(p.queue, 1) - (unsigned)p.queue_base);
         __syncthreads();
-        const int f = *s_next;
+        const int t = *s_next;
         __syncthreads();   // (s_next is rewritten, and both LDS buffers refilled, only after everybody has read / finished)
-        if (f >= all || f < 0) break;
-        const int zq = f / total;
-        bzq = nbatch - 1 - zq;
-        tile_order(f - zq * total, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+        if (t >= all || t < 0) break;
+        const int zq = t / total, tq = t - zq * total;
+        int tile_m, tile_n;
+        tile_order(tq, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
+        fast_tile<EPI>(p, tile_m, tile_n, smem, 0, nbatch - 1 - zq);
+      }
+      return;
+    }
+    // gridDim.x < total: persistent workgroups, each walks the tile list with stride gridDim.x
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+      int tile_m, tile_n;
+      if (EPI == 1 && p.tile_snake) {
+        // a triangular-K projection whose PAIRS would not fill the chip twice (launch_fast): one tile per workgroup, workgroups x and
+        // x + total / 2 -- the same compute unit under round-robin placement -- take column tiles j and gx-1-j of one row tile
+        const int q = t / gy, half = gx >> 1;
+        tile_m = t - q * gy;
+        tile_n = q < half ? q : gx - 1 - (q - half);
+      } else if (p.k_off_step) {
+        // K-split of a triangular product: the chunks of one output tile must not meet on one compute unit (workgroup x of every
+        // batch entry lands on about the same CU, and the tiles near the origin are non-empty in EVERY chunk: the launch would last
+        // as long as unsplit) -- each chunk walks the tile list from its own offset
+        int tt = t + (int)blockIdx.y * (total / (int)gridDim.y);
+        if (tt >= total) tt -= total;
+        tile_order(tt, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
       } else {
-        if (t >= total) break;
-        if (EPI == 1 && p.tile_snake) {
-          // a triangular-K projection whose PAIRS would not fill the chip twice (launch_fast): one tile per workgroup, workgroups x and
-          // x + total / 2 -- the same compute unit under round-robin placement -- take column tiles j and gx-1-j of one row tile
-          const int q = t / gy, half = gx >> 1;
-          tile_m = t - q * gy;
-          tile_n = q < half ? q : gx - 1 - (q - half);
-        } else if (p.k_off_step) {
-          // K-split of a triangular product: the chunks of one output tile must not meet on one compute unit (workgroup x of every
-          // batch entry lands on about the same CU, and the tiles near the origin are non-empty in EVERY chunk: the launch would last
-          // as long as unsplit) -- each chunk walks the tile list from its own offset
-          int tt = t + (int)blockIdx.y * (total / (int)gridDim.y);
-          if (tt >= total) tt -= total;
-          tile_order(tt, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
-        } else {
-          tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
-        }
+        tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
       }
-      fast_tile<EPI>(p, tile_m, tile_n, smem, 0, bzq);
-      if (!queued) {
-        t += (int)gridDim.x;
-        if (t < total) __syncthreads();  // both LDS buffers are about to be refilled
-      }
+      fast_tile<EPI>(p, tile_m, tile_n, smem);
+      if (t + (int)gridDim.x < total) __syncthreads();  // both LDS buffers are about to be refilled
     }
   } else {
     // The workgroups of one row tile (block ids tile_m + j gy: the same XCD, all resident together) read the same rows of A.
@@ -875,26 +904,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
 // counters of the tile-queue launches: a ring of device words per device, never reset -- a launch of `fetches` fetches (one per tile
 // and one failing fetch per workgroup) on a word leaves it at a value the host knows, which is the base of the next launch on that
 // word (two launches would have to be 1024 launches apart AND in flight together to meet on a word).  No memset, no packet.
-int queue_slot(unsigned fetches, int** out, unsigned* base) {
+int queue_slot(unsigned fetches, int words, int** out, unsigned* base) {   // words: 1, or 8 (one per XCD, all advancing alike)
   constexpr int kRing = 1024, kMaxDev = 16;
   static std::mutex mu;
-  static int* ring[kMaxDev] = {};
-  static unsigned* value[kMaxDev] = {};
-  static unsigned next[kMaxDev] = {};
+  static int* ring[2][kMaxDev] = {};
+  static unsigned* value[2][kMaxDev] = {};
+  static unsigned next[2][kMaxDev] = {};
+  const int w = words == 8 ? 1 : 0;
   int dev = 0;
   GPK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDev) return GPK_E_UNSUPPORTED;
   std::lock_guard<std::mutex> lock(mu);
-  if (!ring[dev]) {
-    GPK_HIP(hipMalloc((void**)&ring[dev], sizeof(int) * kRing));
-    GPK_HIP(hipMemset(ring[dev], 0, sizeof(int) * kRing));
-    value[dev] = (unsigned*)calloc(kRing, sizeof(unsigned));
-    if (!value[dev]) return GPK_E_ARG;
+  if (!ring[w][dev]) {
+    GPK_HIP(hipMalloc((void**)&ring[w][dev], sizeof(int) * kRing * words));
+    GPK_HIP(hipMemset(ring[w][dev], 0, sizeof(int) * kRing * words));
+    value[w][dev] = (unsigned*)calloc(kRing, sizeof(unsigned));
+    if (!value[w][dev]) return GPK_E_ARG;
   }
-  const unsigned slot = next[dev]++ % kRing;
-  *out = ring[dev] + slot;
-  *base = value[dev][slot];
-  value[dev][slot] += fetches;
+  const unsigned slot = next[w][dev]++ % kRing;
+  *out = ring[w][dev] + (size_t)slot * words;
+  *base = value[w][dev][slot];
+  value[w][dev][slot] += fetches;
   return 0;
 }
 
@@ -1009,7 +1039,8 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     const unsigned wgs = (unsigned)(all < qw ? all : qw);
     int* q = nullptr;
     unsigned qbase = 0;
-    const int rcq = queue_slot((unsigned)all + wgs, &q, &qbase);
+    b.queue_xcd = (nb == 1 && !a.k_off_step && wgs >= 64 && GPK_TUNE(QUEUE_PER_XCD, 0)) ? 1 : 0;
+    const int rcq = b.queue_xcd ? queue_slot((unsigned)((total + 7) >> 3) + wgs, 8, &q, &qbase) : queue_slot((unsigned)all + wgs, 1, &q, &qbase);
     if (rcq) return rcq;
     b.queue = q;
     b.queue_base = (int)qbase;
