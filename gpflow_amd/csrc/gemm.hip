@@ -792,7 +792,9 @@ __device__ __forceinline__ void fast_tile(const GemmArgs& p, int tile_m, int til
 // pair = 1 (triangular-K operand, b_tri = 1): the K range of column tile j shrinks with j, so a workgroup
 // takes column tiles j and gx-1-j back to back -- every workgroup then carries the same number of K slabs
 // and the launch finishes together instead of waiting for the full-K tiles.
-template <int EPI, bool PAIR>
+// QUEUE (round 6, late): the queue form is its own instantiation -- with the queue loops and the static walk in ONE kernel it carried
+// three inlined copies of the tile, 25 000 instructions and 241 spilled registers.
+template <int EPI, bool PAIR, bool QUEUE = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int gy, int total, int compact) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (p.sig_ptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)   // entry signal (GemmArgs::sig_ptr)
@@ -806,49 +808,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast(GemmArgs p, int gx, int g
       const long long t0 = wall_clock64();
       while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
     }
-    // (ONE call site of the tile -- a single loop that either fetches from the queue or walks statically -- brings the kernel from 25 000
-    //  instructions and 241 spilled registers (all outside the K loop) to 19 000 and 84, and is 2 % SLOWER on every workload: Cm 1.79 - 1.81
-    //  against 1.75 - 1.77 ms, GPR C2 30.9 - 31.0 against 30.3 - 30.6 ms, same box, profiles/r06_ab_single_call_site.log.  The copies stay.)
-    if (p.queue) {
+    // (ONE call site of the tile in ONE kernel -- a single loop that either fetches from the queue or walks statically -- was 84 spilled
+    //  registers and 2 % SLOWER on every workload: Cm 1.79 - 1.81 against 1.75 - 1.77 ms, GPR C2 30.9 - 31.0 against 30.3 - 30.6 ms, same
+    //  box, profiles/r06_ab_single_call_site.log.)
+    if constexpr (QUEUE) {
       // Tile QUEUE (round 6): persistent workgroups take (batch entry, tile) pairs from a device counter, last batch entry first.  For
       // launches whose tiles differ widely in K -- the K chunks of a triangular x triangular product: 480 of 1024 pairs non-empty, 8 to
       // 32 slabs each -- a static assignment leaves the launch as long as its most loaded compute unit.  Every pair is computed by exactly
       // one workgroup and written to its own output tile: results do not depend on who took what.
+      // (One queue per XCD -- a contiguous eighth of the tile sequence per L2, workgroups helping the other queues once theirs is empty --
+      //  was measured and removed: FETCH_SIZE of the first N = 16384 trailing update is 50 % higher with the single queue, but C2 30.85 /
+      //  30.99 against 30.72 / 30.73 ms, profiles/r06_ab_gpr_tile_queue.log.)
       volatile int* s_next = reinterpret_cast<volatile int*>(&smem[BK]);   // (the padding of LDS row 0: no tile access touches it)
       const int nbatch = p.batch > 0 ? p.batch : 1;
       const int all = total * nbatch;
-      if (p.queue_xcd) {
-        // (A/B knob, off: FETCH_SIZE of the first trailing update rose from 2.75e6 to 4.17e6 KB with the single queue -- tiles no longer stay on
-        //  "their" XCD -- but the per-XCD queues below bought nothing: C2 30.85 / 30.99 against 30.72 / 30.73 ms, profiles/r06_ab_gpr_tile_queue.log)
-        // One queue per XCD (single problems): tile_order gives XCD x -- workgroups with blockIdx.x % 8 == x -- a contiguous eighth of the
-        // tile sequence so that neighbouring tiles share operand panels in that XCD's L2; a workgroup drains its home queue first and
-        // then helps the others.  Every queue holds L = ceil(total / 8) entries (the last may be a phantom) and every workgroup fails
-        // exactly once on every queue: all eight words advance by L + gridDim.x per launch, which is what the host books.
-        const int L = (total + 7) >> 3;
-        int cur = (int)blockIdx.x & 7;
-        unsigned exhausted = 0;   // (thread 0 only)
-        for (;;) {
-          if (threadIdx.x == 0) {
-            int lin = -1;
-            while (exhausted != 0xffu) {
-              const int local = (int)((unsigned)atomicAdd(p.queue + cur, 1) - (unsigned)p.queue_base);
-              if (local >= 0 && local < L) { lin = local * 8 + cur; break; }
-              exhausted |= 1u << cur;
-              for (int i = 0; i < 8 && (exhausted >> cur & 1u); ++i) cur = (cur + 1) & 7;
-            }
-            *s_next = lin;
-          }
-          __syncthreads();
-          const int t = *s_next;
-          __syncthreads();
-          if (t < 0) break;
-          if (t >= total) continue;   // (phantom entry of a queue one short)
-          int tile_m, tile_n;
-          tile_order(t, p.b_tri, gx, gy, total, compact, tile_m, tile_n);
-          fast_tile<EPI>(p, tile_m, tile_n, smem, 0, 0);
-        }
-        return;
-      }
       for (;;) {
         if (threadIdx.x == 0) *s_next = (int)((unsigned)atomicAdd(p.queue, 1) - (unsigned)p.queue_base);
         __syncthreads();
@@ -1039,12 +1012,16 @@ int launch_fast(hipStream_t s, const GemmArgs& a) {
     const unsigned wgs = (unsigned)(all < qw ? all : qw);
     int* q = nullptr;
     unsigned qbase = 0;
-    b.queue_xcd = (nb == 1 && !a.k_off_step && wgs >= 64 && GPK_TUNE(QUEUE_PER_XCD, 0)) ? 1 : 0;
-    const int rcq = b.queue_xcd ? queue_slot((unsigned)((total + 7) >> 3) + wgs, 8, &q, &qbase) : queue_slot((unsigned)all + wgs, 1, &q, &qbase);
+    const int rcq = queue_slot((unsigned)all + wgs, 1, &q, &qbase);
     if (rcq) return rcq;
     b.queue = q;
     b.queue_base = (int)qbase;
-    hipLaunchKernelGGL((gemm_nt_fast<EPI, false>), dim3(wgs, 1, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total, compact);
+    if constexpr (EPI == 0) {
+      static const hipError_t attrq = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast<0, false, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+      GPK_HIP(attrq);
+      hipLaunchKernelGGL((gemm_nt_fast<0, false, true>), dim3(wgs, 1, 1), dim3(256), LDS_BYTES, s, b, gx, gy, total, compact);
+    }
     GPK_LAUNCH_CHECK();
     return 0;
   }

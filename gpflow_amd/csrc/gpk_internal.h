@@ -96,7 +96,7 @@ struct GemmArgs {
   const int* wait_ptr; int wait_val;
   int* wait_info;   // device int that receives INT_MAX if the bounded wait expires (the factorisation's status word)
   int tile_queue;   // fast path, epi 0: persistent workgroups that take their tiles from a device counter (launches with more than 512 tiles)
-  int* queue; int queue_base; int queue_xcd;   // set by the launcher only: that counter (queue_xcd: eight, one per XCD) and its value before this launch
+  int* queue; int queue_base;   // set by the launcher only: that counter and its value before this launch
   int tile64;       // epi 0 only: take the generic kernel's 64 x 64 tiles (36 KB of LDS per workgroup: fits beside any other workgroup on a CU)
   int tile_snake;   // set by the launcher only (generic kernel, under-filled triangular-K projections): heavy / light tiles alternate per CU
   int tail_first1;  // set by the launcher only (generic 64 x 64 kernel; launch_fast, "tail split"): 1 + first position, 0 = off
