@@ -378,6 +378,9 @@ int solve_group_fwd(hipStream_t s, const Bulk& bulk, double* E, long lde, double
   if (c1 < n) {
     GemmArgs u = gemm_base(rows, n - c1, c1 - c0, -1.0, Eo + c0, ldeo, L + (long)c1 * ldl + c0, ldl, 1.0,
                            E + c1, lde, batch, strideEo, strideL, strideE);
+    // (round 6, late: this update on the CU-masked stream B with TWO persistent workgroups per compute unit of its mask -- K loop at 88 %
+    //  instead of 79 %, the 32 CUs outside the mask free for the chain, hand-over by events -- makes every SVGP workload 10 - 20 % SLOWER:
+    //  Cm 1.94 - 1.96 against 1.75 - 1.79 ms, profiles/r06_ab_xbulk_masked.log.  A third active hardware queue, as in rounds 2 - 3.)
     bulk.apply(u);
     rc = gpk_launch_gemm(s, u);
     if (rc) return rc;
