@@ -492,9 +492,7 @@ def svgp_elbo_and_grad(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.Tensor, q_mu
 
     # branch_q in two parts: its HBM-bound preparation (At^T r, the transposes of W) and its chip-filling GEMMs
     def branch_q_prep():
-        # At^T r - q_mu: a thin product -- ONE pass over A (gpk_row_stats' At V form), not a GEMM with a 64-column tile for P columns
-        # (that launch took 67 us alone and 523 us beside the main branch's product, profiles/r06_train_timeline_fused_glue.txt)
-        g_mu = ops.row_stats(A, V=r, want_sumsq=False)[1].sub_(q_mu, alpha=kl_weight)
+        g_mu = splitk_gemm_nt(A, r.t().contiguous()) - kl_weight * q_mu                # At^T r - q_mu
         if q_diag:
             return g_mu, None, None
         Wg, ag = (Wc, 2.0) if het else (W, 2.0 * c)
@@ -869,7 +867,7 @@ def svgp_elbo_and_grad_unwhitened(Z: torch.Tensor, Xb: torch.Tensor, Yb: torch.T
     Kuf_bar = ops.transpose(Kfu_bar)
     # q(u) gradients: data part through A2t, KL part through Kuu^-1
     Kinv_qmu_t = ops.gemm_nt(alphat, LinvT, b_tri=1)                                    # (Linv^T alpha)^T  [P, M]
-    g_qmu = ops.row_stats(A2, V=r, want_sumsq=False)[1] - k * Kinv_qmu_t.t()
+    g_qmu = splitk_gemm_nt(A2, r.t().contiguous()) - k * Kinv_qmu_t.t()
     if q_diag:   # d/dq_mp = 2c colsum(A2t^2)_m q_mp - k ((Kuu^-1)_mm q_mp - 1 / q_mp)
         colsq2c = 2.0 * ((A2t * A2t) * cvec[:, None]).sum(0) if het else (2.0 * c) * ops.row_stats(A2)[0]
         g_qs = colsq2c[:, None] * qd - k * (kinv_diag[:, None] * qd - 1.0 / qd)
