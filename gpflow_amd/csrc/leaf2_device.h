@@ -644,10 +644,14 @@ __device__ __forceinline__ void leaf2_body(double* __restrict__ S, double* __res
     if (wave == 0 && lane == 0 && info) {                // first failing pivot of the matrix wins (an earlier leaf may have reported)
       const int b0 = sync[W_BAD0], b1 = sync[W_BAD1];
       const int b = b0 < b1 ? b0 : b1;
-      if (info[0] == 0) {
-        if (b != 0x7fffffff) info[0] = col0 + b + 1;
-        else if (sync[W_TIMEOUT]) info[0] = 0x7fffffff;  // a hand-off inside the leaf timed out (gpk.h: INT_MAX)
-      }
+      int v = 0;
+      if (b != 0x7fffffff) v = col0 + b + 1;
+      else if (sync[W_TIMEOUT]) v = 0x7fffffff;          // a hand-off inside the leaf timed out (gpk.h: INT_MAX)
+      // The leaf of column 0 is the first writer of a factorisation's status word and RESETS it: no 4-byte memset packet (a fill kernel
+      // plus the event the panel stream then waits for: ~20 us in the step timeline) ahead of the chain.  (Bounded waits of other streams
+      // raise the word to INT_MAX after 0.5 s at the earliest.)
+      if (col0 == 0) info[0] = v;
+      else if (v != 0 && info[0] == 0) info[0] = v;
     }
   }
   if (dbg && tid == 0) {

@@ -531,7 +531,12 @@ __device__ __forceinline__ void leaf_body(double* __restrict__ S, double* __rest
   }
   if (!FACTORED && info) {
     // bad_col is wave-0 state; lane 0 of wave 0 reports (first failing pivot of the matrix wins)
-    if (tid == 0 && bad_col >= 0 && info[0] == 0) info[0] = col0 + bad_col + 1;
+    // (the leaf of column 0 resets the word: see leaf2_device.h)
+    if (tid == 0) {
+      const int v = bad_col >= 0 ? col0 + bad_col + 1 : 0;
+      if (col0 == 0) info[0] = v;
+      else if (v != 0 && info[0] == 0) info[0] = v;
+    }
   }
 }
 

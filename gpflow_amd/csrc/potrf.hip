@@ -464,8 +464,11 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   if (!A || !invd || n < 0 || extra < 0 || lda < n) return GPK_E_ARG;
   if (tri && (tri != n || extra < n || batch > 1)) return GPK_E_ARG;
   if (batch <= 0) batch = 1;
-  if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, S));
-  if (n == 0) return 0;
+  // (the status word is reset by the leaf of column 0 -- leaf2_device.h -- not by a memset packet ahead of the fork below)
+  if (n == 0) {
+    if (info) GPK_HIP(hipMemsetAsync(info, 0, sizeof(int) * batch, S));
+    return 0;
+  }
   // tri = n: the LAST n extra rows are the identity (written here) and come back as L^-T.  Row j of that block stays
   // zero left of column j, so column group [c0, c1) only has to process its first c1 rows: n^3 / 3 flop instead of n^3.
   // tri_prefilled: the caller (or its x_prologue) puts an UPPER-TRIANGULAR block there itself -- tril(q_sqrt)^T of the
