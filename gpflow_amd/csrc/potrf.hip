@@ -629,7 +629,9 @@ int potrf_core(hipStream_t S, double* A, int n, int extra, long lda, int batch, 
   const int xgroup_first = std::max(NB, (GPK_TUNE(XGROUP_FIRST, 0) > 0 ? (GPK_TUNE(XGROUP_FIRST, 0) / NB) * NB : xgroup));
   // (A/B, profiles/r05_ab_extra_row_stream.log: M = 2048 x 8192 rows 1.97 - 1.99 -> 1.934 ms without the shrinking groups;
   //  M = 1024, whose every panel is a group already, keeps them: 0.76 against 0.78 ms)
-  const int tail_zone_max_rows = n > 1024 ? GPK_TUNE(XTAIL_ZONE_MAX_ROWS, 6144) : (1 << 30);
+  // (round 6, late: with the 41-us chain period the extra-row stream finishes last at M = 1024 too -- the two single-block groups at the end ran as
+  //  three launches BEHIND the last leaf: C3 0.683 - 0.690 -> 0.662 - 0.678 ms, C5 shared 1.18 -> 1.15, profiles/r06_ab_tail_zone_small.log)
+  const int tail_zone_max_rows = n > 1024 ? GPK_TUNE(XTAIL_ZONE_MAX_ROWS, 6144) : GPK_TUNE(XTAIL_ZONE_MAX_ROWS_SMALL, 6144);
   // (A/B, profiles/r05_ab_extra_row_stream.log: latency kernel everywhere 1.903 1.907 | tiled from 150 workgroups 1.867 1.869 |
   //  from 250: 1.886 1.896 | always: 1.883 1.897; caps of 16 / 32 / 64 walking workgroups on the latency kernel: 2.41 / 2.06 / 1.94)
   // (all three "many extra rows" switches -- this one, the progressive first group, no shrinking groups at the end -- were measured
