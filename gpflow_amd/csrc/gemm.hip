@@ -191,8 +191,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
 
   // per-thread staging slots: chunk c = tid + 256 q  ->  tile row c>>3, k offset (c&7)*2.
   // Rows are clamped (then zero-selected) so the fast path is branch-free: all loads of a slab
-  // are issued back to back and drain under the MFMAs of the previous slab.
-  d2 ra[A_CH], rb[B_CH];
+  // are issued back to back and drain under the MFMAs of the previous slabs.
+  // TWO register sets (round 6, late): the loads of slab s+2 go out at the top of slab s, so a slab's data has two slab times to
+  // arrive instead of one.  This kernel's slab is short -- 16 MFMAs per wave for a 64 x 64 tile, 0.43 us -- and its K loop ran at the
+  // global-load round trip instead (0.97 us per slab: the 64 x 64 remainders of the capped extra-row updates, K = 512, took 62 / 52 /
+  // 35 us per SVGP step; the heaviest tile of a few-row projection walks 128 slabs).  Same arithmetic, same order.
+  d2 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
   const double* pa[A_CH];
   const double* pb[B_CH];
   bool va[A_CH], vb[B_CH];
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
     pb[q] = B + (long)(vb[q] ? row : p.n - 1) * p.ldb + (c & 7) * 2;
   }
   const d2 zero2 = {0.0, 0.0};
-  auto gload = [&](int k0) {
+  auto gload = [&](int k0, d2* __restrict__ ra, d2* __restrict__ rb) {
     if (vec_ok && k0 + BK <= ke) {  // wave-uniform
 #pragma unroll
       for (int q = 0; q < A_CH; ++q) {
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const d2* __restrict__ ra, const d2* __restrict__ rb) {
 #pragma unroll
     for (int q = 0; q < A_CH; ++q) {
       const int c = tid + 256 * q;
@@ -251,14 +255,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
 
   const int nkt = ke > kb ? (ke - kb + BK - 1) / BK : 0;
   if (nkt > 0) {
-    gload(kb);
-    lstore(0);
+    gload(kb, ra0, rb0);
+    lstore(0, ra0, rb0);
+    if (nkt > 1) gload(kb + BK, ra1, rb1);
     __syncthreads();
   }
   const int frag_r = lane & 15, frag_k = lane >> 4;
-  for (int kt = 0; kt < nkt; ++kt) {
+  // slab j travels in register set j & 1: at slab kt its own set is free again (stored to LDS during slab kt - 1) and takes slab
+  // kt + 2; the other set holds slab kt + 1, requested a whole slab ago
+  auto step = [&](int kt, d2* __restrict__ fa_, d2* __restrict__ fb_, const d2* __restrict__ na_, const d2* __restrict__ nb_) {
     const int cur = kt & 1;
-    if (kt + 1 < nkt) gload(kb + (kt + 1) * BK);
+    if (kt + 2 < nkt) gload(kb + (kt + 2) * BK, fa_, fb_);
+    __builtin_amdgcn_sched_barrier(0);   // (the loads go out BEFORE anything waits for the other set: without this the zero-select of lstore is hoisted above them)
     const double* as = smem + cur * BUF + (wm * WM + frag_r) * LDSS + frag_k;
     const double* bs = smem + cur * BUF + (BM + wn * WN + frag_r) * LDSS + frag_k;
 #pragma unroll
@@ -274,8 +282,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int gx, int
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) lstore(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nkt) lstore(cur ^ 1, na_, nb_);
     __syncthreads();
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(kt, ra0, rb0, ra1, rb1);
+    if (kt + 1 < nkt) step(kt + 1, ra1, rb1, ra0, rb0);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
